@@ -1,0 +1,180 @@
+/*
+ * ebm_hip.h -- C ABI of libebm_hip.so: the MI355X (gfx950) kernels behind torchebm's
+ * Langevin / HMC sampler inner loop.
+ *
+ * The reference (soran-ghaderi/torchebm) is a pure-Python library with no FFI layer;
+ * its boundary for this path is the Python class API.  These entry
+ * points are what a ctypes binding inside the reference would call; each one names the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points)
+ *   - the caller owns every buffer; the library never allocates or frees device memory
+ *     and keeps no pointer after a call returns;
+ *   - device pointers are fp32, row-major contiguous, 16-byte aligned;
+ *   - `stream` is a hipStream_t (NULL = the default stream); calls only ENQUEUE work
+ *     and return, they never synchronise the device or the host;
+ *   - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = EBM_E* argument
+ *     error; the text is available from ebm_last_error_string() (thread local);
+ *   - no C++ exception crosses the boundary; no mutable global state.
+ *
+ * Random numbers ("native RNG", used when a noise pointer is NULL)
+ *   Philox4x32-10 keyed by `seed`.  For step s (64-bit, = offset + local step index)
+ *   and flat element e:  counter = { lo32(e/4), hi32(e/4), lo32(s), hi32(s) }, the
+ *   four 32-bit outputs o0..o3 give, by Box-Muller on (o0,o1) and (o2,o3), the four
+ *   standard normals of elements 4*(e/4)+0..3.  Uniforms (HMC accept) use
+ *   u = (o[e%4] >> 8) * 2^-24 in [0,1).  The stream therefore depends only on
+ *   (seed, offset, step, element) -- never on launch geometry -- and the fused k-step
+ *   kernels, the per-step kernel and ebm_noise_fill_f32 all draw the same field.
+ */
+#ifndef EBM_HIP_H
+#define EBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBM_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define EBM_API __attribute__((visibility("default")))
+#else
+#define EBM_API
+#endif
+
+/* argument errors (negative); positive return values are hipError_t */
+#define EBM_EINVAL  (-1)  /* bad size / NULL pointer / misaligned pointer          */
+#define EBM_EKIND   (-2)  /* unknown or unsupported energy kind for this entry     */
+#define EBM_EDIM    (-3)  /* dim outside the range the fused kernel supports       */
+
+/* Analytic energies the kernels fuse (reference: torchebm/core/base_model.py). */
+enum {
+  EBM_ENERGY_DOUBLE_WELL = 0, /* E = h * sum_j (x_j^2 - b^2)^2   base_model.py:130-148  s[0]=h  s[1]=(float)(b*b)           */
+  EBM_ENERGY_HARMONIC    = 1, /* E = (0.5*k) * sum_j x_j^2       base_model.py:213-229  s[0]=(float)(0.5*k)                 */
+  EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1) */
+  EBM_ENERGY_GMM         = 3  /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
+                                 s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]                   */
+};
+
+typedef struct ebm_energy {
+  int32_t kind;        /* EBM_ENERGY_*                              */
+  int32_t n_comp;      /* mixture components (GMM), else 0          */
+  float   s[4];        /* scalar parameters, see the enum           */
+  const float* dev0;   /* device parameter arrays, see the enum     */
+  const float* dev1;
+} ebm_energy_t;
+
+/* noise kinds for ebm_noise_fill_f32 */
+enum { EBM_NOISE_NORMAL = 0, EBM_NOISE_UNIFORM = 1, EBM_NOISE_RAW_U32 = 2 };
+
+/* mass kinds for the HMC / leapfrog entries (reference: samplers/hmc.py:92-159, integrators/leapfrog.py:91-101) */
+enum { EBM_MASS_NONE = 0, EBM_MASS_SCALAR = 1, EBM_MASS_DIAG = 2 };
+
+EBM_API int ebm_version(void);
+EBM_API const char* ebm_last_error_string(void);
+
+/*
+ * One Euler-Maruyama step with an externally supplied gradient.
+ * Replaces BaseSDERungeKuttaIntegrator.step with the EulerMaruyama tableau
+ * (core/base_integrator.py:673-731, integrators/euler_maruyama.py:55-65) and is the HIP
+ * counterpart of the Triton POC kernel (cuda/fused_langevin.py:34-62).
+ * Arithmetic, each op rounded to fp32, no FMA contraction:
+ *     x1  = x - eta * grad            (= x + eta*(1.0*drift), drift = -grad)
+ *     dw  = eps * sqrt_eta            (sqrt_eta  = (float) sqrt((double)eta))
+ *     out = x1 + noise_coef * dw      (noise_coef = (float) sqrt(2*sigma^2), 0 => ODE step, no noise drawn)
+ *     out = clamp(out, cmin, cmax)    if clamp_on   (samplers/langevin_dynamics.py:166-167)
+ * eps = noise[e] if noise != NULL, else the native RNG field at step `offset`.
+ * `out` may alias `x`.  `grad` may be NULL (zero drift).
+ */
+EBM_API int ebm_langevin_step_f32(const float* x, const float* grad, float* out, const float* noise,
+                          int64_t n_elem, float eta, float sqrt_eta, float noise_coef,
+                          int32_t clamp_on, float cmin, float cmax,
+                          uint64_t seed, uint64_t offset, void* stream);
+
+/*
+ * k fused Langevin steps for an analytic energy: gradient + EM update + noise + clamp
+ * + thinned trajectory stores, state resident in registers/LDS across the k steps.
+ * Replaces the hot loop of LangevinDynamics.sample (samplers/langevin_dynamics.py:154-185)
+ * including BaseModel.gradient (core/base_model.py:62-127) for the fused energies.
+ *   x            [n_chains, dim]    in/out
+ *   coef_table   NULL, or device float[k_steps][4] = {eta_i, sqrt_eta_i, noise_coef_i, 0}
+ *                (pre-expanded schedulers, core/schedulable.py:55-75); when NULL the three
+ *                scalars are used for every step
+ *   traj         NULL, or [n_chains, k_steps/thin, dim]; row j is the state after step (j+1)*thin
+ *   noise        NULL (native RNG, steps offset .. offset+k-1), or [k_steps, n_chains, dim]
+ */
+EBM_API int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                           int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                           const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                           int32_t thin, float* traj, const float* noise,
+                           uint64_t seed, uint64_t offset, void* stream);
+
+/*
+ * n_mh fused HMC transitions for an analytic energy: momentum draw, Hamiltonian,
+ * L leapfrog steps (safe mode: force clamp +-1e6, NaN scrub), Metropolis accept.
+ * Replaces the hot loop of HamiltonianMonteCarlo.sample (samplers/hmc.py:243-312),
+ * LeapfrogIntegrator.integrate (integrators/leapfrog.py:116-187) and the clamps of
+ * core/base_integrator.py:875-889.
+ *   x            [n_chains, dim]   in/out
+ *   eps_table    NULL, or device float[n_mh] (scheduled step size per MH step)
+ *   mass         EBM_MASS_*: none / scalar (a double, as the Python float it mirrors: the kernel uses
+ *                (float)sqrt(m) for the momentum draw, (float)m for the kinetic energy and
+ *                (float)max(m,1e-10) in the drift) / device float[dim]
+ *   traj         NULL, or [n_chains, n_mh/thin, dim]
+ *   accept_mask  NULL, or uint8[n_mh, n_chains]   (1 = proposal accepted)
+ *   accept_count NULL, or uint32[n_mh], must be zeroed by the caller; receives the number
+ *                of accepted chains per MH step (wavefront ballot + one atomic per wave)
+ *   p_noise      NULL (native RNG), or [n_mh, n_chains, dim] standard normals
+ *   u            NULL (native RNG), or [n_mh, n_chains] uniforms in [0,1)
+ * Native RNG consumes two steps per transition: offset+2t (momentum), offset+2t+1 (uniform).
+ */
+EBM_API int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                      int32_t n_mh, int32_t n_leapfrog, float eps, const float* eps_table,
+                      int32_t mass_kind, double mass_scalar, const float* mass_diag,
+                      int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                      const float* p_noise, const float* u,
+                      uint64_t seed, uint64_t offset, void* stream);
+
+/*
+ * Leapfrog sub-steps with an externally supplied force (opaque drift closure):
+ * LeapfrogIntegrator.step / .integrate (integrators/leapfrog.py:63-187).
+ *   kick_drift:  f = clamp(force) if safe;  p_half = p + (0.5*eps)*f;  x_new = x + eps*p_half [/ max(m,1e-10)]
+ *   kick:        f = clamp(force) if safe;  p_new  = p_half + (0.5*eps)*f;  if safe: nan_to_num(x_new, p_new)
+ * `x_new` of kick is updated in place (the NaN scrub); outputs may alias inputs.
+ */
+EBM_API int ebm_leapfrog_kick_drift_f32(const float* x, const float* p, const float* force,
+                                float* x_new, float* p_half, int64_t n_chains, int32_t dim,
+                                float eps, int32_t mass_kind, double mass_scalar,
+                                const float* mass_diag, int32_t safe, void* stream);
+EBM_API int ebm_leapfrog_kick_f32(float* x_new, const float* p_half, const float* force, float* p_new,
+                          int64_t n_elem, float eps, int32_t safe, void* stream);
+
+/*
+ * Metropolis accept for the per-step HMC path (samplers/hmc.py:277-292):
+ *   d = clamp(h0 - h1, -50, 50); a = min(1, exp(d)); acc = u < a; x = acc ? x_prop : x
+ * u = u_or_null[c], or the native uniform field at step `offset`.
+ */
+EBM_API int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, const float* h1,
+                       const float* u, uint8_t* accept_mask, uint32_t* accept_count,
+                       int64_t n_chains, int32_t dim, uint64_t seed, uint64_t offset, void* stream);
+
+/* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
+ * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */
+EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains,
+                        int32_t dim, float* energy_out, float* grad_out, void* stream);
+
+/* Column statistics for the sampler diagnostics (samplers/langevin_dynamics.py:173-185):
+ * mean[dim], biased var[dim] clamped to [1e-10, 1e10].  `work` = zeroed device double[2*dim]. */
+EBM_API int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, float* mean_out,
+                        float* var_out, double* work, void* stream);
+
+/* Fill `out[n_elem]` with the native RNG field at step `offset` (tests / verification /
+ * BaseSampler._init_state-style draws): normals, uniforms in [0,1), or raw u32 bits. */
+EBM_API int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_t seed,
+                       uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBM_HIP_H */

@@ -1,0 +1,223 @@
+// C-ABI entry points of libebm_hip.so (declared in include/ebm_hip.h): argument
+// validation, error strings, and dispatch to the kernel launchers.  Nothing here
+// allocates device memory or synchronises.
+#include <cstdarg>
+#include <cstdio>
+
+#include "ebm_common.h"
+
+namespace ebm {
+
+// launchers implemented in the kernel translation units
+int launch_langevin_step(const float*, const float*, float*, const float*, int64_t, float, float,
+                         float, int, float, float, uint64_t, uint64_t, hipStream_t);
+int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int32_t, float, float,
+                               float, const float*, int, float, float, int32_t, float*,
+                               const float*, uint64_t, uint64_t, hipStream_t);
+int launch_langevin_chain_rows(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float,
+                               float, const float*, int, float, float, int32_t, float*,
+                               const float*, uint64_t, uint64_t, hipStream_t);
+int launch_hmc_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float,
+                     const float*, int32_t, double, const float*, int32_t, float*, uint8_t*,
+                     uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
+int launch_leapfrog_kick_drift(const float*, const float*, const float*, float*, float*, int64_t,
+                               int32_t, float, int32_t, double, const float*, int32_t, hipStream_t);
+int launch_leapfrog_kick(float*, const float*, const float*, float*, int64_t, float, int32_t,
+                         hipStream_t);
+int launch_hmc_accept(float*, const float*, const float*, const float*, const float*, uint8_t*,
+                      uint32_t*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
+int launch_energy_grad(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*,
+                       hipStream_t);
+int launch_chain_stats(const float*, int64_t, int32_t, float*, float*, double*, hipStream_t);
+int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+namespace {
+
+int check_energy(const ebm_energy_t* en, int32_t dim, const char* who) {
+  if (!en) return fail(EBM_EINVAL, "%s: energy descriptor is NULL", who);
+  switch (en->kind) {
+    case EBM_ENERGY_DOUBLE_WELL:
+    case EBM_ENERGY_HARMONIC:
+      return 0;
+    case EBM_ENERGY_GAUSSIAN:
+      if (!en->dev0 || !en->dev1) return fail(EBM_EINVAL, "%s: Gaussian energy needs mean and precision pointers", who);
+      return 0;
+    case EBM_ENERGY_GMM:
+      if (!en->dev0 || !en->dev1 || en->n_comp < 1) return fail(EBM_EINVAL, "%s: mixture energy needs means, log-weights and n_comp >= 1", who);
+      if (en->n_comp > 64) return fail(EBM_EDIM, "%s: at most 64 mixture components are supported (got %d)", who, en->n_comp);
+      return 0;
+    default:
+      return fail(EBM_EKIND, "%s: unknown energy kind %d", who, en->kind);
+  }
+  (void)dim;
+}
+
+int check_state(const void* x, int64_t n_chains, int32_t dim, const char* who) {
+  if (!x) return fail(EBM_EINVAL, "%s: state pointer is NULL", who);
+  if (n_chains < 0 || dim < 1) return fail(EBM_EINVAL, "%s: bad shape [%lld, %d]", who, (long long)n_chains, dim);
+  if (!aligned16(x)) return fail(EBM_EINVAL, "%s: state pointer must be 16-byte aligned", who);
+  return 0;
+}
+
+}  // namespace
+}  // namespace ebm
+
+using namespace ebm;
+
+extern "C" {
+
+int ebm_version(void) { return EBM_ABI_VERSION; }
+
+const char* ebm_last_error_string(void) { return g_err; }
+
+int ebm_langevin_step_f32(const float* x, const float* grad, float* out, const float* noise,
+                          int64_t n_elem, float eta, float sqrt_eta, float noise_coef,
+                          int32_t clamp_on, float cmin, float cmax, uint64_t seed, uint64_t offset,
+                          void* stream) {
+  const char* who = "ebm_langevin_step_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x || !out) return fail(EBM_EINVAL, "%s: x/out is NULL", who);
+  if (!aligned16(x) || !aligned16(out) || (grad && !aligned16(grad)) || (noise && !aligned16(noise)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_langevin_step(x, grad, out, noise, n_elem, eta, sqrt_eta, noise_coef, clamp_on,
+                              cmin, cmax, seed, offset, (hipStream_t)stream);
+}
+
+int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                           int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                           const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                           int32_t thin, float* traj, const float* noise, uint64_t seed,
+                           uint64_t offset, void* stream) {
+  const char* who = "ebm_langevin_chain_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
+  if (n_chains == 0 || k_steps == 0) return 0;
+  if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)) || (noise && !aligned16(noise)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  if (energy->kind == EBM_ENERGY_DOUBLE_WELL || energy->kind == EBM_ENERGY_HARMONIC)
+    return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
+                                      k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
+                                      cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef,
+                                    coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
+                                    (hipStream_t)stream);
+}
+
+int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                      int32_t n_mh, int32_t n_leapfrog, float eps, const float* eps_table,
+                      int32_t mass_kind, double mass_scalar, const float* mass_diag, int32_t thin,
+                      float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                      const float* p_noise, const float* u, uint64_t seed, uint64_t offset,
+                      void* stream) {
+  const char* who = "ebm_hmc_chain_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (n_mh < 0 || thin < 1 || n_leapfrog < 1)
+    return fail(EBM_EINVAL, "%s: n_mh=%d thin=%d n_leapfrog=%d", who, n_mh, thin, n_leapfrog);
+  if (mass_kind < EBM_MASS_NONE || mass_kind > EBM_MASS_DIAG || (mass_kind == EBM_MASS_DIAG && !mass_diag))
+    return fail(EBM_EINVAL, "%s: bad mass specification (kind %d)", who, mass_kind);
+  if ((p_noise == nullptr) != (u == nullptr))
+    return fail(EBM_EINVAL, "%s: p_noise and u must be given together", who);
+  if (n_chains == 0 || n_mh == 0) return 0;
+  if ((traj && !aligned16(traj)) || (p_noise && !aligned16(p_noise)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_hmc_chain(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind,
+                          mass_scalar, mass_diag, thin, traj, accept_mask, accept_count, p_noise, u,
+                          seed, offset, (hipStream_t)stream);
+}
+
+int ebm_leapfrog_kick_drift_f32(const float* x, const float* p, const float* force, float* x_new,
+                                float* p_half, int64_t n_chains, int32_t dim, float eps,
+                                int32_t mass_kind, double mass_scalar, const float* mass_diag,
+                                int32_t safe, void* stream) {
+  const char* who = "ebm_leapfrog_kick_drift_f32";
+  if (n_chains < 0 || dim < 1) return fail(EBM_EINVAL, "%s: bad shape", who);
+  if (n_chains == 0) return 0;
+  if (!x || !p || !force || !x_new || !p_half) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  if (mass_kind == EBM_MASS_DIAG && !mass_diag) return fail(EBM_EINVAL, "%s: diagonal mass is NULL", who);
+  if (!aligned16(x) || !aligned16(p) || !aligned16(force) || !aligned16(x_new) || !aligned16(p_half))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_leapfrog_kick_drift(x, p, force, x_new, p_half, n_chains, dim, eps, mass_kind,
+                                    mass_scalar, mass_diag, safe, (hipStream_t)stream);
+}
+
+int ebm_leapfrog_kick_f32(float* x_new, const float* p_half, const float* force, float* p_new,
+                          int64_t n_elem, float eps, int32_t safe, void* stream) {
+  const char* who = "ebm_leapfrog_kick_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x_new || !p_half || !force || !p_new) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  if (!aligned16(x_new) || !aligned16(p_half) || !aligned16(force) || !aligned16(p_new))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_leapfrog_kick(x_new, p_half, force, p_new, n_elem, eps, safe, (hipStream_t)stream);
+}
+
+int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, const float* h1,
+                       const float* u, uint8_t* accept_mask, uint32_t* accept_count,
+                       int64_t n_chains, int32_t dim, uint64_t seed, uint64_t offset, void* stream) {
+  const char* who = "ebm_hmc_accept_f32";
+  if (n_chains < 0 || dim < 1) return fail(EBM_EINVAL, "%s: bad shape", who);
+  if (n_chains == 0) return 0;
+  if (!x || !x_prop || !h0 || !h1) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_hmc_accept(x, x_prop, h0, h1, u, accept_mask, accept_count, n_chains, dim, seed,
+                           offset, (hipStream_t)stream);
+}
+
+int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,
+                        float* energy_out, float* grad_out, void* stream) {
+  const char* who = "ebm_energy_grad_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (n_chains == 0) return 0;
+  if (grad_out && !aligned16(grad_out)) return fail(EBM_EINVAL, "%s: grad_out must be 16-byte aligned", who);
+  return launch_energy_grad(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
+}
+
+int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, float* mean_out,
+                        float* var_out, double* work, void* stream) {
+  const char* who = "ebm_chain_stats_f32";
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (!mean_out || !var_out || !work) return fail(EBM_EINVAL, "%s: NULL output/workspace", who);
+  if (n_chains == 0) return fail(EBM_EINVAL, "%s: no chains", who);
+  return launch_chain_stats(x, n_chains, dim, mean_out, var_out, work, (hipStream_t)stream);
+}
+
+int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_t seed, uint64_t offset,
+                       void* stream) {
+  const char* who = "ebm_noise_fill_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!out || !aligned16(out)) return fail(EBM_EINVAL, "%s: out must be a 16-byte aligned pointer", who);
+  if (kind < EBM_NOISE_NORMAL || kind > EBM_NOISE_RAW_U32) return fail(EBM_EINVAL, "%s: bad kind %d", who, kind);
+  return launch_noise_fill(out, n_elem, kind, seed, offset, (hipStream_t)stream);
+}
+
+}  // extern "C"

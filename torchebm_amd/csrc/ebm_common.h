@@ -1,0 +1,115 @@
+// Device-side helpers shared by the gfx950 kernels: Philox4x32-10, Box-Muller on the
+// hardware transcendental unit, NaN-propagating clamps, error plumbing.
+//
+// This translation unit is compiled with -ffp-contract=off: every `a*b+c` written with
+// plain operators is a rounded multiply followed by a rounded add, which is what the
+// reference's eager torch ops do.  FMAs appear only where
+// written explicitly (__builtin_fmaf), i.e. inside the RNG.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ebm_hip.h"
+
+namespace ebm {
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);  // api.hip
+int  fail(int code, const char* fmt, ...);
+int  check_launch(const char* what);
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Known-answer vectors are checked in
+// tests/test_rng.py through ebm_noise_fill_f32(kind=RAW_U32).
+// One round = two 32x32->64 multiplies (v_mad_u64_u32) + two 3-input xors (v_xor3_b32);
+// the key schedule is wave-uniform and stays on the scalar unit.
+// ---------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+struct RngKey {
+  uint32_t k0, k1;  // seed
+};
+
+__device__ __forceinline__ U4 philox_at(RngKey key, uint64_t group, uint64_t step) {
+  return philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), (uint32_t)step,
+                       (uint32_t)(step >> 32), key.k0, key.k1);
+}
+
+// (0, 1]: never 0, so the log below is finite; same mapping as cuRAND's uniform.
+__device__ __forceinline__ float u01_open_low(uint32_t r) {
+  return __builtin_fmaf((float)r, 0x1p-32f, 0x1p-33f);
+}
+// [0, 1): 24 random mantissa bits (torch.rand's convention on the GPU).
+__device__ __forceinline__ float u01_half_open(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
+
+// Box-Muller on the transcendental unit: v_log_f32 is log2, v_sin/v_cos take
+// revolutions, so 2*pi*u2 needs no range reduction at all.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = u01_open_low(a);
+  const float rev = (float)b * 0x1p-32f;
+  // -2 ln(u1) = (-2 ln 2) * log2(u1)
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
+  n0 = r * __builtin_amdgcn_sinf(rev);
+  n1 = r * __builtin_amdgcn_cosf(rev);
+}
+
+struct F4 {
+  float v[4];
+};
+
+__device__ __forceinline__ F4 normal4_at(RngKey key, uint64_t group, uint64_t step) {
+  const U4 o = philox_at(key, group, step);
+  F4 n;
+  box_muller(o.x, o.y, n.v[0], n.v[1]);
+  box_muller(o.z, o.w, n.v[2], n.v[3]);
+  return n;
+}
+
+__device__ __forceinline__ uint32_t pick(U4 o, int r) {
+  return r == 0 ? o.x : (r == 1 ? o.y : (r == 2 ? o.z : o.w));
+}
+
+// ---------------------------------------------------------------------------------
+// torch.clamp semantics: NaN passes through (fminf/fmaxf would swallow it).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
+  v = (v < lo) ? lo : v;
+  v = (v > hi) ? hi : v;
+  return v;
+}
+
+// torch.nan_to_num_(nan=0.0): NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX.
+__device__ __forceinline__ float nan_to_num0(float v) {
+  if (v != v) return 0.0f;
+  if (v == __builtin_inff()) return 3.402823466e+38f;
+  if (v == -__builtin_inff()) return -3.402823466e+38f;
+  return v;
+}
+
+__host__ __device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__host__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace ebm

@@ -1,0 +1,245 @@
+// Langevin hot path for gfx950: the per-step Euler-Maruyama kernel and the k-fused
+// chain kernel for element-wise energies (DoubleWell, Harmonic).
+//
+// Data layout: the chain matrix x[n_chains, dim] is fp32 row-major; for element-wise
+// energies it is processed as a flat array of n_chains*dim elements, one float4 (= one
+// Philox counter) per lane, so a wave64 load/store is one fully coalesced 1 KiB request.
+// The k-fused kernel keeps its four elements in VGPRs for all k steps: HBM is touched
+// once for the read and once for the write, plus the thinned trajectory rows.
+#include "ebm_common.h"
+
+namespace ebm {
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+struct StepCoef {
+  float eta, sqrt_eta, noise_coef;
+};
+
+// Reference arithmetic for one element (core/base_integrator.py:397,728-729), each op
+// rounded separately:  x + eta*(1.0*(-g))  ==  x - fl(eta*g)  bit for bit.
+__device__ __forceinline__ float em_update(float x, float g, float eps, StepCoef c) {
+  const float x1 = x - c.eta * g;
+  const float dw = eps * c.sqrt_eta;
+  return x1 + c.noise_coef * dw;
+}
+
+// Gradients in autograd's operation order.
+template <int KIND>
+__device__ __forceinline__ float elem_grad(float x, float s0, float s1) {
+  if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) {
+    const float u = x * x - s1;                // x.pow(2) - b**2
+    return (s0 * (2.0f * u)) * (2.0f * x);     // pow backward twice: (h*(2u)) * (2x)
+  } else {
+    return s0 * (2.0f * x);                    // (0.5k) * (2x)
+  }
+}
+
+__device__ __forceinline__ F4 load4(const float* __restrict__ p, int64_t e0, int n_valid, bool vec) {
+  F4 r;
+  if (vec && n_valid == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p + e0);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = (i < n_valid) ? p[e0 + i] : 0.0f;
+  }
+  return r;
+}
+
+__device__ __forceinline__ void store4(float* __restrict__ p, int64_t e0, int n_valid, bool vec, F4 r) {
+  if (vec && n_valid == 4) {
+    *reinterpret_cast<float4*>(p + e0) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < n_valid) p[e0 + i] = r.v[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// per-step kernel (external gradient)
+// ---------------------------------------------------------------------------------
+struct StepArgs {
+  const float* x;
+  const float* grad;
+  float* out;
+  const float* noise;
+  int64_t n_elem;
+  StepCoef c;
+  int clamp_on;
+  float cmin, cmax;
+  RngKey key;
+  uint64_t step;
+};
+
+template <bool NOISE_PTR>
+__global__ __launch_bounds__(kBlock) void langevin_step_kernel(StepArgs a) {
+  const int64_t n_groups = ceil_div64(a.n_elem, 4);
+  const bool draw = a.c.noise_coef != 0.0f;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
+       g += (int64_t)gridDim.x * kBlock) {
+    const int64_t e0 = g * 4;
+    const int64_t left = a.n_elem - e0;
+    const int nv = left >= 4 ? 4 : (int)left;
+    const F4 x = load4(a.x, e0, nv, true);
+    F4 gr;
+    if (a.grad) gr = load4(a.grad, e0, nv, true);
+    else gr = F4{{0.f, 0.f, 0.f, 0.f}};
+    F4 eps = F4{{0.f, 0.f, 0.f, 0.f}};
+    if (draw) {
+      if constexpr (NOISE_PTR) eps = load4(a.noise, e0, nv, true);
+      else eps = normal4_at(a.key, (uint64_t)g, a.step);
+    }
+    F4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = draw ? em_update(x.v[i], gr.v[i], eps.v[i], a.c) : (x.v[i] - a.c.eta * gr.v[i]);
+      if (a.clamp_on) v = clamp_nanprop(v, a.cmin, a.cmax);
+      o.v[i] = v;
+    }
+    store4(a.out, e0, nv, true, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k-fused chain kernel, element-wise energies
+// ---------------------------------------------------------------------------------
+struct ChainArgs {
+  float* x;
+  int64_t n_elem;
+  int32_t dim;
+  int32_t k_steps;
+  StepCoef c;
+  const float4* table;  // [k] or null
+  int clamp_on;
+  float cmin, cmax;
+  int32_t thin;
+  int32_t n_kept;
+  float* traj;
+  const float* noise;  // [k][n_elem] or null
+  float s0, s1;
+  RngKey key;
+  uint64_t step0;
+};
+
+template <int KIND, bool NOISE_PTR>
+__global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e0 = g * 4;
+  if (e0 >= a.n_elem) return;
+  const int64_t left = a.n_elem - e0;
+  const int nv = left >= 4 ? 4 : (int)left;
+
+  F4 x = load4(a.x, e0, nv, true);
+
+  // trajectory addressing: traj[c, j, d] with flat e = c*dim + d
+  const bool traj_vec = (a.dim & 3) == 0;
+  int64_t tbase[4];
+  if (a.traj) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t e = e0 + i;
+      const int64_t c = e / a.dim;
+      const int64_t d = e - c * a.dim;
+      tbase[i] = c * (int64_t)a.n_kept * a.dim + d;
+    }
+  }
+  const bool noise_vec = (a.n_elem & 3) == 0;
+
+  StepCoef c = a.c;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  for (int i = 0; i < a.k_steps; ++i) {
+    if (a.table) {  // wave-uniform: scalar loads
+      const float4 t = a.table[i];
+      c.eta = t.x; c.sqrt_eta = t.y; c.noise_coef = t.z;
+    }
+    F4 eps;
+    if constexpr (NOISE_PTR) eps = load4(a.noise + (int64_t)i * a.n_elem, e0, nv, noise_vec);
+    else eps = normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = elem_grad<KIND>(x.v[j], a.s0, a.s1);
+      float v = em_update(x.v[j], gr, eps.v[j], c);
+      if (a.clamp_on) v = clamp_nanprop(v, a.cmin, a.cmax);
+      x.v[j] = v;
+    }
+    if (a.traj) {
+      if (--until_keep == 0) {
+        until_keep = a.thin;
+        if (traj_vec && nv == 4) {
+          *reinterpret_cast<float4*>(a.traj + tbase[0] + keep_off) =
+              make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nv) a.traj[tbase[j] + keep_off] = x.v[j];
+        }
+        keep_off += a.dim;
+      }
+    }
+  }
+  store4(a.x, e0, nv, true, x);
+}
+
+int grid_for(int64_t n_threads, int max_blocks) {
+  int64_t b = ceil_div64(n_threads, kBlock);
+  if (b < 1) b = 1;
+  if (max_blocks > 0 && b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// host entry points (called from api.hip)
+// ---------------------------------------------------------------------------------
+int launch_langevin_step(const float* x, const float* grad, float* out, const float* noise,
+                         int64_t n_elem, float eta, float sqrt_eta, float noise_coef, int clamp_on,
+                         float cmin, float cmax, uint64_t seed, uint64_t offset, hipStream_t st) {
+  StepArgs a;
+  a.x = x; a.grad = grad; a.out = out; a.noise = noise; a.n_elem = n_elem;
+  a.c = StepCoef{eta, sqrt_eta, noise_coef};
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step = offset;
+  // memory-bound streaming op: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
+  const int grid = grid_for(ceil_div64(n_elem, 4), 256 * 8);
+  if (noise) hipLaunchKernelGGL(langevin_step_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(langevin_step_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a);
+  return check_launch("ebm_langevin_step_f32");
+}
+
+int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n_chains, int32_t dim,
+                               int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                               const float* coef_table, int clamp_on, float cmin, float cmax,
+                               int32_t thin, float* traj, const float* noise, uint64_t seed,
+                               uint64_t offset, hipStream_t st) {
+  ChainArgs a;
+  a.x = x; a.n_elem = n_chains * (int64_t)dim; a.dim = dim; a.k_steps = k_steps;
+  a.c = StepCoef{eta, sqrt_eta, noise_coef};
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
+  a.s0 = s0; a.s1 = s1;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
+  const int64_t n_groups = ceil_div64(a.n_elem, 4);
+  const int64_t blocks = ceil_div64(n_groups, kBlock);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
+  const dim3 grid((unsigned)blocks), block(kBlock);
+#define EBM_LAUNCH(KIND)                                                                         \
+  do {                                                                                           \
+    if (noise) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, true>), grid, block, 0, st, a);  \
+    else hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, false>), grid, block, 0, st, a);       \
+  } while (0)
+  if (kind == EBM_ENERGY_DOUBLE_WELL) EBM_LAUNCH(EBM_ENERGY_DOUBLE_WELL);
+  else EBM_LAUNCH(EBM_ENERGY_HARMONIC);
+#undef EBM_LAUNCH
+  return check_launch("ebm_langevin_chain_f32");
+}
+
+}  // namespace ebm

@@ -1,0 +1,235 @@
+// Small streaming kernels around the hot path: native-RNG fill, the leapfrog sub-steps and
+// Metropolis accept used when the force comes from an opaque drift closure (autograd
+// models), and the column statistics behind the sampler diagnostics.
+#include "ebm_common.h"
+
+namespace ebm {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 blocks; grid-stride beyond that
+
+int grid_for(int64_t n_threads) {
+  int64_t b = ceil_div64(n_threads, kBlock);
+  if (b < 1) b = 1;
+  if (b > kMaxGrid) b = kMaxGrid;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void noise_fill_kernel(float* __restrict__ out, int64_t n_elem,
+                                                            int kind, RngKey key, uint64_t step) {
+  const int64_t n_groups = ceil_div64(n_elem, 4);
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
+       g += (int64_t)gridDim.x * kBlock) {
+    float r[4];
+    if (kind == EBM_NOISE_NORMAL) {
+      const F4 n = normal4_at(key, (uint64_t)g, step);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = n.v[i];
+    } else {
+      const U4 o = philox_at(key, (uint64_t)g, step);
+      const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r[i] = (kind == EBM_NOISE_UNIFORM) ? u01_half_open(w[i]) : __uint_as_float(w[i]);
+    }
+    const int64_t e0 = g * 4;
+    if (e0 + 4 <= n_elem) {
+      *reinterpret_cast<float4*>(out + e0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      for (int i = 0; i < 4; ++i)
+        if (e0 + i < n_elem) out[e0 + i] = r[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// leapfrog sub-steps (integrators/leapfrog.py:156-185), arithmetic in reference order:
+//   (0.5*eps) is formed first as an fp32 scalar tensor, then multiplied into the force.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kick_drift_kernel(
+    const float* __restrict__ x, const float* __restrict__ p, const float* __restrict__ force,
+    float* __restrict__ x_new, float* __restrict__ p_half, int64_t n_elem, int32_t dim, float eps,
+    float half_eps, int mass_kind, float mass_scalar, const float* __restrict__ mass_diag, int safe) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elem;
+       e += (int64_t)gridDim.x * kBlock) {
+    float f = force[e];
+    if (safe) f = clamp_nanprop(f, -1e6f, 1e6f);
+    const float ph = p[e] + half_eps * f;
+    float xn;
+    if (mass_kind == EBM_MASS_NONE) {
+      xn = x[e] + eps * ph;
+    } else {
+      float m = mass_scalar;  // already max(mass, 1e-10) for the scalar form
+      if (mass_kind == EBM_MASS_DIAG) {
+        m = mass_diag[e % dim];
+        m = (m < 1e-10f) ? 1e-10f : m;  // torch.clamp(mass, min=1e-10)
+      }
+      xn = x[e] + (eps * ph) / m;
+    }
+    p_half[e] = ph;
+    x_new[e] = xn;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void kick_kernel(float* __restrict__ x_new,
+                                                      const float* __restrict__ p_half,
+                                                      const float* __restrict__ force,
+                                                      float* __restrict__ p_new, int64_t n_elem,
+                                                      float half_eps, int safe) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elem;
+       e += (int64_t)gridDim.x * kBlock) {
+    float f = force[e];
+    if (safe) f = clamp_nanprop(f, -1e6f, 1e6f);
+    float pn = p_half[e] + half_eps * f;
+    if (safe) {
+      pn = nan_to_num0(pn);
+      const float xv = x_new[e];
+      const float xs = nan_to_num0(xv);
+      if (!(xs == xv)) x_new[e] = xs;  // store only when the scrub changed something
+    }
+    p_new[e] = pn;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Metropolis accept, one lane-group of `lanes` lanes per chain row (samplers/hmc.py:277-292)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
+    float* __restrict__ x, const float* __restrict__ x_prop, const float* __restrict__ h0,
+    const float* __restrict__ h1, const float* __restrict__ u, uint8_t* __restrict__ mask,
+    uint32_t* __restrict__ count, int64_t n_chains, int32_t dim, RngKey key, uint64_t step) {
+  // phase 1: one lane per chain decides; phase 2: the block copies accepted rows.
+  __shared__ uint8_t acc_s[kBlock];
+  for (int64_t c0 = (int64_t)blockIdx.x * kBlock; c0 < n_chains; c0 += (int64_t)gridDim.x * kBlock) {
+    const int64_t c = c0 + threadIdx.x;
+    bool acc = false;
+    if (c < n_chains) {
+      const float d = clamp_nanprop(h0[c] - h1[c], -50.0f, 50.0f);
+      float a = expf(d);
+      a = (a > 1.0f) ? 1.0f : a;  // clamp_(max=1), NaN stays NaN
+      float uu;
+      if (u) uu = u[c];
+      else uu = u01_half_open(pick(philox_at(key, (uint64_t)(c >> 2), step), (int)(c & 3)));
+      acc = uu < a;
+      if (mask) mask[c] = acc ? 1 : 0;
+    }
+    if (count) {
+      const unsigned long long b = __ballot(acc);
+      if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+    }
+    acc_s[threadIdx.x] = acc ? 1 : 0;
+    __syncthreads();
+    const int64_t rows = (n_chains - c0) < kBlock ? (n_chains - c0) : kBlock;
+    const int64_t n = rows * dim;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+      const int64_t r = i / dim;
+      if (acc_s[r]) x[c0 * dim + i] = x_prop[c0 * dim + i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// column statistics: two passes with fp64 accumulators (sum, then centred squares),
+// per-block LDS partials then one fp64 atomic per column per block.
+// ---------------------------------------------------------------------------------
+constexpr int kStatCols = 64;   // columns per block tile
+constexpr int kStatRows = 4;    // row lanes per block tile (kBlock / kStatCols)
+
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __restrict__ x,
+                                                             int64_t n_chains, int32_t dim,
+                                                             double* __restrict__ work) {
+  __shared__ double part[kStatRows][kStatCols];
+  const int col = blockIdx.x * kStatCols + (threadIdx.x % kStatCols);
+  const int rlane = threadIdx.x / kStatCols;
+  double acc = 0.0;
+  if (col < dim) {
+    double mean = 0.0;
+    if (PASS == 1) mean = work[col] / (double)n_chains;
+    for (int64_t r = (int64_t)blockIdx.y * kStatRows + rlane; r < n_chains;
+         r += (int64_t)gridDim.y * kStatRows) {
+      const double v = (double)x[r * dim + col];
+      if (PASS == 0) acc += v;
+      else acc += (v - mean) * (v - mean);
+    }
+  }
+  part[rlane][threadIdx.x % kStatCols] = acc;
+  __syncthreads();
+  if (rlane == 0 && col < dim) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kStatRows; ++i) s += part[i][threadIdx.x];
+    atomicAdd(&work[PASS * dim + col], s);
+  }
+}
+
+__global__ void chain_stats_finish_kernel(const double* __restrict__ work, int64_t n_chains,
+                                          int32_t dim, float* __restrict__ mean_out,
+                                          float* __restrict__ var_out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= dim) return;
+  const double inv = 1.0 / (double)n_chains;
+  mean_out[col] = (float)(work[col] * inv);
+  float v = (float)(work[dim + col] * inv);
+  v = clamp_nanprop(v, 1e-10f, 1e10f);
+  var_out[col] = v;
+}
+
+}  // namespace
+
+int launch_noise_fill(float* out, int64_t n_elem, int32_t kind, uint64_t seed, uint64_t offset,
+                      hipStream_t st) {
+  const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(noise_fill_kernel, dim3(grid_for(ceil_div64(n_elem, 4))), dim3(kBlock), 0, st,
+                     out, n_elem, kind, key, offset);
+  return check_launch("ebm_noise_fill_f32");
+}
+
+int launch_leapfrog_kick_drift(const float* x, const float* p, const float* force, float* x_new,
+                               float* p_half, int64_t n_chains, int32_t dim, float eps,
+                               int32_t mass_kind, double mass_scalar, const float* mass_diag,
+                               int32_t safe, hipStream_t st) {
+  const int64_t n = n_chains * (int64_t)dim;
+  const float half_eps = 0.5f * eps;
+  const float safe_mass = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);  // max(mass, 1e-10)
+  hipLaunchKernelGGL(kick_drift_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, x, p, force, x_new,
+                     p_half, n, dim, eps, half_eps, mass_kind, safe_mass, mass_diag, safe);
+  return check_launch("ebm_leapfrog_kick_drift_f32");
+}
+
+int launch_leapfrog_kick(float* x_new, const float* p_half, const float* force, float* p_new,
+                         int64_t n_elem, float eps, int32_t safe, hipStream_t st) {
+  const float half_eps = 0.5f * eps;
+  hipLaunchKernelGGL(kick_kernel, dim3(grid_for(n_elem)), dim3(kBlock), 0, st, x_new, p_half, force,
+                     p_new, n_elem, half_eps, safe);
+  return check_launch("ebm_leapfrog_kick_f32");
+}
+
+int launch_hmc_accept(float* x, const float* x_prop, const float* h0, const float* h1,
+                      const float* u, uint8_t* mask, uint32_t* count, int64_t n_chains, int32_t dim,
+                      uint64_t seed, uint64_t offset, hipStream_t st) {
+  const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(hmc_accept_kernel, dim3(grid_for(n_chains)), dim3(kBlock), 0, st, x, x_prop, h0,
+                     h1, u, mask, count, n_chains, dim, key, offset);
+  return check_launch("ebm_hmc_accept_f32");
+}
+
+int launch_chain_stats(const float* x, int64_t n_chains, int32_t dim, float* mean_out,
+                       float* var_out, double* work, hipStream_t st) {
+  const int gx = (dim + kStatCols - 1) / kStatCols;
+  int64_t gy = ceil_div64(n_chains, kStatRows * 64);  // >= 64 rows per row-lane
+  if (gy < 1) gy = 1;
+  const int64_t cap = (256 * 8 + gx - 1) / gx;
+  if (gy > cap) gy = cap;
+  const dim3 grid(gx, (unsigned)gy);
+  hipLaunchKernelGGL(chain_stats_kernel<0>, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
+  hipLaunchKernelGGL(chain_stats_kernel<1>, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
+  hipLaunchKernelGGL(chain_stats_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, work,
+                     n_chains, dim, mean_out, var_out);
+  return check_launch("ebm_chain_stats_f32");
+}
+
+}  // namespace ebm
