@@ -1,0 +1,77 @@
+"""Oracle: Euler-Maruyama step and the Langevin chain with injected noise.
+
+Follows torchebm/core/base_integrator.py:673-731 (step), :387-397 (stage combine),
+torchebm/samplers/langevin_dynamics.py:154-185 (loop, clamp, thinning, diagnostics).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+
+def em_step(x: torch.Tensor, grad: torch.Tensor, eps: Optional[torch.Tensor], eta: float, sigma: Optional[float]):
+    """One step.  ``eta``/``sigma`` are Python floats; every line is one rounded tensor op,
+    exactly the reference's sequence:
+        k0 = drift = -grad                                   langevin_dynamics.py:154
+        x1 = x + eta * (1.0 * k0)                            base_integrator.py:397 (b = [1.])
+        dw = eps * eta**0.5                                  :728
+        x' = x1 + (2.0 * sigma**2)**0.5 * dw                 :729
+    """
+    k0 = -grad
+    x1 = x + eta * (1.0 * k0)
+    if sigma is None or eps is None:
+        return x1
+    dw = eps * (eta**0.5)
+    return x1 + (2.0 * sigma**2) ** 0.5 * dw
+
+
+def langevin_chain(
+    energy,
+    x0: torch.Tensor,
+    noise: torch.Tensor,
+    etas: Sequence[float],
+    sigmas: Sequence[float],
+    clamp: Optional[Tuple[float, float]] = None,
+    thin: int = 1,
+    want_traj: bool = False,
+    want_diag: bool = False,
+):
+    """k = len(etas) steps with ``noise[i]`` as the step-i Wiener draw.
+
+    Returns ``(x_final, trajectory_or_None, diagnostics_or_None)``; trajectory is
+    ``[n, k // thin, dim]`` and diagnostics are ``mean``/``var``/``energy`` per kept step
+    (biased variance clamped to [1e-10, 1e10]; n == 1 special case) as in
+    langevin_dynamics.py:170-185.
+    """
+    x = x0.clone()
+    k = len(etas)
+    n = x.shape[0]
+    n_kept = k // thin
+    traj = torch.empty((n, n_kept) + tuple(x.shape[1:]), dtype=x.dtype) if want_traj else None
+    diag: Optional[Dict[str, torch.Tensor]] = None
+    if want_diag:
+        diag = {
+            "mean": torch.empty((n_kept,) + tuple(x.shape[1:]), dtype=x.dtype),
+            "var": torch.empty((n_kept,) + tuple(x.shape[1:]), dtype=x.dtype),
+            "energy": torch.empty(n_kept, dtype=x.dtype),
+        }
+    keep = 0
+    for i in range(k):
+        x = em_step(x, energy.grad(x), noise[i], etas[i], sigmas[i])
+        if clamp is not None:
+            x = x.clamp_(*clamp)
+        if (i + 1) % thin == 0:
+            if traj is not None:
+                traj[:, keep] = x
+            if diag is not None:
+                if n > 1:
+                    diag["mean"][keep] = x.mean(dim=0)
+                    diag["var"][keep] = x.var(dim=0, unbiased=False).clamp_(min=1e-10, max=1e10)
+                else:
+                    diag["mean"][keep] = x.squeeze(0)
+                    diag["var"][keep].zero_()
+                diag["energy"][keep] = energy.energy(x).mean()
+            keep += 1
+    return x, traj, diag

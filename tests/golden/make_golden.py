@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the authoring container: it imports soran-ghaderi/torchebm from
+/root/reference (read-only), drives the reference's own LangevinDynamics /
+HamiltonianMonteCarlo / integrators on CPU with a seeded generator, and records
+
+  * the inputs (x0, energy parameters, step-size / noise-scale values per step),
+  * the exact noise the reference consumed -- recovered by replaying an identically
+    seeded generator in the reference's draw order (Langevin: one randn per step,
+    base_integrator.py:722-725; HMC: momentum normal_ then torch.rand per transition,
+    hmc.py:245,285),
+  * the reference's outputs (final state, trajectory, diagnostics).
+
+The fixtures are data only; no reference source is copied.  tests/test_oracle_golden.py
+checks the oracle/ restatement against them bit for bit, the -m gpu tests check the HIP
+kernels against the oracle on the same inputs.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.pt
+"""
+
+import hashlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    raise SystemExit("reference checkout not found; fixtures can only be regenerated in the authoring container")
+sys.path.insert(0, REF)
+_v = types.ModuleType("torchebm._version")  # setuptools_scm file absent from the checkout
+_v.__version__ = "0.0.0+reference"
+sys.modules["torchebm._version"] = _v
+
+import torch  # noqa: E402
+from torchebm.core import (  # noqa: E402
+    BaseModel,
+    DoubleWellModel,
+    ExponentialDecayScheduler,
+    GaussianModel,
+    HarmonicModel,
+    LinearScheduler,
+)
+from torchebm.integrators import EulerMaruyamaIntegrator, LeapfrogIntegrator  # noqa: E402
+from torchebm.samplers import HamiltonianMonteCarlo, LangevinDynamics  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)
+
+
+class RefGMM(BaseModel):
+    """The build's mixture energy evaluated through the REFERENCE's BaseModel.gradient."""
+
+    def __init__(self, means, sigma=1.0):
+        super().__init__()
+        self.register_buffer("means", means)
+        self.sigma = sigma
+        k = means.shape[0]
+        self.register_buffer("log_weights", torch.log(torch.full((k,), 1.0 / k, dtype=torch.float64)).to(torch.float32))
+
+    def forward(self, x):
+        sq = (x.unsqueeze(1) - self.means.unsqueeze(0)).pow(2).sum(dim=-1)
+        return -torch.logsumexp(self.log_weights - sq / (2.0 * self.sigma**2), dim=1)
+
+
+def ring_means(k, dim, radius=4.0):
+    import math
+
+    ang = torch.arange(k, dtype=torch.float64) * (2.0 * math.pi / k)
+    m = torch.zeros(k, dim, dtype=torch.float64)
+    m[:, 0] = radius * torch.cos(ang)
+    m[:, 1] = radius * torch.sin(ang)
+    return m.to(torch.float32)
+
+
+def make_energy(spec):
+    kind = spec["kind"]
+    if kind == "double_well":
+        return DoubleWellModel(barrier_height=spec["h"], b=spec["b"])
+    if kind == "harmonic":
+        return HarmonicModel(k=spec["k"])
+    if kind == "gaussian":
+        return GaussianModel(spec["mean"], spec["cov"])
+    if kind == "gmm":
+        return RefGMM(spec["means"], spec["sigma"])
+    raise ValueError(kind)
+
+
+def sched_values(s, k):
+    """Values the sampler loop reads at iterations 0..k-1."""
+    if isinstance(s, float):
+        return [s] * k
+    s.reset()
+    out = []
+    for _ in range(k):
+        out.append(s.get_value())
+        s.step()
+    s.reset()
+    return out
+
+
+def sha(t):
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def langevin_case(name, energy, n, dim, k, step_size, noise_scale, seed, clamp=None, thin=1, x0_scale=1.0, store_noise=True):
+    model = make_energy(energy)
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(n, dim, generator=g) * x0_scale
+    run_seed = seed + 1000
+    sampler = LangevinDynamics(model, step_size=step_size, noise_scale=noise_scale, clamp=clamp)
+    out_final = sampler.sample(x=x0.clone(), n_steps=k, generator=torch.Generator().manual_seed(run_seed))
+    traj, diag = sampler.sample(
+        x=x0.clone(), n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True,
+        generator=torch.Generator().manual_seed(run_seed),
+    )
+    replay = torch.Generator().manual_seed(run_seed)
+    noise = torch.stack([torch.randn(n, dim, generator=replay) for _ in range(k)])
+    fx = {
+        "sampler": "langevin", "name": name, "energy": energy, "n": n, "dim": dim, "k": k, "thin": thin,
+        "clamp": clamp, "run_seed": run_seed, "x0": x0,
+        "etas": sched_values(step_size, k), "sigmas": sched_values(noise_scale, k),
+        "noise": noise if store_noise else None,
+        "ref": {"x": out_final, "trajectory": traj, "diagnostics": diag, "sha_x": sha(out_final)},
+    }
+    torch.save(fx, os.path.join(HERE, name + ".pt"))
+    print(f"{name:28s} x sha {fx['ref']['sha_x']}  sum {out_final.double().sum().item():+.8f}")
+
+
+def hmc_case(name, energy, n, dim, T, L, step_size, seed, mass=None, thin=1, x0=None, x0_scale=1.0, store_noise=True):
+    model = make_energy(energy)
+    g = torch.Generator().manual_seed(seed)
+    if x0 is None:
+        x0 = torch.randn(n, dim, generator=g) * x0_scale
+    run_seed = seed + 1000
+    sampler = HamiltonianMonteCarlo(model, step_size=step_size, n_leapfrog_steps=L, mass=mass)
+    out_final = sampler.sample(x=x0.clone(), n_steps=T, generator=torch.Generator().manual_seed(run_seed))
+    traj, diag = sampler.sample(
+        x=x0.clone(), n_steps=T, thin=thin, return_trajectory=True, return_diagnostics=True,
+        generator=torch.Generator().manual_seed(run_seed),
+    )
+    _, diag_all = sampler.sample(
+        x=x0.clone(), n_steps=T, thin=1, return_diagnostics=True, generator=torch.Generator().manual_seed(run_seed)
+    )
+    replay = torch.Generator().manual_seed(run_seed)
+    ps, us = [], []
+    for _ in range(T):
+        ps.append(torch.empty(n, dim).normal_(generator=replay))
+        us.append(torch.rand(n, generator=replay))
+    fx = {
+        "sampler": "hmc", "name": name, "energy": energy, "n": n, "dim": dim, "T": T, "L": L, "thin": thin,
+        "mass": mass, "run_seed": run_seed, "x0": x0, "eps": sched_values(step_size, T),
+        "p_noise": torch.stack(ps) if store_noise else None, "u": torch.stack(us) if store_noise else None,
+        "ref": {
+            "x": out_final, "trajectory": traj, "diagnostics": diag,
+            "acceptance_rate_all": diag_all["acceptance_rate"], "sha_x": sha(out_final),
+        },
+    }
+    torch.save(fx, os.path.join(HERE, name + ".pt"))
+    print(f"{name:28s} x sha {fx['ref']['sha_x']}  acc {diag_all['acceptance_rate'].tolist()}")
+
+
+def integrator_cases():
+    """Hand-checkable single steps through the reference integrators (cf. the reference's
+    tests/integrators/test_euler_maruyama.py:402-449, test_leapfrog.py:218-289)."""
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(37, 5, generator=g)
+    p = torch.randn(37, 5, generator=g)
+    noise = torch.randn(37, 5, generator=g)
+    drift = lambda x_, t_: -(x_**3)  # noqa: E731
+    em = EulerMaruyamaIntegrator()
+    lf = LeapfrogIntegrator()
+    mass_t = torch.rand(5, generator=g) + 0.5
+    fx = {
+        "x": x, "p": p, "noise": noise, "mass_t": mass_t,
+        "em_sde": em.step({"x": x}, 0.01, drift=drift, noise=noise, noise_scale=0.7)["x"],
+        "em_ode": em.step({"x": x}, 0.01, drift=drift)["x"],
+        "lf_step": lf.step({"x": x, "p": p}, 0.05, drift=drift),
+        "lf_step_mass": lf.step({"x": x, "p": p}, 0.05, 2.5, drift=drift),
+        "lf_int_mass_t_safe": lf.integrate({"x": x, "p": p}, 0.05, 7, mass_t, drift=drift, safe=True),
+    }
+    bad = x.clone()
+    bad[0, 0] = float("nan")
+    bad[1, 1] = float("inf")
+    fx["bad_x"] = bad
+    fx["lf_step_safe_bad"] = lf.step({"x": bad, "p": p}, 0.05, drift=drift, safe=True)
+    torch.save(fx, os.path.join(HERE, "integrators.pt"))
+    print("integrators.pt")
+
+
+def main():
+    dw = {"kind": "double_well", "h": 2.0, "b": 1.0}
+    dw2 = {"kind": "double_well", "h": 0.7, "b": 1.3}
+    har = {"kind": "harmonic", "k": 1.5}
+    g2 = {"kind": "gaussian", "mean": torch.tensor([0.5, -0.25]), "cov": torch.tensor([[1.0, 0.8], [0.8, 1.0]])}
+    gg = torch.Generator().manual_seed(5)
+    a = torch.randn(8, 8, generator=gg)
+    g8 = {"kind": "gaussian", "mean": torch.randn(8, generator=gg), "cov": a @ a.t() / 8 + 0.5 * torch.eye(8)}
+    gmm = {"kind": "gmm", "means": ring_means(8, 32), "sigma": 1.0}
+    gmm6 = {"kind": "gmm", "means": ring_means(5, 6, radius=2.0), "sigma": 0.8}
+
+    # ---- Langevin -----------------------------------------------------------------
+    langevin_case("ld_dw_64x64", dw, 64, 64, 16, 0.01, 1.0, seed=11)
+    langevin_case("ld_dw_37x3_clamp_thin3", dw2, 37, 3, 16, 0.02, 0.8, seed=12, clamp=(-1.25, 1.5), thin=3)
+    langevin_case("ld_har_100x2_sched", har, 100, 2, 16, LinearScheduler(0.05, 0.005, 10),
+                  ExponentialDecayScheduler(1.0, 0.9, 0.3), seed=13, thin=2)
+    langevin_case("ld_gauss2d_128", g2, 128, 2, 16, 0.05, 1.0, seed=14)
+    langevin_case("ld_gauss8_64", g8, 64, 8, 16, 0.02, 1.0, seed=15, thin=4)
+    langevin_case("ld_gmm8_64x32", gmm, 64, 32, 16, 0.05, 1.0, seed=16, x0_scale=3.0)
+    langevin_case("ld_gmm5_50x6", gmm6, 50, 6, 12, 0.03, 0.9, seed=17, x0_scale=2.0, thin=5)
+    langevin_case("ld_dw_1x8", dw, 1, 8, 8, 0.01, 1.0, seed=18)
+    # SURVEY.md §8c checksum cases (noise is replayed from the seed, not stored)
+    langevin_survey()
+
+    # ---- HMC ----------------------------------------------------------------------
+    hmc_case("hmc_dw_64x32_L5", dw, 64, 32, 8, 5, 0.05, seed=21)
+    hmc_case("hmc_dw_100x32_L20_mass", dw, 100, 32, 8, 20, 0.05, seed=22, mass=2.0, thin=3)
+    mt = torch.tensor([0.5, 2.0])
+    hmc_case("hmc_har_90x2_masst", har, 90, 2, 8, 10, LinearScheduler(0.3, 0.1, 6), seed=23, mass=mt)
+    hmc_case("hmc_gauss2d_128", g2, 128, 2, 8, 10, 0.2, seed=24)
+    hmc_case("hmc_gauss8_64", g8, 64, 8, 8, 8, 0.15, seed=25, thin=2)
+    hmc_case("hmc_gmm8_128x32_L20", gmm, 128, 32, 8, 20, 0.1, seed=26, x0_scale=3.0)
+    hmc_case("hmc_dw_40x100_L10", dw, 40, 100, 6, 10, 0.03, seed=27)
+    hmc_case("hmc_gmm5_33x6", gmm6, 33, 6, 8, 7, 0.2, seed=28, x0_scale=2.0)
+    # extreme values stay finite (reference tests/samplers/test_hmc.py:835-896)
+    big = torch.full((16, 4), 1e4)
+    big[8:] = -1e6
+    hmc_case("hmc_dw_extreme", dw, 16, 4, 4, 5, 0.01, seed=29, x0=big)
+    hmc_survey()
+    integrator_cases()
+
+
+def langevin_survey():
+    # LD-DW seed123 512x64 k50 eta=.01 sigma=1   -> sha a8aa46964a7b47d0
+    g = torch.Generator().manual_seed(123)
+    model = DoubleWellModel()
+    sampler = LangevinDynamics(model, step_size=0.01, noise_scale=1.0)
+    x = sampler.sample(dim=64, n_samples=512, n_steps=50, generator=g)
+    fx = {"name": "survey_ld_dw", "seed": 123, "n": 512, "dim": 64, "k": 50, "eta": 0.01, "sigma": 1.0,
+          "ref": {"x": x, "sha_x": sha(x)}}
+    torch.save(fx, os.path.join(HERE, "survey_ld_dw.pt"))
+    print(f"survey_ld_dw                 x sha {sha(x)} (SURVEY: a8aa46964a7b47d0)")
+    # LD-Gauss2D seed0 1024x2 k100 eta=.01 -> bf22286dd8d04457
+    g = torch.Generator().manual_seed(0)
+    model = GaussianModel(torch.zeros(2), torch.eye(2))  # BASELINE config 1
+    sampler = LangevinDynamics(model, step_size=0.01, noise_scale=1.0)
+    x = sampler.sample(dim=2, n_samples=1024, n_steps=100, generator=g)
+    fx = {"name": "survey_ld_gauss2d", "seed": 0, "n": 1024, "dim": 2, "k": 100, "eta": 0.01, "sigma": 1.0,
+          "ref": {"x": x, "sha_x": sha(x)}}
+    torch.save(fx, os.path.join(HERE, "survey_ld_gauss2d.pt"))
+    print(f"survey_ld_gauss2d            x sha {sha(x)} (SURVEY: bf22286dd8d04457)")
+
+
+def hmc_survey():
+    # HMC-DW seed7 1024x32 eps=.05 L20 T10 -> d807b174f55c084b
+    g = torch.Generator().manual_seed(7)
+    sampler = HamiltonianMonteCarlo(DoubleWellModel(), step_size=0.05, n_leapfrog_steps=20)
+    x, d = sampler.sample(dim=32, n_samples=1024, n_steps=10, return_diagnostics=True, generator=g)
+    fx = {"name": "survey_hmc_dw", "seed": 7, "n": 1024, "dim": 32, "T": 10, "L": 20, "eps": 0.05,
+          "ref": {"x": x, "sha_x": sha(x), "acceptance_rate": d["acceptance_rate"]}}
+    torch.save(fx, os.path.join(HERE, "survey_hmc_dw.pt"))
+    print(f"survey_hmc_dw                x sha {sha(x)} (SURVEY: d807b174f55c084b)")
+
+
+if __name__ == "__main__":
+    main()

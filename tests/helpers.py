@@ -1,0 +1,55 @@
+"""Shared test helpers: golden fixtures, oracle/package energy construction."""
+
+import glob
+import os
+
+import torch
+
+import oracle
+import torchebm_amd as ta
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.pt")))
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+
+
+def oracle_energy(spec):
+    kind = spec["kind"]
+    if kind == "double_well":
+        return oracle.DoubleWell(spec["h"], spec["b"])
+    if kind == "harmonic":
+        return oracle.Harmonic(spec["k"])
+    if kind == "gaussian":
+        return oracle.Gaussian(spec["mean"], spec["cov"])
+    if kind == "gmm":
+        return oracle.GaussianMixture(spec["means"], spec["sigma"])
+    raise ValueError(kind)
+
+
+def package_model(spec, device=None):
+    kind = spec["kind"]
+    if kind == "double_well":
+        return ta.DoubleWellModel(barrier_height=spec["h"], b=spec["b"], device=device)
+    if kind == "harmonic":
+        return ta.HarmonicModel(k=spec["k"], device=device)
+    if kind == "gaussian":
+        return ta.GaussianModel(spec["mean"], spec["cov"], device=device)
+    if kind == "gmm":
+        return ta.GaussianMixtureModel(spec["means"], sigma=spec["sigma"], device=device)
+    raise ValueError(kind)
+
+
+def mass_to(mass, device):
+    return mass.to(device) if torch.is_tensor(mass) else mass
+
+
+def hip_calls(name):
+    from torchebm_amd import _lib
+
+    return _lib.call_counts[name]

@@ -1,0 +1,147 @@
+"""ctypes binding of ``libebm_hip.so`` (C ABI: ``include/ebm_hip.h``).
+
+This is the only place the package touches the shared library.  Everything is
+pointer-and-size: tensors are passed as ``data_ptr()``, the stream as
+``torch.cuda.current_stream().cuda_stream``.  There is no fallback of any kind:
+if the library is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import Counter
+from typing import Optional
+
+import torch  # imported first on purpose: it loads the HIP runtime (libamdhip64.so.7) that our library links against
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
+
+ABI_VERSION = 1
+
+# energy kinds / enums: keep in sync with include/ebm_hip.h
+ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM = 0, 1, 2, 3
+NOISE_NORMAL, NOISE_UNIFORM, NOISE_RAW_U32 = 0, 1, 2
+MASS_NONE, MASS_SCALAR, MASS_DIAG = 0, 1, 2
+
+#: entry points declared in include/ebm_hip.h (tests check the library exports every one)
+EXPORTS = (
+    "ebm_version",
+    "ebm_last_error_string",
+    "ebm_langevin_step_f32",
+    "ebm_langevin_chain_f32",
+    "ebm_hmc_chain_f32",
+    "ebm_leapfrog_kick_drift_f32",
+    "ebm_leapfrog_kick_f32",
+    "ebm_hmc_accept_f32",
+    "ebm_energy_grad_f32",
+    "ebm_chain_stats_f32",
+    "ebm_noise_fill_f32",
+)
+
+#: number of calls made through each entry point in this process (tests use it to
+#: prove that a GPU test really went through the HIP library)
+call_counts: Counter = Counter()
+
+
+class EnergyDesc(C.Structure):
+    """Mirror of ``ebm_energy_t``."""
+
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("n_comp", C.c_int32),
+        ("s", C.c_float * 4),
+        ("dev0", C.c_void_p),
+        ("dev1", C.c_void_p),
+    ]
+
+
+_f, _i32, _i64, _u64, _p, _d = C.c_float, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p, C.c_double
+_ENERGY_P = C.POINTER(EnergyDesc)
+
+_PROTOTYPES = {
+    "ebm_version": (C.c_int, []),
+    "ebm_last_error_string": (C.c_char_p, []),
+    "ebm_langevin_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _u64, _u64, _p]),
+    "ebm_langevin_chain_f32": (
+        C.c_int,
+        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _u64, _u64, _p],
+    ),
+    "ebm_hmc_chain_f32": (
+        C.c_int,
+        [_ENERGY_P, _p, _i64, _i32, _i32, _i32, _f, _p, _i32, _d, _p, _i32, _p, _p, _p, _p, _p, _u64, _u64, _p],
+    ),
+    "ebm_leapfrog_kick_drift_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _d, _p, _i32, _p]),
+    "ebm_leapfrog_kick_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _i32, _p]),
+    "ebm_hmc_accept_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _u64, _u64, _p]),
+    "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
+    "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def is_built() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"torchebm_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C torchebm_amd/csrc`). "
+            "There is no CPU/PyTorch fallback for CUDA-device sampling."
+        )
+    handle = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = handle.ebm_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"torchebm_amd: libebm_hip.so ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    _lib = handle
+    return handle
+
+
+def check(rc: int, name: str) -> None:
+    if rc == 0:
+        return
+    msg = lib().ebm_last_error_string()
+    text = msg.decode("utf-8", "replace") if msg else ""
+    if rc == -1:
+        raise ValueError(f"{name}: {text}")
+    raise RuntimeError(f"{name} failed (code {rc}): {text}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address of a tensor, or NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dense_f32(t: torch.Tensor) -> torch.Tensor:
+    """fp32, contiguous, 16-byte aligned view or copy of ``t`` (what the ABI requires)."""
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    fn = getattr(lib(), name)
+    call_counts[name] += 1
+    check(fn(*args), name)

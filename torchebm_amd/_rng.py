@@ -1,0 +1,57 @@
+"""Host-side view of a ``torch.Generator``'s Philox state for the HIP kernels.
+
+The kernels draw from a Philox4x32-10 stream addressed by ``(seed, step, element)``
+(see ``include/ebm_hip.h``).  ``seed`` is the generator's seed and ``step`` starts at
+``philox_offset // 4``; after a call that consumed ``n`` steps the generator's offset is
+advanced by ``4 * n``.  All of this is host bookkeeping on the generator object -- no
+device read, no synchronisation (the reference's Triton POC drew its seed with
+``torch.randint(...).item()``, a host sync: cuda/fused_langevin.py:121-122).
+
+This preserves the generator contract of the reference's tests/test_generator.py:74-113:
+same seed => identical samples, different seeds differ, ``generator=None`` consumes the
+device's default generator, an explicit generator leaves the default one untouched.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+def _resolve(generator: Optional[torch.Generator], device: torch.device) -> torch.Generator:
+    if generator is None:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return torch.cuda.default_generators[idx]
+    if generator.device.type != device.type:
+        # same failure class as torch.randn(..., device=cuda, generator=<cpu generator>)
+        raise RuntimeError(
+            f"Expected a '{device.type}' device type for generator but found '{generator.device.type}'"
+        )
+    return generator
+
+
+def _get_offset(gen: torch.Generator) -> int:
+    if hasattr(gen, "get_offset"):
+        return int(gen.get_offset())
+    state = gen.get_state()  # CUDA generator state: 8 bytes seed + 8 bytes offset (host tensor)
+    return int.from_bytes(bytes(state[8:16].tolist()), "little")
+
+
+def _set_offset(gen: torch.Generator, offset: int) -> None:
+    if hasattr(gen, "set_offset"):
+        gen.set_offset(offset)
+        return
+    state = gen.get_state().clone()
+    state[8:16] = torch.tensor(list(int(offset).to_bytes(8, "little")), dtype=torch.uint8)
+    gen.set_state(state)
+
+
+def reserve(generator: Optional[torch.Generator], device: torch.device, n_steps: int) -> Tuple[int, int]:
+    """Return ``(seed, first_step)`` for a kernel call that consumes ``n_steps`` RNG steps
+    and advance the generator past them."""
+    gen = _resolve(generator, device)
+    seed = int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    offset = _get_offset(gen)
+    _set_offset(gen, offset + 4 * int(n_steps))
+    return seed, offset // 4

@@ -1,0 +1,261 @@
+"""Energy models: ``BaseModel`` and the analytic energies the HIP kernels fuse.
+
+Host-side mirror of the reference's torchebm/core/base_model.py: ``forward`` gives the
+energy per sample, the default ``gradient`` is autograd (:62-127) -- no analytic energy
+in the reference overrides it, so the closed-form gradients live only inside the kernels
+(``csrc/langevin.hip``, ``csrc/rows.hip``), written in autograd's operation order.
+
+Each analytic model advertises itself to the samplers through ``fused_spec()``; a
+subclass that overrides ``forward``/``gradient`` is no longer the same function and is
+not fused (it takes the per-step kernel + ``gradient()`` route instead).
+
+``GaussianMixtureModel`` does not exist in the reference; it is
+defined here so BASELINE config 3 has an energy, and its oracle is the reference's HMC
+driving autograd on this ``forward``.
+"""
+
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Optional, Sequence, Union
+
+import torch
+
+from .. import _lib
+from .module import TorchEBMModule
+
+
+@dataclass
+class FusedSpec:
+    """What ``ebm_energy_t`` needs (include/ebm_hip.h), with tensors kept alive here."""
+
+    kind: int
+    scalars: Sequence[float] = (0.0, 0.0, 0.0, 0.0)
+    n_comp: int = 0
+    dev0: Optional[torch.Tensor] = None
+    dev1: Optional[torch.Tensor] = None
+    elementwise: bool = False  # gradient of coordinate j depends on x_j only
+
+    def to_c(self) -> "_lib.EnergyDesc":
+        d = _lib.EnergyDesc()
+        d.kind = self.kind
+        d.n_comp = self.n_comp
+        for i, v in enumerate(self.scalars):
+            d.s[i] = float(v)
+        d.dev0 = _lib.ptr(self.dev0)
+        d.dev1 = _lib.ptr(self.dev1)
+        return d
+
+
+class BaseModel(TorchEBMModule, ABC):
+    """Unnormalised negative log-density ``E(x)``; ``gradient`` defaults to autograd."""
+
+    #: compute the autograd gradient in fp32 whatever the input dtype (base_model.py:22-27)
+    force_fp32_gradient: bool = False
+
+    def __init__(self, dtype: torch.dtype = torch.float32, *args, **kwargs):
+        super().__init__(dtype=dtype, *args, **kwargs)
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Energy per sample, shape ``(batch,)``."""
+
+    def gradient(self, x: torch.Tensor, model_kwargs: Optional[dict] = None) -> torch.Tensor:
+        r"""``\nabla_x E(x)`` by autograd, detached, in ``x``'s dtype (base_model.py:62-127)."""
+        in_dtype = x.dtype
+        if self.device and x.device != self.device:
+            x = x.to(self.device)
+        work_dtype = torch.float32 if self.force_fp32_gradient else in_dtype
+        with torch.enable_grad():
+            leaf = x.detach().to(dtype=work_dtype).requires_grad_(True)
+            with self.autocast_context():
+                energy = self.forward(leaf, **(model_kwargs or {}))
+            if energy.shape != (leaf.shape[0],):
+                raise ValueError(
+                    f"BaseModel forward() output expected shape ({leaf.shape[0]},), but got {energy.shape}."
+                )
+            if energy.grad_fn is None:
+                raise RuntimeError(
+                    "Cannot compute gradient: `forward` method did not use the input `x` in a differentiable way."
+                )
+            (grad,) = torch.autograd.grad(energy, leaf, grad_outputs=torch.ones_like(energy))
+        if grad is None:
+            raise RuntimeError("Gradient computation failed unexpectedly. Check the forward pass implementation.")
+        return grad.to(in_dtype).detach()
+
+    # ---- hook for the fused kernels ------------------------------------------------
+    def fused_spec(self) -> Optional[FusedSpec]:
+        """Descriptor for the fused HIP kernels, or ``None`` (the default: not fusable)."""
+        return None
+
+    def _is_exactly(self, cls: type) -> bool:
+        mine = type(self)
+        return mine.forward is cls.forward and mine.gradient is BaseModel.gradient
+
+
+class DoubleWellModel(BaseModel):
+    r"""``E(x) = h \sum_j (x_j^2 - b^2)^2`` (base_model.py:130-148)."""
+
+    def __init__(self, barrier_height: float = 2.0, b: float = 1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.barrier_height = barrier_height
+        self.b = b
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        wells = (x.pow(2) - self.b**2).pow(2)
+        return self.barrier_height * wells.sum(dim=-1)
+
+    def fused_spec(self) -> Optional[FusedSpec]:
+        if not self._is_exactly(DoubleWellModel):
+            return None
+        # b**2 is formed in double and enters the fp32 tensor op as a cast scalar
+        return FusedSpec(_lib.ENERGY_DOUBLE_WELL, (self.barrier_height, self.b**2, 0.0, 0.0), elementwise=True)
+
+
+class HarmonicModel(BaseModel):
+    r"""``E(x) = \tfrac12 k \sum_j x_j^2`` (base_model.py:213-229)."""
+
+    def __init__(self, k: float = 1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.k = k
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        return 0.5 * self.k * x.pow(2).sum(dim=-1)
+
+    def fused_spec(self) -> Optional[FusedSpec]:
+        if not self._is_exactly(HarmonicModel):
+            return None
+        return FusedSpec(_lib.ENERGY_HARMONIC, (0.5 * self.k, 0.0, 0.0, 0.0), elementwise=True)
+
+
+class GaussianModel(BaseModel):
+    r"""``E(x) = \tfrac12 (x-\mu)^\top \Sigma^{-1} (x-\mu)`` (base_model.py:151-210)."""
+
+    def __init__(self, mean: torch.Tensor, cov: torch.Tensor, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if mean.ndim != 1:
+            raise ValueError("Mean must be a 1D tensor.")
+        if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
+            raise ValueError("Covariance must be a 2D square matrix.")
+        if mean.shape[0] != cov.shape[0]:
+            raise ValueError("Mean vector dimension must match covariance matrix dimension.")
+        self.register_buffer("mean", mean.to(dtype=self.dtype, device=self.device))
+        try:
+            precision = torch.inverse(cov)
+        except RuntimeError as exc:
+            raise ValueError(f"Failed to invert covariance matrix: {exc}. Ensure it is invertible.") from exc
+        self.register_buffer("cov_inv", precision.to(dtype=self.dtype, device=self.device))
+        self._sym_cache: Optional[tuple] = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        d = self.mean.shape[0]
+        if x.ndim != 2 or x.shape[1] != d:
+            raise ValueError(f"Input x expected batch_shape (batch_size, {d}), but got {x.shape}")
+        x = x.to(dtype=self.dtype, device=self.device)
+        prec = self.cov_inv.to(dtype=self.dtype, device=x.device)
+        delta = x - self.mean
+        if delta.shape[0] > 1:
+            # batched form: P (d x d, broadcast) @ delta (d x 1), then delta^T @ that
+            p_delta = torch.bmm(prec.unsqueeze(0).expand(delta.shape[0], -1, -1), delta.unsqueeze(-1))
+            return 0.5 * torch.bmm(delta.unsqueeze(1), p_delta).squeeze(-1).squeeze(-1)
+        return 0.5 * torch.sum(delta * torch.matmul(delta, prec), dim=-1)
+
+    def fused_spec(self) -> Optional[FusedSpec]:
+        if not self._is_exactly(GaussianModel) or self.cov_inv.dtype != torch.float32:
+            return None
+        # autograd of 0.5 d^T P d is 0.5 (P + P^T) d: hand the kernel the symmetrised matrix
+        key = (self.cov_inv.data_ptr(), self.cov_inv._version, self.cov_inv.device)
+        if self._sym_cache is None or self._sym_cache[0] != key:
+            sym = (0.5 * (self.cov_inv + self.cov_inv.t())).contiguous()
+            self._sym_cache = (key, sym)
+        return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1])
+
+
+class GaussianMixtureModel(BaseModel):
+    r"""Isotropic Gaussian mixture energy
+
+    .. math:: E(x) = -\log \sum_k w_k \exp\!\big(-\lVert x-\mu_k\rVert^2 / (2\sigma^2)\big)
+
+    (up to the additive constant of the normaliser).  ``mean`` exposes the mixture mean so
+    that ``HamiltonianMonteCarlo`` can infer ``dim`` the way it does for ``GaussianModel``.
+
+    Args:
+        means: ``[K, dim]`` component centres.
+        sigma: shared component standard deviation.
+        weights: ``[K]`` mixture weights (normalised internally); uniform when ``None``.
+    """
+
+    def __init__(
+        self,
+        means: torch.Tensor,
+        sigma: float = 1.0,
+        weights: Optional[torch.Tensor] = None,
+        *args,
+        **kwargs,
+    ):
+        super().__init__(*args, **kwargs)
+        if means.ndim != 2:
+            raise ValueError("means must be a [K, dim] tensor.")
+        if sigma <= 0:
+            raise ValueError("sigma must be positive")
+        k = means.shape[0]
+        if weights is None:
+            weights = torch.full((k,), 1.0 / k)
+        if weights.ndim != 1 or weights.shape[0] != k or bool((weights <= 0).any()):
+            raise ValueError("weights must be a positive [K] tensor.")
+        weights = weights.to(torch.float64)
+        log_w = torch.log(weights / weights.sum())
+        self.sigma = float(sigma)
+        self.register_buffer("means", means.to(dtype=self.dtype, device=self.device).contiguous())
+        self.register_buffer("log_weights", log_w.to(dtype=self.dtype, device=self.device))
+        mix_mean = (weights[:, None] / weights.sum() * means.to(torch.float64)).sum(dim=0)
+        self.register_buffer("mean", mix_mean.to(dtype=self.dtype, device=self.device))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        if x.ndim != 2 or x.shape[1] != self.means.shape[1]:
+            raise ValueError(f"Input x expected shape (batch_size, {self.means.shape[1]}), but got {x.shape}")
+        sq_dist = (x.unsqueeze(1) - self.means.unsqueeze(0)).pow(2).sum(dim=-1)  # [B, K]
+        logits = self.log_weights - sq_dist / (2.0 * self.sigma**2)
+        return -torch.logsumexp(logits, dim=1)
+
+    def fused_spec(self) -> Optional[FusedSpec]:
+        if not self._is_exactly(GaussianMixtureModel) or self.means.dtype != torch.float32:
+            return None
+        if self.means.shape[0] > 64:
+            return None
+        s2 = self.sigma**2
+        return FusedSpec(
+            _lib.ENERGY_GMM,
+            (1.0 / (2.0 * s2), 1.0 / s2, 0.0, 0.0),
+            n_comp=int(self.means.shape[0]),
+            dev0=self.means,
+            dev1=self.log_weights,
+        )
+
+
+def ring_mixture(
+    n_components: int = 8,
+    dim: int = 32,
+    radius: float = 4.0,
+    sigma: float = 1.0,
+    device: Union[str, torch.device, None] = None,
+) -> GaussianMixtureModel:
+    """BASELINE config 3's energy: K equal-weight modes on a circle of ``radius`` in the
+    first two coordinates (centres as in the reference's GaussianMixtureDataset,
+    datasets/generators.py:179-184), zero elsewhere."""
+    ang = torch.arange(n_components, dtype=torch.float64) * (2.0 * math.pi / n_components)
+    means = torch.zeros(n_components, dim, dtype=torch.float64)
+    means[:, 0] = radius * torch.cos(ang)
+    if dim > 1:
+        means[:, 1] = radius * torch.sin(ang)
+    return GaussianMixtureModel(means.to(torch.float32), sigma=sigma, device=device)

@@ -1,0 +1,221 @@
+"""Loss bases: ``BaseLoss`` and ``BaseContrastiveDivergence`` (replay buffer).
+
+Host-side mirror of the reference's torchebm/core/base_loss.py:22-114 (BaseLoss) and
+:116-530 (BaseContrastiveDivergence).  This is the *caller* of the sampler hot path
+(SURVEY.md §8 row C): it only needs ``sampler.sample(x=, n_steps=, model_kwargs=,
+generator=)`` to hand back a detached ``[B, ...]`` tensor.  All of its own arithmetic is
+plain PyTorch.
+"""
+
+from __future__ import annotations
+
+import logging
+import warnings
+from abc import ABC, abstractmethod
+from typing import Any, Optional, Tuple, Union
+
+import torch
+
+from .module import TorchEBMModule, warn_once
+from .schedules import Schedulable
+
+logger = logging.getLogger(__name__)
+
+
+class BaseLoss(Schedulable, TorchEBMModule, ABC):
+    def __init__(
+        self,
+        dtype: torch.dtype = torch.float32,
+        device: Optional[Union[str, torch.device]] = None,
+        *args: Any,
+        **kwargs: Any,
+    ):
+        super().__init__(*args, device=device, dtype=dtype, **kwargs)
+
+    def _resolve_model_kwargs(self, model_kwargs: Optional[dict], legacy_kwargs: Optional[dict] = None, *, warn_key: str) -> dict:
+        if legacy_kwargs:
+            warn_once(
+                warn_key,
+                "Passing model conditioning as bare keyword arguments is deprecated; pass model_kwargs={...} instead.",
+            )
+            model_kwargs = {**legacy_kwargs, **(model_kwargs or {})}
+        return self._prepare_model_kwargs(model_kwargs)
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor: ...
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}()"
+
+    __str__ = __repr__
+
+
+class BaseContrastiveDivergence(BaseLoss):
+    """CD machinery shared by the CD variants: where negative chains start (data, or a
+    persistent replay buffer with stratified reads and FIFO writes)."""
+
+    def __init__(
+        self,
+        model,
+        sampler,
+        k_steps: int = 1,
+        persistent: bool = False,
+        buffer_size: int = 100,
+        new_sample_ratio: float = 0.0,
+        init_steps: int = 0,
+        dtype: torch.dtype = torch.float32,
+        device: Optional[Union[str, torch.device]] = None,
+        *args,
+        **kwargs,
+    ):
+        super().__init__(*args, dtype=dtype, device=device, **kwargs)
+        self.model = model
+        self.sampler = sampler
+        self.k_steps = k_steps
+        self.persistent = persistent
+        self.buffer_size = buffer_size
+        self.new_sample_ratio = new_sample_ratio
+        self.init_steps = init_steps
+        # both live in state_dict once the lazy initialisation has happened
+        self.register_buffer("replay_buffer", None)
+        self.register_buffer("buffer_ptr", torch.tensor(0, dtype=torch.long, device=self.device))
+        self._write_pos = 0  # host copy of buffer_ptr: the FIFO never reads the device scalar
+        self.buffer_initialized = False
+
+    # ---- replay buffer ------------------------------------------------------------------
+    def initialize_buffer(
+        self,
+        data_shape_no_batch: Tuple[int, ...],
+        buffer_chunk_size: int = 1024,
+        init_noise_scale: float = 0.01,
+        generator: Optional[torch.Generator] = None,
+    ) -> Optional[torch.Tensor]:
+        """Fill the buffer with small Gaussian noise, then (optionally) burn it in with
+        ``init_steps`` sampler steps, chunk by chunk (base_loss.py:190-264)."""
+        if not self.persistent or self.buffer_initialized:
+            return None
+        if self.buffer_size <= 0:
+            raise ValueError(f"Replay buffer size must be positive, got {self.buffer_size}")
+        shape = (self.buffer_size,) + tuple(data_shape_no_batch)
+        logger.info("Initializing replay buffer with shape %s...", shape)
+        self.replay_buffer = torch.randn(shape, dtype=self.dtype, device=self.device, generator=generator) * init_noise_scale
+        if self.init_steps > 0:
+            chunk = min(self.buffer_size, buffer_chunk_size)
+            with torch.no_grad():
+                for lo in range(0, self.buffer_size, chunk):
+                    hi = min(lo + chunk, self.buffer_size)
+                    seed_rows = self.replay_buffer[lo:hi].clone()
+                    try:
+                        with self.autocast_context():
+                            burned = self.sampler.sample(x=seed_rows, n_steps=self.init_steps, generator=generator).detach()
+                    except Exception as exc:  # keep the noise for this chunk, like the reference
+                        warnings.warn(f"Error during buffer initialization sampling for chunk {lo}-{hi}: {exc}. Keeping noise for this chunk.")
+                        continue
+                    if burned.shape == seed_rows.shape:
+                        self.replay_buffer[lo:hi] = burned
+                    else:
+                        warnings.warn(
+                            f"Sampler output shape mismatch during buffer init. Expected {seed_rows.shape}, "
+                            f"got {burned.shape}. Skipping update for chunk {lo}-{hi}."
+                        )
+        self.buffer_ptr.zero_()
+        self._write_pos = 0
+        self.buffer_initialized = True
+        return self.replay_buffer
+
+    def get_start_points(self, x: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Chain starts: a copy of the data (CD) or stratified reads of the buffer (PCD:
+        one row per stride with a random in-stride offset, base_loss.py:266-337)."""
+        x = x.to(device=self.device, dtype=self.dtype)
+        batch = x.shape[0]
+        if not self.persistent:
+            return x.detach().clone()
+        if not self.buffer_initialized:
+            self.initialize_buffer(tuple(x.shape[1:]), generator=generator)
+            if not self.buffer_initialized:
+                raise RuntimeError("Buffer initialization failed.")
+        if self.buffer_size < batch:
+            warnings.warn(
+                f"Buffer size ({self.buffer_size}) is smaller than batch size ({batch}). Sampling with replacement.",
+                UserWarning,
+            )
+            rows = torch.randint(0, self.buffer_size, (batch,), device=self.device, generator=generator)
+        else:
+            stride = self.buffer_size // batch
+            base = torch.arange(0, batch, device=self.device) * stride
+            jitter = torch.randint(0, stride, (batch,), device=self.device, generator=generator)
+            rows = (base + jitter) % self.buffer_size
+        starts = self.replay_buffer[rows]
+        if self.new_sample_ratio > 0.0:
+            n_new = max(1, int(batch * self.new_sample_ratio))
+            pick = torch.randperm(batch, device=self.device, generator=generator)[:n_new]
+            bump = torch.randn_like(starts[pick], device=self.device, dtype=self.dtype, generator=generator) * 0.01
+            starts[pick] = starts[pick] + bump
+        return starts
+
+    def get_negative_samples(self, x, batch_size, data_shape, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        kw = dict(dtype=self.dtype, device=self.device)
+        if not self.persistent or not self.buffer_initialized:
+            return torch.randn((batch_size,) + tuple(data_shape), generator=generator, **kw)
+        n_new = max(1, int(batch_size * self.new_sample_ratio))
+        n_old = batch_size - n_new
+        out = torch.empty((batch_size,) + tuple(data_shape), **kw)
+        out[:n_new] = torch.randn((n_new,) + tuple(data_shape), generator=generator, **kw)
+        if n_old > 0:
+            rows = torch.randint(0, self.buffer_size, (n_old,), device=self.device, generator=generator)
+            out[n_new:] = self.replay_buffer[rows]
+        return out
+
+    def update_buffer(self, samples: torch.Tensor) -> None:
+        """FIFO write with wrap-around; the write position is tracked on the host
+        (base_loss.py:390-426)."""
+        if not self.persistent or not self.buffer_initialized:
+            return
+        samples = samples.to(device=self.device, dtype=self.dtype).detach()
+        batch, cap, pos = samples.shape[0], self.buffer_size, self._write_pos
+        if batch >= cap:
+            self.replay_buffer[:] = samples[-cap:]
+            new_pos = 0
+        else:
+            new_pos = (pos + batch) % cap
+            if new_pos > pos:
+                self.replay_buffer[pos:new_pos] = samples
+            else:
+                head = cap - pos
+                self.replay_buffer[pos:] = samples[:head]
+                self.replay_buffer[:new_pos] = samples[head:]
+        self._write_pos = new_pos
+        self.buffer_ptr.fill_(new_pos)
+
+    def mix_buffer_across_ranks(self, process_group=None, generator: Optional[torch.Generator] = None) -> None:
+        """Shuffle the union of all ranks' buffers with one shared permutation and keep this
+        rank's slice: an exact partition of the union (base_loss.py:428-481)."""
+        if not self.persistent:
+            raise RuntimeError("mix_buffer_across_ranks requires a persistent loss (persistent=True).")
+        if not self.buffer_initialized:
+            raise RuntimeError(
+                "The replay buffer is not initialized; run one training step or call initialize_buffer() first."
+            )
+        from ..utils.distributed import all_gather_cat, broadcast_tensor, get_rank, get_world_size
+
+        if get_world_size(process_group) == 1:
+            return
+        union = all_gather_cat(self.replay_buffer, group=process_group)
+        perm = broadcast_tensor(torch.randperm(union.shape[0], generator=generator), src=0, group=process_group)
+        lo = get_rank(process_group) * self.buffer_size
+        self.replay_buffer.copy_(union[perm[lo : lo + self.buffer_size].to(union.device)])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._write_pos = int(self.buffer_ptr.item())
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor, *args, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]: ...
+
+    @abstractmethod
+    def compute_loss(self, x: torch.Tensor, pred_x: torch.Tensor, *args, **kwargs) -> torch.Tensor: ...
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}(model={self.model}, sampler={self.sampler})"
+
+    __str__ = __repr__

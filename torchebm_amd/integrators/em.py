@@ -1,0 +1,27 @@
+"""Euler-Maruyama integrator (reference: torchebm/integrators/euler_maruyama.py:11-65).
+
+A one-stage tableau on top of ``BaseSDERungeKuttaIntegrator``; on a CUDA fp32 state its
+``step`` is a single launch of ``ebm_langevin_step_f32`` (update + in-kernel Philox noise).
+The backward (implicit) variant of the reference is outside the hot path.
+"""
+
+from __future__ import annotations
+
+from ..core.integrator_base import BaseSDERungeKuttaIntegrator
+
+
+class EulerMaruyamaIntegrator(BaseSDERungeKuttaIntegrator):
+    r"""``x_{n+1} = x_n + f(x_n, t_n) h + \sqrt{2 D}\,\Delta W_n``; Euler's method when no
+    diffusion is given."""
+
+    @property
+    def tableau_a(self):
+        return ((),)
+
+    @property
+    def tableau_b(self):
+        return (1.0,)
+
+    @property
+    def tableau_c(self):
+        return (0.0,)

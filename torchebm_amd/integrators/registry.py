@@ -1,0 +1,69 @@
+"""Integrator registry and the ``resolve_integrator`` socket the samplers plug into
+(reference: torchebm/integrators/integrator_utils.py:8-111).
+
+Only the integrators on the Langevin/HMC path are registered; the ODE-flow family of the
+reference (heun, rk4, dopri5, ...) is out of scope and asking for one is an explicit error.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Type, Union
+
+import torch
+
+from ..core.integrator_base import BaseIntegrator
+
+_REGISTRY = {
+    "euler": "EulerMaruyamaIntegrator",
+    "euler_maruyama": "EulerMaruyamaIntegrator",
+    "leapfrog": "LeapfrogIntegrator",
+}
+
+_REFERENCE_ONLY = (
+    "backward_euler_maruyama", "heun", "adaptive_heun", "bosh3", "dopri5", "dopri8", "rk4", "rk438",
+    "midpoint", "generalised_leapfrog", "generalized_leapfrog",
+)
+
+
+def get_integrator(name: str, device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> BaseIntegrator:
+    """Construct an integrator from its registry name with default settings."""
+    from . import EulerMaruyamaIntegrator, LeapfrogIntegrator  # late: avoids an import cycle
+
+    classes = {"EulerMaruyamaIntegrator": EulerMaruyamaIntegrator, "LeapfrogIntegrator": LeapfrogIntegrator}
+    try:
+        cls = classes[_REGISTRY[name]]
+    except (KeyError, TypeError):
+        if isinstance(name, str) and name in _REFERENCE_ONLY:
+            raise ValueError(
+                f"Integrator {name!r} belongs to the reference's ODE/flow family, which torchebm_amd does not "
+                f"implement (Langevin/HMC hot path only). Valid names: {', '.join(sorted(_REGISTRY))}"
+            ) from None
+        raise ValueError(f"Unknown integrator {name!r}. Valid names: {', '.join(sorted(_REGISTRY))}") from None
+    return cls(device=device, dtype=dtype)
+
+
+def resolve_integrator(
+    integrator: Union[str, BaseIntegrator, None],
+    *,
+    default: str,
+    family: Type[BaseIntegrator],
+    owner: str,
+    device: Optional[torch.device] = None,
+    dtype: Optional[torch.dtype] = None,
+) -> BaseIntegrator:
+    """``None`` / name -> a fresh instance on the sampler's device/dtype; an instance is
+    taken as-is but must be of ``family`` and already match device and dtype (no ``.to()``)."""
+    if isinstance(integrator, BaseIntegrator):
+        if not isinstance(integrator, family):
+            raise TypeError(f"{owner} requires a {family.__name__}; got {type(integrator).__name__}")
+        if integrator.device != device or integrator.dtype != dtype:
+            raise ValueError(
+                f"{owner} device/dtype ({device}, {dtype}) does not match the integrator's "
+                f"({integrator.device}, {integrator.dtype}). Construct the integrator with matching "
+                f"device/dtype; no implicit .to() is performed."
+            )
+        return integrator
+    made = get_integrator(default if integrator is None else integrator, device=device, dtype=dtype)
+    if not isinstance(made, family):
+        raise TypeError(f"{owner} requires a {family.__name__}; got {type(made).__name__}")
+    return made

@@ -1,0 +1,337 @@
+r"""Hamiltonian Monte Carlo sampler (reference: torchebm/samplers/hmc.py:19-315).
+
+Per transition: draw ``p ~ N(0, M)``; ``H0 = U(x) + K(p)``; ``L`` leapfrog steps in safe
+mode; ``H1``; accept with probability ``min(1, exp(H0 - H1))``.  The RNG draw order per
+transition is momentum normals, then the accept uniforms.
+
+Execution routes (chosen once per ``sample()`` call):
+
+``fused``  CUDA fp32 2-D state + analytic energy + default leapfrog: all transitions run
+           inside ONE launch of ``ebm_hmc_chain_f32`` (per-chain energies are wavefront
+           reductions, the accept decision never leaves the wave).
+``step``   CUDA fp32, any other model: Philox momentum fill, ``LeapfrogIntegrator`` on the
+           HIP kick kernels around ``model.gradient`` (autograd), HIP Metropolis kernel.
+``eager``  CPU state, or configurations outside the hot path: the reference loop in torch.
+
+``RiemannianManifoldHMC`` of the reference is out of scope.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+
+from .. import _lib, _rng
+from ..core.energies import BaseModel, FusedSpec
+from ..core.integrator_base import BaseSymplecticIntegrator
+from ..core.module import warn_once
+from ..core.sampler_base import BaseSampler
+from ..core.schedules import BaseScheduler, Schedulable
+from ..integrators.registry import resolve_integrator
+from ..integrators.symplectic import LeapfrogIntegrator, _mass_args
+
+
+class HamiltonianMonteCarlo(BaseSampler):
+    """Hamiltonian Monte Carlo.
+
+    Args:
+        model: energy model.
+        step_size: leapfrog step size (float or ``BaseScheduler``).
+        n_leapfrog_steps: leapfrog steps per proposal.
+        mass: ``None``, a float, or a per-dimension tensor.
+        dtype, device: where the chains live.
+        integrator: ``None`` (leapfrog), a registry name, or a separable
+            ``BaseSymplecticIntegrator`` instance matching the sampler's device/dtype.
+    """
+
+    def __init__(
+        self,
+        model: BaseModel,
+        step_size: Union[float, BaseScheduler] = 1e-3,
+        n_leapfrog_steps: int = 10,
+        mass: Optional[Union[float, torch.Tensor]] = None,
+        dtype: torch.dtype = torch.float32,
+        device: Optional[Union[str, torch.device]] = None,
+        integrator: Union[str, BaseSymplecticIntegrator, None] = None,
+    ):
+        super().__init__(model=model, dtype=dtype, device=device)
+        self._register_param("step_size", step_size, positive=True)
+        if n_leapfrog_steps <= 0:
+            raise ValueError("n_leapfrog_steps must be positive")
+        self.n_leapfrog_steps = n_leapfrog_steps
+        if mass is not None and not isinstance(mass, float):
+            mass = mass.to(self.device)
+        self.mass = mass
+        integ = resolve_integrator(
+            integrator,
+            default="leapfrog",
+            family=BaseSymplecticIntegrator,
+            owner="HamiltonianMonteCarlo",
+            device=self.device,
+            dtype=self.dtype,
+        )
+        if not integ.separable:
+            raise TypeError(
+                "HamiltonianMonteCarlo requires a separable symplectic integrator (drift/mass contract); "
+                f"got non-separable {type(integ).__name__}. Use RiemannianManifoldHMC for non-separable "
+                "Hamiltonians."
+            )
+        self.integrator = integ
+
+    # ---------------------------------------------------------------------------------
+    # momentum / kinetic energy in torch ops (eager + step routes; hmc.py:92-159)
+    # ---------------------------------------------------------------------------------
+    def _scale_momentum_(self, p: torch.Tensor) -> torch.Tensor:
+        if self.mass is None:
+            return p
+        if isinstance(self.mass, float):
+            return p.mul_(math.sqrt(self.mass))
+        return p.mul_(torch.sqrt(self.mass).view((1,) * (p.ndim - 1) + (-1,)))
+
+    def _initialize_momentum(self, shape: torch.Size, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """``p ~ N(0, M)`` with torch's own generator stream (CPU / eager route)."""
+        buf = getattr(self, "_momentum_buf", None)
+        if buf is None or buf.shape != shape or buf.dtype != self.dtype or buf.device != self.device:
+            buf = torch.empty(shape, dtype=self.dtype, device=self.device)
+            self._momentum_buf = buf
+        return self._scale_momentum_(buf.normal_(generator=generator))
+
+    def _compute_kinetic_energy(self, p: torch.Tensor) -> torch.Tensor:
+        """``K(p) = 0.5 p^T M^{-1} p`` per chain."""
+        if self.mass is None:
+            return 0.5 * torch.sum(p.square(), dim=-1)
+        if isinstance(self.mass, float):
+            return 0.5 * torch.sum(p.square(), dim=-1) / self.mass
+        return 0.5 * torch.sum(p.square() / self.mass.view((1,) * (p.ndim - 1) + (-1,)), dim=-1)
+
+    # ---------------------------------------------------------------------------------
+    # routing
+    # ---------------------------------------------------------------------------------
+    def _route(self, x: torch.Tensor, model_kwargs: Dict[str, Any]) -> Tuple[str, Optional[FusedSpec]]:
+        if not x.is_cuda:
+            return "eager", None
+        plain = type(self.integrator) is LeapfrogIntegrator
+        if x.dtype != torch.float32 or not plain or (self.use_mixed_precision and self.autocast_available):
+            warn_once(
+                "hmc-eager-cuda",
+                "torchebm_amd: HamiltonianMonteCarlo with a non-fp32 state, autocast, or a non-default integrator "
+                "is not accelerated by the HIP kernels; running the eager torch loop on the GPU.",
+                UserWarning,
+            )
+            return "eager", None
+        spec = None
+        mass_ok = self.mass is None or isinstance(self.mass, float) or (
+            torch.is_tensor(self.mass) and self.mass.ndim == 1 and self.mass.numel() == x.shape[-1]
+        )
+        if (
+            not model_kwargs
+            and x.ndim == 2
+            and x.shape[1] <= 1024
+            and mass_ok
+            and hasattr(self.model, "fused_spec")
+            and not isinstance(self.model, Schedulable)
+        ):
+            spec = self.model.fused_spec()
+            if spec is not None and any(t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)):
+                spec = None
+        return ("fused", spec) if spec is not None else ("step", None)
+
+    # ---------------------------------------------------------------------------------
+    # public API
+    # ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(
+        self,
+        x: Optional[torch.Tensor] = None,
+        dim: Optional[int] = None,
+        n_steps: int = 100,
+        n_samples: int = 1,
+        thin: int = 1,
+        return_trajectory: bool = False,
+        return_diagnostics: bool = False,
+        reset_schedulers: bool = True,
+        *,
+        model_kwargs: Optional[Dict[str, Any]] = None,
+        generator: Optional[torch.Generator] = None,
+    ) -> Union[torch.Tensor, Tuple[torch.Tensor, Dict[str, torch.Tensor]]]:
+        """Generate samples; ``n_steps`` is the number of MH proposals.
+
+        Diagnostics keys: ``"mean"``, ``"var"`` (``[n_kept, dim]``), ``"energy"`` and
+        ``"acceptance_rate"`` (``[n_kept]``).  ``dim`` is inferred from ``model.mean`` when
+        neither ``x`` nor ``dim`` is given.
+
+        Raises:
+            ValueError: ``thin < 1``, or the state dimension cannot be determined.
+        """
+        if thin < 1:
+            raise ValueError("thin must be >= 1")
+        if reset_schedulers:
+            self.reset_schedulers()
+        model_kwargs = self._prepare_model_kwargs(model_kwargs)
+        if x is None and dim is None:
+            mean = getattr(self.model, "mean", None)
+            if not isinstance(mean, torch.Tensor):
+                raise ValueError("dim must be provided when x is None and cannot be inferred from model")
+            dim = mean.shape[0]
+        x = self._init_state(x, dim, n_samples, generator)
+        route, spec = self._route(x, model_kwargs)
+        if route == "fused":
+            return self._sample_fused(x, spec, n_steps, thin, return_trajectory, return_diagnostics, generator)
+        return self._sample_stepwise(
+            x, model_kwargs, n_steps, thin, return_trajectory, return_diagnostics, generator, hip=(route == "step")
+        )
+
+    def _new_outputs(self, n: int, dim: int, n_kept: int, want_traj: bool, want_diag: bool):
+        kw = dict(dtype=self.dtype, device=self.device)
+        traj = torch.empty((n, n_kept, dim), **kw) if want_traj else None
+        diag = None
+        if want_diag:
+            diag = {
+                "mean": torch.empty(n_kept, dim, **kw),
+                "var": torch.empty(n_kept, dim, **kw),
+                "energy": torch.empty(n_kept, **kw),
+                "acceptance_rate": torch.empty(n_kept, **kw),
+            }
+        return traj, diag
+
+    # ---------------------------------------------------------------------------------
+    # route: per-transition loop
+    # ---------------------------------------------------------------------------------
+    def _sample_stepwise(self, x, model_kwargs, n_steps, thin, want_traj, want_diag, generator, hip: bool):
+        n, dim = x.shape[0], x.shape[1]
+        n_kept = n_steps // thin
+        traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
+        drift = lambda x_, t_: -self._model_gradient(x_, model_kwargs)  # noqa: E731
+        if hip:
+            x = _lib.dense_f32(x)
+            seed, step0 = _rng.reserve(generator, x.device, 2 * n_steps)
+            stream = _lib.stream_handle(x.device)
+            row_dim = x.numel() // max(n, 1)
+        keep = 0
+        with self.autocast_context():
+            for i in range(n_steps):
+                if hip:
+                    p = torch.empty_like(x)
+                    _lib.call("ebm_noise_fill_f32", _lib.ptr(p), p.numel(), _lib.NOISE_NORMAL, seed, step0 + 2 * i, stream)
+                    p = self._scale_momentum_(p)
+                else:
+                    p = self._initialize_momentum(x.shape, generator)
+
+                h0 = self._model_energy(x, model_kwargs).clamp_(min=-1e10, max=1e10) + self._compute_kinetic_energy(
+                    p
+                ).clamp_(min=0.0, max=1e10)
+                prop = self.integrator.integrate(
+                    {"x": x, "p": p},
+                    step_size=self.get_scheduled_value("step_size"),
+                    n_steps=self.n_leapfrog_steps,
+                    mass=self.mass,
+                    drift=drift,
+                    safe=True,
+                )
+                x_prop, p_prop = prop["x"], prop["p"]
+                h1 = self._model_energy(x_prop, model_kwargs).clamp_(min=-1e10, max=1e10) + self._compute_kinetic_energy(
+                    p_prop
+                ).clamp_(min=0.0, max=1e10)
+
+                if hip:
+                    mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+                    x_next = x.clone()
+                    _lib.call(
+                        "ebm_hmc_accept_f32",
+                        _lib.ptr(x_next), _lib.ptr(_lib.dense_f32(x_prop)), _lib.ptr(_lib.dense_f32(h0)),
+                        _lib.ptr(_lib.dense_f32(h1)), None, _lib.ptr(mask), None, n, row_dim,
+                        seed, step0 + 2 * i + 1, stream,
+                    )
+                    x = x_next
+                    accepted = mask
+                else:
+                    delta = (h0 - h1).clamp_(min=-50.0, max=50.0)
+                    accept_prob = torch.exp(delta).clamp_(max=1.0)
+                    u = torch.rand(n, device=self.device, generator=generator)
+                    accepted = u < accept_prob
+                    x = torch.where(accepted.view(-1, *([1] * (x.ndim - 1))), x_prop, x)
+
+                if (i + 1) % thin == 0:
+                    if traj is not None:
+                        traj[:, keep, :] = x
+                    if diag is not None:
+                        diag["mean"][keep] = x.mean(dim=0)
+                        diag["var"][keep] = (
+                            x.var(dim=0, unbiased=False).clamp_(min=1e-10, max=1e10)
+                            if n > 1
+                            else torch.zeros(dim, dtype=self.dtype, device=self.device)
+                        )
+                        diag["energy"][keep] = self._model_energy(x, model_kwargs).clamp_(min=-1e10, max=1e10).mean()
+                        diag["acceptance_rate"][keep] = accepted.float().mean()
+                    keep += 1
+                self.step_schedulers()
+        out = traj if want_traj else x
+        return (out, diag) if want_diag else out
+
+    # ---------------------------------------------------------------------------------
+    # route: fused HIP kernel
+    # ---------------------------------------------------------------------------------
+    def _launch_hmc(self, spec_c, state, n, dim, eps_vals, t0, n_mh, thin, traj, counts, seed, step, stream):
+        kind, m_scalar, m_diag = _mass_args(self.mass, state)
+        if len(eps_vals) == 1:
+            eps, table = eps_vals[0], None
+        else:
+            eps = eps_vals[t0]
+            table = torch.tensor(eps_vals[t0 : t0 + n_mh], dtype=torch.float32).to(state.device, non_blocking=True)
+        cptr = None if counts is None else counts.data_ptr() + 4 * t0
+        _lib.call(
+            "ebm_hmc_chain_f32",
+            spec_c, _lib.ptr(state), n, dim, n_mh, self.n_leapfrog_steps, eps, _lib.ptr(table),
+            kind, m_scalar, _lib.ptr(m_diag), thin, _lib.ptr(traj), None, cptr, None, None,
+            seed, step, stream,
+        )
+
+    def _sample_fused(self, x, spec: FusedSpec, n_steps, thin, want_traj, want_diag, generator):
+        n, dim = x.shape
+        n_kept = n_steps // thin
+        state = _lib.dense_f32(x).clone()
+        traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
+        sched = self.schedulers["step_size"]
+        eps_vals = [sched.get_value()] if sched.is_constant() else sched.preview(n_steps)
+        seed, step0 = _rng.reserve(generator, x.device, 2 * n_steps)
+        stream = _lib.stream_handle(x.device)
+        spec_c = spec.to_c()
+
+        if n_steps > 0 and n > 0:
+            if not want_diag:
+                self._launch_hmc(spec_c, state, n, dim, eps_vals, 0, n_steps, thin, traj, None, seed, step0, stream)
+            else:
+                counts = torch.zeros(n_steps, dtype=torch.int32, device=x.device)  # uint32 bit pattern
+                work = torch.empty(2 * dim, dtype=torch.float64, device=x.device)
+                energy = torch.empty(n, dtype=torch.float32, device=x.device)
+                done = 0
+                for keep in range(n_kept):
+                    self._launch_hmc(
+                        spec_c, state, n, dim, eps_vals, done, thin, thin, None, counts, seed, step0 + 2 * done, stream
+                    )
+                    done += thin
+                    if traj is not None:
+                        traj[:, keep, :] = state
+                    if n > 1:
+                        work.zero_()
+                        _lib.call(
+                            "ebm_chain_stats_f32",
+                            _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
+                            _lib.ptr(work), stream,
+                        )
+                    else:
+                        diag["mean"][keep] = state[0]
+                        diag["var"][keep].zero_()
+                    _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
+                    diag["energy"][keep] = energy.clamp_(min=-1e10, max=1e10).mean()
+                    diag["acceptance_rate"][keep] = counts[done - 1].to(torch.float32) / n
+                if done < n_steps:
+                    self._launch_hmc(
+                        spec_c, state, n, dim, eps_vals, done, n_steps - done, thin, None, None, seed,
+                        step0 + 2 * done, stream,
+                    )
+        self.advance_schedulers(n_steps)
+        out = traj if want_traj else state
+        return (out, diag) if want_diag else out

@@ -1,0 +1,303 @@
+r"""Langevin dynamics sampler (reference: torchebm/samplers/langevin_dynamics.py:16-188).
+
+.. math:: x_{t+1} = x_t - \eta \nabla_x U(x_t) + \sqrt{2\eta}\,\sigma\,\epsilon_t
+
+Three execution routes, chosen once per ``sample()`` call:
+
+``fused``  CUDA fp32 state + one of the analytic energies + default Euler-Maruyama
+           integrator: the whole k-step loop (gradient, update, Philox noise, clamp, thinned
+           trajectory) is ONE launch of ``ebm_langevin_chain_f32``; schedulers are
+           pre-expanded on the host into a per-step coefficient table.
+``step``   CUDA fp32 state, any other model (e.g. an MLP energy, conditioning): the gradient
+           comes from ``model.gradient`` (autograd) and each step is one launch of
+           ``ebm_langevin_step_f32`` (update + noise + clamp fused).
+``eager``  CPU state (BASELINE config 1) -- or a configuration outside the hot path
+           (non-fp32, non-default integrator): the reference's loop with eager torch ops.
+
+A CUDA state never silently runs on the CPU and never skips the HIP library: ``fused`` and
+``step`` raise if ``libebm_hip.so`` is missing.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+
+from .. import _lib, _rng
+from ..core.energies import BaseModel, FusedSpec
+from ..core.integrator_base import BaseSDERungeKuttaIntegrator
+from ..core.module import warn_once
+from ..core.sampler_base import BaseSampler
+from ..core.schedules import BaseScheduler, Schedulable
+from ..integrators.em import EulerMaruyamaIntegrator
+from ..integrators.registry import resolve_integrator
+
+
+def em_coefficients(eta: float, sigma: float) -> Tuple[float, float, float]:
+    """The three scalars of one Euler-Maruyama step, computed in double exactly as the
+    reference's Python-float arithmetic does (base_integrator.py:728-729): they are cast to
+    fp32 only when they enter the tensor ops / the kernel."""
+    return eta, eta**0.5, (2.0 * sigma**2) ** 0.5
+
+
+class LangevinDynamics(BaseSampler):
+    """Langevin dynamics sampler.
+
+    Args:
+        model: energy model to sample from.
+        step_size: step size, a float or a ``BaseScheduler``.
+        noise_scale: noise scale, a float or a ``BaseScheduler``.
+        decay: stored, unused (as in the reference).
+        clamp: optional ``(min, max)`` applied to the state after every step.
+        dtype, device: where the chains live.
+        integrator: ``None`` (Euler-Maruyama), a registry name, or a
+            ``BaseSDERungeKuttaIntegrator`` instance matching the sampler's device/dtype.
+    """
+
+    def __init__(
+        self,
+        model: BaseModel,
+        step_size: Union[float, BaseScheduler] = 1e-3,
+        noise_scale: Union[float, BaseScheduler] = 1.0,
+        decay: float = 0.0,
+        clamp: Optional[Tuple[float, float]] = None,
+        dtype: torch.dtype = torch.float32,
+        device: Optional[Union[str, torch.device]] = None,
+        integrator: Union[str, BaseSDERungeKuttaIntegrator, None] = None,
+    ):
+        super().__init__(model=model, dtype=dtype, device=device)
+        self._register_param("step_size", step_size, positive=True)
+        self._register_param("noise_scale", noise_scale, positive=True)
+        if clamp is not None and clamp[0] >= clamp[1]:
+            raise ValueError(f"clamp min must be < max, got {clamp}")
+        self.clamp = clamp
+        self.decay = decay
+        self.integrator = resolve_integrator(
+            integrator,
+            default="euler_maruyama",
+            family=BaseSDERungeKuttaIntegrator,
+            owner="LangevinDynamics",
+            device=self.device,
+            dtype=self.dtype,
+        )
+
+    # ---------------------------------------------------------------------------------
+    # routing
+    # ---------------------------------------------------------------------------------
+    def _route(self, x: torch.Tensor, model_kwargs: Dict[str, Any]) -> Tuple[str, Optional[FusedSpec]]:
+        if not x.is_cuda:
+            return "eager", None
+        plain_em = type(self.integrator) is EulerMaruyamaIntegrator
+        if x.dtype != torch.float32 or not plain_em or (self.use_mixed_precision and self.autocast_available):
+            warn_once(
+                "langevin-eager-cuda",
+                "torchebm_amd: LangevinDynamics with a non-fp32 state, autocast, or a non-default integrator is "
+                "not accelerated by the HIP kernels; running the eager torch loop on the GPU.",
+                UserWarning,
+            )
+            return "eager", None
+        spec = None
+        if not model_kwargs and hasattr(self.model, "fused_spec") and not isinstance(self.model, Schedulable):
+            spec = self.model.fused_spec()
+            if spec is not None and not (spec.elementwise or x.ndim == 2):
+                spec = None
+            if spec is not None and any(
+                t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)
+            ):
+                spec = None
+        return ("fused", spec) if spec is not None else ("step", None)
+
+    # ---------------------------------------------------------------------------------
+    # public API
+    # ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(
+        self,
+        x: Optional[torch.Tensor] = None,
+        dim: Optional[Union[int, Tuple[int, ...]]] = None,
+        n_steps: int = 100,
+        n_samples: int = 1,
+        thin: int = 1,
+        return_trajectory: bool = False,
+        return_diagnostics: bool = False,
+        reset_schedulers: bool = True,
+        *,
+        model_kwargs: Optional[Dict[str, Any]] = None,
+        generator: Optional[torch.Generator] = None,
+    ) -> Union[torch.Tensor, Tuple[torch.Tensor, Dict[str, torch.Tensor]]]:
+        """Generate samples.
+
+        Returns the final state ``[n, *shape]`` (or, with ``return_trajectory``, the kept
+        trajectory ``[n, n_steps // thin, *shape]``), optionally with a diagnostics dict
+        holding ``"mean"``/``"var"`` (``[n_kept, *shape]``) and ``"energy"`` (``[n_kept]``).
+
+        Raises:
+            ValueError: ``thin < 1``, or ``x`` and ``dim`` both ``None``.
+        """
+        if thin < 1:
+            raise ValueError("thin must be >= 1")
+        if reset_schedulers:
+            self.reset_schedulers()
+        x = self._init_state(x, dim, n_samples, generator)
+        model_kwargs = self._prepare_model_kwargs(model_kwargs)
+        route, spec = self._route(x, model_kwargs)
+        if route == "fused":
+            return self._sample_fused(x, spec, n_steps, thin, return_trajectory, return_diagnostics, generator)
+        return self._sample_stepwise(
+            x, model_kwargs, n_steps, thin, return_trajectory, return_diagnostics, generator, hip=(route == "step")
+        )
+
+    # ---------------------------------------------------------------------------------
+    # shared helpers
+    # ---------------------------------------------------------------------------------
+    def _new_outputs(self, x: torch.Tensor, n_kept: int, want_traj: bool, want_diag: bool):
+        n, shape = x.shape[0], tuple(x.shape[1:])
+        traj = torch.empty((n, n_kept, *shape), dtype=self.dtype, device=self.device) if want_traj else None
+        diag = None
+        if want_diag:
+            diag = {
+                "mean": torch.empty(n_kept, *shape, dtype=self.dtype, device=self.device),
+                "var": torch.empty(n_kept, *shape, dtype=self.dtype, device=self.device),
+                "energy": torch.empty(n_kept, dtype=self.dtype, device=self.device),
+            }
+        return traj, diag
+
+    def _clamp_args(self) -> Tuple[int, float, float]:
+        if self.clamp is None:
+            return 0, 0.0, 0.0
+        return 1, float(self.clamp[0]), float(self.clamp[1])
+
+    # ---------------------------------------------------------------------------------
+    # route: per-step loop (eager torch ops, or the per-step HIP kernel)
+    # ---------------------------------------------------------------------------------
+    def _sample_stepwise(self, x, model_kwargs, n_steps, thin, want_traj, want_diag, generator, hip: bool):
+        n = x.shape[0]
+        n_kept = n_steps // thin
+        traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
+        keep = 0
+        if hip:
+            x = _lib.dense_f32(x)
+            seed, step0 = _rng.reserve(generator, x.device, n_steps)
+            stream = _lib.stream_handle(x.device)
+            clamp_on, cmin, cmax = self._clamp_args()
+        else:
+            drift = lambda x_, t_: -self._model_gradient(x_, model_kwargs)  # noqa: E731
+        with self.autocast_context():
+            for i in range(n_steps):
+                eta = self.get_scheduled_value("step_size")
+                sigma = self.get_scheduled_value("noise_scale")
+                if hip:
+                    grad = _lib.dense_f32(self._model_gradient(x, model_kwargs))
+                    out = torch.empty_like(x)
+                    a, sq, coef = em_coefficients(eta, sigma)
+                    _lib.call(
+                        "ebm_langevin_step_f32",
+                        _lib.ptr(x), _lib.ptr(grad), _lib.ptr(out), None, x.numel(),
+                        a, sq, coef, clamp_on, cmin, cmax, seed, step0 + i, stream,
+                    )
+                    x = out
+                else:
+                    x = self.integrator.step(
+                        state={"x": x}, step_size=eta, noise_scale=sigma, drift=drift, generator=generator
+                    )["x"]
+                    if self.clamp is not None:
+                        x = x.clamp_(*self.clamp)
+                self.step_schedulers()
+
+                if (i + 1) % thin == 0:
+                    if traj is not None:
+                        traj[:, keep] = x
+                    if diag is not None:
+                        if n > 1:
+                            diag["mean"][keep] = x.mean(dim=0)
+                            diag["var"][keep] = x.var(dim=0, unbiased=False).clamp_(min=1e-10, max=1e10)
+                        else:
+                            diag["mean"][keep] = x.squeeze(0)
+                            diag["var"][keep].zero_()
+                        diag["energy"][keep] = self._model_energy(x, model_kwargs).mean()
+                    keep += 1
+        out = traj if want_traj else x
+        return (out, diag) if want_diag else out
+
+    # ---------------------------------------------------------------------------------
+    # route: k-fused HIP kernel
+    # ---------------------------------------------------------------------------------
+    def _coef_rows(self, k: int) -> Tuple[bool, List[Tuple[float, float, float]]]:
+        """Pre-expand the two schedulers for the next k steps (values are read before
+        ``step_schedulers()`` in the reference loop, i.e. at step counts 0..k-1)."""
+        s_eta, s_sig = self.schedulers["step_size"], self.schedulers["noise_scale"]
+        constant = s_eta.is_constant() and s_sig.is_constant()
+        if constant:
+            return True, [em_coefficients(s_eta.get_value(), s_sig.get_value())]
+        etas, sigmas = s_eta.preview(k), s_sig.preview(k)
+        return False, [em_coefficients(e, s) for e, s in zip(etas, sigmas)]
+
+    def _launch_chain(self, spec_c, x, n, dim, rows, row0, k, thin, traj, seed, step, stream):
+        """One ``ebm_langevin_chain_f32`` launch for steps [row0, row0+k) of ``rows``."""
+        clamp_on, cmin, cmax = self._clamp_args()
+        if len(rows) == 1:  # constant schedule: scalars, no table
+            a, sq, coef = rows[0]
+            table = None
+        else:
+            a, sq, coef = rows[row0]
+            host = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows[row0 : row0 + k]], dtype=torch.float32)
+            table = host.to(x.device, non_blocking=True)
+        _lib.call(
+            "ebm_langevin_chain_f32",
+            spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(table),
+            clamp_on, cmin, cmax, thin, _lib.ptr(traj), None, seed, step, stream,
+        )
+
+    def _sample_fused(self, x, spec: FusedSpec, n_steps, thin, want_traj, want_diag, generator):
+        shape = tuple(x.shape[1:])
+        n = x.shape[0]
+        dim = 1
+        for s in shape:
+            dim *= s
+        n_kept = n_steps // thin
+        state = _lib.dense_f32(x).clone()  # the kernel updates in place; never touch the caller's tensor
+        traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
+        _, rows = self._coef_rows(n_steps)
+        seed, step0 = _rng.reserve(generator, x.device, n_steps)
+        stream = _lib.stream_handle(x.device)
+        spec_c = spec.to_c()
+
+        if n_steps > 0 and n > 0:
+            if not want_diag:
+                # one launch for the whole call; thinned rows are stored by the kernel
+                self._launch_chain(spec_c, state, n, dim, rows, 0, n_steps, thin, traj, seed, step0, stream)
+            else:
+                # diagnostics need the whole population at every kept step: one launch per
+                # `thin` steps, then the column-statistics and energy kernels
+                work = torch.empty(2 * dim, dtype=torch.float64, device=x.device)
+                energy = torch.empty(n, dtype=torch.float32, device=x.device)
+                done = 0
+                for keep in range(n_kept):
+                    self._launch_chain(spec_c, state, n, dim, rows, done, thin, thin, None, seed, step0 + done, stream)
+                    done += thin
+                    if traj is not None:
+                        traj[:, keep] = state.view(n, *shape)
+                    if n > 1:
+                        work.zero_()
+                        _lib.call(
+                            "ebm_chain_stats_f32",
+                            _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
+                            _lib.ptr(work), stream,
+                        )
+                    else:
+                        diag["mean"][keep] = state.view(*shape)
+                        diag["var"][keep].zero_()
+                    if state.ndim == 2:
+                        _lib.call(
+                            "ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream
+                        )
+                        diag["energy"][keep] = energy.mean()
+                    else:  # >2-D state: the model's own reduction over the last axis defines "energy"
+                        diag["energy"][keep] = self._model_energy(state, {}).mean()
+                if done < n_steps:
+                    self._launch_chain(spec_c, state, n, dim, rows, done, n_steps - done, thin, None, seed, step0 + done, stream)
+        self.advance_schedulers(n_steps)
+        final = state.view(n, *shape)
+        out = traj if want_traj else final
+        return (out, diag) if want_diag else out

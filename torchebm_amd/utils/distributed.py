@@ -1,0 +1,65 @@
+"""Guarded collectives (reference: torchebm/utils/distributed.py:21-125).
+
+The sampler itself never communicates: chains are independent, each rank owns a contiguous
+block of rows and seeds its generator ``base_seed + rank``.  The one exchange on the path is
+the read-back of the sharded final state -- ``all_gather_cat`` -- which on ROCm's "nccl"
+backend is an RCCL all-gather over xGMI (one equal-sized shard per rank, rank-ordered).
+Every helper is the identity when ``torch.distributed`` is not initialised.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size(group=None) -> int:
+    return dist.get_world_size(group) if is_distributed() else 1
+
+
+def get_rank(group=None) -> int:
+    return dist.get_rank(group) if is_distributed() else 0
+
+
+def all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate ``x`` from every rank along dim 0, in rank order.  Shapes must match
+    across ranks.  Uses a single ``all_gather_into_tensor`` (one large message per peer
+    instead of ``world`` list entries) -- the shape that suits point-to-point xGMI links."""
+    world = get_world_size(group)
+    if world == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+def broadcast_tensor(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """Broadcast ``x`` from ``src``; a CPU tensor hops through the GPU when the backend is
+    NCCL/RCCL (which cannot move host memory)."""
+    if get_world_size(group) == 1:
+        return x
+    backend = dist.get_backend(group)
+    if backend == "nccl" and not x.is_cuda:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        y = x.to(dev)
+        dist.broadcast(y, src=src, group=group)
+        return y.to(x.device)
+    dist.broadcast(x, src=src, group=group)
+    return x
+
+
+def shard_rows(n_total: int, group=None) -> tuple:
+    """``(start, count)`` of this rank's contiguous block of ``n_total`` chains; the first
+    ``n_total % world`` ranks take one extra row."""
+    world, rank = get_world_size(group), get_rank(group)
+    base, extra = divmod(n_total, world)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
