@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the Langevin hot path (BASELINE.json metric: MCMC chain-steps/sec).
+
+A "step" is one ``LangevinDynamics.sample()`` call over the per-GPU batch of BASELINE
+config 2: DoubleWell(h=2, b=1), n_chains = 2^20, dim = 64, k = 200 Euler-Maruyama steps,
+eta = 0.01, sigma = 1, fp32, initial state already resident in HBM.  One call = one launch
+of the fused kernel ``ebm_langevin_chain_f32`` = n_chains * k chain-steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, chains sharded by rank (weak scaling: 2^20 chains per GPU, seed
+base+rank, no collective inside the k steps); the final state of every step is read back
+with ONE RCCL all-gather (``all_gather_cat``) issued asynchronously so that it overlaps the
+next step's kernel; the last one is waited for inside the timed region.
+
+Output: one JSON line on rank 0 (see DESIGN.md §Measurement for the roofline accounting).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torchebm_amd as ta  # noqa: E402
+from torchebm_amd import _lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+ETA, SIGMA = 0.01, 1.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    # workload overrides (tests / experiments); the defaults are BASELINE config 2
+    ap.add_argument("--n-chains", type=int, default=1 << 20, help="chains PER GPU")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = plumbing dry-run (gloo)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(dim: int, k_full: int):
+    """The reference's CPU path, restated (oracle/), timed on this box's host cores on a bounded
+    sample of the same workload: DoubleWell, dim=64, n = 2^17 chains, k = 20 steps, per-step
+    torch.randn + autograd gradient + the eager update ops (what the reference executes)."""
+    import oracle
+
+    n, k = 1 << 17, 20
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    en = oracle.DoubleWell(2.0, 1.0)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(n, dim, generator=g)
+
+    def run():
+        x = x0
+        for _ in range(k):
+            eps = torch.randn(n, dim, generator=g)
+            x = oracle.em_step(x, en.grad_autograd(x), eps, ETA, SIGMA)
+        return x
+
+    run()  # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    return {
+        "value": n * k / t,
+        "unit": "chain-steps/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle (torch CPU restatement of the reference loop, autograd gradient), DoubleWell n=2^17 dim={dim} "
+                  f"k={k}, median of 3 ({t:.2f} s each); rate is per chain-step, independent of k",
+    }
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = args.device == "cuda"
+    if world > 1:
+        import torch.distributed as dist
+
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if on_gpu else "gloo")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    n, dim, k = args.n_chains, args.dim, args.k
+    model = ta.DoubleWellModel(barrier_height=2.0, b=1.0, device=device)
+    sampler = ta.LangevinDynamics(model, step_size=ETA, noise_scale=SIGMA, device=device)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x0 = torch.randn(n, dim, device=device, generator=gen)
+
+    gathered = None
+    pending = None
+
+    def one_step():
+        nonlocal gathered, pending
+        out = sampler.sample(x=x0, n_steps=k, generator=gen)
+        if world > 1:
+            import torch.distributed as dist
+
+            if pending is not None:
+                pending.wait()
+            if gathered is None:
+                gathered = torch.empty((world * n, dim), dtype=out.dtype, device=device)
+            pending = dist.all_gather_into_tensor(gathered, out.contiguous(), async_op=True)
+        return out
+
+    def fence():
+        nonlocal pending
+        if pending is not None:
+            pending.wait()
+            pending = None
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    if on_gpu:
+        _lib.timed_events["ebm_langevin_chain_f32"] = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = None
+    if on_gpu:
+        pairs = _lib.timed_events.pop("ebm_langevin_chain_f32")
+        if pairs:
+            kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+    if rank == 0:
+        chain_steps = world * n * k * args.steps
+        value = chain_steps / elapsed
+        algo_bytes = n * k * 8 * dim  # read x_t + write x_{t+1}, fp32, per chain-step
+        roof = None
+        if kernel_ms:
+            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            traffic = read_traffic()
+            roof = {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
+                "kernel": "langevin_chain_elem_kernel<DoubleWell>",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            }
+        line = {
+            "metric": "MCMC chain-steps/sec",
+            "value": value,
+            "unit": "chain-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"LangevinDynamics.sample on DoubleWell(h=2,b=1): n_chains={n} per GPU, dim={dim}, "
+                            f"k={k} steps per call, eta={ETA}, sigma={SIGMA} (BASELINE configs[1])",
+                "n_chains_per_gpu": n,
+                "dim": dim,
+                "k_steps": k,
+                "parallelism": f"chains sharded x{world}" + (", async RCCL all-gather of the final state per call" if world > 1 else ""),
+                "device": args.device,
+            },
+            "roofline": roof,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dim, k),
+        }
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/ebm_hip.h declares."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from torchebm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    return sorted(set(re.findall(r"EBM_API\s+[\w\s\*]+?\b(ebm_\w+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_lists():
+    assert _declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_is_built_and_exports_every_symbol():
+    assert _lib.is_built(), f"{_lib.LIB_PATH} missing: run __graft_entry__.build()"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(handle, name), name
+
+
+def test_version_and_error_string():
+    lib = _lib.lib()
+    assert lib.ebm_version() == _lib.ABI_VERSION
+    assert isinstance(lib.ebm_last_error_string(), bytes)
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Validation happens before any launch: NULL state -> EBM_EINVAL -> ValueError."""
+    desc = _lib.EnergyDesc()
+    desc.kind = _lib.ENERGY_DOUBLE_WELL
+    with pytest.raises(ValueError, match="state pointer is NULL"):
+        _lib.call("ebm_langevin_chain_f32", desc, None, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, 0, 0, None)
+    desc.kind = 77
+    with pytest.raises(RuntimeError, match="unknown energy kind"):
+        _lib.call("ebm_langevin_chain_f32", desc, 16, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, 0, 0, None)
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        _lib.call("ebm_noise_fill_f32", 4, 8, 0, 0, 0, None)

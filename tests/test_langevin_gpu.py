@@ -1,0 +1,272 @@
+"""GPU parity tests for the Langevin path: the HIP kernels (through the C ABI) against the
+CPU oracle on the golden fixtures' inputs, plus native-RNG consistency, the sampler API on a
+CUDA device, and size-independent properties at BASELINE.json's full size.
+
+Tolerances: the update arithmetic of the element-wise energies is written op-for-op like the
+reference, so with injected noise those cases must agree to a few ulp accumulated over k steps
+(|dx| <= 2e-6 at k=16; in practice they are bit-identical); Gaussian / mixture gradients use a
+different summation order than torch's bmm / logsumexp: |dx| <= 2e-5."""
+
+import math
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import golden_names, hip_calls, load_golden, oracle_energy, package_model
+from torchebm_amd import _lib
+from torchebm_amd.samplers.langevin import em_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain_call(spec, x, k, rows, clamp, thin, traj, noise, seed=0, step=0):
+    n, dim = x.shape
+    a, sq, coef = rows[0]
+    table = None
+    if len(rows) > 1:
+        table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=x.device)
+    clamp_on, cmin, cmax = (0, 0.0, 0.0) if clamp is None else (1, clamp[0], clamp[1])
+    _lib.call(
+        "ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, a, sq, coef, _lib.ptr(table),
+        clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(noise), seed, step, _lib.stream_handle(x.device),
+    )
+
+
+@pytest.mark.parametrize("name", golden_names("ld_"))
+def test_chain_kernel_injected_noise_matches_oracle(cuda_device, name):
+    fx = load_golden(name)
+    en = oracle_energy(fx["energy"])
+    want_x, want_traj, _ = oracle.langevin_chain(
+        en, fx["x0"], fx["noise"], fx["etas"], fx["sigmas"], clamp=fx["clamp"], thin=fx["thin"], want_traj=True
+    )
+    assert torch.equal(want_x, fx["ref"]["x"])  # the oracle is the reference here
+    model = package_model(fx["energy"], device=cuda_device)
+    spec = model.fused_spec()
+    assert spec is not None
+    x = fx["x0"].to(cuda_device).clone()
+    noise = fx["noise"].to(cuda_device).contiguous()
+    k, thin = fx["k"], fx["thin"]
+    rows = [em_coefficients(e, s) for e, s in zip(fx["etas"], fx["sigmas"])]
+    if len(set(rows)) == 1:
+        rows = rows[:1]
+    traj = torch.full((fx["n"], k // thin, fx["dim"]), float("nan"), device=cuda_device)
+    _chain_call(spec, x, k, rows, fx["clamp"], thin, traj, noise)
+    tol = 2e-6 if fx["energy"]["kind"] in ("double_well", "harmonic") else 2e-5
+    assert (x.cpu() - want_x).abs().max().item() <= tol
+    assert (traj.cpu() - want_traj).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("name", ["ld_dw_64x64", "ld_dw_37x3_clamp_thin3", "ld_har_100x2_sched", "ld_dw_1x8"])
+def test_elementwise_chain_is_bit_exact(cuda_device, name):
+    """No contraction, autograd op order: DoubleWell/Harmonic chains equal the reference bit for bit."""
+    fx = load_golden(name)
+    spec = package_model(fx["energy"], device=cuda_device).fused_spec()
+    x = fx["x0"].to(cuda_device).clone()
+    rows = [em_coefficients(e, s) for e, s in zip(fx["etas"], fx["sigmas"])]
+    if len(set(rows)) == 1:
+        rows = rows[:1]
+    _chain_call(spec, x, fx["k"], rows, fx["clamp"], 1, None, fx["noise"].to(cuda_device).contiguous())
+    assert torch.equal(x.cpu(), fx["ref"]["x"])
+
+
+def test_step_kernel_known_answers(cuda_device):
+    """ebm_langevin_step_f32 and the integrator API against the reference's recorded steps."""
+    fx = load_golden("integrators")
+    x, noise = fx["x"].to(cuda_device), fx["noise"].to(cuda_device)
+    em = ta.EulerMaruyamaIntegrator(device=cuda_device)
+    before = hip_calls("ebm_langevin_step_f32")
+    drift = lambda x_, t_: -(x_**3)  # noqa: E731
+    got = em.step({"x": x}, 0.01, drift=drift, noise=noise, noise_scale=0.7)["x"]
+    assert torch.equal(got.cpu(), fx["em_sde"])
+    got = em.step({"x": x}, 0.01, drift=drift)["x"]
+    assert torch.equal(got.cpu(), fx["em_ode"])
+    assert hip_calls("ebm_langevin_step_f32") == before + 2
+    assert torch.equal(x.cpu(), fx["x"])  # input untouched
+    with pytest.raises(ValueError, match="drift must be provided"):
+        em.step({"x": x}, 0.01)
+
+
+def test_native_rng_fused_chain_equals_per_step_and_injected(cuda_device):
+    """Three ways to run the same chain draw the same Philox field and agree bit for bit:
+    (a) the k-fused kernel, (b) k launches of the per-step kernel fed with torch-autograd
+    gradients, (c) the k-fused kernel with the field materialised by ebm_noise_fill_f32."""
+    n, dim, k, eta, sigma = 300, 20, 9, 0.01, 1.0
+    model = ta.DoubleWellModel(device=cuda_device)
+    spec = model.fused_spec()
+    x0 = torch.randn(n, dim, device=cuda_device)
+    seed, step0 = 0xABCDEF12345, 1000
+    rows = [em_coefficients(eta, sigma)]
+    xa = x0.clone()
+    _chain_call(spec, xa, k, rows, None, 1, None, None, seed, step0)
+    xb = x0.clone()
+    a, sq, coef = rows[0]
+    for i in range(k):
+        g = model.gradient(xb)
+        out = torch.empty_like(xb)
+        _lib.call("ebm_langevin_step_f32", xb.data_ptr(), g.data_ptr(), out.data_ptr(), None, xb.numel(),
+                  a, sq, coef, 0, 0.0, 0.0, seed, step0 + i, _lib.stream_handle(cuda_device))
+        xb = out
+    noise = torch.empty(k, n, dim, device=cuda_device)
+    for i in range(k):
+        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * dim, _lib.NOISE_NORMAL, seed, step0 + i,
+                  _lib.stream_handle(cuda_device))
+    xc = x0.clone()
+    _chain_call(spec, xc, k, rows, None, 1, None, noise)
+    assert torch.equal(xa, xb)
+    assert torch.equal(xa, xc)
+    assert not torch.equal(xa, x0)
+
+
+def test_sampler_routes_and_generator_contract(cuda_device):
+    """tests/test_generator.py:74-113 of the reference, on the fused route."""
+    model = ta.DoubleWellModel(device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
+    x0 = torch.randn(512, 16, device=cuda_device)
+    keep = x0.clone()
+    before = hip_calls("ebm_langevin_chain_f32")
+    g1 = torch.Generator(device=cuda_device).manual_seed(5)
+    g2 = torch.Generator(device=cuda_device).manual_seed(5)
+    g3 = torch.Generator(device=cuda_device).manual_seed(6)
+    a = s.sample(x=x0, n_steps=20, generator=g1)
+    b = s.sample(x=x0, n_steps=20, generator=g2)
+    c = s.sample(x=x0, n_steps=20, generator=g3)
+    assert hip_calls("ebm_langevin_chain_f32") == before + 3
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(x0, keep)  # the caller's tensor is never modified
+    # consecutive calls on one generator continue the stream
+    d = s.sample(x=x0, n_steps=20, generator=g1)
+    assert not torch.equal(a, d)
+    # generator=None consumes the device default generator; explicit generator leaves it alone
+    torch.manual_seed(123)
+    e1 = s.sample(x=x0, n_steps=5)
+    torch.manual_seed(123)
+    e2 = s.sample(x=x0, n_steps=5)
+    assert torch.equal(e1, e2)
+    torch.manual_seed(123)
+    _ = s.sample(x=x0, n_steps=5, generator=g3)
+    e3 = s.sample(x=x0, n_steps=5)
+    assert torch.equal(e1, e3)
+    with pytest.raises(RuntimeError, match="generator"):
+        s.sample(x=x0, n_steps=2, generator=torch.Generator().manual_seed(0))
+    # dim / n_samples initialisation and output contract
+    out, diag = s.sample(dim=8, n_samples=64, n_steps=12, thin=4, return_trajectory=True, return_diagnostics=True,
+                         generator=g1)
+    assert out.shape == (64, 3, 8) and diag["mean"].shape == (3, 8) and diag["energy"].shape == (3,)
+    assert out.is_cuda and torch.isfinite(out).all()
+
+
+def test_sampler_fused_vs_step_route_same_generator(cuda_device):
+    """A subclass of an analytic model is not fused: it takes the per-step route (autograd
+    gradient + ebm_langevin_step_f32) and, drawing the same Philox field, lands on the very
+    same samples as the fused route."""
+
+    class MyWell(ta.DoubleWellModel):
+        def forward(self, x):
+            return super().forward(x)
+
+    fused = ta.LangevinDynamics(ta.DoubleWellModel(device=cuda_device), step_size=0.02, clamp=(-2.0, 2.0), device=cuda_device)
+    stepw = ta.LangevinDynamics(MyWell(device=cuda_device), step_size=0.02, clamp=(-2.0, 2.0), device=cuda_device)
+    x0 = torch.randn(257, 12, device=cuda_device)
+    before = hip_calls("ebm_langevin_step_f32")
+    a = fused.sample(x=x0, n_steps=15, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    b = stepw.sample(x=x0, n_steps=15, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    assert hip_calls("ebm_langevin_step_f32") == before + 15
+    assert torch.equal(a, b)
+    assert a.abs().max().item() <= 2.0
+
+
+def test_schedulers_thin_trajectory_diagnostics_fused(cuda_device):
+    """Scheduled step size / noise scale through the coefficient table; trajectory and
+    diagnostics against the oracle run on the same (materialised) noise."""
+    n, dim, k, thin = 200, 12, 14, 3
+    model = ta.DoubleWellModel(device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=ta.core.LinearScheduler(0.05, 0.01, 10),
+                            noise_scale=ta.core.CosineScheduler(1.0, 0.2, 12), device=cuda_device)
+    x0 = torch.randn(n, dim, device=cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(77)
+    off = gen.get_offset() if hasattr(gen, "get_offset") else 0
+    traj, diag = s.sample(x=x0, n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True, generator=gen)
+    assert s.schedulers["step_size"].step_count == k and s.schedulers["noise_scale"].step_count == k
+    noise = torch.empty(k, n, dim, device=cuda_device)
+    for i in range(k):
+        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * dim, _lib.NOISE_NORMAL, 77, off // 4 + i,
+                  _lib.stream_handle(cuda_device))
+    etas = ta.core.LinearScheduler(0.05, 0.01, 10).preview(k)
+    sigmas = ta.core.CosineScheduler(1.0, 0.2, 12).preview(k)
+    wx, wtraj, wdiag = oracle.langevin_chain(oracle.DoubleWell(), x0.cpu(), noise.cpu(), etas, sigmas, thin=thin,
+                                             want_traj=True, want_diag=True)
+    assert torch.equal(traj.cpu(), wtraj)
+    torch.testing.assert_close(diag["mean"].cpu(), wdiag["mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["var"].cpu(), wdiag["var"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["energy"].cpu(), wdiag["energy"], rtol=1e-5, atol=1e-5)
+    # a second call without reset continues the schedule
+    s.sample(x=x0, n_steps=3, reset_schedulers=False, generator=gen)
+    assert s.schedulers["step_size"].step_count == k + 3
+
+
+def test_no_host_sync_in_sample(cuda_device):
+    """reference tests/core/test_gpu_first.py:116-136: sample() must not synchronise."""
+    model = ta.DoubleWellModel(device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
+    x0 = torch.randn(256, 8, device=cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(1)
+    s.sample(x=x0, n_steps=3, generator=gen)  # warm-up (library load, allocator)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        s.sample(x=x0, n_steps=10, generator=gen)
+        s.sample(x=x0, n_steps=10, thin=2, return_trajectory=True, return_diagnostics=True, generator=gen)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+
+
+def test_gaussian_moment_recovery_native_rng(cuda_device):
+    """reference tests/samplers/test_langevin_dynamics.py:183-213 (rtol/atol 0.2/0.4) -- here
+    with 16k chains the Monte-Carlo error is far below that, so we ask for 0.05."""
+    mean = torch.tensor([1.0, -1.0], device=cuda_device)
+    cov = torch.tensor([[1.0, 0.5], [0.5, 2.0]], device=cuda_device)
+    model = ta.GaussianModel(mean, cov, device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    before = hip_calls("ebm_langevin_chain_f32")
+    x = s.sample(dim=2, n_samples=16384, n_steps=400, generator=torch.Generator(device=cuda_device).manual_seed(3))
+    assert hip_calls("ebm_langevin_chain_f32") == before + 1
+    torch.testing.assert_close(x.mean(0), mean, rtol=0.05, atol=0.05)
+    torch.testing.assert_close(torch.cov(x.T), cov, rtol=0.08, atol=0.08)
+
+
+def test_clamp_semantics(cuda_device):
+    """reference tests/samplers/test_langevin_dynamics.py:216-249."""
+    model = ta.HarmonicModel(device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.5, noise_scale=3.0, clamp=(-0.25, 0.5), device=cuda_device)
+    traj = s.sample(dim=5, n_samples=333, n_steps=10, return_trajectory=True)
+    assert traj.min().item() >= -0.25 and traj.max().item() <= 0.5
+    assert (traj == 0.5).any() and (traj == -0.25).any()
+    with pytest.raises(ValueError):
+        ta.LangevinDynamics(model, clamp=(1.0, 1.0), device=cuda_device)
+
+
+def test_full_size_properties_config2(cuda_device):
+    """BASELINE config 2 shape (n=2^20, dim=64) at a short k: determinism, chain independence
+    from launch geometry (a sub-block of chains run alone gives the same rows), finiteness,
+    and the DoubleWell stationary moments E|x| ~ 0.85 after k=200."""
+    n, dim = 1 << 20, 64
+    model = ta.DoubleWellModel(device=cuda_device)
+    spec = model.fused_spec()
+    x0 = torch.randn(n, dim, device=cuda_device)
+    rows = [em_coefficients(0.01, 1.0)]
+    a = x0.clone()
+    _chain_call(spec, a, 200, rows, None, 1, None, None, seed=2024, step=0)
+    b = x0.clone()
+    _chain_call(spec, b, 200, rows, None, 1, None, None, seed=2024, step=0)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    m = a.abs().mean().item()
+    assert abs(m - 0.854) < 0.01, m
+    # the noise field is addressed by flat element index: rows [0, 4096) processed on their
+    # own see exactly the same field as inside the big launch
+    c = x0[:4096].clone()
+    _chain_call(spec, c, 200, rows, None, 1, None, None, seed=2024, step=0)
+    assert torch.equal(c, a[:4096])
+    # two chains never share noise
+    assert (a[0] - a[1]).abs().max().item() > 1e-3

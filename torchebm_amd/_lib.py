@@ -140,8 +140,21 @@ def dense_f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+#: when an entry-point name is a key here, every call to it is bracketed by a pair of
+#: timing events recorded on the launch stream (bench.py reads kernel durations from it)
+timed_events: dict = {}
+
+
 def call(name: str, *args) -> None:
     """Invoke an int-returning entry point and raise on a non-zero status."""
     fn = getattr(lib(), name)
     call_counts[name] += 1
+    pairs = timed_events.get(name)
+    if pairs is None:
+        check(fn(*args), name)
+        return
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()  # current stream == the stream handed to the kernel (stream_handle)
     check(fn(*args), name)
+    stop.record()
+    pairs.append((start, stop))
