@@ -46,6 +46,7 @@ from torchebm.integrators import EulerMaruyamaIntegrator, LeapfrogIntegrator  # 
 from torchebm.samplers import HamiltonianMonteCarlo, LangevinDynamics  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root, for the oracle package
 torch.set_num_threads(1)
 
 
@@ -148,7 +149,16 @@ def hmc_case(name, energy, n, dim, T, L, step_size, seed, mass=None, thin=1, x0=
     for _ in range(T):
         ps.append(torch.empty(n, dim).normal_(generator=replay))
         us.append(torch.rand(n, generator=replay))
+    # the accept/reject decisions themselves are not returned by the reference; take them from
+    # the oracle restatement AFTER checking that it reproduces the reference bit for bit here
+    import oracle
+    from tests.helpers import oracle_energy
+
+    o = oracle.hmc_chain(oracle_energy(energy), x0, torch.stack(ps), torch.stack(us), sched_values(step_size, T), L,
+                         mass=mass, thin=thin, want_traj=True)
+    assert torch.equal(o["x"], out_final) and torch.equal(o["trajectory"], traj), name
     fx = {
+        "accepted": o["accepted"], "margin": o["margin"],
         "sampler": "hmc", "name": name, "energy": energy, "n": n, "dim": dim, "T": T, "L": L, "thin": thin,
         "mass": mass, "run_seed": run_seed, "x0": x0, "eps": sched_values(step_size, T),
         "p_noise": torch.stack(ps) if store_noise else None, "u": torch.stack(us) if store_noise else None,

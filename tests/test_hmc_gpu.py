@@ -35,10 +35,9 @@ def _hmc_call(spec, x, eps_vals, L, mass, thin, traj, mask, counts, p_noise, u, 
 @pytest.mark.parametrize("name", golden_names("hmc_"))
 def test_hmc_kernel_injected_noise_matches_oracle(cuda_device, name):
     fx = load_golden(name)
-    en = oracle_energy(fx["energy"])
-    want = oracle.hmc_chain(en, fx["x0"], fx["p_noise"], fx["u"], fx["eps"], fx["L"], mass=fx["mass"], thin=fx["thin"],
-                            want_traj=True)
-    assert torch.equal(want["x"], fx["ref"]["x"])  # the oracle is the reference here
+    # expected values: the reference's outputs and the oracle's accept decisions, both stored in
+    # the fixture (the oracle was asserted bit-identical to the reference when it was generated)
+    want = {"x": fx["ref"]["x"], "trajectory": fx["ref"]["trajectory"], "accepted": fx["accepted"], "margin": fx["margin"]}
     model = package_model(fx["energy"], device=cuda_device)
     spec = model.fused_spec()
     n, dim, T, thin = fx["n"], fx["dim"], fx["T"], fx["thin"]

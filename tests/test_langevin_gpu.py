@@ -37,11 +37,9 @@ def _chain_call(spec, x, k, rows, clamp, thin, traj, noise, seed=0, step=0):
 @pytest.mark.parametrize("name", golden_names("ld_"))
 def test_chain_kernel_injected_noise_matches_oracle(cuda_device, name):
     fx = load_golden(name)
-    en = oracle_energy(fx["energy"])
-    want_x, want_traj, _ = oracle.langevin_chain(
-        en, fx["x0"], fx["noise"], fx["etas"], fx["sigmas"], clamp=fx["clamp"], thin=fx["thin"], want_traj=True
-    )
-    assert torch.equal(want_x, fx["ref"]["x"])  # the oracle is the reference here
+    # expected values: the reference's own outputs stored in the fixture (the oracle reproduces
+    # them bit for bit in tests/test_oracle_golden.py)
+    want_x, want_traj = fx["ref"]["x"], fx["ref"]["trajectory"]
     model = package_model(fx["energy"], device=cuda_device)
     spec = model.fused_spec()
     assert spec is not None
