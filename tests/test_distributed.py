@@ -1,0 +1,115 @@
+"""The N > 1 path on CPU: two gloo processes (reference: tests/distributed/dist_harness.py).
+Chains are sharded by rank with per-rank generators (base_seed + rank), sampled independently,
+and read back with one all-gather; plus bench.py's multi-process plumbing under torchrun."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE_SEED = 4321
+N_TOTAL, DIM, K = 101, 6, 9  # 101 chains: uneven shards (51 + 50)
+
+
+def _worker(rank, world, init_file, out_dir):
+    os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    sys.path.insert(0, ROOT)
+    import torchebm_amd as ta
+    from torchebm_amd.utils import all_gather_cat, broadcast_tensor, get_rank, get_world_size, shard_rows
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        assert get_world_size() == world and get_rank() == rank
+        start, count = shard_rows(N_TOTAL)
+        x_all = torch.randn(N_TOTAL, DIM, generator=torch.Generator().manual_seed(0))
+        sampler = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+        gen = torch.Generator().manual_seed(BASE_SEED + rank)
+        mine = sampler.sample(x=x_all[start : start + count], n_steps=K, generator=gen)
+        # equal-sized shards are required by all_gather: pad the short shard, trim after
+        pad = (N_TOTAL + world - 1) // world
+        padded = torch.zeros(pad, DIM)
+        padded[:count] = mine
+        gathered = all_gather_cat(padded)
+        assert gathered.shape == (world * pad, DIM)
+        t = broadcast_tensor(torch.full((3,), float(rank + 7)), src=1)
+        # PCD buffer mixing is an exact partition of the union (reference test_pcd_buffer_ranks.py:83-105)
+        cd = ta.ContrastiveDivergence(ta.DoubleWellModel(), sampler, k_steps=1, persistent=True, buffer_size=8, init_steps=0)
+        cd.get_start_points(torch.zeros(4, DIM))
+        cd.replay_buffer.copy_((torch.arange(8.0) + 100 * rank)[:, None].expand(8, DIM))
+        cd.mix_buffer_across_ranks(generator=torch.Generator().manual_seed(5))
+        torch.save({"start": start, "count": count, "mine": mine, "gathered": gathered, "bcast": t,
+                    "mixed": cd.replay_buffer[:, 0].clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_and_readback_gloo():
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rdv")
+        mp.start_processes(_worker, args=(world, init_file, tmp), nprocs=world, join=True, start_method="spawn")
+        res = [torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(world)]
+    sys.path.insert(0, ROOT)
+    import torchebm_amd as ta
+
+    # shards tile [0, N_TOTAL) contiguously
+    assert res[0]["start"] == 0 and res[0]["count"] == 51 and res[1]["start"] == 51 and res[1]["count"] == 50
+    # every rank's shard equals what a single process computes for those rows with that rank's seed
+    x_all = torch.randn(N_TOTAL, DIM, generator=torch.Generator().manual_seed(0))
+    sampler = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+    for r in range(world):
+        s, c = res[r]["start"], res[r]["count"]
+        want = sampler.sample(x=x_all[s : s + c], n_steps=K, generator=torch.Generator().manual_seed(BASE_SEED + r))
+        assert torch.equal(res[r]["mine"], want)
+    # the gather is rank-ordered and identical on every rank
+    assert torch.equal(res[0]["gathered"], res[1]["gathered"])
+    g = res[0]["gathered"]
+    assert torch.equal(g[:51], res[0]["mine"]) and torch.equal(g[51 : 51 + 50], res[1]["mine"])
+    # different ranks, different noise
+    assert not torch.equal(res[0]["mine"][:50], res[1]["mine"][:50])
+    assert torch.equal(res[0]["bcast"], torch.full((3,), 8.0)) and torch.equal(res[1]["bcast"], torch.full((3,), 8.0))
+    union = torch.cat([res[0]["mixed"], res[1]["mixed"]]).sort().values
+    assert torch.equal(union, torch.cat([torch.arange(8.0), torch.arange(8.0) + 100]))
+    assert not torch.equal(res[0]["mixed"].sort().values, torch.arange(8.0))  # rows actually moved
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_contract_two_processes_cpu():
+    """bench.py launched exactly as the driver does for N > 1 (torch.distributed.run, one process
+    per device), on the CPU plumbing path with gloo: one JSON line from rank 0, aggregate value."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--device", "cpu", "--n-chains", "256", "--dim", "8", "--k", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["metric"] == "MCMC chain-steps/sec" and rec["unit"] == "chain-steps/s" and rec["higher_is_better"] is True
+    assert rec["value"] == pytest.approx(2 * 256 * 3 * 2 / (rec["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert rec["cpu_baseline"] is None  # rank 0 at N = 1 only
+
+
+def test_bench_contract_single_process_cpu():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--device", "cpu",
+           "--n-chains", "128", "--dim", "4", "--k", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec
+    assert rec["n_gpus"] == 1 and rec["dtype"] == "f32" and rec["data"] == "synthetic" and rec["vs_baseline"] is None

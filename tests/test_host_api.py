@@ -1,0 +1,509 @@
+"""Host-side logic on CPU: API contract, CPU route against the golden fixtures, schedulers,
+integrator plug-in rules, generator contract, contrastive divergence.  No GPU needed.
+Modelled on the reference's tests/samplers/test_api_contract.py, test_langevin_dynamics.py,
+test_hmc.py, tests/test_generator.py and tests/losses/test_contrastive_divergence.py."""
+
+import inspect
+import math
+import os
+
+import pytest
+import torch
+
+import torchebm_amd as ta
+from helpers import golden_names, load_golden, package_model
+from torchebm_amd import _lib
+from torchebm_amd.core import (
+    BaseSDERungeKuttaIntegrator,
+    BaseSymplecticIntegrator,
+    ConstantScheduler,
+    CosineScheduler,
+    ExponentialDecayScheduler,
+    LinearScheduler,
+    MultiStepScheduler,
+    TemperatureScheduler,
+    WarmupScheduler,
+)
+from torchebm_amd.integrators import get_integrator, resolve_integrator
+
+torch.set_num_threads(1)
+EXACT = ("double_well", "harmonic")
+
+
+def _check(got, want, kind):
+    if kind in EXACT:
+        assert torch.equal(got, want)
+    else:
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# sample() contract
+# ---------------------------------------------------------------------------------------
+EXPECTED_PARAMS = [
+    ("x", None), ("dim", None), ("n_steps", 100), ("n_samples", 1), ("thin", 1),
+    ("return_trajectory", False), ("return_diagnostics", False), ("reset_schedulers", True),
+]
+
+
+@pytest.mark.parametrize("cls", [ta.LangevinDynamics, ta.HamiltonianMonteCarlo])
+def test_sample_signature(cls):
+    sig = inspect.signature(cls.sample)
+    params = list(sig.parameters.values())[1:]
+    for p, (name, default) in zip(params, EXPECTED_PARAMS):
+        assert p.name == name and p.default == default and p.kind == p.POSITIONAL_OR_KEYWORD
+    tail = {p.name: p for p in params[len(EXPECTED_PARAMS):]}
+    assert set(tail) == {"model_kwargs", "generator"}
+    assert all(p.kind == p.KEYWORD_ONLY and p.default is None for p in tail.values())
+
+
+def test_constructor_signatures_and_validation():
+    names = list(inspect.signature(ta.LangevinDynamics.__init__).parameters)[1:]
+    assert names == ["model", "step_size", "noise_scale", "decay", "clamp", "dtype", "device", "integrator"]
+    names = list(inspect.signature(ta.HamiltonianMonteCarlo.__init__).parameters)[1:]
+    assert names == ["model", "step_size", "n_leapfrog_steps", "mass", "dtype", "device", "integrator"]
+    m = ta.DoubleWellModel()
+    with pytest.raises(ValueError, match="step_size must be positive"):
+        ta.LangevinDynamics(m, step_size=0.0)
+    with pytest.raises(ValueError, match="noise_scale must be positive"):
+        ta.LangevinDynamics(m, noise_scale=-1.0)
+    with pytest.raises(ValueError, match="clamp min must be < max"):
+        ta.LangevinDynamics(m, clamp=(1.0, 0.0))
+    with pytest.raises(ValueError, match="n_leapfrog_steps must be positive"):
+        ta.HamiltonianMonteCarlo(m, n_leapfrog_steps=0)
+    s = ta.LangevinDynamics(m)
+    with pytest.raises(ValueError, match="thin must be >= 1"):
+        s.sample(dim=2, thin=0)
+    with pytest.raises(ValueError, match="dim must be provided"):
+        s.sample()
+    with pytest.raises(ValueError, match="dim must be provided"):
+        ta.HamiltonianMonteCarlo(m).sample(n_samples=3, n_steps=1)
+
+
+def test_return_types_thin_and_tuple_dim():
+    s = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+    out = s.sample(dim=3, n_samples=5, n_steps=7)
+    assert isinstance(out, torch.Tensor) and out.shape == (5, 3)
+    traj = s.sample(dim=3, n_samples=5, n_steps=7, thin=2, return_trajectory=True)
+    assert traj.shape == (5, 3, 3)
+    out, diag = s.sample(dim=3, n_samples=5, n_steps=7, thin=3, return_diagnostics=True)
+    assert out.shape == (5, 3) and diag["mean"].shape == (2, 3) and diag["var"].shape == (2, 3) and diag["energy"].shape == (2,)
+    assert s.sample(dim=(3,), n_samples=4, n_steps=2).shape == (4, 3)
+
+    class Flat(ta.core.BaseModel):  # a model that accepts [B, 2, 3] states
+        def forward(self, x):
+            return 0.5 * x.flatten(1).pow(2).sum(-1)
+
+    out = ta.LangevinDynamics(Flat(), step_size=0.01).sample(dim=(2, 3), n_samples=4, n_steps=2)
+    assert out.shape == (4, 2, 3)
+    one, diag = s.sample(dim=3, n_samples=1, n_steps=2, return_diagnostics=True)
+    assert torch.equal(diag["var"], torch.zeros(2, 3))
+    h = ta.HamiltonianMonteCarlo(ta.GaussianModel(torch.zeros(2), torch.eye(2)), step_size=0.1)
+    out, diag = h.sample(n_samples=6, n_steps=4, thin=2, return_diagnostics=True)
+    assert out.shape == (6, 2) and set(diag) == {"mean", "var", "energy", "acceptance_rate"}
+    assert diag["acceptance_rate"].shape == (2,)
+
+
+# ---------------------------------------------------------------------------------------
+# CPU route (BASELINE config 1 plumbing) against the reference's recorded outputs
+# ---------------------------------------------------------------------------------------
+def _sched(values):
+    """Rebuild a scheduler object producing the recorded per-step values (constant or table)."""
+    if len(set(values)) == 1:
+        return values[0]
+
+    class Table(ta.core.BaseScheduler):
+        def __init__(self, vals):
+            super().__init__(vals[0])
+            self.vals = list(vals)
+
+        def _compute_value(self):
+            return self.vals[min(self.step_count, len(self.vals) - 1)]
+
+    return Table(values)
+
+
+@pytest.mark.parametrize("name", golden_names("ld_"))
+def test_langevin_cpu_route_reproduces_reference(name):
+    fx = load_golden(name)
+    kind = fx["energy"]["kind"]
+    s = ta.LangevinDynamics(package_model(fx["energy"]), step_size=_sched(fx["etas"]), noise_scale=_sched(fx["sigmas"]),
+                            clamp=fx["clamp"])
+    gen = torch.Generator().manual_seed(fx["run_seed"])
+    x0 = fx["x0"].clone()
+    out = s.sample(x=x0, n_steps=fx["k"], generator=gen)
+    _check(out, fx["ref"]["x"], kind)
+    assert torch.equal(x0, fx["x0"])
+    traj, diag = s.sample(x=x0, n_steps=fx["k"], thin=fx["thin"], return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator().manual_seed(fx["run_seed"]))
+    _check(traj, fx["ref"]["trajectory"], kind)
+    for key in ("mean", "var", "energy"):
+        torch.testing.assert_close(diag[key], fx["ref"]["diagnostics"][key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("hmc_"))
+def test_hmc_cpu_route_reproduces_reference(name):
+    fx = load_golden(name)
+    kind = fx["energy"]["kind"]
+    s = ta.HamiltonianMonteCarlo(package_model(fx["energy"]), step_size=_sched(fx["eps"]), n_leapfrog_steps=fx["L"],
+                                 mass=fx["mass"])
+    out, diag = s.sample(x=fx["x0"].clone(), n_steps=fx["T"], thin=1, return_diagnostics=True,
+                         generator=torch.Generator().manual_seed(fx["run_seed"]))
+    _check(out, fx["ref"]["x"], kind)
+    assert torch.equal(diag["acceptance_rate"], fx["ref"]["acceptance_rate_all"])
+
+
+def test_config1_checksum():
+    """BASELINE config 1: LangevinDynamics on the 2-D Gaussian, n=1024, k=100, CPU."""
+    fx = load_golden("survey_ld_gauss2d")
+    s = ta.LangevinDynamics(ta.GaussianModel(torch.zeros(2), torch.eye(2)), step_size=0.01, noise_scale=1.0)
+    x = s.sample(dim=2, n_samples=1024, n_steps=100, generator=torch.Generator().manual_seed(0))
+    torch.testing.assert_close(x, fx["ref"]["x"], rtol=2e-5, atol=2e-5)
+    fx = load_golden("survey_ld_dw")
+    s = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01, noise_scale=1.0)
+    x = s.sample(dim=64, n_samples=512, n_steps=50, generator=torch.Generator().manual_seed(123))
+    assert torch.equal(x, fx["ref"]["x"])
+
+
+def test_integrators_cpu_known_answers():
+    fx = load_golden("integrators")
+    drift = lambda x_, t_: -(x_**3)  # noqa: E731
+    em, lf = ta.EulerMaruyamaIntegrator(), ta.LeapfrogIntegrator()
+    x, p = fx["x"], fx["p"]
+    assert torch.equal(em.step({"x": x}, 0.01, drift=drift, noise=fx["noise"], noise_scale=0.7)["x"], fx["em_sde"])
+    assert torch.equal(em.step({"x": x}, 0.01, drift=drift)["x"], fx["em_ode"])
+    out = lf.step({"x": x, "p": p}, 0.05, 2.5, drift=drift)
+    assert torch.equal(out["x"], fx["lf_step_mass"]["x"]) and torch.equal(out["p"], fx["lf_step_mass"]["p"])
+    out = lf.integrate({"x": x, "p": p}, 0.05, 7, fx["mass_t"], drift=drift, safe=True)
+    assert torch.equal(out["x"], fx["lf_int_mass_t_safe"]["x"]) and torch.equal(out["p"], fx["lf_int_mass_t_safe"]["p"])
+    out = lf.step({"x": fx["bad_x"], "p": p}, 0.05, drift=drift, safe=True)
+    assert torch.equal(out["x"], fx["lf_step_safe_bad"]["x"])
+    assert torch.equal(x, fx["x"]) and torch.equal(p, fx["p"])
+    with pytest.raises(ValueError, match="drift must be provided"):
+        lf.step({"x": x, "p": p}, 0.05)
+    with pytest.raises(ValueError, match="n_steps must be positive"):
+        lf.integrate({"x": x, "p": p}, 0.05, -1, drift=drift)
+    with torch.inference_mode():
+        a = lf.integrate({"x": x, "p": p}, 0.05, 3, drift=drift)
+    b = lf.integrate({"x": x, "p": p}, 0.05, 3, drift=drift, inference_mode=True)
+    assert torch.equal(a["x"], b["x"])
+
+
+# ---------------------------------------------------------------------------------------
+# integrator plug-in rules (reference tests/samplers/test_langevin_dynamics.py:252-299)
+# ---------------------------------------------------------------------------------------
+def test_integrator_resolution_rules():
+    m = ta.DoubleWellModel()
+    assert isinstance(ta.LangevinDynamics(m).integrator, ta.EulerMaruyamaIntegrator)
+    assert isinstance(ta.LangevinDynamics(m, integrator="euler_maruyama").integrator, ta.EulerMaruyamaIntegrator)
+    inst = ta.EulerMaruyamaIntegrator(device=torch.device("cpu"), dtype=torch.float32)
+    assert ta.LangevinDynamics(m, integrator=inst).integrator is inst
+    with pytest.raises(TypeError, match="requires a BaseSDERungeKuttaIntegrator"):
+        ta.LangevinDynamics(m, integrator=ta.LeapfrogIntegrator(device=torch.device("cpu"), dtype=torch.float32))
+    with pytest.raises(TypeError, match="requires a BaseSDERungeKuttaIntegrator"):
+        ta.LangevinDynamics(m, integrator="leapfrog")
+    with pytest.raises(ValueError, match="does not match"):
+        ta.LangevinDynamics(m, integrator=ta.EulerMaruyamaIntegrator(dtype=torch.float64))
+    with pytest.raises(ValueError, match="Unknown integrator"):
+        ta.LangevinDynamics(m, integrator="nope")
+    with pytest.raises(ValueError, match="ODE/flow family"):
+        get_integrator("dopri5")
+    assert isinstance(ta.HamiltonianMonteCarlo(m).integrator, ta.LeapfrogIntegrator)
+
+    class NonSeparable(BaseSymplecticIntegrator):
+        separable = False
+
+        def step(self, state, step_size, *a, **k):
+            return state
+
+        def integrate(self, state, step_size, n_steps, *a, **k):
+            return state
+
+    with pytest.raises(TypeError, match="separable"):
+        ta.HamiltonianMonteCarlo(m, integrator=NonSeparable(device=torch.device("cpu"), dtype=torch.float32))
+    r = resolve_integrator(None, default="leapfrog", family=BaseSymplecticIntegrator, owner="X",
+                           device=torch.device("cpu"), dtype=torch.float32)
+    assert isinstance(r, ta.LeapfrogIntegrator) and not isinstance(r, BaseSDERungeKuttaIntegrator)
+
+
+def test_custom_integrator_instance_is_used_on_the_eager_route():
+    calls = []
+
+    class Counting(ta.EulerMaruyamaIntegrator):
+        def step(self, state, step_size, **kw):
+            calls.append(step_size)
+            return super().step(state, step_size, **kw)
+
+    s = ta.LangevinDynamics(ta.HarmonicModel(), step_size=0.1, integrator=Counting(device=torch.device("cpu"), dtype=torch.float32))
+    s.sample(dim=2, n_samples=3, n_steps=4)
+    assert calls == [0.1] * 4
+
+
+# ---------------------------------------------------------------------------------------
+# generator contract (reference tests/test_generator.py:74-113)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("make", [
+    lambda: ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01),
+    lambda: ta.HamiltonianMonteCarlo(ta.DoubleWellModel(), step_size=0.05, n_leapfrog_steps=3),
+])
+def test_generator_contract_cpu(make):
+    s = make()
+    a = s.sample(dim=4, n_samples=32, n_steps=5, generator=torch.Generator().manual_seed(1))
+    b = s.sample(dim=4, n_samples=32, n_steps=5, generator=torch.Generator().manual_seed(1))
+    c = s.sample(dim=4, n_samples=32, n_steps=5, generator=torch.Generator().manual_seed(2))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    torch.manual_seed(7)
+    d1 = s.sample(dim=4, n_samples=32, n_steps=5)
+    torch.manual_seed(7)
+    d2 = s.sample(dim=4, n_samples=32, n_steps=5)
+    assert torch.equal(d1, d2)
+    torch.manual_seed(7)
+    state = torch.get_rng_state()
+    s.sample(dim=4, n_samples=32, n_steps=5, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(state, torch.get_rng_state())  # explicit generator leaves the global RNG alone
+
+
+# ---------------------------------------------------------------------------------------
+# schedulers and pre-expansion
+# ---------------------------------------------------------------------------------------
+def _walk(s, k):
+    out = []
+    for _ in range(k):
+        out.append(s.get_value())
+        s.step()
+    return out
+
+
+@pytest.mark.parametrize("make", [
+    lambda: ConstantScheduler(0.3),
+    lambda: ExponentialDecayScheduler(1.0, 0.9, 0.5),
+    lambda: LinearScheduler(1.0, 0.0, 5),
+    lambda: CosineScheduler(0.1, 0.001, 7),
+    lambda: MultiStepScheduler(0.1, [2, 5], 0.1),
+    lambda: WarmupScheduler(CosineScheduler(0.1, 0.01, 6), 3, 0.01),
+    lambda: TemperatureScheduler(0.5, 0.4, 8),
+])
+def test_preview_and_advance_match_stepping(make):
+    a, b = make(), make()
+    assert a.preview(12) == _walk(b, 12)
+    assert a.step_count == 0  # preview did not touch it
+    a.advance(12)
+    assert a.step_count == b.step_count == 12 and a.get_value() == b.get_value()
+    a.reset()
+    assert a.step_count == 0 and a.get_value() == make().get_value()
+    c = make()
+    c.load_state_dict(b.state_dict())
+    assert c.get_value() == b.get_value() and c.step_count == 12
+
+
+def test_scheduler_formulas_and_validation():
+    assert _walk(LinearScheduler(1.0, 0.0, 5), 7) == pytest.approx([1.0, 0.8, 0.6, 0.4, 0.2, 0.0, 0.0])
+    assert _walk(ExponentialDecayScheduler(1.0, 0.9, 0.8), 4) == pytest.approx([1.0, 0.9, 0.81, 0.8])
+    assert _walk(MultiStepScheduler(1.0, [1, 3], 0.5), 5) == pytest.approx([1.0, 0.5, 0.5, 0.25, 0.25])
+    c = _walk(CosineScheduler(1.0, 0.0, 4), 6)
+    assert c[0] == 1.0 and c[2] == pytest.approx(0.5) and c[4] == 0.0 and c[5] == 0.0
+    w = _walk(WarmupScheduler(ConstantScheduler(1.0), 4, 0.0), 7)
+    assert w == pytest.approx([0.0, 0.25, 0.5, 0.75, 1.0, 1.0, 1.0])
+    t = TemperatureScheduler(0.36, tau_star=0.5, n_steps=4)
+    assert _walk(t, 5) == pytest.approx([0.0, 0.0, 0.0, math.sqrt(0.18), 0.6])
+    for bad in (lambda: ExponentialDecayScheduler(1.0, 1.5), lambda: LinearScheduler(1.0, 0.0, 0),
+                lambda: MultiStepScheduler(1.0, [3, 2]), lambda: TemperatureScheduler(-1.0)):
+        with pytest.raises(ValueError):
+            bad()
+    with pytest.raises(TypeError):
+        ConstantScheduler("x")
+
+
+def test_sampler_steps_and_resets_schedulers():
+    s = ta.LangevinDynamics(ta.HarmonicModel(), step_size=LinearScheduler(0.1, 0.01, 10))
+    s.sample(dim=2, n_samples=2, n_steps=4)
+    assert s.schedulers["step_size"].step_count == 4
+    s.sample(dim=2, n_samples=2, n_steps=3, reset_schedulers=False)
+    assert s.schedulers["step_size"].step_count == 7
+    s.sample(dim=2, n_samples=2, n_steps=2)
+    assert s.schedulers["step_size"].step_count == 2
+    with pytest.raises(KeyError):
+        s.get_scheduled_value("nope")
+
+
+# ---------------------------------------------------------------------------------------
+# energies
+# ---------------------------------------------------------------------------------------
+def test_energy_models_and_fused_specs():
+    x = torch.randn(9, 5)
+    dw = ta.DoubleWellModel(1.5, 0.7)
+    torch.testing.assert_close(dw.gradient(x), 4 * 1.5 * x * (x**2 - 0.49))
+    spec = dw.fused_spec()
+    assert spec.kind == _lib.ENERGY_DOUBLE_WELL and spec.elementwise and spec.scalars[0] == 1.5 and spec.scalars[1] == 0.7**2
+    hm = ta.HarmonicModel(3.0)
+    torch.testing.assert_close(hm.gradient(x), 3.0 * x)
+    assert hm.fused_spec().scalars[0] == 1.5
+    g = ta.GaussianModel(torch.zeros(2), torch.tensor([[2.0, 0.3], [0.3, 1.0]]))
+    sp = g.fused_spec()
+    assert sp.kind == _lib.ENERGY_GAUSSIAN and torch.equal(sp.dev1, sp.dev1.t())
+    with pytest.raises(ValueError):
+        g(torch.randn(4, 3))
+    with pytest.raises(ValueError):
+        ta.GaussianModel(torch.zeros(2, 1), torch.eye(2))
+    with pytest.raises(ValueError):
+        ta.GaussianModel(torch.zeros(2), torch.zeros(2, 2))
+    gm = ta.core.ring_mixture(8, 32)
+    assert gm.fused_spec().n_comp == 8 and gm.mean.shape == (32,)
+    xx = torch.randn(6, 32)
+    r = torch.softmax(gm.log_weights - ((xx[:, None] - gm.means[None]) ** 2).sum(-1) / 2, dim=1)
+    torch.testing.assert_close(gm.gradient(xx), (r[:, :, None] * (xx[:, None] - gm.means[None])).sum(1), rtol=1e-5, atol=1e-6)
+
+    class Sub(ta.DoubleWellModel):
+        def forward(self, x):
+            return super().forward(x) + 1.0
+
+    assert Sub().fused_spec() is None  # not the same function any more: never fused
+
+    class NoGrad(ta.core.BaseModel):
+        def forward(self, x):
+            return torch.zeros(x.shape[0])
+
+    with pytest.raises(RuntimeError, match="differentiable"):
+        NoGrad().gradient(x)
+
+    class BadShape(ta.core.BaseModel):
+        def forward(self, x):
+            return x.sum()
+
+    with pytest.raises(ValueError, match="expected shape"):
+        BadShape().gradient(x)
+    assert dw.gradient(x.double()).dtype == torch.float64
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libebm_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.call("ebm_noise_fill_f32", 16, 4, 0, 0, 0, None)
+
+
+# ---------------------------------------------------------------------------------------
+# contrastive divergence (caller of the path)
+# ---------------------------------------------------------------------------------------
+class FakeSampler:
+    """Duck-typed sampler (reference tests/losses/test_contrastive_divergence.py:112-152)."""
+
+    def __init__(self, shift=0.5):
+        self.shift = shift
+        self.calls = []
+
+    def sample(self, x=None, n_steps=1, **kw):
+        self.calls.append((tuple(x.shape), n_steps, sorted(kw)))
+        return (x + self.shift).detach()
+
+
+class TinyEnergy(ta.core.BaseModel):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([1.0, -0.5]))
+
+    def forward(self, x):
+        return (x * self.w).sum(-1) ** 2
+
+
+def test_cd_loss_and_gradients():
+    model, fake = TinyEnergy(), FakeSampler()
+    cd = ta.ContrastiveDivergence(model, fake, k_steps=7, energy_reg_weight=0.0)
+    x = torch.randn(16, 2)
+    loss, neg = cd(x)
+    assert fake.calls == [((16, 2), 7, ["generator", "model_kwargs"])]
+    assert torch.equal(neg, x + 0.5)
+    torch.testing.assert_close(loss, model(x).mean() - model(neg).mean())
+    loss.backward()
+    assert model.w.grad is not None and torch.isfinite(model.w.grad).all()
+    cd2 = ta.ContrastiveDivergence(model, fake, k_steps=1, energy_reg_weight=0.1)
+    l2, _ = cd2(x)
+    torch.testing.assert_close(l2, loss.detach() + 0.1 * ((model(x) ** 2).mean() + (model(neg) ** 2).mean()))
+
+
+def test_cd_nonfinite_loss_falls_back():
+    class NanEnergy(ta.core.BaseModel):
+        def forward(self, x):
+            return x.sum(-1) * float("nan")
+
+    loss, _ = ta.ContrastiveDivergence(NanEnergy(), FakeSampler(), k_steps=1)(torch.randn(4, 2))
+    assert loss.item() == pytest.approx(0.1)
+
+
+def test_pcd_buffer_fifo_and_stratified_reads():
+    model, fake = TinyEnergy(), FakeSampler(0.0)
+    cd = ta.ContrastiveDivergence(model, fake, k_steps=1, persistent=True, buffer_size=12, init_steps=0, new_sample_ratio=0.0)
+    x = torch.randn(4, 2)
+    g = torch.Generator().manual_seed(0)
+    starts = cd.get_start_points(x, generator=g)
+    assert cd.buffer_initialized and cd.replay_buffer.shape == (12, 2) and starts.shape == (4, 2)
+    assert cd.replay_buffer.abs().max() < 0.1  # 0.01-scale noise
+    cd.replay_buffer.copy_(torch.arange(12.0)[:, None].expand(12, 2))
+    rows = cd.get_start_points(x, generator=g)[:, 0]
+    assert all(3 * i <= rows[i].item() < 3 * (i + 1) for i in range(4))  # one row per stride
+    cd.update_buffer(torch.full((5, 2), 100.0))
+    assert cd._write_pos == 5 and cd.buffer_ptr.item() == 5 and (cd.replay_buffer[:5] == 100).all()
+    cd.update_buffer(torch.full((9, 2), 200.0))  # wraps: rows 5..11 then 0..1
+    assert cd._write_pos == 2 and (cd.replay_buffer[5:] == 200).all() and (cd.replay_buffer[:2] == 200).all()
+    assert (cd.replay_buffer[2:5] == 100).all()
+    cd.update_buffer(torch.arange(40.0).view(20, 2))  # larger than the buffer: keeps the last 12
+    assert cd._write_pos == 0 and torch.equal(cd.replay_buffer, torch.arange(40.0).view(20, 2)[-12:])
+    sd = cd.state_dict()
+    assert "replay_buffer" in sd and "buffer_ptr" in sd
+    with pytest.warns(UserWarning, match="smaller than batch size"):
+        cd.get_start_points(torch.randn(20, 2))
+
+
+def test_pcd_training_step_with_real_sampler_cpu():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 16), torch.nn.SiLU(), torch.nn.Linear(16, 1))
+
+    class Mlp(ta.core.BaseModel):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return self.net(x).squeeze(-1)
+
+    model = Mlp()
+    sampler = ta.LangevinDynamics(model, step_size=0.1, noise_scale=1.0)
+    cd = ta.ContrastiveDivergence(model, sampler, k_steps=3, persistent=True, buffer_size=64, init_steps=2)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    before = [p.detach().clone() for p in model.parameters()]
+    loss, neg = cd(torch.randn(32, 2), generator=torch.Generator().manual_seed(1))
+    assert neg.shape == (32, 2) and not neg.requires_grad and torch.isfinite(loss)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torchebm"), reason="reference checkout not present")
+def test_reference_cd_runs_unmodified_on_this_sampler():
+    """Drop-in check (authoring container only): the REFERENCE's ContrastiveDivergence drives this
+    package's LangevinDynamics and gets the same negatives as with its own sampler."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, types
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r)
+v = types.ModuleType("torchebm._version"); v.__version__ = "0"; sys.modules["torchebm._version"] = v
+import torch
+from torchebm.core import DoubleWellModel as RefDW
+from torchebm.losses import ContrastiveDivergence as RefCD
+from torchebm.samplers import LangevinDynamics as RefLD
+import torchebm_amd as ta
+x = torch.randn(64, 4, generator=torch.Generator().manual_seed(0))
+ref_model = RefDW()
+mine = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+theirs = RefLD(ref_model, step_size=0.01)
+la, na = RefCD(ref_model, mine, k_steps=5)(x, generator=torch.Generator().manual_seed(1))
+lb, nb = RefCD(ref_model, theirs, k_steps=5)(x, generator=torch.Generator().manual_seed(1))
+assert torch.equal(na, nb) and torch.equal(la, lb)
+print("dropin-ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "dropin-ok" in out.stdout, out.stderr[-2000:]

@@ -100,8 +100,8 @@ class LangevinDynamics(BaseSampler):
         spec = None
         if not model_kwargs and hasattr(self.model, "fused_spec") and not isinstance(self.model, Schedulable):
             spec = self.model.fused_spec()
-            if spec is not None and not (spec.elementwise or x.ndim == 2):
-                spec = None
+            if spec is not None and x.ndim != 2:
+                spec = None  # the analytic energies reduce over the last axis only: [n, dim] states
             if spec is not None and any(
                 t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)
             ):
