@@ -102,10 +102,9 @@ __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
 
 // torch.nan_to_num_(nan=0.0): NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX.
 __device__ __forceinline__ float nan_to_num0(float v) {
-  if (v != v) return 0.0f;
-  if (v == __builtin_inff()) return 3.402823466e+38f;
-  if (v == -__builtin_inff()) return -3.402823466e+38f;
-  return v;
+  float r = (v > 3.402823466e+38f) ? 3.402823466e+38f : v;   // +inf
+  r = (v < -3.402823466e+38f) ? -3.402823466e+38f : r;       // -inf
+  return (v != v) ? 0.0f : r;                                  // NaN
 }
 
 __host__ __device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -6,6 +6,8 @@
 // Philox counter) per lane, so a wave64 load/store is one fully coalesced 1 KiB request.
 // The k-fused kernel keeps its four elements in VGPRs for all k steps: HBM is touched
 // once for the read and once for the write, plus the thinned trajectory rows.
+#include <cstdlib>
+
 #include "ebm_common.h"
 
 namespace ebm {
@@ -185,6 +187,41 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a
   store4(a.x, e0, nv, true, x);
 }
 
+// ---------------------------------------------------------------------------------
+// Lean variant for the headline case (native RNG, constant coefficients, no clamp, no
+// trajectory): nothing but Philox + Box-Muller + gradient + update inside the loop, and GPT
+// independent float4 groups per lane so that the quarter-rate 64-bit multiplies of one
+// group overlap the transcendentals / packed-f32 math of another.  A block owns
+// 256*GPT consecutive groups; lane t takes groups t, t+256, ... (each wave access stays
+// one contiguous 1 KiB piece).
+// ---------------------------------------------------------------------------------
+template <int KIND, int GPT>
+__global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
+  const int64_t g0 = (int64_t)blockIdx.x * (kBlock * GPT) + threadIdx.x;
+  F4 x[GPT];
+  int nv[GPT];
+#pragma unroll
+  for (int j = 0; j < GPT; ++j) {
+    const int64_t e0 = (g0 + (int64_t)j * kBlock) * 4;
+    const int64_t left = a.n_elem - e0;
+    nv[j] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+    x[j] = load4(a.x, e0 < a.n_elem ? e0 : 0, nv[j], true);
+  }
+  const StepCoef c = a.c;
+  for (int i = 0; i < a.k_steps; ++i) {
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+      const F4 eps = normal4_at(a.key, (uint64_t)(g0 + (int64_t)j * kBlock), a.step0 + (uint64_t)i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        x[j].v[q] = em_update(x[j].v[q], elem_grad<KIND>(x[j].v[q], a.s0, a.s1), eps.v[q], c);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GPT; ++j)
+    if (nv[j] > 0) store4(a.x, (g0 + (int64_t)j * kBlock) * 4, nv[j], true, x[j]);
+}
+
 int grid_for(int64_t n_threads, int max_blocks) {
   int64_t b = ceil_div64(n_threads, kBlock);
   if (b < 1) b = 1;
@@ -231,6 +268,24 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   const int64_t blocks = ceil_div64(n_groups, kBlock);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
   const dim3 grid((unsigned)blocks), block(kBlock);
+  if (!noise && !traj && !coef_table && !clamp_on) {
+    static const int gpt_env = [] {
+      const char* e = getenv("EBM_CHAIN_GPT");
+      return e ? atoi(e) : 0;
+    }();
+    const int gpt = (gpt_env == 1 || gpt_env == 2 || gpt_env == 4) ? gpt_env : 2;
+    const dim3 lgrid((unsigned)ceil_div64(n_groups, (int64_t)kBlock * gpt));
+#define EBM_LEAN(KIND)                                                                            \
+  do {                                                                                            \
+    if (gpt == 1) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 1>), lgrid, block, 0, st, a);      \
+    else if (gpt == 2) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 2>), lgrid, block, 0, st, a); \
+    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 4>), lgrid, block, 0, st, a);               \
+  } while (0)
+    if (kind == EBM_ENERGY_DOUBLE_WELL) EBM_LEAN(EBM_ENERGY_DOUBLE_WELL);
+    else EBM_LEAN(EBM_ENERGY_HARMONIC);
+#undef EBM_LEAN
+    return check_launch("ebm_langevin_chain_f32");
+  }
 #define EBM_LAUNCH(KIND)                                                                         \
   do {                                                                                           \
     if (noise) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, true>), grid, block, 0, st, a);  \

@@ -1,0 +1,579 @@
+// Shared device templates of the row-coupled kernels (hmc.hip, rows_langevin.hip).
+//
+// Layout ("lane group per chain"): a chain row x[c, 0:dim] is owned by G consecutive
+// lanes of one wavefront (G a power of two, 1..64), each lane holding NV float4 vectors:
+// lane lg owns columns (v*G + lg)*4 .. +3 for v < NV.  A wave64 therefore covers 64/G
+// whole chains, its global loads/stores of the chain matrix are contiguous 16-byte
+// pieces (fully coalesced for dim % 4 == 0), and every per-chain scalar -- potential
+// energy, kinetic energy, mixture log-likelihoods, the Metropolis decision -- is a
+// cross-lane reduction inside the wavefront (DPP for spans <= 16 lanes, bpermute above),
+// never a trip through memory.  The state stays in VGPRs across all MH / Langevin steps;
+// LDS holds the shared energy parameters (precision matrix, mixture means) and the
+// per-wave exchange buffer the Gaussian mat-vec needs.
+//
+// FULL = (dim == 4*G*NV): every slot of every lane is a real column, so the per-slot
+// validity selects disappear from the inner loops; lanes of chains past n_chains then
+// compute on zeros and are only prevented from loading/storing.
+#pragma once
+#include "ebm_common.h"
+
+namespace ebm {
+namespace rows {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kParamLdsBudget = 56 * 1024;  // bytes of LDS the shared parameters may take
+
+// ---------------------------------------------------------------------------------
+// cross-lane helpers
+// ---------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// All-reduce sum over the G lanes of a chain; every lane of the group ends with the
+// bit-identical total (each level adds a value to its mirror image).
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (G >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if constexpr (G >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if constexpr (G >= 32) v += __shfl_xor(v, 16);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ bool group_any(bool flag) {
+  if constexpr (G == 1) return flag;
+  const unsigned long long b = __ballot(flag);
+  if constexpr (G == 64) return b != 0ull;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = ((1ull << (G & 63)) - 1ull) << (lane & ~(G - 1));
+  return (b & m) != 0ull;
+}
+
+// ---------------------------------------------------------------------------------
+// geometry of one lane
+// ---------------------------------------------------------------------------------
+template <int G_, int NV_, bool FULL_>
+struct Lane {
+  static constexpr int G = G_;
+  static constexpr int NV = NV_;
+  static constexpr bool FULL = FULL_;
+
+  int64_t chain;      // chain row owned by this lane's group
+  int lg;             // lane index inside the group
+  int chain_in_wave;  // 0 .. 64/G-1
+  bool active;        // chain < n_chains
+  bool vec_ok;        // dim % 4 == 0: float4 global accesses are aligned
+  int dim;
+  int col[NV];        // first column of vector v
+  unsigned valid;     // bit (v*4+i): column col[v]+i < dim and the chain is active
+
+  __device__ __forceinline__ void init(int64_t n_chains, int dim_) {
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    chain = tid / G;
+    lg = (int)(tid % G);
+    chain_in_wave = (threadIdx.x & 63) / G;
+    active = chain < n_chains;
+    dim = dim_;
+    vec_ok = FULL || (dim_ & 3) == 0;
+    valid = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      col[v] = (v * G + lg) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (active && col[v] + i < dim_) valid |= 1u << (v * 4 + i);
+    }
+  }
+  // "this slot is a real element that takes part in the arithmetic"
+  __device__ __forceinline__ bool ok(int v, int i) const {
+    if constexpr (FULL) return true;
+    return (valid >> (v * 4 + i)) & 1u;
+  }
+  // "this slot may be loaded from / stored to memory"
+  __device__ __forceinline__ bool mem_ok(int v, int i) const { return (valid >> (v * 4 + i)) & 1u; }
+  __device__ __forceinline__ bool mem_full(int v) const { return ((valid >> (v * 4)) & 0xFu) == 0xFu; }
+  __device__ __forceinline__ bool col_ok(int v, int i) const {
+    if constexpr (FULL) return true;
+    return col[v] + i < dim;
+  }
+};
+
+template <int NV>
+struct Slice {
+  float a[NV][4];
+};
+
+template <class LaneT>
+__device__ __forceinline__ void load_slice(const LaneT& L, const float* __restrict__ base,
+                                           int64_t row_off, Slice<LaneT::NV>& s) {
+#pragma unroll
+  for (int v = 0; v < LaneT::NV; ++v) {
+    if (L.vec_ok && L.mem_full(v)) {
+      const float4 t = *reinterpret_cast<const float4*>(base + row_off + L.col[v]);
+      s.a[v][0] = t.x; s.a[v][1] = t.y; s.a[v][2] = t.z; s.a[v][3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.a[v][i] = L.mem_ok(v, i) ? base[row_off + L.col[v] + i] : 0.0f;
+    }
+  }
+}
+
+template <class LaneT>
+__device__ __forceinline__ void store_slice(const LaneT& L, float* __restrict__ base,
+                                            int64_t row_off, const Slice<LaneT::NV>& s) {
+#pragma unroll
+  for (int v = 0; v < LaneT::NV; ++v) {
+    if (L.vec_ok && L.mem_full(v)) {
+      *reinterpret_cast<float4*>(base + row_off + L.col[v]) =
+          make_float4(s.a[v][0], s.a[v][1], s.a[v][2], s.a[v][3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (L.mem_ok(v, i)) base[row_off + L.col[v] + i] = s.a[v][i];
+    }
+  }
+}
+
+// Load a [dim] parameter vector slice (mean, diagonal mass); `fill` in invalid slots.
+template <class LaneT>
+__device__ __forceinline__ void load_param_slice(const LaneT& L, const float* __restrict__ p,
+                                                 float fill, Slice<LaneT::NV>& s) {
+#pragma unroll
+  for (int v = 0; v < LaneT::NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.a[v][i] = L.col_ok(v, i) ? p[L.col[v] + i] : fill;
+}
+
+// Native-RNG normals for this lane's slice at `step` (flat element e = chain*dim + col).
+template <class LaneT>
+__device__ __forceinline__ void normal_slice(const LaneT& L, RngKey key, uint64_t step,
+                                             Slice<LaneT::NV>& s) {
+  const uint64_t row0 = (uint64_t)L.chain * (uint64_t)L.dim;
+#pragma unroll
+  for (int v = 0; v < LaneT::NV; ++v) {
+    if (L.vec_ok) {  // e % 4 == 0: the slice vector is exactly one Philox counter
+      const F4 n = normal4_at(key, (row0 + (uint64_t)L.col[v]) >> 2, step);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.a[v][i] = n.v[i];
+    } else {
+      uint64_t have = ~0ull;
+      F4 n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t e = row0 + (uint64_t)(L.col[v] + i);
+        if ((e >> 2) != have) {
+          have = e >> 2;
+          n = normal4_at(key, have, step);
+        }
+        const int r = (int)(e & 3);
+        s.a[v][i] = r == 0 ? n.v[0] : (r == 1 ? n.v[1] : (r == 2 ? n.v[2] : n.v[3]));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// energies: E(x) (group-reduced, identical on every lane of the group) and dE/dx for
+// this lane's slice.  Slots with !ok() hold x = 0 and must yield g = 0 and no energy.
+// ---------------------------------------------------------------------------------
+struct EnergyParams {
+  int kind;
+  int n_comp;
+  int n_comp_pad;     // components staged in LDS (>= 8: rows past n_comp are zero, their log-weight -inf)
+  float s0, s1;
+  const float* dev0;  // global
+  const float* dev1;
+  int param_in_lds;   // shared parameters were staged into LDS
+  int dim_pad;        // row stride of the staged parameters (dim rounded up to 4)
+};
+
+// LDS carve-up (dynamic shared memory, 16-byte aligned):
+//   [0, param_floats)                      shared parameters (P rows / mixture means + log-weights)
+//   [param_floats, + waves * xchg_floats)  per-wave exchange rows (Gaussian only)
+struct Smem {
+  float* param;
+  float* xchg;  // this wave's exchange buffer
+};
+
+template <int KIND, class LaneT>
+struct Energy;
+
+template <class LaneT>
+struct Energy<EBM_ENERGY_DOUBLE_WELL, LaneT> {
+  static constexpr int G = LaneT::G, NV = LaneT::NV;
+  float h, b2;
+  __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem&) {
+    h = P.s0; b2 = P.s1;
+  }
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv = x.a[v][i];
+        const float u = xv * xv - b2;
+        const bool ok = L.ok(v, i);
+        g.a[v][i] = ok ? (h * (2.0f * u)) * (2.0f * xv) : 0.0f;
+        if (WANT_E) acc += ok ? u * u : 0.0f;
+      }
+    if (!WANT_E) return 0.0f;
+    return h * group_sum<G>(acc);
+  }
+};
+
+template <class LaneT>
+struct Energy<EBM_ENERGY_HARMONIC, LaneT> {
+  static constexpr int G = LaneT::G, NV = LaneT::NV;
+  float hk;
+  __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem&) { hk = P.s0; }
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval(const LaneT&, const Slice<NV>& x, Slice<NV>& g) const {
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv = x.a[v][i];  // invalid slots are 0 and contribute 0
+        g.a[v][i] = hk * (2.0f * xv);
+        if (WANT_E) acc += xv * xv;
+      }
+    if (!WANT_E) return 0.0f;
+    return hk * group_sum<G>(acc);
+  }
+};
+
+// Gaussian: g = Ps d with Ps = (P + P^T)/2 (what autograd returns for 0.5 d^T P d), staged
+// row-major in LDS; d is exchanged through the wave's LDS row so that every lane can walk
+// all dim coordinates of its chain.  Ps symmetric => column slice of row j == needed block.
+template <class LaneT>
+struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
+  static constexpr int G = LaneT::G, NV = LaneT::NV;
+  Slice<NV> mu;
+  const float* P_lds;
+  const float* P_glb;
+  float* xrow;  // this chain's exchange row in LDS
+  int dim_pad;
+  __device__ __forceinline__ void init(const EnergyParams& P, const LaneT& L, const Smem& S) {
+    load_param_slice(L, P.dev0, 0.0f, mu);
+    P_lds = P.param_in_lds ? S.param : nullptr;
+    P_glb = P.dev1;
+    dim_pad = P.dim_pad;
+    xrow = S.xchg + L.chain_in_wave * (G * NV * 4);
+  }
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    Slice<NV> d;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d.a[v][i] = L.ok(v, i) ? x.a[v][i] - mu.a[v][i] : 0.0f;
+        g.a[v][i] = 0.0f;
+      }
+      *reinterpret_cast<float4*>(xrow + L.col[v]) = make_float4(d.a[v][0], d.a[v][1], d.a[v][2], d.a[v][3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (P_lds) {
+      for (int j = 0; j < L.dim; ++j) {
+        const float dj = xrow[j];
+        const float* row = P_lds + j * dim_pad;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const float4 pr = *reinterpret_cast<const float4*>(row + L.col[v]);
+          g.a[v][0] = __builtin_fmaf(pr.x, dj, g.a[v][0]);
+          g.a[v][1] = __builtin_fmaf(pr.y, dj, g.a[v][1]);
+          g.a[v][2] = __builtin_fmaf(pr.z, dj, g.a[v][2]);
+          g.a[v][3] = __builtin_fmaf(pr.w, dj, g.a[v][3]);
+        }
+      }
+    } else {  // precision matrix too large for LDS: stream rows from L2
+      for (int j = 0; j < L.dim; ++j) {
+        const float dj = xrow[j];
+        const float* row = P_glb + (int64_t)j * L.dim;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (L.col_ok(v, i)) g.a[v][i] = __builtin_fmaf(row[L.col[v] + i], dj, g.a[v][i]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!L.ok(v, i)) g.a[v][i] = 0.0f;
+        if (WANT_E) acc = __builtin_fmaf(d.a[v][i], g.a[v][i], acc);
+      }
+    if (!WANT_E) return 0.0f;
+    return 0.5f * group_sum<G>(acc);
+  }
+};
+
+// Gaussian mixture (isotropic, shared sigma): one pass over the K components with a
+// running max (online softmax).  g = s1 * (x - sum_k r_k mu_k), E = -(m + log sum_k e^{l_k-m}).
+template <class LaneT>
+struct Energy<EBM_ENERGY_GMM, LaneT> {
+  static constexpr int G = LaneT::G, NV = LaneT::NV;
+  const float* mu_lds;
+  const float* mu_glb;
+  const float* logw;
+  int K, dim_pad;
+  float inv2s2, invs2;
+  __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem& S) {
+    mu_lds = P.param_in_lds ? S.param : nullptr;
+    mu_glb = P.dev0;
+    logw = P.param_in_lds ? S.param + P.n_comp_pad * P.dim_pad : P.dev1;
+    K = P.n_comp;
+    dim_pad = P.dim_pad;
+    inv2s2 = P.s0;
+    invs2 = P.s1;
+  }
+  __device__ __forceinline__ void load_mu(const LaneT& L, int k, int v, float (&m)[4]) const {
+    if (mu_lds) {
+      const float4 t = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + L.col[v]);
+      m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        m[i] = L.col_ok(v, i) ? mu_glb[(int64_t)k * L.dim + L.col[v] + i] : 0.0f;
+    }
+  }
+  // K <= 8 (staged in LDS, padded to exactly 8 components whose log-weight is -inf): two
+  // branch-free passes over register-held logits.  All 8 distances and their cross-lane
+  // reductions are independent, so they pipeline; no running-max dependency chain and one
+  // exp per component instead of two.
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval_small(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    constexpr int KM = 8;
+    float logit[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      float dist = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 m = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + L.col[v]);
+        const float mk[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float df = L.ok(v, i) ? x.a[v][i] - mk[i] : 0.0f;
+          dist = __builtin_fmaf(df, df, dist);
+        }
+      }
+      logit[k] = dist;
+    }
+    float top = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      logit[k] = __builtin_fmaf(-group_sum<G>(logit[k]), inv2s2, logw[k]);
+      top = logit[k] > top ? logit[k] : top;
+    }
+    float sum = 0.0f;
+    Slice<NV> acc;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc.a[v][i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      const float w = __expf(logit[k] - top);  // 0 for the padding components
+      sum += w;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 m = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + L.col[v]);
+        acc.a[v][0] = __builtin_fmaf(w, m.x, acc.a[v][0]);
+        acc.a[v][1] = __builtin_fmaf(w, m.y, acc.a[v][1]);
+        acc.a[v][2] = __builtin_fmaf(w, m.z, acc.a[v][2]);
+        acc.a[v][3] = __builtin_fmaf(w, m.w, acc.a[v][3]);
+      }
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        g.a[v][i] = L.ok(v, i) ? invs2 * (x.a[v][i] - acc.a[v][i] * inv) : 0.0f;
+    if (!WANT_E) return 0.0f;
+    return -(top + logf(sum));
+  }
+
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    if (K <= 8 && mu_lds) return eval_small<WANT_E>(L, x, g);
+    float run_max = -__builtin_inff();
+    float run_sum = 0.0f;
+    Slice<NV> acc;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc.a[v][i] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      float mk[NV][4];
+      float dist = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        load_mu(L, k, v, mk[v]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float df = L.ok(v, i) ? x.a[v][i] - mk[v][i] : 0.0f;
+          dist = __builtin_fmaf(df, df, dist);
+        }
+      }
+      dist = group_sum<G>(dist);
+      const float logit = __builtin_fmaf(-dist, inv2s2, logw[k]);
+      const float new_max = logit > run_max ? logit : run_max;
+      const float scale = __expf(run_max - new_max);  // 0 on the first component
+      const float w = __expf(logit - new_max);
+      run_sum = __builtin_fmaf(run_sum, scale, w);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc.a[v][i] = __builtin_fmaf(w, mk[v][i], acc.a[v][i] * scale);
+      run_max = new_max;
+    }
+    const float inv = 1.0f / run_sum;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        g.a[v][i] = L.ok(v, i) ? invs2 * (x.a[v][i] - acc.a[v][i] * inv) : 0.0f;
+    if (!WANT_E) return 0.0f;
+    return -(run_max + logf(run_sum));
+  }
+};
+
+// Stage the shared parameters into LDS (all threads of the block), zero-padded rows.
+__device__ __forceinline__ void stage_params(const EnergyParams& P, int dim, float* dst) {
+  if (!P.param_in_lds) return;
+  if (P.kind == EBM_ENERGY_GAUSSIAN) {
+    const int n = dim * P.dim_pad;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const int r = i / P.dim_pad, c = i - r * P.dim_pad;
+      dst[i] = (c < dim) ? P.dev1[(int64_t)r * dim + c] : 0.0f;
+    }
+  } else if (P.kind == EBM_ENERGY_GMM) {
+    const int n = P.n_comp_pad * P.dim_pad;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const int r = i / P.dim_pad, c = i - r * P.dim_pad;
+      dst[i] = (c < dim && r < P.n_comp) ? P.dev0[(int64_t)r * dim + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < P.n_comp_pad; i += kBlock)
+      dst[n + i] = (i < P.n_comp) ? P.dev1[i] : -__builtin_inff();
+  }
+  __syncthreads();
+}
+
+template <int NV>
+__device__ __forceinline__ Smem carve_smem(float* smem, int param_floats) {
+  Smem S;
+  S.param = smem;
+  S.xchg = smem + param_floats + (threadIdx.x >> 6) * (64 * NV * 4);
+  return S;
+}
+
+// ---------------------------------------------------------------------------------
+// host side: geometry selection and launch planning
+// ---------------------------------------------------------------------------------
+struct Geometry {
+  int G, NV;
+  bool full;
+};
+
+inline bool pick_geometry(int dim, Geometry& geo) {
+  const int nvec = (dim + 3) / 4;
+  if (nvec <= 64) {
+    int g = 1;
+    while (g < nvec) g <<= 1;
+    geo = Geometry{g, 1, false};
+  } else if (nvec <= 128) {
+    geo = Geometry{64, 2, false};
+  } else if (nvec <= 256) {
+    geo = Geometry{64, 4, false};
+  } else {
+    return false;
+  }
+  geo.full = dim == 4 * geo.G * geo.NV;
+  return true;
+}
+
+// Decide where the shared parameters live and how much dynamic LDS the launch needs.
+inline void plan_params(const ebm_energy_t& e, int dim, const Geometry& geo, EnergyParams& P,
+                        int& param_floats, size_t& smem_bytes) {
+  P.kind = e.kind; P.n_comp = e.n_comp; P.s0 = e.s[0]; P.s1 = e.s[1];
+  P.n_comp_pad = e.n_comp < 8 ? 8 : e.n_comp;
+  P.dev0 = e.dev0; P.dev1 = e.dev1;
+  P.dim_pad = (dim + 3) & ~3;
+  P.param_in_lds = 0;
+  param_floats = 0;
+  size_t xchg = 0;
+  if (e.kind == EBM_ENERGY_GAUSSIAN) {
+    const size_t need = (size_t)dim * P.dim_pad;
+    if (need * 4 <= (size_t)kParamLdsBudget) { P.param_in_lds = 1; param_floats = (int)need; }
+    xchg = (size_t)kWavesPerBlock * 64 * geo.NV * 4;
+  } else if (e.kind == EBM_ENERGY_GMM) {
+    const size_t need = (size_t)P.n_comp_pad * P.dim_pad + (size_t)((P.n_comp_pad + 3) & ~3);
+    if (need * 4 <= (size_t)kParamLdsBudget) { P.param_in_lds = 1; param_floats = (int)need; }
+  }
+  smem_bytes = ((size_t)param_floats + xchg) * sizeof(float);
+}
+
+inline int64_t blocks_for(int64_t n_chains, const Geometry& geo) {
+  return ceil_div64(n_chains, kBlock / geo.G);
+}
+
+// KERNEL<KIND, G, NV, FULL> dispatch.  FULL variants exist for NV == 1 only (dim <= 256);
+// larger rows always carry their validity mask.
+#define EBM_GEO_LAUNCH(KERNEL, KIND, geo, ...)                                                   \
+  do {                                                                                           \
+    if (geo.NV == 1 && geo.full) {                                                               \
+      switch (geo.G) {                                                                           \
+        case 1:  hipLaunchKernelGGL((KERNEL<KIND, 1, 1, true>), __VA_ARGS__); break;             \
+        case 2:  hipLaunchKernelGGL((KERNEL<KIND, 2, 1, true>), __VA_ARGS__); break;             \
+        case 4:  hipLaunchKernelGGL((KERNEL<KIND, 4, 1, true>), __VA_ARGS__); break;             \
+        case 8:  hipLaunchKernelGGL((KERNEL<KIND, 8, 1, true>), __VA_ARGS__); break;             \
+        case 16: hipLaunchKernelGGL((KERNEL<KIND, 16, 1, true>), __VA_ARGS__); break;            \
+        case 32: hipLaunchKernelGGL((KERNEL<KIND, 32, 1, true>), __VA_ARGS__); break;            \
+        default: hipLaunchKernelGGL((KERNEL<KIND, 64, 1, true>), __VA_ARGS__); break;            \
+      }                                                                                          \
+    } else if (geo.NV == 1) {                                                                    \
+      switch (geo.G) {                                                                           \
+        case 1:  hipLaunchKernelGGL((KERNEL<KIND, 1, 1, false>), __VA_ARGS__); break;            \
+        case 2:  hipLaunchKernelGGL((KERNEL<KIND, 2, 1, false>), __VA_ARGS__); break;            \
+        case 4:  hipLaunchKernelGGL((KERNEL<KIND, 4, 1, false>), __VA_ARGS__); break;            \
+        case 8:  hipLaunchKernelGGL((KERNEL<KIND, 8, 1, false>), __VA_ARGS__); break;            \
+        case 16: hipLaunchKernelGGL((KERNEL<KIND, 16, 1, false>), __VA_ARGS__); break;           \
+        case 32: hipLaunchKernelGGL((KERNEL<KIND, 32, 1, false>), __VA_ARGS__); break;           \
+        default: hipLaunchKernelGGL((KERNEL<KIND, 64, 1, false>), __VA_ARGS__); break;           \
+      }                                                                                          \
+    } else if (geo.NV == 2) {                                                                    \
+      hipLaunchKernelGGL((KERNEL<KIND, 64, 2, false>), __VA_ARGS__);                             \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((KERNEL<KIND, 64, 4, false>), __VA_ARGS__);                             \
+    }                                                                                            \
+  } while (0)
+
+#define EBM_KIND_LAUNCH(KERNEL, kind, geo, ...)                                                  \
+  do {                                                                                           \
+    switch (kind) {                                                                              \
+      case EBM_ENERGY_DOUBLE_WELL: EBM_GEO_LAUNCH(KERNEL, EBM_ENERGY_DOUBLE_WELL, geo, __VA_ARGS__); break; \
+      case EBM_ENERGY_HARMONIC:    EBM_GEO_LAUNCH(KERNEL, EBM_ENERGY_HARMONIC, geo, __VA_ARGS__); break;    \
+      case EBM_ENERGY_GAUSSIAN:    EBM_GEO_LAUNCH(KERNEL, EBM_ENERGY_GAUSSIAN, geo, __VA_ARGS__); break;    \
+      default:                     EBM_GEO_LAUNCH(KERNEL, EBM_ENERGY_GMM, geo, __VA_ARGS__); break;         \
+    }                                                                                            \
+  } while (0)
+
+}  // namespace rows
+}  // namespace ebm

@@ -1,0 +1,149 @@
+// k-fused Langevin chain for energies whose gradient couples the coordinates of a chain
+// (Gaussian, Gaussian mixture), and the stand-alone energy / gradient kernel.
+// Layout and energies: rows.h.  Reference: torchebm/samplers/langevin_dynamics.py:154-185,
+// torchebm/core/base_integrator.py:711-731, torchebm/core/base_model.py:181-210.
+#include "rows.h"
+
+namespace ebm {
+using namespace rows;
+
+namespace {
+
+extern __shared__ __attribute__((aligned(16))) float rows_smem[];
+
+struct RowChainArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t dim;
+  int32_t k_steps;
+  float eta, sqrt_eta, noise_coef;
+  const float4* table;
+  int clamp_on;
+  float cmin, cmax;
+  int32_t thin, n_kept;
+  float* traj;
+  const float* noise;
+  RngKey key;
+  uint64_t step0;
+  EnergyParams energy;
+  int param_floats;
+};
+
+template <int KIND, int G, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArgs a) {
+  using LaneT = Lane<G, NV, FULL>;
+  LaneT L;
+  L.init(a.n_chains, a.dim);
+  const Smem S = carve_smem<NV>(rows_smem, a.param_floats);
+  stage_params(a.energy, a.dim, S.param);
+  Energy<KIND, LaneT> en;
+  en.init(a.energy, L, S);
+
+  const int64_t row = L.active ? L.chain * (int64_t)a.dim : 0;
+  Slice<NV> x;
+  load_slice(L, a.x, row, x);
+  const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * a.dim : 0;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
+
+  for (int s = 0; s < a.k_steps; ++s) {
+    if (a.table) {
+      const float4 t = a.table[s];
+      eta = t.x; sqrt_eta = t.y; noise_coef = t.z;
+    }
+    Slice<NV> g, eps;
+    en.template eval<false>(L, x, g);
+    if (a.noise) load_slice(L, a.noise, ((int64_t)s * a.n_chains) * a.dim + row, eps);
+    else normal_slice(L, a.key, a.step0 + (uint64_t)s, eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // reference op order (base_integrator.py:397,728-729): rounded mul, rounded add, ...
+        const float x1 = x.a[v][i] - eta * g.a[v][i];
+        const float dw = eps.a[v][i] * sqrt_eta;
+        float nv = x1 + noise_coef * dw;
+        if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+        x.a[v][i] = L.ok(v, i) ? nv : 0.0f;
+      }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      store_slice(L, a.traj, traj_row + keep_off, x);
+      keep_off += a.dim;
+    }
+  }
+  store_slice(L, a.x, row, x);
+}
+
+struct EgArgs {
+  const float* x;
+  int64_t n_chains;
+  int32_t dim;
+  float* e_out;
+  float* g_out;
+  EnergyParams energy;
+  int param_floats;
+};
+
+template <int KIND, int G, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void energy_grad_kernel(EgArgs a) {
+  using LaneT = Lane<G, NV, FULL>;
+  LaneT L;
+  L.init(a.n_chains, a.dim);
+  const Smem S = carve_smem<NV>(rows_smem, a.param_floats);
+  stage_params(a.energy, a.dim, S.param);
+  Energy<KIND, LaneT> en;
+  en.init(a.energy, L, S);
+  const int64_t row = L.active ? L.chain * (int64_t)a.dim : 0;
+  Slice<NV> x, g;
+  load_slice(L, a.x, row, x);
+  const float e = en.template eval<true>(L, x, g);
+  if (a.e_out && L.active && L.lg == 0) a.e_out[L.chain] = e;
+  if (a.g_out) store_slice(L, a.g_out, row, g);
+}
+
+}  // namespace
+
+int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim,
+                               int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                               const float* coef_table, int clamp_on, float cmin, float cmax,
+                               int32_t thin, float* traj, const float* noise, uint64_t seed,
+                               uint64_t offset, hipStream_t st) {
+  Geometry geo;
+  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: dim %d > 1024 is not supported for this energy", dim);
+  RowChainArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
+  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
+  size_t smem = 0;
+  plan_params(e, dim, geo, a.energy, a.param_floats, smem);
+  const int64_t blocks = blocks_for(n_chains, geo);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  if (e.kind == EBM_ENERGY_GAUSSIAN)
+    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else
+    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+
+int launch_energy_grad(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim,
+                       float* e_out, float* g_out, hipStream_t st) {
+  Geometry geo;
+  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_energy_grad_f32: dim %d > 1024 is not supported", dim);
+  geo.full = false;  // one evaluation per launch: the masked form is as fast, and halves the variants
+  EgArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.e_out = e_out; a.g_out = g_out;
+  size_t smem = 0;
+  plan_params(e, dim, geo, a.energy, a.param_floats, smem);
+  const int64_t blocks = blocks_for(n_chains, geo);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_energy_grad_f32: too many chains for one launch");
+  EBM_KIND_LAUNCH(energy_grad_kernel, e.kind, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_energy_grad_f32");
+}
+
+}  // namespace ebm
