@@ -204,7 +204,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
-                "kernel": "langevin_chain_elem_kernel<DoubleWell>",
+                "kernel": "langevin_chain_lean_kernel<DoubleWell> (ebm_langevin_chain_f32)",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             }

@@ -273,7 +273,7 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
       const char* e = getenv("EBM_CHAIN_GPT");
       return e ? atoi(e) : 0;
     }();
-    const int gpt = (gpt_env == 1 || gpt_env == 2 || gpt_env == 4) ? gpt_env : 2;
+    const int gpt = (gpt_env == 1 || gpt_env == 2 || gpt_env == 4) ? gpt_env : 1;
     const dim3 lgrid((unsigned)ceil_div64(n_groups, (int64_t)kBlock * gpt));
 #define EBM_LEAN(KIND)                                                                            \
   do {                                                                                            \
