@@ -330,12 +330,16 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
   const float* mu_lds;
   const float* mu_glb;
   const float* logw;
+  float lw8[8];
   int K, dim_pad;
   float inv2s2, invs2;
   __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem& S) {
     mu_lds = P.param_in_lds ? S.param : nullptr;
     mu_glb = P.dev0;
     logw = P.param_in_lds ? S.param + P.n_comp_pad * P.dim_pad : P.dev1;
+    // small-mixture path: the (padded) log-weights are wave-uniform -> scalar loads, SGPRs
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lw8[k] = (k < P.n_comp) ? P.dev1[k < P.n_comp ? k : 0] : -__builtin_inff();
     K = P.n_comp;
     dim_pad = P.dim_pad;
     inv2s2 = P.s0;
@@ -377,7 +381,7 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
     float top = -__builtin_inff();
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
-      logit[k] = __builtin_fmaf(-group_sum<G>(logit[k]), inv2s2, logw[k]);
+      logit[k] = __builtin_fmaf(-group_sum<G>(logit[k]), inv2s2, lw8[k]);
       top = logit[k] > top ? logit[k] : top;
     }
     float sum = 0.0f;
