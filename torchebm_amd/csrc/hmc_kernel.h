@@ -1,0 +1,273 @@
+// HMC transition kernel template (included by the per-energy translation units hmc_*.hip, which
+// only exist so that the energies compile in parallel).  See hmc.hip for the entry point.
+#pragma once
+#include "rows.h"
+
+namespace ebm {
+namespace hmc {
+using namespace rows;
+
+struct HmcArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t dim;
+  int32_t n_mh;
+  int32_t n_leapfrog;
+  float eps;
+  const float* eps_table;
+  int32_t mass_kind;
+  float mass_raw, mass_sqrt, mass_safe;  // scalar mass forms
+  const float* mass_diag;
+  int32_t thin;
+  int32_t n_kept;
+  float* traj;
+  uint8_t* accept_mask;
+  uint32_t* accept_count;
+  const float* p_noise;
+  const float* u;
+  RngKey key;
+  uint64_t step0;
+  EnergyParams energy;
+  int param_floats;
+  int park_offset_floats;  // start of the lane-private parking slots in dynamic LDS
+};
+
+extern __shared__ __attribute__((aligned(16))) float hmc_smem[];
+
+// L leapfrog steps in safe mode.  On entry f = clamp(-dE/dx) at x; on exit x, p are the
+// proposal, f the clamped force there, and the return value is E(x).
+//  * The clamped force at the end of a step is bit-identical to the one the reference
+//    recomputes at the start of the next step, so it is carried over.
+//  * torch's nan_to_num_ is the identity on finite values: the common path only *tests*
+//    x, p for non-finite values (one v_cmp_class each); the scrub itself, and the force
+//    re-evaluation the reference then performs on the scrubbed x, run only for lane groups
+//    that actually hold a NaN/inf.
+template <bool HAS_MASS, class En, class LaneT>
+__device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Slice<LaneT::NV>& x,
+                                                Slice<LaneT::NV>& p, Slice<LaneT::NV>& f,
+                                                const Slice<LaneT::NV>& m_safe, float eps, float half_eps,
+                                                int n_steps, float e_in) {
+  constexpr int NV = LaneT::NV;
+  float e = e_in;
+  for (int l = 0; l < n_steps; ++l) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ph = p.a[v][i] + half_eps * f.a[v][i];
+        float step = eps * ph;
+        if constexpr (HAS_MASS) step = step / m_safe.a[v][i];
+        p.a[v][i] = ph;
+        x.a[v][i] = L.ok(v, i) ? x.a[v][i] + step : 0.0f;
+      }
+    Slice<NV> g;
+    e = en.template eval<true>(L, x, g);
+    bool bad = false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float fn = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+        const float pn = p.a[v][i] + half_eps * fn;
+        f.a[v][i] = fn;
+        p.a[v][i] = L.ok(v, i) ? pn : 0.0f;
+        bad |= !__builtin_isfinite(pn) | !__builtin_isfinite(x.a[v][i]);
+      }
+    if (group_any<LaneT::G>(bad)) {  // rare: scrub, then re-evaluate on the scrubbed position
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          p.a[v][i] = nan_to_num0(p.a[v][i]);
+          x.a[v][i] = nan_to_num0(x.a[v][i]);
+        }
+      e = en.template eval<true>(L, x, g);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+    }
+  }
+  return e;
+}
+
+// MASS: 0 = identity mass (no mass registers at all), 1 = scalar or diagonal mass (three
+// per-slot forms kept in VGPRs).  XC_LDS: park the accepted state in a lane-private LDS slot
+// while the proposal is integrated (wide rows: frees 4*NV VGPRs).
+template <int KIND, int G, int NV, bool FULL, int MASS>
+__global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
+  using LaneT = Lane<G, NV, FULL>;
+  constexpr bool XC_LDS = NV >= 4;
+  LaneT L;
+  L.init(a.n_chains, a.dim);
+  const Smem S = carve_smem<NV>(hmc_smem, a.param_floats);
+  stage_params(a.energy, a.dim, S.param);
+  Energy<KIND, LaneT> en;
+  en.init(a.energy, L, S);
+  // lane-private parking slots sit behind the parameter / exchange area: [v][thread] float4
+  float4* park = reinterpret_cast<float4*>(hmc_smem + a.park_offset_floats) + threadIdx.x;
+
+  const int64_t row = L.active ? L.chain * (int64_t)a.dim : 0;
+  Slice<NV> xc;  // current (accepted) state
+  load_slice(L, a.x, row, xc);
+
+  // mass forms per slot: raw (kinetic energy), sqrt (momentum draw), clamped (drift)
+  constexpr bool has_mass = MASS != 0;
+  const bool diag_mass = has_mass && a.mass_kind == EBM_MASS_DIAG;
+  Slice<has_mass ? NV : 1> m_raw, m_sqrt, m_safe;
+  if constexpr (has_mass) {
+    if (diag_mass) load_param_slice(L, a.mass_diag, 1.0f, m_raw);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (diag_mass) {
+          m_sqrt.a[v][i] = sqrtf(m_raw.a[v][i]);
+          m_safe.a[v][i] = m_raw.a[v][i] < 1e-10f ? 1e-10f : m_raw.a[v][i];
+        } else {
+          m_raw.a[v][i] = a.mass_raw;
+          m_sqrt.a[v][i] = a.mass_sqrt;
+          m_safe.a[v][i] = a.mass_safe;
+        }
+      }
+  }
+
+  // K(p) = 0.5 p^T M^-1 p, clamped to [0, 1e10]  (samplers/hmc.py:136-159, :251-254)
+  auto kinetic = [&](const Slice<NV>& q) -> float {
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sq = q.a[v][i] * q.a[v][i];
+        if constexpr (has_mass) {
+          if (diag_mass) sq = sq / m_raw.a[v][i];
+        }
+        acc += L.ok(v, i) ? sq : 0.0f;
+      }
+    float k = 0.5f * group_sum<G>(acc);
+    if constexpr (has_mass) {
+      if (!diag_mass) k = k / a.mass_raw;
+    }
+    return clamp_nanprop(k, 0.0f, 1e10f);
+  };
+
+  const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * a.dim : 0;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  float eps = a.eps;
+
+  for (int t = 0; t < a.n_mh; ++t) {
+    if (a.eps_table) eps = a.eps_table[t];
+    const float half_eps = 0.5f * eps;
+
+    // ---- momentum draw: p ~ N(0, M)  (samplers/hmc.py:92-134)
+    Slice<NV> p;
+    if (a.p_noise) load_slice(L, a.p_noise, ((int64_t)t * a.n_chains) * a.dim + row, p);
+    else normal_slice(L, a.key, a.step0 + 2ull * (uint64_t)t, p);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float pv = p.a[v][i];
+        if constexpr (has_mass) pv = pv * m_sqrt.a[v][i];
+        p.a[v][i] = L.ok(v, i) ? pv : 0.0f;
+      }
+
+    // ---- H0 and the first (clamped) force
+    Slice<NV> f;
+    const float e0 = en.template eval<true>(L, xc, f);
+    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-f.a[v][i], -1e6f, 1e6f);
+
+    // ---- proposal (integrated in place in xc's registers when the old state is parked in LDS)
+    if constexpr (XC_LDS) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        park[v * kBlock] = make_float4(xc.a[v][0], xc.a[v][1], xc.a[v][2], xc.a[v][3]);
+    }
+    Slice<NV> xprop_store;
+    Slice<NV>& x = XC_LDS ? xc : xprop_store;
+    if constexpr (!XC_LDS) x = xc;
+    float e1;
+    if constexpr (has_mass) e1 = leapfrog_steps<true>(en, L, x, p, f, m_safe, eps, half_eps, a.n_leapfrog, e0);
+    else e1 = leapfrog_steps<false>(en, L, x, p, f, x, eps, half_eps, a.n_leapfrog, e0);
+    const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
+
+    // ---- Metropolis accept (samplers/hmc.py:277-292)
+    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
+    float acc_p = expf(dlt);
+    acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
+    float uu;
+    if (a.u) uu = L.active ? a.u[(int64_t)t * a.n_chains + L.chain] : 2.0f;
+    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)L.chain >> 2, a.step0 + 2ull * (uint64_t)t + 1ull),
+                                 (int)(L.chain & 3)));
+    const bool accept = L.active && (uu < acc_p);
+    if constexpr (XC_LDS) {
+      if (!accept) {  // rejected: bring the parked state back
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const float4 q = park[v * kBlock];
+          xc.a[v][0] = q.x; xc.a[v][1] = q.y; xc.a[v][2] = q.z; xc.a[v][3] = q.w;
+        }
+      }
+    } else {
+      if (accept) xc = x;
+    }
+
+    const bool leader = L.active && L.lg == 0;
+    if (a.accept_mask && leader) a.accept_mask[(int64_t)t * a.n_chains + L.chain] = accept ? 1 : 0;
+    if (a.accept_count) {  // wavefront-level count, one atomic per wave
+      const unsigned long long b = __ballot(accept && leader);
+      if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.accept_count + t, (uint32_t)__popcll(b));
+    }
+
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      store_slice(L, a.traj, traj_row + keep_off, xc);
+      keep_off += a.dim;
+    }
+  }
+  store_slice(L, a.x, row, xc);
+}
+
+// KERNEL<KIND, G, NV, FULL, MASS> over the runtime geometry (see rows.h: EBM_GEO_LAUNCH)
+template <int KIND, int MASS>
+void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
+  const dim3 block(kBlock);
+#define EBM_HMC_G(GV, NVV, FULLV) hipLaunchKernelGGL((hmc_chain_kernel<KIND, GV, NVV, FULLV, MASS>), grid, block, smem, st, a)
+  if (geo.NV == 1) {
+    switch (geo.G) {
+      case 1:  if (geo.full) EBM_HMC_G(1, 1, true);  else EBM_HMC_G(1, 1, false);  break;
+      case 2:  if (geo.full) EBM_HMC_G(2, 1, true);  else EBM_HMC_G(2, 1, false);  break;
+      case 4:  if (geo.full) EBM_HMC_G(4, 1, true);  else EBM_HMC_G(4, 1, false);  break;
+      case 8:  if (geo.full) EBM_HMC_G(8, 1, true);  else EBM_HMC_G(8, 1, false);  break;
+      case 16: if (geo.full) EBM_HMC_G(16, 1, true); else EBM_HMC_G(16, 1, false); break;
+      case 32: if (geo.full) EBM_HMC_G(32, 1, true); else EBM_HMC_G(32, 1, false); break;
+      default: if (geo.full) EBM_HMC_G(64, 1, true); else EBM_HMC_G(64, 1, false); break;
+    }
+  } else if (geo.G == 64 && geo.NV == 2) {
+    EBM_HMC_G(64, 2, false);
+  } else if (geo.G == 64 && geo.NV == 4) {
+    EBM_HMC_G(64, 4, false);
+  } else if (geo.G == 4 && geo.NV == 2) {  // dim-32 alternatives (full rows only)
+    EBM_HMC_G(4, 2, true);
+  } else if (geo.G == 2 && geo.NV == 4) {
+    EBM_HMC_G(2, 4, true);
+  } else {
+    EBM_HMC_G(1, 8, true);
+  }
+#undef EBM_HMC_G
+}
+
+template <int KIND>
+void launch_kind(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
+  if (a.mass_kind == EBM_MASS_NONE) launch_geo<KIND, 0>(geo, grid, smem, st, a);
+  else launch_geo<KIND, 1>(geo, grid, smem, st, a);
+}
+
+}  // namespace hmc
+}  // namespace ebm
