@@ -159,6 +159,24 @@ EBM_API int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, c
                        const float* u, uint8_t* accept_mask, uint32_t* accept_count,
                        int64_t n_chains, int32_t dim, uint64_t seed, uint64_t offset, void* stream);
 
+/*
+ * Noise-free descent samplers (reference: torchebm/samplers/gradient_descent.py).
+ * torch.sub / torch.add with `alpha` are single-rounding FMAs on the CPU reference, and so are these:
+ *   gradient descent (:121-123):   x' = fma(-eta, g(x), x)
+ *   Nesterov (:262-266):           la = fma(mu, v, x);  v' = fma(-eta, g(la), fl(v*mu));  x' = x + v'
+ * ebm_descent_chain_f32 runs k fused steps for an analytic energy (v starts at zero and is not
+ * returned, as in the reference); eta_table = NULL or device float[k]; traj as in the Langevin chain.
+ * ebm_descent_step_f32 is one update with an external gradient (v == NULL: plain descent; else v is
+ * updated in place); ebm_lookahead_f32 forms the Nesterov look-ahead point.  Outputs may alias x.
+ */
+EBM_API int ebm_descent_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                                  int32_t k_steps, float eta, const float* eta_table, int32_t nesterov,
+                                  float momentum, int32_t thin, float* traj, void* stream);
+EBM_API int ebm_descent_step_f32(const float* x, const float* grad, float* v, float* out, int64_t n_elem,
+                                 float eta, float momentum, void* stream);
+EBM_API int ebm_lookahead_f32(const float* x, const float* v, float* out, int64_t n_elem, float momentum,
+                              void* stream);
+
 /* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
  * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */
 EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains,

@@ -43,7 +43,12 @@ from torchebm.core import (  # noqa: E402
     LinearScheduler,
 )
 from torchebm.integrators import EulerMaruyamaIntegrator, LeapfrogIntegrator  # noqa: E402
-from torchebm.samplers import HamiltonianMonteCarlo, LangevinDynamics  # noqa: E402
+from torchebm.samplers import (  # noqa: E402
+    GradientDescentSampler,
+    HamiltonianMonteCarlo,
+    LangevinDynamics,
+    NesterovSampler,
+)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root, for the oracle package
@@ -185,6 +190,22 @@ def _hmc_case(name, energy, n, dim, T, L, step_size, seed, mass, thin, x0, x0_sc
     return True
 
 
+def descent_case(name, energy, n, dim, k, step_size, seed, momentum=None, thin=1, x0_scale=1.0):
+    model = make_energy(energy)
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed)) * x0_scale
+    if momentum is None:
+        sampler = GradientDescentSampler(model, step_size=step_size)
+    else:
+        sampler = NesterovSampler(model, step_size=step_size, momentum=momentum)
+    out = sampler.sample(x=x0.clone(), n_steps=k)
+    traj, diag = sampler.sample(x=x0.clone(), n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True)
+    fx = {"sampler": "descent", "name": name, "energy": energy, "n": n, "dim": dim, "k": k, "thin": thin,
+          "momentum": momentum, "x0": x0, "etas": sched_values(step_size, k),
+          "ref": {"x": out, "trajectory": traj, "diagnostics": diag, "sha_x": sha(out)}}
+    torch.save(fx, os.path.join(HERE, name + ".pt"))
+    print(f"{name:28s} x sha {fx['ref']['sha_x']}")
+
+
 def integrator_cases():
     """Hand-checkable single steps through the reference integrators (cf. the reference's
     tests/integrators/test_euler_maruyama.py:402-449, test_leapfrog.py:218-289)."""
@@ -253,6 +274,14 @@ def main():
     hmc_case("hmc_dw_extreme", dw, 16, 4, 4, 5, 0.01, seed=29, x0=big)
     hmc_survey()
     integrator_cases()
+
+    # ---- noise-free descent ---------------------------------------
+    descent_case("gd_dw_64x16", dw, 64, 16, 12, 0.01, seed=31, thin=3)
+    descent_case("gd_har_37x3_sched", har, 37, 3, 10, LinearScheduler(0.2, 0.02, 8), seed=32)
+    descent_case("gd_gauss8_50", g8, 50, 8, 10, 0.05, seed=33, thin=2)
+    descent_case("nag_dw_64x16", dw, 64, 16, 12, 0.01, seed=34, momentum=0.9, thin=4)
+    descent_case("nag_gmm5_33x6", gmm6, 33, 6, 10, 0.05, seed=35, momentum=0.5, x0_scale=2.0)
+    descent_case("nag_har_20x5_sched", har, 20, 5, 9, ExponentialDecayScheduler(0.3, 0.8, 0.05), seed=36, momentum=0.8, thin=2)
 
 
 def langevin_survey():

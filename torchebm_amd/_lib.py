@@ -35,6 +35,9 @@ EXPORTS = (
     "ebm_leapfrog_kick_drift_f32",
     "ebm_leapfrog_kick_f32",
     "ebm_hmc_accept_f32",
+    "ebm_descent_chain_f32",
+    "ebm_descent_step_f32",
+    "ebm_lookahead_f32",
     "ebm_energy_grad_f32",
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
@@ -75,6 +78,9 @@ _PROTOTYPES = {
     "ebm_leapfrog_kick_drift_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _d, _p, _i32, _p]),
     "ebm_leapfrog_kick_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _i32, _p]),
     "ebm_hmc_accept_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _u64, _u64, _p]),
+    "ebm_descent_chain_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _i32, _f, _p, _i32, _f, _i32, _p, _p]),
+    "ebm_descent_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _p]),
+    "ebm_lookahead_f32": (C.c_int, [_p, _p, _p, _i64, _f, _p]),
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),

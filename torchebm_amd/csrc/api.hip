@@ -29,6 +29,10 @@ int launch_hmc_accept(float*, const float*, const float*, const float*, const fl
 int launch_energy_grad(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*,
                        hipStream_t);
 int launch_chain_stats(const float*, int64_t, int32_t, float*, float*, double*, hipStream_t);
+int launch_descent_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, const float*, int32_t, float,
+                         int32_t, float*, hipStream_t);
+int launch_descent_step(const float*, const float*, float*, float*, int64_t, float, float, hipStream_t);
+int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
 
 namespace {
@@ -189,6 +193,40 @@ int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, const flo
   if (!x || !x_prop || !h0 || !h1) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   return launch_hmc_accept(x, x_prop, h0, h1, u, accept_mask, accept_count, n_chains, dim, seed,
                            offset, (hipStream_t)stream);
+}
+
+int ebm_descent_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                          int32_t k_steps, float eta, const float* eta_table, int32_t nesterov,
+                          float momentum, int32_t thin, float* traj, void* stream) {
+  const char* who = "ebm_descent_chain_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
+  if (n_chains == 0 || k_steps == 0) return 0;
+  if (traj && !aligned16(traj)) return fail(EBM_EINVAL, "%s: traj must be 16-byte aligned", who);
+  return launch_descent_chain(*energy, x, n_chains, dim, k_steps, eta, eta_table, nesterov, momentum, thin,
+                              traj, (hipStream_t)stream);
+}
+
+int ebm_descent_step_f32(const float* x, const float* grad, float* v, float* out, int64_t n_elem,
+                         float eta, float momentum, void* stream) {
+  const char* who = "ebm_descent_step_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x || !grad || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  if (!aligned16(x) || !aligned16(grad) || !aligned16(out) || (v && !aligned16(v)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_descent_step(x, grad, v, out, n_elem, eta, momentum, (hipStream_t)stream);
+}
+
+int ebm_lookahead_f32(const float* x, const float* v, float* out, int64_t n_elem, float momentum,
+                      void* stream) {
+  const char* who = "ebm_lookahead_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x || !v || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  if (!aligned16(x) || !aligned16(v) || !aligned16(out)) return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_lookahead(x, v, out, n_elem, momentum, (hipStream_t)stream);
 }
 
 int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,

@@ -94,6 +94,34 @@ __global__ __launch_bounds__(kBlock) void kick_kernel(float* __restrict__ x_new,
 }
 
 // ---------------------------------------------------------------------------------
+// noise-free descent updates with an external gradient (samplers/gradient_descent.py:121-123,
+// :262-266): torch.sub/add with alpha are FMAs, and so are these.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void descent_step_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ grad,
+                                                              float* v, float* out, int64_t n_elem,
+                                                              float neg_eta, float mu) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elem;
+       e += (int64_t)gridDim.x * kBlock) {
+    if (v) {
+      const float vn = __builtin_fmaf(neg_eta, grad[e], v[e] * mu);
+      v[e] = vn;
+      out[e] = x[e] + vn;
+    } else {
+      out[e] = __builtin_fmaf(neg_eta, grad[e], x[e]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void lookahead_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ v,
+                                                           float* __restrict__ out, int64_t n_elem, float mu) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elem;
+       e += (int64_t)gridDim.x * kBlock)
+    out[e] = __builtin_fmaf(mu, v[e], x[e]);
+}
+
+// ---------------------------------------------------------------------------------
 // Metropolis accept, one lane-group of `lanes` lanes per chain row (samplers/hmc.py:277-292)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
@@ -206,6 +234,18 @@ int launch_leapfrog_kick(float* x_new, const float* p_half, const float* force, 
   hipLaunchKernelGGL(kick_kernel, dim3(grid_for(n_elem)), dim3(kBlock), 0, st, x_new, p_half, force,
                      p_new, n_elem, half_eps, safe);
   return check_launch("ebm_leapfrog_kick_f32");
+}
+
+int launch_descent_step(const float* x, const float* grad, float* v, float* out, int64_t n_elem, float eta,
+                        float momentum, hipStream_t st) {
+  hipLaunchKernelGGL(descent_step_kernel, dim3(grid_for(n_elem)), dim3(kBlock), 0, st, x, grad, v, out, n_elem,
+                     -eta, momentum);
+  return check_launch("ebm_descent_step_f32");
+}
+
+int launch_lookahead(const float* x, const float* v, float* out, int64_t n_elem, float momentum, hipStream_t st) {
+  hipLaunchKernelGGL(lookahead_kernel, dim3(grid_for(n_elem)), dim3(kBlock), 0, st, x, v, out, n_elem, momentum);
+  return check_launch("ebm_lookahead_f32");
 }
 
 int launch_hmc_accept(float* x, const float* x_prop, const float* h0, const float* h1,

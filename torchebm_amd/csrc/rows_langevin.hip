@@ -76,6 +76,78 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArg
   store_slice(L, a.x, row, x);
 }
 
+// ---------------------------------------------------------------------------------
+// noise-free descent (gradient descent / Nesterov), k fused steps, any analytic energy
+// ---------------------------------------------------------------------------------
+struct DescentArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t dim;
+  int32_t k_steps;
+  float eta;
+  const float* eta_table;
+  int32_t nesterov;
+  float mu;
+  int32_t thin, n_kept;
+  float* traj;
+  EnergyParams energy;
+  int param_floats;
+};
+
+template <int KIND, int G, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void descent_chain_rows_kernel(DescentArgs a) {
+  using LaneT = Lane<G, NV, FULL>;
+  LaneT L;
+  L.init(a.n_chains, a.dim);
+  const Smem S = carve_smem<NV>(rows_smem, a.param_floats);
+  stage_params(a.energy, a.dim, S.param);
+  Energy<KIND, LaneT> en;
+  en.init(a.energy, L, S);
+  const int64_t row = L.active ? L.chain * (int64_t)a.dim : 0;
+  Slice<NV> x, v;
+  load_slice(L, a.x, row, x);
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.a[q][i] = 0.0f;
+  const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * a.dim : 0;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  float eta = a.eta;
+  for (int s = 0; s < a.k_steps; ++s) {
+    if (a.eta_table) eta = a.eta_table[s];
+    Slice<NV> g;
+    if (a.nesterov) {
+      Slice<NV> la;
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) la.a[q][i] = L.ok(q, i) ? __builtin_fmaf(a.mu, v.a[q][i], x.a[q][i]) : 0.0f;
+      en.template eval<false>(L, la, g);
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float vn = __builtin_fmaf(-eta, g.a[q][i], v.a[q][i] * a.mu);
+          v.a[q][i] = L.ok(q, i) ? vn : 0.0f;
+          x.a[q][i] = L.ok(q, i) ? x.a[q][i] + vn : 0.0f;
+        }
+    } else {
+      en.template eval<false>(L, x, g);
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x.a[q][i] = L.ok(q, i) ? __builtin_fmaf(-eta, g.a[q][i], x.a[q][i]) : 0.0f;
+    }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      store_slice(L, a.traj, traj_row + keep_off, x);
+      keep_off += a.dim;
+    }
+  }
+  store_slice(L, a.x, row, x);
+}
+
 struct EgArgs {
   const float* x;
   int64_t n_chains;
@@ -129,6 +201,23 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
   else
     EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_langevin_chain_f32");
+}
+
+int launch_descent_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                         float eta, const float* eta_table, int32_t nesterov, float momentum, int32_t thin,
+                         float* traj, hipStream_t st) {
+  Geometry geo;
+  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_descent_chain_f32: dim %d > 1024 is not supported", dim);
+  geo.full = false;  // deterministic optimiser, not a throughput path: one masked variant per geometry
+  DescentArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps; a.eta = eta; a.eta_table = eta_table;
+  a.nesterov = nesterov; a.mu = momentum; a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj;
+  size_t smem = 0;
+  plan_params(e, dim, geo, a.energy, a.param_floats, smem);
+  const int64_t blocks = blocks_for(n_chains, geo);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_descent_chain_f32: too many chains for one launch");
+  EBM_KIND_LAUNCH(descent_chain_rows_kernel, e.kind, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_descent_chain_f32");
 }
 
 int launch_energy_grad(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim,
