@@ -177,6 +177,21 @@ EBM_API int ebm_descent_step_f32(const float* x, const float* grad, float* v, fl
 EBM_API int ebm_lookahead_f32(const float* x, const float* v, float* out, int64_t n_elem, float momentum,
                               void* stream);
 
+/*
+ * Persistent-CD replay-buffer traffic in one launch each (reference:
+ * torchebm/core/base_loss.py:296-315 stratified read, :390-426 FIFO write).
+ *   gather:  row_i = (i*stride + r_i) % buffer_size,  r_i uniform in {0..stride-1};  out[i,:] = buffer[row_i,:]
+ *            r_i = offsets[i] when offsets != NULL (injected), else floor(o_i * stride / 2^32) with o_i the
+ *            raw 32-bit output of the native RNG field at step `offset`, element i.  rows_out (optional)
+ *            receives row_i.  stride = buffer_size / batch (>= 1).
+ *   scatter: buffer[(write_pos + i) % buffer_size, :] = samples[i, :]   for i < batch <= buffer_size
+ */
+EBM_API int ebm_pcd_gather_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch,
+                               int64_t stride, const int64_t* offsets, int64_t* rows_out,
+                               uint64_t seed, uint64_t offset, void* stream);
+EBM_API int ebm_pcd_scatter_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples,
+                                int64_t batch, int64_t write_pos, void* stream);
+
 /* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
  * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */
 EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains,

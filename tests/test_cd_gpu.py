@@ -84,3 +84,78 @@ def test_pcd_training_config5_shape(cuda_device):
     assert pcd.replay_buffer.shape == (n, 2) and torch.isfinite(pcd.replay_buffer).all()
     assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
     assert "replay_buffer" in pcd.state_dict()
+
+
+# ---------------------------------------------------------------------------------------
+# replay-buffer traffic in one launch each
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cap,batch,dim", [(64, 16, 2), (1000, 37, 5), (4096, 4096, 3)])
+def test_pcd_gather_injected_offsets_equals_torch_indexing(cuda_device, cap, batch, dim):
+    buf = torch.randn(cap, dim, device=cuda_device)
+    stride = cap // batch
+    offs = torch.randint(0, stride, (batch,), device=cuda_device)
+    out = torch.empty(batch, dim, device=cuda_device)
+    rows = torch.empty(batch, dtype=torch.int64, device=cuda_device)
+    _lib.call("ebm_pcd_gather_f32", buf.data_ptr(), cap, dim, out.data_ptr(), batch, stride, offs.data_ptr(), rows.data_ptr(),
+              0, 0, _lib.stream_handle(cuda_device))
+    want_rows = (torch.arange(batch, device=cuda_device) * stride + offs) % cap  # core/base_loss.py:306-312
+    assert torch.equal(rows, want_rows) and torch.equal(out, buf[want_rows])
+
+
+def test_pcd_gather_native_offsets_are_stratified_and_uniform(cuda_device):
+    cap, batch, dim = 1 << 16, 1 << 12, 2
+    stride = cap // batch
+    buf = torch.arange(cap, device=cuda_device, dtype=torch.float32)[:, None].expand(cap, dim).contiguous()
+    out = torch.empty(batch, dim, device=cuda_device)
+    rows = torch.empty(batch, dtype=torch.int64, device=cuda_device)
+    hist = torch.zeros(stride, device=cuda_device)
+    for step in range(50):
+        _lib.call("ebm_pcd_gather_f32", buf.data_ptr(), cap, dim, out.data_ptr(), batch, stride, None, rows.data_ptr(), 77, step,
+                  _lib.stream_handle(cuda_device))
+        lo = torch.arange(batch, device=cuda_device) * stride
+        assert ((rows >= lo) & (rows < lo + stride)).all()  # one row per stratum
+        assert torch.equal(out[:, 0], rows.float())
+        hist += torch.bincount(rows - lo, minlength=stride).float()
+    freq = hist / hist.sum()
+    assert (freq - 1.0 / stride).abs().max().item() < 0.005  # 204 800 draws over 16 bins
+    # reproducible per (seed, step); different steps differ
+    r2 = torch.empty_like(rows)
+    _lib.call("ebm_pcd_gather_f32", buf.data_ptr(), cap, dim, out.data_ptr(), batch, stride, None, r2.data_ptr(), 77, 49,
+              _lib.stream_handle(cuda_device))
+    assert torch.equal(rows, r2)
+
+
+@pytest.mark.parametrize("cap,batch,pos", [(12, 5, 0), (12, 9, 5), (12, 12, 7), (1000, 333, 900)])
+def test_pcd_scatter_equals_torch_fifo(cuda_device, cap, batch, pos):
+    dim = 3
+    buf = torch.randn(cap, dim, device=cuda_device)
+    want = buf.clone()
+    samples = torch.randn(batch, dim, device=cuda_device)
+    end = (pos + batch) % cap  # core/base_loss.py:412-424
+    if batch == cap:
+        idx = (pos + torch.arange(batch, device=cuda_device)) % cap
+        want[idx] = samples
+    elif end > pos:
+        want[pos:end] = samples
+    else:
+        first = cap - pos
+        want[pos:] = samples[:first]
+        want[:end] = samples[first:]
+    _lib.call("ebm_pcd_scatter_f32", buf.data_ptr(), cap, dim, samples.data_ptr(), batch, pos, _lib.stream_handle(cuda_device))
+    assert torch.equal(buf, want)
+
+
+def test_pcd_loss_uses_the_buffer_kernels(cuda_device):
+    model = MLPEnergy(16).to(cuda_device)
+    sampler = ta.LangevinDynamics(model, step_size=0.1, device=cuda_device)
+    pcd = ta.ContrastiveDivergence(model, sampler, k_steps=2, persistent=True, buffer_size=256, init_steps=0,
+                                   new_sample_ratio=0.0, device=cuda_device)
+    data = two_moons(64, 0.05, seed=1, device=cuda_device)
+    g0, s0 = hip_calls("ebm_pcd_gather_f32"), hip_calls("ebm_pcd_scatter_f32")
+    gen = torch.Generator(device=cuda_device).manual_seed(3)
+    for _ in range(5):  # 5 x 64 rows into a 256-row FIFO: wraps once
+        loss, neg = pcd(data, generator=gen)
+    assert hip_calls("ebm_pcd_gather_f32") == g0 + 5 and hip_calls("ebm_pcd_scatter_f32") == s0 + 5
+    assert pcd._write_pos == (5 * 64) % 256 and pcd.buffer_ptr.item() == pcd._write_pos
+    assert torch.equal(pcd.replay_buffer[:64], neg)  # the last batch landed at rows 0..63 after the wrap
+    assert torch.isfinite(loss)

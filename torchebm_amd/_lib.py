@@ -38,6 +38,8 @@ EXPORTS = (
     "ebm_descent_chain_f32",
     "ebm_descent_step_f32",
     "ebm_lookahead_f32",
+    "ebm_pcd_gather_f32",
+    "ebm_pcd_scatter_f32",
     "ebm_energy_grad_f32",
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
@@ -81,6 +83,8 @@ _PROTOTYPES = {
     "ebm_descent_chain_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _i32, _f, _p, _i32, _f, _i32, _p, _p]),
     "ebm_descent_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _p]),
     "ebm_lookahead_f32": (C.c_int, [_p, _p, _p, _i64, _f, _p]),
+    "ebm_pcd_gather_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _u64, _u64, _p]),
+    "ebm_pcd_scatter_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p]),
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),

@@ -16,6 +16,7 @@ from typing import Any, Optional, Tuple, Union
 
 import torch
 
+from .. import _lib, _rng
 from .module import TorchEBMModule, warn_once
 from .schedules import Schedulable
 
@@ -140,18 +141,34 @@ class BaseContrastiveDivergence(BaseLoss):
                 UserWarning,
             )
             rows = torch.randint(0, self.buffer_size, (batch,), device=self.device, generator=generator)
+            starts = self.replay_buffer[rows]
+        elif self._hip_buffer():
+            # one launch: in-kernel Philox offsets + gather (ebm_pcd_gather_f32)
+            stride = self.buffer_size // batch
+            row_elems = self.replay_buffer[0].numel()
+            starts = torch.empty((batch,) + tuple(self.replay_buffer.shape[1:]), dtype=self.dtype, device=self.device)
+            seed, step = _rng.reserve(generator, self.replay_buffer.device, 1)
+            _lib.call(
+                "ebm_pcd_gather_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch,
+                stride, None, None, seed, step, _lib.stream_handle(self.replay_buffer.device),
+            )
         else:
             stride = self.buffer_size // batch
             base = torch.arange(0, batch, device=self.device) * stride
             jitter = torch.randint(0, stride, (batch,), device=self.device, generator=generator)
             rows = (base + jitter) % self.buffer_size
-        starts = self.replay_buffer[rows]
+            starts = self.replay_buffer[rows]
         if self.new_sample_ratio > 0.0:
             n_new = max(1, int(batch * self.new_sample_ratio))
             pick = torch.randperm(batch, device=self.device, generator=generator)[:n_new]
             bump = torch.randn_like(starts[pick], device=self.device, dtype=self.dtype, generator=generator) * 0.01
             starts[pick] = starts[pick] + bump
         return starts
+
+    def _hip_buffer(self) -> bool:
+        """The replay buffer can be served by the HIP gather / scatter kernels."""
+        buf = self.replay_buffer
+        return buf is not None and buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
 
     def get_negative_samples(self, x, batch_size, data_shape, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         kw = dict(dtype=self.dtype, device=self.device)
@@ -176,6 +193,13 @@ class BaseContrastiveDivergence(BaseLoss):
         if batch >= cap:
             self.replay_buffer[:] = samples[-cap:]
             new_pos = 0
+        elif self._hip_buffer() and samples.is_cuda:
+            new_pos = (pos + batch) % cap
+            src = _lib.dense_f32(samples)
+            _lib.call(
+                "ebm_pcd_scatter_f32", _lib.ptr(self.replay_buffer), cap, self.replay_buffer[0].numel(), _lib.ptr(src),
+                batch, pos, _lib.stream_handle(self.replay_buffer.device),
+            )
         else:
             new_pos = (pos + batch) % cap
             if new_pos > pos:

@@ -33,6 +33,9 @@ int launch_descent_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t,
                          int32_t, float*, hipStream_t);
 int launch_descent_step(const float*, const float*, float*, float*, int64_t, float, float, hipStream_t);
 int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStream_t);
+int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
+                      uint64_t, hipStream_t);
+int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
 
 namespace {
@@ -227,6 +230,30 @@ int ebm_lookahead_f32(const float* x, const float* v, float* out, int64_t n_elem
   if (!x || !v || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   if (!aligned16(x) || !aligned16(v) || !aligned16(out)) return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
   return launch_lookahead(x, v, out, n_elem, momentum, (hipStream_t)stream);
+}
+
+int ebm_pcd_gather_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch,
+                       int64_t stride, const int64_t* offsets, int64_t* rows_out, uint64_t seed,
+                       uint64_t offset, void* stream) {
+  const char* who = "ebm_pcd_gather_f32";
+  if (buffer_size < 1 || dim < 1 || batch < 0 || stride < 1 || stride > 0x7fffffffLL)
+    return fail(EBM_EINVAL, "%s: bad sizes (buffer %lld, dim %d, batch %lld, stride %lld)", who, (long long)buffer_size, dim,
+                (long long)batch, (long long)stride);
+  if (batch == 0) return 0;
+  if (!buffer || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, offsets, rows_out, seed, offset,
+                           (hipStream_t)stream);
+}
+
+int ebm_pcd_scatter_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,
+                        int64_t write_pos, void* stream) {
+  const char* who = "ebm_pcd_scatter_f32";
+  if (buffer_size < 1 || dim < 1 || batch < 0 || batch > buffer_size || write_pos < 0 || write_pos >= buffer_size)
+    return fail(EBM_EINVAL, "%s: bad sizes (buffer %lld, batch %lld, write_pos %lld)", who, (long long)buffer_size,
+                (long long)batch, (long long)write_pos);
+  if (batch == 0) return 0;
+  if (!buffer || !samples) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_pcd_scatter(buffer, buffer_size, dim, samples, batch, write_pos, (hipStream_t)stream);
 }
 
 int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,

@@ -122,6 +122,42 @@ __global__ __launch_bounds__(kBlock) void lookahead_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------
+// persistent-CD replay buffer: stratified gather and FIFO scatter, one element per lane so that a
+// row of `dim` floats is read/written by consecutive lanes (core/base_loss.py:296-315, :390-426)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pcd_gather_kernel(const float* __restrict__ buffer, int64_t buffer_size,
+                                                            int32_t dim, float* __restrict__ out, int64_t batch,
+                                                            int64_t stride, const int64_t* __restrict__ offsets,
+                                                            int64_t* __restrict__ rows_out, RngKey key, uint64_t step) {
+  const int64_t n = batch * dim;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = e / dim;
+    const int d = (int)(e - i * dim);
+    int64_t r;
+    if (offsets) {
+      r = offsets[i];
+    } else {
+      const uint32_t o = pick(philox_at(key, (uint64_t)i >> 2, step), (int)(i & 3));
+      r = (int64_t)(((uint64_t)o * (uint64_t)stride) >> 32);  // multiply-shift: uniform in [0, stride)
+    }
+    const int64_t row = (i * stride + r) % buffer_size;
+    out[e] = buffer[row * dim + d];
+    if (rows_out && d == 0) rows_out[i] = row;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pcd_scatter_kernel(float* __restrict__ buffer, int64_t buffer_size,
+                                                             int32_t dim, const float* __restrict__ samples,
+                                                             int64_t batch, int64_t write_pos) {
+  const int64_t n = batch * dim;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = e / dim;
+    const int64_t row = (write_pos + i) % buffer_size;
+    buffer[row * dim + (e - i * dim)] = samples[e];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Metropolis accept, one lane-group of `lanes` lanes per chain row (samplers/hmc.py:277-292)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
@@ -246,6 +282,21 @@ int launch_descent_step(const float* x, const float* grad, float* v, float* out,
 int launch_lookahead(const float* x, const float* v, float* out, int64_t n_elem, float momentum, hipStream_t st) {
   hipLaunchKernelGGL(lookahead_kernel, dim3(grid_for(n_elem)), dim3(kBlock), 0, st, x, v, out, n_elem, momentum);
   return check_launch("ebm_lookahead_f32");
+}
+
+int launch_pcd_gather(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,
+                      const int64_t* offsets, int64_t* rows_out, uint64_t seed, uint64_t offset, hipStream_t st) {
+  const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(pcd_gather_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim, out,
+                     batch, stride, offsets, rows_out, key, offset);
+  return check_launch("ebm_pcd_gather_f32");
+}
+
+int launch_pcd_scatter(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,
+                       int64_t write_pos, hipStream_t st) {
+  hipLaunchKernelGGL(pcd_scatter_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim,
+                     samples, batch, write_pos);
+  return check_launch("ebm_pcd_scatter_f32");
 }
 
 int launch_hmc_accept(float* x, const float* x_prop, const float* h0, const float* h1,
