@@ -53,8 +53,13 @@ enum {
   EBM_ENERGY_DOUBLE_WELL = 0, /* E = h * sum_j (x_j^2 - b^2)^2   base_model.py:130-148  s[0]=h  s[1]=(float)(b*b)           */
   EBM_ENERGY_HARMONIC    = 1, /* E = (0.5*k) * sum_j x_j^2       base_model.py:213-229  s[0]=(float)(0.5*k)                 */
   EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1) */
-  EBM_ENERGY_GMM         = 3  /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
+  EBM_ENERGY_GMM         = 3, /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
                                  s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]                   */
+  EBM_ENERGY_MLP         = 4  /* E = w3 . silu(W2 silu(W1 x + b1) + b2) + b3   (the energy of the reference's
+                                 examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31)
+                                 n_comp = hidden width H (128), dim <= 4,
+                                 dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
+                                 Supported by ebm_langevin_chain_f32 and ebm_energy_grad_f32 only.                          */
 };
 
 typedef struct ebm_energy {

@@ -102,8 +102,28 @@ if "c5" in want:
                       2.0**0.5, 0, 0.0, 0.0, 1, i, st)
 
     t_upd = wall(updates, reps=20, warm=3)
+
+    # the same training loop with the fused MLP-energy sampler (ta.MLPEnergy)
+    torch.manual_seed(0)
+    fmodel = ta.MLPEnergy(2, device=dev)
+    fs = ta.LangevinDynamics(fmodel, step_size=0.1, noise_scale=1.0, device=dev)
+    fpcd = ta.ContrastiveDivergence(fmodel, fs, k_steps=k, persistent=True, buffer_size=n, init_steps=0, device=dev)
+    fopt = torch.optim.Adam(fmodel.parameters(), lr=1e-3)
+
+    def ftrain_step():
+        loss, _ = fpcd(data)
+        fopt.zero_grad()
+        loss.backward()
+        fopt.step()
+
+    tf = wall(ftrain_step, reps=10, warm=3)
+    tf_sample = wall(lambda: fs.sample(x=data, n_steps=k), reps=10, warm=2)
+    mlp_flops = n * k * 2 * (2 * 128 * 128 + 2 * 2 * 128)  # two HxH contractions + the two thin ones, per chain-step
     print(json.dumps({
         "config": "c5 PCD MLP 2-128-128-1 two-moons n=65536 k=20", "s_per_training_step": t, "training_steps_per_s": 1 / t,
         "chain_steps_per_s": n * k / t, "sampler_only_s": t_sample, "hip_update_kernels_only_s": t_upd,
         "update_share_of_sampler": t_upd / t_sample,
+        "fused_mlp": {"s_per_training_step": tf, "training_steps_per_s": 1 / tf, "sampler_only_s": tf_sample,
+                      "sampler_speedup_vs_autograd_route": t_sample / tf_sample,
+                      "sampler_fp32_TFLOPs": mlp_flops / tf_sample / 1e12},
     }), flush=True)

@@ -1,0 +1,124 @@
+"""the fused MLP-energy Langevin kernel (forward + input-gradient on the matrix
+cores, weights in LDS) against autograd.  Tolerances: fp32 MFMA is an exact fmaf chain, but rocBLAS /
+CPU GEMMs sum in another order and the kernel uses the hardware exp/rcp for the sigmoid:
+|dE| <= 2e-5 * (1 + |E|), |dg| <= 2e-4 * (1 + |g|) for one evaluation; a k-step chain amplifies
+that by the dynamics."""
+
+import copy
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd import _lib
+from torchebm_amd.samplers.langevin import em_coefficients
+from torchebm_amd.utils.synthetic import two_moons
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(cuda_device, in_dim=2, seed=0, scale=1.0):
+    torch.manual_seed(seed)
+    cpu = ta.MLPEnergy(in_dim)
+    with torch.no_grad():
+        for p in cpu.parameters():
+            p.mul_(scale)
+    return cpu, copy.deepcopy(cpu).to(cuda_device)
+
+
+@pytest.mark.parametrize("in_dim,n", [(2, 1000), (1, 77), (3, 256), (4, 129)])
+def test_energy_and_gradient_match_autograd(cuda_device, in_dim, n):
+    cpu, gpu = _models(cuda_device, in_dim, seed=in_dim, scale=2.0)
+    spec = gpu.fused_spec()
+    assert spec is not None and spec.kind == _lib.ENERGY_MLP and spec.langevin_only
+    x = torch.randn(n, in_dim) * 2
+    e = torch.empty(n, device=cuda_device)
+    g = torch.empty(n, in_dim, device=cuda_device)
+    _lib.call("ebm_energy_grad_f32", spec.to_c(), x.to(cuda_device).data_ptr(), n, in_dim, e.data_ptr(), g.data_ptr(),
+              _lib.stream_handle(cuda_device))
+    want_e = cpu(x.double().float()).detach()
+    want_g = cpu.gradient(x)
+    # fp64 reference of the same network, to show both fp32 paths are equally close to the truth
+    ref = copy.deepcopy(cpu).double()
+    e64 = ref(x.double()).detach()
+    assert ((e.cpu() - want_e).abs() / (1 + want_e.abs())).max().item() <= 2e-5
+    assert ((g.cpu() - want_g).abs() / (1 + want_g.abs())).max().item() <= 2e-4
+    assert ((e.cpu().double() - e64).abs() / (1 + e64.abs())).max().item() <= 2e-5
+
+
+def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device):
+    cpu, gpu = _models(cuda_device, 2, seed=5)
+    n, k, eta, sigma = 513, 12, 0.05, 1.0
+    x0 = two_moons(n, 0.05, seed=3)
+    noise = torch.randn(k, n, 2, generator=torch.Generator().manual_seed(9))
+    want = x0.clone()
+    for i in range(k):
+        want = oracle.em_step(want, cpu.gradient(want), noise[i], eta, sigma)
+    spec = gpu.fused_spec()
+    x = x0.to(cuda_device).clone()
+    a, sq, coef = em_coefficients(eta, sigma)
+    traj = torch.empty(n, k // 4, 2, device=cuda_device)
+    _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, 2, k, a, sq, coef, None, 0, 0.0, 0.0, 4, traj.data_ptr(),
+              noise.to(cuda_device).data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    torch.testing.assert_close(x.cpu(), want, rtol=1e-3, atol=1e-3)
+    assert torch.equal(traj[:, -1], x)
+
+
+def test_sampler_fused_route_equals_step_route_noise_field(cuda_device):
+    """LangevinDynamics on MLPEnergy takes the fused route (one launch); a subclass takes the
+    per-step route (autograd + update kernel).  Same generator => same Philox field => the two
+    agree to gradient round-off."""
+
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    torch.manual_seed(2)
+    fused_model = ta.MLPEnergy(2, device=cuda_device)
+    step_model = Sub(2, device=cuda_device)
+    step_model.load_state_dict(fused_model.state_dict())
+    assert step_model.fused_spec() is None
+    x0 = two_moons(4096, 0.05, seed=1, device=cuda_device)
+    sf = ta.LangevinDynamics(fused_model, step_size=0.1, clamp=(-3.0, 3.0), device=cuda_device)
+    ss = ta.LangevinDynamics(step_model, step_size=0.1, clamp=(-3.0, 3.0), device=cuda_device)
+    c0, s0 = hip_calls("ebm_langevin_chain_f32"), hip_calls("ebm_langevin_step_f32")
+    a = sf.sample(x=x0, n_steps=20, generator=torch.Generator(device=cuda_device).manual_seed(4))
+    b = ss.sample(x=x0, n_steps=20, generator=torch.Generator(device=cuda_device).manual_seed(4))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1 and hip_calls("ebm_langevin_step_f32") == s0 + 20
+    torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+    assert a.abs().max().item() <= 3.0
+    # diagnostics / trajectory path
+    traj, diag = sf.sample(x=x0, n_steps=6, thin=2, return_trajectory=True, return_diagnostics=True)
+    assert traj.shape == (4096, 3, 2) and torch.isfinite(diag["energy"]).all()
+    torch.testing.assert_close(diag["energy"][-1], fused_model(traj[:, -1]).mean(), rtol=1e-4, atol=1e-4)
+
+
+def test_pcd_training_with_fused_mlp_sampler(cuda_device):
+    """Config 5's training loop with the fused sampler: weights are re-read at every sample() call,
+    so the optimiser's in-place updates are seen by the next launch."""
+    torch.manual_seed(0)
+    model = ta.MLPEnergy(2, device=cuda_device)
+    n, k = 65536, 20
+    data = two_moons(n, 0.05, seed=0, device=cuda_device)
+    sampler = ta.LangevinDynamics(model, step_size=0.1, noise_scale=1.0, device=cuda_device)
+    pcd = ta.ContrastiveDivergence(model, sampler, k_steps=k, persistent=True, buffer_size=n, init_steps=0, device=cuda_device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    gaps = []
+    for _ in range(4):
+        loss, neg = pcd(data)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        gaps.append((model(neg).mean() - model(data).mean()).item())
+        assert torch.isfinite(loss) and torch.isfinite(neg).all()
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 4
+    # the fused kernel saw the updated weights: same start + same seed, different parameters -> different negatives
+    g = torch.Generator(device=cuda_device).manual_seed(1)
+    before = sampler.sample(x=data[:1024], n_steps=5, generator=g)
+    with torch.no_grad():
+        model.net[4].weight.mul_(3.0)
+    after = sampler.sample(x=data[:1024], n_steps=5, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert not torch.equal(before, after)

@@ -15,6 +15,7 @@ from .core import (  # noqa: F401
     GaussianMixtureModel,
     GaussianModel,
     HarmonicModel,
+    MLPEnergy,
 )
 from .integrators import EulerMaruyamaIntegrator, LeapfrogIntegrator  # noqa: F401
 from .losses import ContrastiveDivergence  # noqa: F401

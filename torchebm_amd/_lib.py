@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
 ABI_VERSION = 1
 
 # energy kinds / enums: keep in sync with include/ebm_hip.h
-ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM = 0, 1, 2, 3
+ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM, ENERGY_MLP = 0, 1, 2, 3, 4
 NOISE_NORMAL, NOISE_UNIFORM, NOISE_RAW_U32 = 0, 1, 2
 MASS_NONE, MASS_SCALAR, MASS_DIAG = 0, 1, 2
 

@@ -19,6 +19,7 @@ from .energies import (
     GaussianMixtureModel,
     GaussianModel,
     HarmonicModel,
+    MLPEnergy,
     ring_mixture,
 )
 from .integrator_base import BaseIntegrator, BaseSDERungeKuttaIntegrator, BaseSymplecticIntegrator
@@ -30,7 +31,7 @@ __all__ = [
     "BaseScheduler", "ConstantScheduler", "ExponentialDecayScheduler", "LinearScheduler",
     "CosineScheduler", "MultiStepScheduler", "WarmupScheduler", "TemperatureScheduler", "Schedulable",
     "BaseModel", "DoubleWellModel", "GaussianModel", "HarmonicModel", "GaussianMixtureModel",
-    "FusedSpec", "ring_mixture",
+    "FusedSpec", "MLPEnergy", "ring_mixture",
     "BaseIntegrator", "BaseSDERungeKuttaIntegrator", "BaseSymplecticIntegrator",
     "BaseSampler", "BaseLoss", "BaseContrastiveDivergence",
 ]

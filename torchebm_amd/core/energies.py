@@ -37,6 +37,7 @@ class FusedSpec:
     dev0: Optional[torch.Tensor] = None
     dev1: Optional[torch.Tensor] = None
     elementwise: bool = False  # gradient of coordinate j depends on x_j only
+    langevin_only: bool = False  # fused for Langevin chains / energy-gradient evaluation, not HMC or descent
 
     def to_c(self) -> "_lib.EnergyDesc":
         d = _lib.EnergyDesc()
@@ -241,6 +242,45 @@ class GaussianMixtureModel(BaseModel):
             dev0=self.means,
             dev1=self.log_weights,
         )
+
+
+class MLPEnergy(BaseModel):
+    r"""Two-hidden-layer SiLU MLP energy ``E(x) = w_3^\top \mathrm{silu}(W_2\,\mathrm{silu}(W_1 x + b_1) + b_2) + b_3``
+    -- the trainable energy of the reference's PCD example
+    (examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).
+
+    With ``hidden == 128`` and ``in_dim <= 4`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
+    forward, input-gradient on the matrix cores, update, noise -- in one ``ebm_langevin_chain_f32``
+    launch instead of one autograd round trip per step.  Training is unaffected:
+    the parameters are ordinary ``nn.Linear`` weights and are re-read at every ``sample()`` call.
+    """
+
+    FUSED_HIDDEN = 128
+    FUSED_MAX_DIM = 4
+
+    def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from torch import nn
+
+        self.in_dim, self.hidden = in_dim, hidden
+        self.net = nn.Sequential(
+            nn.Linear(in_dim, hidden), nn.SiLU(), nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, 1)
+        ).to(device=self._torchebm_probe.device, dtype=self._torchebm_probe.dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.net(x).squeeze(-1)
+
+    def fused_spec(self) -> Optional[FusedSpec]:
+        if not self._is_exactly(MLPEnergy) or self.hidden != self.FUSED_HIDDEN or self.in_dim > self.FUSED_MAX_DIM:
+            return None
+        w = self.net[0].weight
+        if not w.is_cuda or w.dtype != torch.float32:
+            return None
+        with torch.no_grad():  # W1[H,in] b1[H] W2[H,H] b2[H] w3[H] b3[1], the order include/ebm_hip.h documents
+            packed = torch.cat([p.detach().reshape(-1) for p in (
+                self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
+                self.net[4].weight, self.net[4].bias)])
+        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True)
 
 
 def ring_mixture(

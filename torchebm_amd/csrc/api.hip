@@ -37,6 +37,9 @@ int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, 
                       uint64_t, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
+int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
+                              int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
+int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -79,10 +82,19 @@ int check_energy(const ebm_energy_t* en, int32_t dim, const char* who) {
       if (!en->dev0 || !en->dev1 || en->n_comp < 1) return fail(EBM_EINVAL, "%s: mixture energy needs means, log-weights and n_comp >= 1", who);
       if (en->n_comp > 64) return fail(EBM_EDIM, "%s: at most 64 mixture components are supported (got %d)", who, en->n_comp);
       return 0;
+    case EBM_ENERGY_MLP:
+      if (!en->dev0) return fail(EBM_EINVAL, "%s: MLP energy needs the packed parameter pointer", who);
+      return 0;
     default:
       return fail(EBM_EKIND, "%s: unknown energy kind %d", who, en->kind);
   }
   (void)dim;
+}
+
+int reject_mlp(const ebm_energy_t* en, const char* who) {
+  if (en->kind == EBM_ENERGY_MLP)
+    return fail(EBM_EKIND, "%s: the MLP energy is fused for Langevin chains and energy/gradient evaluation only", who);
+  return 0;
 }
 
 int check_state(const void* x, int64_t n_chains, int32_t dim, const char* who) {
@@ -129,6 +141,9 @@ int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chain
   if (n_chains == 0 || k_steps == 0) return 0;
   if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)) || (noise && !aligned16(noise)))
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  if (energy->kind == EBM_ENERGY_MLP)
+    return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                     clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
   if (energy->kind == EBM_ENERGY_DOUBLE_WELL || energy->kind == EBM_ENERGY_HARMONIC)
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
@@ -146,6 +161,7 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
                       void* stream) {
   const char* who = "ebm_hmc_chain_f32";
   if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = reject_mlp(energy, who)) return r;
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (n_mh < 0 || thin < 1 || n_leapfrog < 1)
     return fail(EBM_EINVAL, "%s: n_mh=%d thin=%d n_leapfrog=%d", who, n_mh, thin, n_leapfrog);
@@ -203,6 +219,7 @@ int ebm_descent_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains
                           float momentum, int32_t thin, float* traj, void* stream) {
   const char* who = "ebm_descent_chain_f32";
   if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = reject_mlp(energy, who)) return r;
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
   if (n_chains == 0 || k_steps == 0) return 0;
@@ -263,6 +280,8 @@ int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_ch
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (n_chains == 0) return 0;
   if (grad_out && !aligned16(grad_out)) return fail(EBM_EINVAL, "%s: grad_out must be 16-byte aligned", who);
+  if (energy->kind == EBM_ENERGY_MLP)
+    return launch_energy_grad_mlp(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
   return launch_energy_grad(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
 }
 
