@@ -1,8 +1,10 @@
 """Persistent contrastive divergence on two-moons (cf. the reference's
 examples/20-training/01-mcmc-losses/02-persistent-cd/main.py; BASELINE config 5).
 
-The energy is a small MLP, so the gradient comes from autograd (PyTorch-ROCm); every Langevin
-step's update + noise + clamp is one fused HIP kernel launch (`ebm_langevin_step_f32`)."""
+The energy is the reference example's 2-128-128-1 SiLU MLP.  Defined by hand (as in the reference
+script) the sampler uses autograd for the gradient and one fused HIP launch per Langevin step;
+with the packaged `MLPEnergy` (same network) all k steps -- forward, input-gradient on the matrix
+cores, update, noise -- are ONE kernel launch.  Set TORCHEBM_HANDWRITTEN_MLP=1 for the former."""
 
 import os
 import sys
@@ -12,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a source checkout
 from torch import nn
 
-from torchebm_amd.core import BaseModel
+from torchebm_amd.core import BaseModel, MLPEnergy as FusedMLPEnergy
 from torchebm_amd.losses import ContrastiveDivergence
 from torchebm_amd.samplers import LangevinDynamics
 from torchebm_amd.utils.synthetic import two_moons
@@ -33,7 +35,7 @@ class MLPEnergy(BaseModel):
 
 torch.manual_seed(0)
 data = two_moons(n_samples=3000, noise=0.05, seed=0, device=device)
-energy = MLPEnergy().to(device)
+energy = MLPEnergy().to(device) if os.getenv("TORCHEBM_HANDWRITTEN_MLP") == "1" else FusedMLPEnergy(2, device=device)
 sampler = LangevinDynamics(model=energy, step_size=0.1, noise_scale=1.0, device=device)
 pcd = ContrastiveDivergence(model=energy, sampler=sampler, k_steps=10, persistent=True, buffer_size=8192, device=device)
 opt = torch.optim.Adam(energy.parameters(), lr=1e-3)
