@@ -9,10 +9,12 @@ of the fused kernel ``ebm_langevin_chain_f32`` = n_chains * k chain-steps.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+The K timed steps continue the same chains (each call starts from the previous call's state).
+
 N > 1: one process per GPU, chains sharded by rank (weak scaling: 2^20 chains per GPU, seed
-base+rank, no collective inside the k steps); the final state of every step is read back
-with ONE RCCL all-gather (``all_gather_cat``) issued asynchronously so that it overlaps the
-next step's kernel; the last one is waited for inside the timed region.
+base+rank, no collective inside the k steps).  The only exchange on the path is the read-back
+of the final state: ONE RCCL all-gather of the [2^20, 64] shards after the last step, inside
+the timed region (and once during warm-up, so communicator set-up is not timed).
 
 Output: one JSON line on rank 0 (see DESIGN.md §Measurement for the roofline accounting).
 """
@@ -138,31 +140,29 @@ def main():
     x0 = torch.randn(n, dim, device=device, generator=gen)
 
     gathered = None
-    pending = None
-    readback = "none (single process)" if world == 1 else "async all_gather_into_tensor per call"
+    readback = "none (single process)" if world == 1 else "one all_gather_into_tensor of the final state, inside the timed region"
+    state = x0
 
     def one_step():
-        nonlocal gathered, pending, readback
-        out = sampler.sample(x=x0, n_steps=k, generator=gen)
-        if world > 1 and not readback.startswith("disabled"):
-            import torch.distributed as dist
+        # the K steps form one sharded run: every call continues the rank's chains
+        nonlocal state
+        state = sampler.sample(x=state, n_steps=k, generator=gen)
 
-            try:
-                if pending is not None:
-                    pending.wait()
-                if gathered is None:
-                    gathered = torch.empty((world * n, dim), dtype=out.dtype, device=device)
-                pending = dist.all_gather_into_tensor(gathered, out.contiguous(), async_op=True)
-            except Exception as exc:  # report, keep measuring the sharded compute
-                pending = None
-                readback = f"disabled after error: {type(exc).__name__}: {exc}"[:300]
-        return out
+    def read_back():
+        """The path's only collective: rank-ordered all-gather of the final [n, dim] shards."""
+        nonlocal gathered, readback
+        if world == 1 or readback.startswith("disabled"):
+            return
+        import torch.distributed as dist
+
+        try:
+            if gathered is None:
+                gathered = torch.empty((world * n, dim), dtype=state.dtype, device=device)
+            dist.all_gather_into_tensor(gathered, state.contiguous())
+        except Exception as exc:  # report it, keep measuring the sharded compute
+            readback = f"disabled after error: {type(exc).__name__}: {exc}"[:300]
 
     def fence():
-        nonlocal pending
-        if pending is not None:
-            pending.wait()
-            pending = None
         if world > 1:
             import torch.distributed as dist
 
@@ -172,12 +172,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    read_back()  # also creates the RCCL communicator outside the timed region
     fence()
+    state = x0
     if on_gpu:
         _lib.timed_events["ebm_langevin_chain_f32"] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    read_back()
     fence()
     elapsed = time.perf_counter() - t0
 
