@@ -1,0 +1,173 @@
+"""Edge cases on the GPU: empty inputs, ragged sizes (dim % 4 != 0 with the native RNG), the widest
+supported rows, parameter sets that do not fit LDS, large mixtures, non-finite states, and the
+limits where the fused route hands over to the per-step route."""
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd import _lib
+from torchebm_amd.samplers.langevin import em_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(shape_k_n_dim, seed, step0, device, stride=1):
+    k, n, dim = shape_k_n_dim
+    rows = []
+    for i in range(k):  # one allocation per step: the ABI wants 16-byte aligned pointers
+        buf = torch.empty(n, dim, device=device)
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n * dim, _lib.NOISE_NORMAL, seed, step0 + stride * i,
+                  _lib.stream_handle(device))
+        rows.append(buf)
+    return torch.stack(rows)
+
+
+def test_empty_inputs(cuda_device):
+    m = ta.DoubleWellModel(device=cuda_device)
+    s = ta.LangevinDynamics(m, step_size=0.01, device=cuda_device)
+    assert s.sample(x=torch.empty(0, 8, device=cuda_device), n_steps=5).shape == (0, 8)
+    x0 = torch.randn(16, 8, device=cuda_device)
+    assert torch.equal(s.sample(x=x0, n_steps=0), x0)
+    traj, diag = s.sample(x=x0, n_steps=0, return_trajectory=True, return_diagnostics=True)
+    assert traj.shape == (16, 0, 8) and diag["mean"].shape == (0, 8)
+    h = ta.HamiltonianMonteCarlo(m, step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
+    assert h.sample(x=torch.empty(0, 8, device=cuda_device), n_steps=2).shape == (0, 8)
+    assert torch.equal(h.sample(x=x0, n_steps=0), x0)
+    g = ta.samplers.GradientDescentSampler(m, step_size=0.01, device=cuda_device)
+    assert torch.equal(g.sample(x=x0, n_steps=0), x0)
+    # thin larger than n_steps: nothing kept, state still advances
+    out, diag = s.sample(x=x0, n_steps=3, thin=5, return_diagnostics=True)
+    assert diag["energy"].shape == (0,) and not torch.equal(out, x0)
+
+
+@pytest.mark.parametrize("dim,n", [(1, 1001), (3, 257), (5, 100), (6, 33), (30, 64), (100, 37), (250, 9)])
+def test_native_rng_ragged_dims_langevin(cuda_device, dim, n):
+    """dim % 4 != 0 (or tiny / ragged n): the fused chain with its own Philox draws equals the
+    oracle fed with the field materialised by ebm_noise_fill_f32 -- element-wise energy (flat
+    layout) bit-exactly, the mixture (lane-group layout, per-element Philox path) to round-off."""
+    k, eta = 7, 0.01
+    x0 = torch.randn(n, dim).clamp_(-2.5, 2.5)
+    gen = torch.Generator(device=cuda_device).manual_seed(99)
+    s = ta.LangevinDynamics(ta.DoubleWellModel(device=cuda_device), step_size=eta, device=cuda_device)
+    got = s.sample(x=x0.to(cuda_device), n_steps=k, generator=gen)
+    noise = _noise((k, n, dim), 99, 0, cuda_device)
+    want, _, _ = oracle.langevin_chain(oracle.DoubleWell(), x0, noise.cpu(), [eta] * k, [1.0] * k)
+    assert torch.equal(got.cpu(), want)
+    if dim >= 2:
+        means = torch.randn(5, dim, generator=torch.Generator().manual_seed(1)) * 2
+        gm = ta.GaussianMixtureModel(means, sigma=0.9, device=cuda_device)
+        s2 = ta.LangevinDynamics(gm, step_size=0.02, device=cuda_device)
+        got2 = s2.sample(x=x0.to(cuda_device), n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(99))
+        want2, _, _ = oracle.langevin_chain(oracle.GaussianMixture(means, 0.9), x0, noise.cpu(), [0.02] * k, [1.0] * k)
+        torch.testing.assert_close(got2.cpu(), want2, rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("dim,n,kind", [(6, 33, "gmm"), (3, 50, "dw"), (100, 40, "dw"), (250, 9, "har"), (1000, 5, "dw"), (1024, 3, "har")])
+def test_native_rng_ragged_dims_hmc(cuda_device, dim, n, kind):
+    """HMC with in-kernel draws (momentum at step 2t, uniforms at 2t+1) vs the oracle on the
+    materialised field, incl. the widest rows (G=64, NV=4, LDS-parked state)."""
+    T, L, eps = 4, 5, 0.02
+    x0 = torch.randn(n, dim).clamp_(-2.0, 2.0)
+    if kind == "gmm":
+        means = torch.randn(4, dim, generator=torch.Generator().manual_seed(2)) * 2
+        model, en = ta.GaussianMixtureModel(means, sigma=1.1, device=cuda_device), oracle.GaussianMixture(means, 1.1)
+    elif kind == "har":
+        model, en = ta.HarmonicModel(1.3, device=cuda_device), oracle.Harmonic(1.3)
+    else:
+        model, en = ta.DoubleWellModel(device=cuda_device), oracle.DoubleWell()
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, device=cuda_device)
+    before = hip_calls("ebm_hmc_chain_f32")
+    got, diag = s.sample(x=x0.to(cuda_device), n_steps=T, return_diagnostics=True,
+                         generator=torch.Generator(device=cuda_device).manual_seed(7))
+    assert hip_calls("ebm_hmc_chain_f32") == before + T  # diagnostics: one launch per kept step
+    p = _noise((T, n, dim), 7, 0, cuda_device, stride=2)
+    us = []
+    for t in range(T):
+        ut = torch.empty(n, device=cuda_device)
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 7, 2 * t + 1, _lib.stream_handle(cuda_device))
+        us.append(ut)
+    u = torch.stack(us)
+    want = oracle.hmc_chain(en, x0, p.cpu(), u.cpu(), [eps] * T, L, want_diag=True)
+    if want["margin"] > 1e-4:
+        torch.testing.assert_close(diag["acceptance_rate"].cpu(), want["diagnostics"]["acceptance_rate"])
+        scale = want["x"].abs().clamp(min=1.0)
+        assert ((got.cpu() - want["x"]).abs() / scale).max().item() <= 5e-4
+    assert torch.isfinite(got).all()
+
+
+def test_dim_limits_and_handover(cuda_device):
+    m = ta.DoubleWellModel(device=cuda_device)
+    h = ta.HamiltonianMonteCarlo(m, step_size=0.01, n_leapfrog_steps=2, device=cuda_device)
+    x = torch.randn(4, 1025, device=cuda_device).clamp_(-2, 2)
+    a0, k0 = hip_calls("ebm_hmc_chain_f32"), hip_calls("ebm_leapfrog_kick_f32")
+    out = h.sample(x=x, n_steps=1)  # dim > 1024: per-transition route, still HIP kernels
+    assert hip_calls("ebm_hmc_chain_f32") == a0 and hip_calls("ebm_leapfrog_kick_f32") == k0 + 2
+    assert out.shape == (4, 1025) and torch.isfinite(out).all()
+    desc = m.fused_spec().to_c()
+    with pytest.raises(RuntimeError, match="dim 1025"):
+        _lib.call("ebm_hmc_chain_f32", desc, x.data_ptr(), 4, 1025, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None, None,
+                  0, 0, _lib.stream_handle(cuda_device))
+    # the element-wise Langevin chain has no dim limit
+    s = ta.LangevinDynamics(m, step_size=0.001, device=cuda_device)
+    big = torch.randn(3, 5000, device=cuda_device).clamp_(-2, 2)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    assert s.sample(x=big, n_steps=3).shape == (3, 5000) and hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    # a 65-component mixture is not fused (the kernel supports K <= 64): per-step route
+    gm = ta.GaussianMixtureModel(torch.randn(65, 4), device=cuda_device)
+    assert gm.fused_spec() is None
+    s0 = hip_calls("ebm_langevin_step_f32")
+    ta.LangevinDynamics(gm, step_size=0.01, device=cuda_device).sample(dim=4, n_samples=8, n_steps=2)
+    assert hip_calls("ebm_langevin_step_f32") == s0 + 2
+
+
+def test_large_mixture_and_large_precision_matrix(cuda_device):
+    """K = 40 components (online-softmax path) and a 160 x 160 precision matrix (does not fit the LDS
+    budget: rows streamed from L2) against autograd."""
+    x = torch.randn(50, 12) * 2
+    means = torch.randn(40, 12, generator=torch.Generator().manual_seed(3)) * 3
+    w = torch.rand(40, generator=torch.Generator().manual_seed(4)) + 0.1
+    gm = ta.GaussianMixtureModel(means, sigma=1.5, weights=w, device=cuda_device)
+    e, g = torch.empty(50, device=cuda_device), torch.empty(50, 12, device=cuda_device)
+    _lib.call("ebm_energy_grad_f32", gm.fused_spec().to_c(), x.to(cuda_device).data_ptr(), 50, 12, e.data_ptr(), g.data_ptr(),
+              _lib.stream_handle(cuda_device))
+    cpu = ta.GaussianMixtureModel(means, sigma=1.5, weights=w)
+    torch.testing.assert_close(e.cpu(), cpu(x), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(g.cpu(), cpu.gradient(x), rtol=2e-5, atol=2e-5)
+
+    d = 160
+    a = torch.randn(d, d, generator=torch.Generator().manual_seed(5))
+    cov = a @ a.t() / d + torch.eye(d)
+    mean = torch.randn(d, generator=torch.Generator().manual_seed(6))
+    gcpu = ta.GaussianModel(mean, cov)
+    ggpu = ta.GaussianModel(mean, cov, device=cuda_device)
+    xx = torch.randn(21, d) * 2
+    e, g = torch.empty(21, device=cuda_device), torch.empty(21, d, device=cuda_device)
+    _lib.call("ebm_energy_grad_f32", ggpu.fused_spec().to_c(), xx.to(cuda_device).data_ptr(), 21, d, e.data_ptr(), g.data_ptr(),
+              _lib.stream_handle(cuda_device))
+    torch.testing.assert_close(e.cpu(), gcpu(xx), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(g.cpu(), gcpu.gradient(xx), rtol=1e-4, atol=1e-4)
+    out = ta.LangevinDynamics(ggpu, step_size=0.01, device=cuda_device).sample(x=xx.to(cuda_device), n_steps=5)
+    assert torch.isfinite(out).all()
+
+
+def test_non_finite_states(cuda_device):
+    """reference tests/samplers/test_hmc.py:835-896 / test_leapfrog.py:502-529: extreme and NaN
+    inputs stay finite through safe-mode leapfrog; a NaN energy rejects."""
+    m = ta.DoubleWellModel(device=cuda_device)
+    h = ta.HamiltonianMonteCarlo(m, step_size=0.01, n_leapfrog_steps=5, device=cuda_device)
+    x = torch.full((64, 8), 1e4, device=cuda_device)
+    x[32:] = -1e6
+    out, d = h.sample(x=x, n_steps=3, return_diagnostics=True)
+    assert torch.isfinite(out).all() and torch.isfinite(d["mean"]).all()
+    bad = torch.randn(64, 8, device=cuda_device)
+    bad[0, 0] = float("nan")
+    bad[1, 3] = float("inf")
+    out = h.sample(x=bad, n_steps=2)
+    assert torch.isfinite(out[2:]).all()  # the other chains are untouched by their neighbours' NaNs
+    assert torch.isnan(out[0, 0]) or torch.isfinite(out[0, 0])  # chain 0 either rejected (keeps NaN) or was scrubbed
+    s = ta.LangevinDynamics(m, step_size=0.01, clamp=(-3.0, 3.0), device=cuda_device)
+    o = s.sample(x=bad, n_steps=3)
+    assert torch.isnan(o[0, 0]) and torch.isfinite(o[2:]).all()  # torch.clamp propagates NaN, and so does the kernel
