@@ -3,6 +3,7 @@
 // allocates device memory or synchronises.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "ebm_common.h"
 
@@ -40,6 +41,10 @@ int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t)
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
+bool gauss_mfma_supported(int32_t dim);
+int launch_langevin_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                     const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
+                                     hipStream_t);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -148,6 +153,13 @@ int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chain
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
                                       cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  if (energy->kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim)) {
+    // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
+    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+    if (!force_rows)
+      return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                              clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  }
   return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef,
                                     coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
                                     (hipStream_t)stream);

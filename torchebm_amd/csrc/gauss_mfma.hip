@@ -1,0 +1,199 @@
+// k-fused Langevin chain for the dense Gaussian energy on the matrix cores (dim a multiple of 32,
+// dim <= 128):  g = Ps (x - mu)  is the only dense contraction on the whole path (SURVEY.md §7 "hard
+// parts", §8 a4), so it goes to the exact-f32 MFMA instead of an LDS mat-vec.
+// Reference: torchebm/core/base_model.py:181-210 (energy), samplers/langevin_dynamics.py:154-185.
+//
+// Mapping (same idea as mlp.hip): a wavefront owns 32 chains; lane l = (m, h), m = l & 31 the chain,
+// h = l >> 5 the K-half of v_mfma_f32_32x32x2_f32.  The chain state itself lives in the C/D layout of
+// the 32x32 tiles: register r of tile t holds coordinate k = 32 t + (r&3) + 8 (r>>2) + 4 h of chain m,
+// so that  g^T[i, m] = sum_k Ps[i, k] d[k, m]  takes its B-operand straight from the state registers
+// (the K index is enumerated in the order the layout already holds it) and produces g in the very
+// layout x is stored in: update, clamp, trajectory stores are register-to-register, and four
+// consecutive registers are four consecutive coordinates = one Philox counter = one float4 access.
+// Ps = (P + P^T)/2 is symmetric, so the A-operand Ps[i = 32 it + m][k] is read as Ps[k][32 it + m]:
+// consecutive lanes, consecutive LDS banks.
+#include "ebm_common.h"
+
+namespace ebm {
+namespace {
+
+constexpr int kBlock = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GaussArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t dim;
+  int32_t k_steps;
+  float eta, sqrt_eta, noise_coef;
+  const float4* table;
+  int clamp_on;
+  float cmin, cmax;
+  int32_t thin, n_kept;
+  float* traj;
+  const float* noise;
+  RngKey key;
+  uint64_t step0;
+  const float* mean;  // [dim]
+  const float* prec;  // [dim, dim], symmetric
+};
+
+extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
+
+template <int NT>
+__global__ __launch_bounds__(kBlock, 2) void gauss_langevin_mfma_kernel(GaussArgs a) {
+  constexpr int DIM = 32 * NT;
+  float* Ps = gauss_smem;            // [DIM][DIM]
+  float* mus = gauss_smem + DIM * DIM;  // [DIM]
+  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) Ps[i] = a.prec[i];
+  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = a.mean[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const bool active = chain < a.n_chains;
+  const int64_t row = active ? chain * (int64_t)DIM : 0;
+
+  // state in the C/D layout; quad q of tile t = coordinates 32t + 8q + 4h .. +3
+  f32x16 x[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k0 = 32 * t + 8 * q + 4 * h;
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (active) xv = *reinterpret_cast<const float4*>(a.x + row + k0);
+      x[t][4 * q + 0] = xv.x; x[t][4 * q + 1] = xv.y; x[t][4 * q + 2] = xv.z; x[t][4 * q + 3] = xv.w;
+    }
+
+  float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * DIM : 0;
+
+  for (int step = 0; step < a.k_steps; ++step) {
+    if (a.table) {
+      const float4 tb = a.table[step];
+      eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
+    }
+    // ---- g^T = Ps d^T on the matrix cores
+    f32x16 g[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = 0.0f;
+    // software-pipelined: the LDS operands of K-step s+1 are requested before the MFMAs of K-step s
+    // issue, so their latency hides under 2*NT*64 matrix-pipe cycles
+    auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
+    float pa[NT], pb[NT], ma, mb;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) pa[it] = Ps[k_of(0) * DIM + 32 * it + m];
+    ma = mus[k_of(0)];
+    // (Slotting the step's Philox + Box-Muller work between the MFMA groups was tried and buys nothing:
+    //  SQ_VALU_MFMA_COEXEC_CYCLES reads 0 for this kernel -- the f32 MFMA executes on the same FP32 lanes
+    //  as the VALU, so the two never overlap; profiles/r01_pmc_gauss_mfma.txt.)
+#pragma unroll
+    for (int s = 0; s < 16 * NT; ++s) {
+      if (s + 1 < 16 * NT) {
+        const int kn = k_of(s + 1);
+#pragma unroll
+        for (int it = 0; it < NT; ++it) pb[it] = Ps[kn * DIM + 32 * it + m];
+        mb = mus[kn];
+      }
+      const float d = x[s >> 4][s & 15] - ma;  // B[k = h][m]: the K index this half holds in register s & 15
+#pragma unroll
+      for (int it = 0; it < NT; ++it)           // A[row = m][k = h] = Ps[32 it + m][k] (symmetric: read as a row)
+        g[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it], d, g[it], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NT; ++it) pa[it] = pb[it];
+      ma = mb;
+    }
+    // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 32 * t + 8 * q + 4 * h;
+        F4 eps;
+        if (a.noise) {
+          float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (active) nv = *reinterpret_cast<const float4*>(a.noise + ((int64_t)step * a.n_chains) * DIM + row + k0);
+          eps.v[0] = nv.x; eps.v[1] = nv.y; eps.v[2] = nv.z; eps.v[3] = nv.w;
+        } else {
+          eps = normal4_at(a.key, ((uint64_t)chain * DIM + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
+          const float dw = eps.v[i] * sqrt_eta;
+          float nv = x1 + noise_coef * dw;
+          if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+          x[t][4 * q + i] = nv;
+        }
+        if constexpr (NT >= 3) __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
+      }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      if (active) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(a.traj + traj_row + keep_off + 32 * t + 8 * q + 4 * h) =
+                make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+      }
+      keep_off += DIM;
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(a.x + row + 32 * t + 8 * q + 4 * h) =
+            make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+  }
+}
+
+template <int NT>
+int launch_nt(const GaussArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)((32 * NT) * (32 * NT) + 32 * NT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_mfma_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL(gauss_langevin_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+
+}  // namespace
+
+bool gauss_mfma_supported(int32_t dim) { return dim >= 32 && dim <= 128 && (dim % 32) == 0; }
+
+int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                                     float eta, float sqrt_eta, float noise_coef, const float* coef_table,
+                                     int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
+                                     const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
+  GaussArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
+  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
+  switch (dim / 32) {
+    case 1: return launch_nt<1>(a, st);
+    case 2: return launch_nt<2>(a, st);
+    case 3: return launch_nt<3>(a, st);
+    default: return launch_nt<4>(a, st);
+  }
+}
+
+}  // namespace ebm

@@ -102,21 +102,32 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_langevin_chain_kernel(MlpArgs a
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // software-pipelined: the LDS operands of K-step s+1 are requested before the MFMAs of K-step s
+    // issue, so their latency hides under 4 x 64 matrix-pipe cycles
+    float w2a[kTiles], w2b[kTiles];
+    float4 w1a = *reinterpret_cast<const float4*>(W1s + h * 8), w1b = w1a;
+    float b1a = W1s[h * 8 + 4], b1b = b1a;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) w2a[t] = W2s[(t * 32 + m) * kW2Stride + h];
     for (int s = 0; s < H / 2; ++s) {
-      const int i = 2 * s + h;
-      const float4 w1 = *reinterpret_cast<const float4*>(W1s + i * 8);
-      float a1 = W1s[i * 8 + 4];
-      a1 = __builtin_fmaf(w1.x, x[0], a1);
-      a1 = __builtin_fmaf(w1.y, x[1], a1);
-      a1 = __builtin_fmaf(w1.z, x[2], a1);
-      a1 = __builtin_fmaf(w1.w, x[3], a1);
+      const int in = 2 * (s + 1 < H / 2 ? s + 1 : s) + h;  // next K index (clamped on the last step)
+      w1b = *reinterpret_cast<const float4*>(W1s + in * 8);
+      b1b = W1s[in * 8 + 4];
+#pragma unroll
+      for (int t = 0; t < kTiles; ++t) w2b[t] = W2s[(t * 32 + m) * kW2Stride + in];
+      float a1 = b1a;
+      a1 = __builtin_fmaf(w1a.x, x[0], a1);
+      a1 = __builtin_fmaf(w1a.y, x[1], a1);
+      a1 = __builtin_fmaf(w1a.z, x[2], a1);
+      a1 = __builtin_fmaf(w1a.w, x[3], a1);
       const float h1 = a1 * sigmoidf_fast(a1);  // B[k = h][m]
 #pragma unroll
-      for (int t = 0; t < kTiles; ++t) {
-        const float w2 = W2s[(t * 32 + m) * kW2Stride + i];  // A[row = m][k = h] = W2[j = 32t + m][i]
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2, h1, acc[t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep one K-step's loads next to its MFMAs (bounded registers)
+      for (int t = 0; t < kTiles; ++t)           // A[row = m][k = h] = W2[j = 32t + m][i]
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], h1, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: next loads, this step's MFMAs
+      w1a = w1b; b1a = b1b;
+#pragma unroll
+      for (int t = 0; t < kTiles; ++t) w2a[t] = w2b[t];
     }
     // ------------------------------------------------------------ energy, d2 = w3 * silu'(a2)
     float e_part = 0.0f;
@@ -137,19 +148,26 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_langevin_chain_kernel(MlpArgs a
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tac[t][r] = 0.0f;
+    {
+      float wa[kTiles], wb[kTiles];
 #pragma unroll
-    for (int jt = 0; jt < kTiles; ++jt)
+      for (int t = 0; t < kTiles; ++t) wa[t] = W2s[row_of(0, h) * kW2Stride + t * 32 + m];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = jt * 32 + row_of(r, h);       // the K index this half holds in register r
-        const float d2 = acc[jt][r];                // B[k = h][m]
+      for (int s = 0; s < 16 * kTiles; ++s) {     // K-step s: tile jt = s >> 4, register r = s & 15
+        if (s + 1 < 16 * kTiles) {
+          const int jn = ((s + 1) >> 4) * 32 + row_of((s + 1) & 15, h);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-          const float w2 = W2s[j * kW2Stride + t * 32 + m];  // A[row = m][k = h] = W2[j][i = 32t + m]
-          tac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2, d2, tac[t], 0, 0, 0);
+          for (int t = 0; t < kTiles; ++t) wb[t] = W2s[jn * kW2Stride + t * 32 + m];
         }
+        const float d2 = acc[s >> 4][s & 15];     // B[k = h][m]: the K index j this half holds in register s & 15
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)          // A[row = m][k = h] = W2[j][i = 32t + m]
+          tac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], d2, tac[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) wa[t] = wb[t];
       }
+    }
     // ------------------------------------------------------------ g = W1^T (T^T * silu'(a1))
     float g[kMaxDim] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
