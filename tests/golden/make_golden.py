@@ -110,12 +110,13 @@ def sha(t):
     return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()[:16]
 
 
-def langevin_case(name, energy, n, dim, k, step_size, noise_scale, seed, clamp=None, thin=1, x0_scale=1.0, store_noise=True):
+def langevin_case(name, energy, n, dim, k, step_size, noise_scale, seed, clamp=None, thin=1, x0_scale=1.0, store_noise=True,
+                  integrator=None):
     model = make_energy(energy)
     g = torch.Generator().manual_seed(seed)
     x0 = torch.randn(n, dim, generator=g) * x0_scale
     run_seed = seed + 1000
-    sampler = LangevinDynamics(model, step_size=step_size, noise_scale=noise_scale, clamp=clamp)
+    sampler = LangevinDynamics(model, step_size=step_size, noise_scale=noise_scale, clamp=clamp, integrator=integrator)
     out_final = sampler.sample(x=x0.clone(), n_steps=k, generator=torch.Generator().manual_seed(run_seed))
     traj, diag = sampler.sample(
         x=x0.clone(), n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True,
@@ -125,7 +126,7 @@ def langevin_case(name, energy, n, dim, k, step_size, noise_scale, seed, clamp=N
     noise = torch.stack([torch.randn(n, dim, generator=replay) for _ in range(k)])
     fx = {
         "sampler": "langevin", "name": name, "energy": energy, "n": n, "dim": dim, "k": k, "thin": thin,
-        "clamp": clamp, "run_seed": run_seed, "x0": x0,
+        "clamp": clamp, "run_seed": run_seed, "x0": x0, "integrator": integrator,
         "etas": sched_values(step_size, k), "sigmas": sched_values(noise_scale, k),
         "noise": noise if store_noise else None,
         "ref": {"x": out_final, "trajectory": traj, "diagnostics": diag, "sha_x": sha(out_final)},
@@ -255,6 +256,8 @@ def main():
     langevin_case("ld_gmm8_64x32", gmm, 64, 32, 16, 0.05, 1.0, seed=16, x0_scale=3.0)
     langevin_case("ld_gmm5_50x6", gmm6, 50, 6, 12, 0.03, 0.9, seed=17, x0_scale=2.0, thin=5)
     langevin_case("ld_dw_1x8", dw, 1, 8, 8, 0.01, 1.0, seed=18)
+    langevin_case("heun_dw_40x6", dw, 40, 6, 10, 0.01, 1.0, seed=19, integrator="heun", thin=2)
+    langevin_case("heun_gauss2d_64", g2, 64, 2, 8, 0.05, 0.7, seed=20, integrator="heun")
     # SURVEY.md §8c checksum cases (noise is replayed from the seed, not stored)
     langevin_survey()
 

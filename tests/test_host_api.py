@@ -507,3 +507,19 @@ print("dropin-ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "dropin-ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", golden_names("heun_"))
+def test_heun_langevin_reproduces_reference(name):
+    """LangevinDynamics(integrator="heun") (reference tests/samplers/test_langevin_dynamics.py:259-268):
+    the generic explicit-tableau step against the reference's recorded run."""
+    from torchebm_amd.integrators import HeunIntegrator
+
+    fx = load_golden(name)
+    s = ta.LangevinDynamics(package_model(fx["energy"]), step_size=fx["etas"][0], noise_scale=fx["sigmas"][0], integrator="heun")
+    assert type(s.integrator) is HeunIntegrator
+    out = s.sample(x=fx["x0"].clone(), n_steps=fx["k"], generator=torch.Generator().manual_seed(fx["run_seed"]))
+    _check(out, fx["ref"]["x"], fx["energy"]["kind"])
+    traj = s.sample(x=fx["x0"].clone(), n_steps=fx["k"], thin=fx["thin"], return_trajectory=True,
+                    generator=torch.Generator().manual_seed(fx["run_seed"]))
+    _check(traj, fx["ref"]["trajectory"], fx["energy"]["kind"])

@@ -1,7 +1,7 @@
 """Integrators on the Langevin/HMC path (reference package: torchebm/integrators)."""
 
-from .em import EulerMaruyamaIntegrator
+from .em import EulerMaruyamaIntegrator, HeunIntegrator
 from .symplectic import LeapfrogIntegrator
 from .registry import get_integrator, resolve_integrator
 
-__all__ = ["EulerMaruyamaIntegrator", "LeapfrogIntegrator", "get_integrator", "resolve_integrator"]
+__all__ = ["EulerMaruyamaIntegrator", "HeunIntegrator", "LeapfrogIntegrator", "get_integrator", "resolve_integrator"]

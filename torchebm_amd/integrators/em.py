@@ -25,3 +25,23 @@ class EulerMaruyamaIntegrator(BaseSDERungeKuttaIntegrator):
     @property
     def tableau_c(self):
         return (0.0,)
+
+
+class HeunIntegrator(BaseSDERungeKuttaIntegrator):
+    r"""Heun (improved Euler) predictor-corrector drift update with the same Euler-order noise term
+    (reference: torchebm/integrators/heun.py; ``LangevinDynamics(integrator="heun")`` in the reference's
+    tests/samplers/test_langevin_dynamics.py:259-268).  Two drift evaluations per step; runs the generic
+    explicit-tableau path (eager torch ops) -- SURVEY.md §8f n3 lists it as a follow-up, it is not one
+    of the fused kernels."""
+
+    @property
+    def tableau_a(self):
+        return ((), (1.0,))
+
+    @property
+    def tableau_b(self):
+        return (0.5, 0.5)
+
+    @property
+    def tableau_c(self):
+        return (0.0, 1.0)

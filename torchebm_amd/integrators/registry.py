@@ -16,20 +16,22 @@ from ..core.integrator_base import BaseIntegrator
 _REGISTRY = {
     "euler": "EulerMaruyamaIntegrator",
     "euler_maruyama": "EulerMaruyamaIntegrator",
+    "heun": "HeunIntegrator",
     "leapfrog": "LeapfrogIntegrator",
 }
 
 _REFERENCE_ONLY = (
-    "backward_euler_maruyama", "heun", "adaptive_heun", "bosh3", "dopri5", "dopri8", "rk4", "rk438",
+    "backward_euler_maruyama", "adaptive_heun", "bosh3", "dopri5", "dopri8", "rk4", "rk438",
     "midpoint", "generalised_leapfrog", "generalized_leapfrog",
 )
 
 
 def get_integrator(name: str, device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> BaseIntegrator:
     """Construct an integrator from its registry name with default settings."""
-    from . import EulerMaruyamaIntegrator, LeapfrogIntegrator  # late: avoids an import cycle
+    from . import EulerMaruyamaIntegrator, HeunIntegrator, LeapfrogIntegrator  # late: avoids an import cycle
 
-    classes = {"EulerMaruyamaIntegrator": EulerMaruyamaIntegrator, "LeapfrogIntegrator": LeapfrogIntegrator}
+    classes = {"EulerMaruyamaIntegrator": EulerMaruyamaIntegrator, "HeunIntegrator": HeunIntegrator,
+               "LeapfrogIntegrator": LeapfrogIntegrator}
     try:
         cls = classes[_REGISTRY[name]]
     except (KeyError, TypeError):
