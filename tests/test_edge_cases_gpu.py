@@ -131,7 +131,8 @@ def test_large_mixture_and_large_precision_matrix(cuda_device):
     w = torch.rand(40, generator=torch.Generator().manual_seed(4)) + 0.1
     gm = ta.GaussianMixtureModel(means, sigma=1.5, weights=w, device=cuda_device)
     e, g = torch.empty(50, device=cuda_device), torch.empty(50, 12, device=cuda_device)
-    _lib.call("ebm_energy_grad_f32", gm.fused_spec().to_c(), x.to(cuda_device).data_ptr(), 50, 12, e.data_ptr(), g.data_ptr(),
+    x_d = x.to(cuda_device)  # keep the device copy alive across the launch
+    _lib.call("ebm_energy_grad_f32", gm.fused_spec().to_c(), x_d.data_ptr(), 50, 12, e.data_ptr(), g.data_ptr(),
               _lib.stream_handle(cuda_device))
     cpu = ta.GaussianMixtureModel(means, sigma=1.5, weights=w)
     torch.testing.assert_close(e.cpu(), cpu(x), rtol=2e-5, atol=2e-5)
@@ -145,7 +146,8 @@ def test_large_mixture_and_large_precision_matrix(cuda_device):
     ggpu = ta.GaussianModel(mean, cov, device=cuda_device)
     xx = torch.randn(21, d) * 2
     e, g = torch.empty(21, device=cuda_device), torch.empty(21, d, device=cuda_device)
-    _lib.call("ebm_energy_grad_f32", ggpu.fused_spec().to_c(), xx.to(cuda_device).data_ptr(), 21, d, e.data_ptr(), g.data_ptr(),
+    xx_d = xx.to(cuda_device)
+    _lib.call("ebm_energy_grad_f32", ggpu.fused_spec().to_c(), xx_d.data_ptr(), 21, d, e.data_ptr(), g.data_ptr(),
               _lib.stream_handle(cuda_device))
     torch.testing.assert_close(e.cpu(), gcpu(xx), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(g.cpu(), gcpu.gradient(xx), rtol=1e-4, atol=1e-4)
@@ -200,5 +202,5 @@ def test_gaussian_mfma_chain_matches_oracle(cuda_device, dim, n):
     rows = [em_coefficients(e, 0.8) for e in etas]
     table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=cuda_device)
     _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
-              1, -2.5, 2.5, 1, None, noise.contiguous().data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+              1, -2.5, 2.5, 1, None, noise.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
     torch.testing.assert_close(x.cpu(), wx, rtol=5e-5, atol=5e-5)

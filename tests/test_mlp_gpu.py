@@ -36,7 +36,8 @@ def test_energy_and_gradient_match_autograd(cuda_device, in_dim, n):
     x = torch.randn(n, in_dim) * 2
     e = torch.empty(n, device=cuda_device)
     g = torch.empty(n, in_dim, device=cuda_device)
-    _lib.call("ebm_energy_grad_f32", spec.to_c(), x.to(cuda_device).data_ptr(), n, in_dim, e.data_ptr(), g.data_ptr(),
+    x_d = x.to(cuda_device)  # keep the device copy alive across the launch
+    _lib.call("ebm_energy_grad_f32", spec.to_c(), x_d.data_ptr(), n, in_dim, e.data_ptr(), g.data_ptr(),
               _lib.stream_handle(cuda_device))
     want_e = cpu(x.double().float()).detach()
     want_g = cpu.gradient(x)
@@ -60,8 +61,9 @@ def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device)
     x = x0.to(cuda_device).clone()
     a, sq, coef = em_coefficients(eta, sigma)
     traj = torch.empty(n, k // 4, 2, device=cuda_device)
+    noise_d = noise.to(cuda_device)
     _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, 2, k, a, sq, coef, None, 0, 0.0, 0.0, 4, traj.data_ptr(),
-              noise.to(cuda_device).data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+              noise_d.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
     torch.testing.assert_close(x.cpu(), want, rtol=1e-3, atol=1e-3)
     assert torch.equal(traj[:, -1], x)
 
