@@ -240,11 +240,12 @@ class HamiltonianMonteCarlo(BaseSampler):
                 if hip:
                     mask = torch.empty(n, dtype=torch.uint8, device=x.device)
                     x_next = x.clone()
+                    # locals keep any dense copies alive until the launch that reads them is enqueued
+                    xp_d, h0_d, h1_d = _lib.dense_f32(x_prop), _lib.dense_f32(h0), _lib.dense_f32(h1)
                     _lib.call(
                         "ebm_hmc_accept_f32",
-                        _lib.ptr(x_next), _lib.ptr(_lib.dense_f32(x_prop)), _lib.ptr(_lib.dense_f32(h0)),
-                        _lib.ptr(_lib.dense_f32(h1)), None, _lib.ptr(mask), None, n, row_dim,
-                        seed, step0 + 2 * i + 1, stream,
+                        _lib.ptr(x_next), _lib.ptr(xp_d), _lib.ptr(h0_d), _lib.ptr(h1_d), None, _lib.ptr(mask), None,
+                        n, row_dim, seed, step0 + 2 * i + 1, stream,
                     )
                     x = x_next
                     accepted = mask
