@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kBlock) void noise_fill_kernel(float* __restrict__ 
     }
     const int64_t e0 = g * 4;
     if (e0 + 4 <= n_elem) {
+      // (a non-temporal store was measured SLOWER for this write-only stream: 0.064 vs 0.053 ms at 2^26)
       *reinterpret_cast<float4*>(out + e0) = make_float4(r[0], r[1], r[2], r[3]);
     } else {
       for (int i = 0; i < 4; ++i)
