@@ -98,6 +98,18 @@ EBM_API int ebm_langevin_step_f32(const float* x, const float* grad, float* out,
                           uint64_t seed, uint64_t offset, void* stream);
 
 /*
+ * The same step with the RNG coordinates read from DEVICE memory: rng_state = {seed, step} (two
+ * uint64).  Kernel arguments are frozen when a launch is captured into a HIP graph; keeping
+ * (seed, step) in a device buffer that the graph itself advances lets one captured
+ * "gradient + update" iteration be replayed k times per sample() call with fresh noise every time
+ * (the launch-bound autograd route of BASELINE config 5).  No injected-noise form.
+ */
+EBM_API int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* out, int64_t n_elem,
+                                      float eta, float sqrt_eta, float noise_coef,
+                                      int32_t clamp_on, float cmin, float cmax,
+                                      const uint64_t* rng_state, void* stream);
+
+/*
  * k fused Langevin steps for an analytic energy: gradient + EM update + noise + clamp
  * + thinned trajectory stores, state resident in registers/LDS across the k steps.
  * Replaces the hot loop of LangevinDynamics.sample (samplers/langevin_dynamics.py:154-185)

@@ -89,6 +89,11 @@ if "c5" in want:
 
     t = wall(train_step, reps=10, warm=3)
     t_sample = wall(lambda: s.sample(x=data, n_steps=k), reps=10, warm=2)
+    # the same route with one iteration captured in a HIP graph and replayed k times per call
+    s.capture_graph = True
+    t_graph = wall(train_step, reps=10, warm=3)
+    t_graph_sample = wall(lambda: s.sample(x=data, n_steps=k), reps=10, warm=2)
+    s.capture_graph = False
     # the fused update alone (same 20 launches, gradient precomputed)
     from torchebm_amd import _lib
     x = data.clone()
@@ -123,6 +128,7 @@ if "c5" in want:
         "config": "c5 PCD MLP 2-128-128-1 two-moons n=65536 k=20", "s_per_training_step": t, "training_steps_per_s": 1 / t,
         "chain_steps_per_s": n * k / t, "sampler_only_s": t_sample, "hip_update_kernels_only_s": t_upd,
         "update_share_of_sampler": t_upd / t_sample,
+        "hip_graph": {"s_per_training_step": t_graph, "training_steps_per_s": 1 / t_graph, "sampler_only_s": t_graph_sample},
         "fused_mlp": {"s_per_training_step": tf, "training_steps_per_s": 1 / tf, "sampler_only_s": tf_sample,
                       "sampler_speedup_vs_autograd_route": t_sample / tf_sample,
                       "sampler_fp32_TFLOPs": mlp_flops / tf_sample / 1e12},

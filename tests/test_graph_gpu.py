@@ -1,0 +1,94 @@
+"""The per-step Langevin route replayed from a HIP graph (``sampler.capture_graph = True``).
+
+One iteration -- autograd gradient of an arbitrary nn.Module energy, ``ebm_langevin_step_dev_f32`` in
+place, the device-side Philox step counter += 1 -- is captured once and replayed n_steps times.  The
+noise field is a function of (seed, step, element) only, so the graph route must reproduce the eager
+step route BIT FOR BIT under the same generator, and must keep the generator contract (fresh noise on
+every call, offset advanced by 4 per step)."""
+
+import pytest
+import torch
+from torch import nn
+
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd.core.schedules import LinearScheduler
+from torchebm_amd.utils.synthetic import two_moons
+
+pytestmark = pytest.mark.gpu
+
+
+class Net(ta.BaseModel):
+    def __init__(self, dim=2, hidden=64):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden), nn.SiLU(), nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, 1))
+
+    def forward(self, x):
+        return self.net(x).squeeze(-1)
+
+
+def _pair(cuda_device, **kw):
+    torch.manual_seed(0)
+    model = Net().to(cuda_device)
+    eager = ta.LangevinDynamics(model, step_size=0.05, noise_scale=1.0, device=cuda_device, **kw)
+    graph = ta.LangevinDynamics(model, step_size=0.05, noise_scale=1.0, device=cuda_device, **kw)
+    graph.capture_graph = True
+    return model, eager, graph
+
+
+def _gen(cuda_device, seed):
+    return torch.Generator(device=cuda_device).manual_seed(seed)
+
+
+def test_graph_route_is_bit_identical_to_the_eager_step_route(cuda_device):
+    model, eager, graph = _pair(cuda_device, clamp=(-2.5, 2.5))
+    x0 = two_moons(4099, 0.05, seed=1, device=cuda_device)
+    s0, d0 = hip_calls("ebm_langevin_step_f32"), hip_calls("ebm_langevin_step_dev_f32")
+    want = eager.sample(x=x0, n_steps=15, generator=_gen(cuda_device, 7))
+    got = graph.sample(x=x0, n_steps=15, generator=_gen(cuda_device, 7))
+    assert hip_calls("ebm_langevin_step_f32") == s0 + 15
+    # 3 warm-up launches + the captured one; the 15 replays do not pass through the host binding
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 4
+    assert torch.equal(got, want)
+    assert got.abs().max().item() <= 2.5
+    # second call re-uses the captured graph (no new launches through the binding) and continues the
+    # generator: a different noise field, identical again to the eager route continuing ITS generator
+    ge, gg = _gen(cuda_device, 3), _gen(cuda_device, 3)
+    e1, g1 = eager.sample(x=x0, n_steps=5, generator=ge), graph.sample(x=x0, n_steps=5, generator=gg)
+    e2, g2 = eager.sample(x=x0, n_steps=5, generator=ge), graph.sample(x=x0, n_steps=5, generator=gg)
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 4
+    assert torch.equal(e1, g1) and torch.equal(e2, g2) and not torch.equal(g1, g2)
+    assert ge.get_offset() == gg.get_offset() == 4 * 10
+    assert x0.data_ptr() != g2.data_ptr()                       # result is not the graph's static buffer
+
+
+def test_graph_route_trajectory_diagnostics_and_weight_updates(cuda_device):
+    model, eager, graph = _pair(cuda_device)
+    x0 = two_moons(1024, 0.05, seed=2, device=cuda_device)
+    (tw, dw) = eager.sample(x=x0, n_steps=8, thin=2, return_trajectory=True, return_diagnostics=True, generator=_gen(cuda_device, 1))
+    (tg, dg) = graph.sample(x=x0, n_steps=8, thin=2, return_trajectory=True, return_diagnostics=True, generator=_gen(cuda_device, 1))
+    assert tg.shape == (1024, 4, 2) and torch.equal(tg, tw)
+    for key in ("mean", "var", "energy"):
+        torch.testing.assert_close(dg[key], dw[key], rtol=1e-6, atol=1e-6)
+    # in-place parameter updates (what an optimiser does) are seen by the next replay
+    before = graph.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 5))
+    with torch.no_grad():
+        model.net[4].weight.mul_(4.0)
+    after = graph.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 5))
+    assert not torch.equal(before, after)
+    assert torch.equal(after, eager.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 5)))
+    # a new batch shape re-captures
+    d0 = hip_calls("ebm_langevin_step_dev_f32")
+    small = graph.sample(x=x0[:100], n_steps=3, generator=_gen(cuda_device, 6))
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 4
+    assert torch.equal(small, eager.sample(x=x0[:100], n_steps=3, generator=_gen(cuda_device, 6)))
+
+
+def test_scheduled_step_size_falls_back_to_the_eager_route(cuda_device):
+    torch.manual_seed(0)
+    model = Net().to(cuda_device)
+    s = ta.LangevinDynamics(model, step_size=LinearScheduler(0.05, 0.01, 10), device=cuda_device)
+    s.capture_graph = True
+    s0 = hip_calls("ebm_langevin_step_f32")
+    out = s.sample(x=two_moons(256, 0.05, seed=0, device=cuda_device), n_steps=6)
+    assert hip_calls("ebm_langevin_step_f32") == s0 + 6 and torch.isfinite(out).all()

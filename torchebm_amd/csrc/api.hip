@@ -11,7 +11,7 @@ namespace ebm {
 
 // launchers implemented in the kernel translation units
 int launch_langevin_step(const float*, const float*, float*, const float*, int64_t, float, float,
-                         float, int, float, float, uint64_t, uint64_t, hipStream_t);
+                         float, int, float, float, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
                                const float*, uint64_t, uint64_t, hipStream_t);
@@ -131,7 +131,20 @@ int ebm_langevin_step_f32(const float* x, const float* grad, float* out, const f
   if (!aligned16(x) || !aligned16(out) || (grad && !aligned16(grad)) || (noise && !aligned16(noise)))
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
   return launch_langevin_step(x, grad, out, noise, n_elem, eta, sqrt_eta, noise_coef, clamp_on,
-                              cmin, cmax, seed, offset, (hipStream_t)stream);
+                              cmin, cmax, seed, offset, nullptr, (hipStream_t)stream);
+}
+
+int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* out, int64_t n_elem, float eta,
+                              float sqrt_eta, float noise_coef, int32_t clamp_on, float cmin, float cmax,
+                              const uint64_t* rng_state, void* stream) {
+  const char* who = "ebm_langevin_step_dev_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x || !out || !rng_state) return fail(EBM_EINVAL, "%s: x/out/rng_state is NULL", who);
+  if (!aligned16(x) || !aligned16(out) || (grad && !aligned16(grad)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_langevin_step(x, grad, out, nullptr, n_elem, eta, sqrt_eta, noise_coef, clamp_on, cmin, cmax, 0, 0,
+                              rng_state, (hipStream_t)stream);
 }
 
 int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,

@@ -75,12 +75,26 @@ struct StepArgs {
   float cmin, cmax;
   RngKey key;
   uint64_t step;
+  const uint64_t* rng_dev;  // optional {seed, step} in device memory (HIP-graph replays): overrides key/step
 };
+
+__device__ __forceinline__ void resolve_rng(const StepArgs& a, RngKey& key, uint64_t& step) {
+  key = a.key;
+  step = a.step;
+  if (a.rng_dev) {  // wave-uniform scalar loads
+    const uint64_t seed = a.rng_dev[0];
+    key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    step = a.rng_dev[1];
+  }
+}
 
 template <bool NOISE_PTR>
 __global__ __launch_bounds__(kBlock) void langevin_step_kernel(StepArgs a) {
   const int64_t n_groups = ceil_div64(a.n_elem, 4);
   const bool draw = a.c.noise_coef != 0.0f;
+  RngKey key;
+  uint64_t step;
+  resolve_rng(a, key, step);
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
        g += (int64_t)gridDim.x * kBlock) {
     const int64_t e0 = g * 4;
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void langevin_step_kernel(StepArgs a) {
     F4 eps = F4{{0.f, 0.f, 0.f, 0.f}};
     if (draw) {
       if constexpr (NOISE_PTR) eps = load4(a.noise, e0, nv, true);
-      else eps = normal4_at(a.key, (uint64_t)g, a.step);
+      else eps = normal4_at(key, (uint64_t)g, step);
     }
     F4 o;
 #pragma unroll
@@ -114,6 +128,9 @@ template <bool NOISE_PTR, int U>
 __global__ __launch_bounds__(kBlock) void langevin_step_wide_kernel(StepArgs a) {
   const int64_t n_full = a.n_elem / 4;  // whole float4 groups; the launcher sends ragged tails to the plain kernel
   const bool draw = a.c.noise_coef != 0.0f;
+  RngKey key;
+  uint64_t step;
+  resolve_rng(a, key, step);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t g0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; g0 < n_full; g0 += stride * U) {
     v4f xv[U], gv[U], nv[U];
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void langevin_step_wide_kernel(StepArgs a) 
       F4 eps = F4{{0.f, 0.f, 0.f, 0.f}};
       if (draw) {
         if constexpr (NOISE_PTR) eps = F4{{nv[j].x, nv[j].y, nv[j].z, nv[j].w}};
-        else eps = normal4_at(a.key, (uint64_t)g, a.step);
+        else eps = normal4_at(key, (uint64_t)g, step);
       }
       const float xin[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
       const float gin[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
@@ -279,8 +296,10 @@ int grid_for(int64_t n_threads, int max_blocks) {
 // ---------------------------------------------------------------------------------
 int launch_langevin_step(const float* x, const float* grad, float* out, const float* noise,
                          int64_t n_elem, float eta, float sqrt_eta, float noise_coef, int clamp_on,
-                         float cmin, float cmax, uint64_t seed, uint64_t offset, hipStream_t st) {
+                         float cmin, float cmax, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
+                         hipStream_t st) {
   StepArgs a;
+  a.rng_dev = rng_dev;
   a.x = x; a.grad = grad; a.out = out; a.noise = noise; a.n_elem = n_elem;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
   a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;

@@ -197,49 +197,57 @@ __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// column statistics: two passes with fp64 accumulators (sum, then centred squares),
-// per-block LDS partials then one fp64 atomic per column per block.
+// column statistics: one pass with shifted fp64 accumulators, per-block LDS partials, then one fp64
+// atomic per column per block.
 // ---------------------------------------------------------------------------------
 constexpr int kStatCols = 64;   // columns per block tile
 constexpr int kStatRows = 4;    // row lanes per block tile (kBlock / kStatCols)
 
-template <int PASS>
+// One pass, shifted sums in fp64: with s_c = x[0, c] as the shift, S1 = sum (x - s), S2 = sum (x - s)^2;
+// mean = s + S1/n, var = (S2 - S1^2/n)/n.  The shift removes the cancellation of the textbook
+// one-pass formula when |mean| >> std, fp64 accumulators remove the rest.
 __global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __restrict__ x,
                                                              int64_t n_chains, int32_t dim,
                                                              double* __restrict__ work) {
-  __shared__ double part[kStatRows][kStatCols];
+  __shared__ double part1[kStatRows][kStatCols];
+  __shared__ double part2[kStatRows][kStatCols];
   const int col = blockIdx.x * kStatCols + (threadIdx.x % kStatCols);
   const int rlane = threadIdx.x / kStatCols;
-  double acc = 0.0;
+  double s1 = 0.0, s2 = 0.0;
   if (col < dim) {
-    double mean = 0.0;
-    if (PASS == 1) mean = work[col] / (double)n_chains;
+    const double shift = (double)x[col];
     for (int64_t r = (int64_t)blockIdx.y * kStatRows + rlane; r < n_chains;
          r += (int64_t)gridDim.y * kStatRows) {
-      const double v = (double)x[r * dim + col];
-      if (PASS == 0) acc += v;
-      else acc += (v - mean) * (v - mean);
+      const double v = (double)x[r * dim + col] - shift;
+      s1 += v;
+      s2 += v * v;
     }
   }
-  part[rlane][threadIdx.x % kStatCols] = acc;
+  part1[rlane][threadIdx.x % kStatCols] = s1;
+  part2[rlane][threadIdx.x % kStatCols] = s2;
   __syncthreads();
   if (rlane == 0 && col < dim) {
-    double s = 0.0;
+    double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < kStatRows; ++i) s += part[i][threadIdx.x];
-    atomicAdd(&work[PASS * dim + col], s);
+    for (int i = 0; i < kStatRows; ++i) {
+      a1 += part1[i][threadIdx.x];
+      a2 += part2[i][threadIdx.x];
+    }
+    atomicAdd(&work[col], a1);
+    atomicAdd(&work[dim + col], a2);
   }
 }
 
-__global__ void chain_stats_finish_kernel(const double* __restrict__ work, int64_t n_chains,
-                                          int32_t dim, float* __restrict__ mean_out,
+__global__ void chain_stats_finish_kernel(const float* __restrict__ x, const double* __restrict__ work,
+                                          int64_t n_chains, int32_t dim, float* __restrict__ mean_out,
                                           float* __restrict__ var_out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= dim) return;
-  const double inv = 1.0 / (double)n_chains;
-  mean_out[col] = (float)(work[col] * inv);
-  float v = (float)(work[dim + col] * inv);
-  v = clamp_nanprop(v, 1e-10f, 1e10f);
+  const double n = (double)n_chains;
+  const double s1 = work[col], s2 = work[dim + col];
+  mean_out[col] = (float)((double)x[col] + s1 / n);
+  float v = (float)((s2 - s1 * s1 / n) / n);
+  v = clamp_nanprop(v, 1e-10f, 1e10f);  // langevin_dynamics.py:176-178
   var_out[col] = v;
 }
 
@@ -317,9 +325,8 @@ int launch_chain_stats(const float* x, int64_t n_chains, int32_t dim, float* mea
   const int64_t cap = (256 * 8 + gx - 1) / gx;
   if (gy > cap) gy = cap;
   const dim3 grid(gx, (unsigned)gy);
-  hipLaunchKernelGGL(chain_stats_kernel<0>, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
-  hipLaunchKernelGGL(chain_stats_kernel<1>, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
-  hipLaunchKernelGGL(chain_stats_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, work,
+  hipLaunchKernelGGL(chain_stats_kernel, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
+  hipLaunchKernelGGL(chain_stats_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, x, work,
                      n_chains, dim, mean_out, var_out);
   return check_launch("ebm_chain_stats_f32");
 }

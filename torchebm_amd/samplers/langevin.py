@@ -176,6 +176,8 @@ class LangevinDynamics(BaseSampler):
         n_kept = n_steps // thin
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         keep = 0
+        if hip and self.capture_graph and self._graph_eligible(model_kwargs):
+            return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
         if hip:
             x = _lib.dense_f32(x)
             seed, step0 = _rng.reserve(generator, x.device, n_steps)
@@ -218,6 +220,88 @@ class LangevinDynamics(BaseSampler):
                         diag["energy"][keep] = self._model_energy(x, model_kwargs).mean()
                     keep += 1
         out = traj if want_traj else x
+        return (out, diag) if want_diag else out
+
+    # ---------------------------------------------------------------------------------
+    # route: per-step loop replayed from a HIP graph (opt-in: ``sampler.capture_graph = True``)
+    # ---------------------------------------------------------------------------------
+    #: Capture one "autograd gradient + fused update" iteration of the step route into a HIP graph and
+    #: replay it n_steps times per call.  The step route is launch-bound (BASELINE config 5: ~13 small
+    #: kernels per Langevin step): a replay costs one submission instead of 13.  The Philox
+    #: coordinates live in a device buffer advanced inside the graph (``ebm_langevin_step_dev_f32``), so
+    #: every replay draws fresh noise and the generator contract is unchanged.  Requirements: constant
+    #: step size / noise scale, no conditioning, a model whose forward is static-shape and free of
+    #: host-side randomness or data-dependent control flow (the usual CUDA-graph rules).
+    capture_graph: bool = False
+
+    def _graph_eligible(self, model_kwargs: Dict[str, Any]) -> bool:
+        return (
+            not model_kwargs
+            and not self.use_mixed_precision
+            and self.schedulers["step_size"].is_constant()
+            and self.schedulers["noise_scale"].is_constant()
+        )
+
+    def _graph_for(self, x: torch.Tensor):
+        a, sq, coef = em_coefficients(self.get_scheduled_value("step_size"), self.get_scheduled_value("noise_scale"))
+        key = (
+            tuple(x.shape), x.device, (a, sq, coef), self._clamp_args(),
+            tuple(p.data_ptr() for p in self.model.parameters()),
+        )
+        cached = getattr(self, "_step_graph", None)
+        if cached is not None and cached["key"] == key:
+            return cached
+        state = torch.empty_like(x)                                        # static buffers of the graph
+        rng = torch.zeros(2, dtype=torch.int64, device=x.device)           # {seed, step} as raw 64-bit patterns
+        clamp_on, cmin, cmax = self._clamp_args()
+
+        def body():
+            grad = _lib.dense_f32(self._model_gradient(state, {}))
+            _lib.call(
+                "ebm_langevin_step_dev_f32",
+                _lib.ptr(state), _lib.ptr(grad), _lib.ptr(state), state.numel(), a, sq, coef,
+                clamp_on, cmin, cmax, _lib.ptr(rng), _lib.stream_handle(x.device),
+            )
+            rng[1:2].add_(1)
+
+        state.copy_(x)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                                      # warm-up off the capture stream
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        self._step_graph = {"key": key, "graph": graph, "state": state, "rng": rng}
+        return self._step_graph
+
+    def _sample_graph(self, x, n_steps, thin, traj, diag, want_traj, want_diag, generator):
+        x = _lib.dense_f32(x)
+        n = x.shape[0]
+        g = self._graph_for(x)
+        seed, step0 = _rng.reserve(generator, x.device, n_steps)
+        as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v  # noqa: E731  (bit pattern of a uint64)
+        g["state"].copy_(x)
+        g["rng"].copy_(torch.tensor([as_i64(seed), as_i64(step0)], dtype=torch.int64), non_blocking=True)
+        state, keep = g["state"], 0
+        for i in range(n_steps):
+            g["graph"].replay()
+            if (i + 1) % thin == 0:
+                if traj is not None:
+                    traj[:, keep] = state
+                if diag is not None:
+                    if n > 1:
+                        diag["mean"][keep] = state.mean(dim=0)
+                        diag["var"][keep] = state.var(dim=0, unbiased=False).clamp_(min=1e-10, max=1e10)
+                    else:
+                        diag["mean"][keep] = state.squeeze(0)
+                        diag["var"][keep].zero_()
+                    diag["energy"][keep] = self._model_energy(state, {}).mean()
+                keep += 1
+        self.advance_schedulers(n_steps)
+        out = traj if want_traj else state.clone()
         return (out, diag) if want_diag else out
 
     # ---------------------------------------------------------------------------------
