@@ -133,7 +133,7 @@ def misc_cases():
             _lib.call("ebm_chain_stats_f32", x.data_ptr(), n, dim, mean.data_ptr(), var.data_ptr(), work.data_ptr(), st)
 
         ms, best = timeit(run, reps=20)
-        report("chain_stats_2^20x64", ms, best, n, "rows", 2 * n * dim * 4)
+        report("chain_stats_2^20x64", ms, best, n, "rows", n * dim * 4)
     if selected("energy_grad"):
         n, dim = 1 << 20, 64
         x = torch.randn(n, dim, device=dev)
