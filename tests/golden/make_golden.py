@@ -286,6 +286,48 @@ def main():
     descent_case("nag_gmm5_33x6", gmm6, 33, 6, 10, 0.05, seed=35, momentum=0.5, x0_scale=2.0)
     descent_case("nag_har_20x5_sched", har, 20, 5, 9, ExponentialDecayScheduler(0.3, 0.8, 0.05), seed=36, momentum=0.8, thin=2)
 
+    # ---- Energy Matching negatives ---------------------------------
+    energy_matching_cases()
+
+
+def energy_matching_case(name, energy, n, dim, k, seed, noise_fraction, epsilon_max=0.15, tau_star=0.6, dt=0.01):
+    """the negatives of the reference's EnergyMatchingLoss (two Langevin calls, a
+    TemperatureScheduler sweep and a constant sqrt(eps_max)), with the draws it consumed."""
+    from torchebm.core import TemperatureScheduler
+    from torchebm.losses import EnergyMatchingLoss
+    from torchebm.losses.loss_utils import trimmed_mean
+
+    model = make_energy(energy)
+    x1 = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1000)) * 0.3 + 1.0
+    loss = EnergyMatchingLoss(model=model, lambda_cd=2.0, epsilon_max=epsilon_max, tau_star=tau_star,
+                              n_langevin_steps=k, langevin_dt=dt, noise_fraction=noise_fraction)
+    neg = loss._sample_negatives(x1, generator=torch.Generator().manual_seed(seed))
+    n_noise = int(round(n * noise_fraction))
+    g = torch.Generator().manual_seed(seed)                      # replay the draw order
+    fx = {"name": name, "energy": energy, "seed": seed, "n": n, "dim": dim, "k": k, "dt": dt, "x1": x1,
+          "noise_fraction": noise_fraction, "epsilon_max": epsilon_max, "tau_star": tau_star, "n_noise": n_noise}
+    if n_noise > 0:
+        fx["init"] = torch.randn(n_noise, dim, generator=g)
+        fx["noise_sweep"] = torch.stack([torch.randn(n_noise, dim, generator=g) for _ in range(k)])
+        fx["sigma_sweep"] = sched_values(TemperatureScheduler(epsilon_max=epsilon_max, tau_star=tau_star, n_steps=k), k)
+    if n - n_noise > 0:
+        fx["pick"] = torch.randperm(n, generator=g)[: n - n_noise]
+        fx["noise_const"] = torch.stack([torch.randn(n - n_noise, dim, generator=g) for _ in range(k)])
+    e_pos, e_neg = model(x1), model(neg)
+    cd_value = e_pos.mean() - trimmed_mean(e_neg, loss.cd_trim_fraction)
+    fx["ref"] = {"negatives": neg, "sha_negatives": sha(neg), "cd_value": cd_value,
+                 "cd_loss": torch.clamp(loss.lambda_cd * cd_value, min=-loss.cd_clamp)}
+    torch.save(fx, os.path.join(HERE, name + ".pt"))
+    print(f"{name:28s} negatives sha {sha(neg)}  cd_value {cd_value.item():+.6f}")
+
+
+def energy_matching_cases():
+    dw = {"kind": "double_well", "h": 2.0, "b": 1.0}
+    har = {"kind": "harmonic", "k": 1.5}
+    energy_matching_case("em_dw_61x4", dw, 61, 4, 24, seed=41, noise_fraction=0.5)
+    energy_matching_case("em_har_40x3_allnoise", har, 40, 3, 10, seed=42, noise_fraction=1.0, tau_star=0.3)
+    energy_matching_case("em_dw_32x8_alldata", dw, 32, 8, 12, seed=43, noise_fraction=0.0)
+
 
 def langevin_survey():
     # LD-DW seed123 512x64 k50 eta=.01 sigma=1   -> sha a8aa46964a7b47d0 (SURVEY.md §8c)

@@ -18,5 +18,5 @@ from .core import (  # noqa: F401
     MLPEnergy,
 )
 from .integrators import EulerMaruyamaIntegrator, LeapfrogIntegrator  # noqa: F401
-from .losses import ContrastiveDivergence  # noqa: F401
+from .losses import ContrastiveDivergence, EnergyMatchingContrastive  # noqa: F401
 from .samplers import HamiltonianMonteCarlo, LangevinDynamics  # noqa: F401
