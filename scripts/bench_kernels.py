@@ -71,8 +71,7 @@ def chain_case(name, model, n, dim, k, clamp=None, thin=1, traj=False, table=Fal
                   thin, _lib.ptr(tr), None, 1, 0, st)
 
     ms, best = timeit(run)
-    report(name, ms, best, n * k, "chain_steps", n * k * 8 * dim, n=n, dim=dim, k=k,
-           gpt=os.environ.get("EBM_CHAIN_GPT", "default"))
+    report(name, ms, best, n * k, "chain_steps", n * k * 8 * dim, n=n, dim=dim, k=k)
 
 
 def step_case(name, n_elem, noise_ptr=False):

@@ -248,38 +248,36 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a
 }
 
 // ---------------------------------------------------------------------------------
-// Lean variant for the headline case (native RNG, constant coefficients, no clamp, no
-// trajectory): nothing but Philox + Box-Muller + gradient + update inside the loop, and GPT
-// independent float4 groups per lane so that the quarter-rate 64-bit multiplies of one
-// group overlap the transcendentals / packed-f32 math of another.  A block owns
-// 256*GPT consecutive groups; lane t takes groups t, t+256, ... (each wave access stays
-// one contiguous 1 KiB piece).
+// Lean variant (native RNG, no trajectory): nothing but Philox + Box-Muller + gradient + update
+// inside the loop.  The per-step coefficient table (schedulers, the Energy-Matching temperature
+// sweep) and the clamp are compile-time switches, so the headline case -- constant coefficients,
+// no clamp -- carries neither a branch nor a live register for them.  One float4 group per lane:
+// 2 or 4 independent groups per lane were measured and change nothing (8.96 / 9.05 / 8.91 ms on
+// config 2; the loop is VALU-issue bound at 8 waves/SIMD either way).
 // ---------------------------------------------------------------------------------
-template <int KIND, int GPT>
+template <int KIND, bool TABLE, bool CLAMP>
 __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
-  const int64_t g0 = (int64_t)blockIdx.x * (kBlock * GPT) + threadIdx.x;
-  F4 x[GPT];
-  int nv[GPT];
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) {
-    const int64_t e0 = (g0 + (int64_t)j * kBlock) * 4;
-    const int64_t left = a.n_elem - e0;
-    nv[j] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
-    x[j] = load4(a.x, e0 < a.n_elem ? e0 : 0, nv[j], true);
-  }
-  const StepCoef c = a.c;
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e0 = g * 4;
+  if (e0 >= a.n_elem) return;
+  const int64_t left = a.n_elem - e0;
+  const int nv = left >= 4 ? 4 : (int)left;
+  F4 x = load4(a.x, e0, nv, true);
+  StepCoef c = a.c;
   for (int i = 0; i < a.k_steps; ++i) {
+    if constexpr (TABLE) {  // wave-uniform: scalar loads
+      const float4 t = a.table[i];
+      c.eta = t.x; c.sqrt_eta = t.y; c.noise_coef = t.z;
+    }
+    const F4 eps = normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i);
 #pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      const F4 eps = normal4_at(a.key, (uint64_t)(g0 + (int64_t)j * kBlock), a.step0 + (uint64_t)i);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        x[j].v[q] = em_update(x[j].v[q], elem_grad<KIND>(x[j].v[q], a.s0, a.s1), eps.v[q], c);
+    for (int q = 0; q < 4; ++q) {
+      float v = em_update(x.v[q], elem_grad<KIND>(x.v[q], a.s0, a.s1), eps.v[q], c);
+      if constexpr (CLAMP) v = clamp_nanprop(v, a.cmin, a.cmax);
+      x.v[q] = v;
     }
   }
-#pragma unroll
-  for (int j = 0; j < GPT; ++j)
-    if (nv[j] > 0) store4(a.x, (g0 + (int64_t)j * kBlock) * 4, nv[j], true, x[j]);
+  store4(a.x, e0, nv, true, x);
 }
 
 int grid_for(int64_t n_threads, int max_blocks) {
@@ -338,18 +336,13 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   const int64_t blocks = ceil_div64(n_groups, kBlock);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (!noise && !traj && !coef_table && !clamp_on) {
-    static const int gpt_env = [] {
-      const char* e = getenv("EBM_CHAIN_GPT");
-      return e ? atoi(e) : 0;
-    }();
-    const int gpt = (gpt_env == 1 || gpt_env == 2 || gpt_env == 4) ? gpt_env : 1;
-    const dim3 lgrid((unsigned)ceil_div64(n_groups, (int64_t)kBlock * gpt));
-#define EBM_LEAN(KIND)                                                                            \
-  do {                                                                                            \
-    if (gpt == 1) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 1>), lgrid, block, 0, st, a);      \
-    else if (gpt == 2) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 2>), lgrid, block, 0, st, a); \
-    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, 4>), lgrid, block, 0, st, a);               \
+  if (!noise && !traj) {
+#define EBM_LEAN(KIND)                                                                                   \
+  do {                                                                                                   \
+    if (coef_table && clamp_on) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, true, true>), grid, block, 0, st, a);    \
+    else if (coef_table) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, true, false>), grid, block, 0, st, a);         \
+    else if (clamp_on) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, false, true>), grid, block, 0, st, a);           \
+    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, false, false>), grid, block, 0, st, a);                        \
   } while (0)
     if (kind == EBM_ENERGY_DOUBLE_WELL) EBM_LEAN(EBM_ENERGY_DOUBLE_WELL);
     else EBM_LEAN(EBM_ENERGY_HARMONIC);
