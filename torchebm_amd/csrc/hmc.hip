@@ -41,9 +41,10 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     return s ? atoi(s) : 0;
   }();
   if (dim == 32 && (nv_env == 2 || nv_env == 4 || nv_env == 8)) geo = Geometry{8 / nv_env, nv_env, true};
-  // measured on MI355X (profiles/r01_bench_kernels.jsonl): the small-mixture energy runs 1.4x
-  // faster with 2 lanes x 4 vectors per chain (one DPP level, half the redundant softmax work)
-  else if (dim == 32 && nv_env == 0 && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8) geo = Geometry{2, 4, true};
+  // measured on MI355X (profiles/r01_bench_kernels.jsonl): the small-mixture energy is fastest with
+  // ONE lane per chain -- the means become wave-uniform scalar operands (no LDS traffic, no cross-lane
+  // reduction): 1.22 ms per 10 transitions vs 1.76 for (2,4) and 2.3 for the generic (8,1)
+  else if (dim == 32 && nv_env == 0 && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8) geo = Geometry{1, 8, true};
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   a.park_offset_floats = (int)(smem / sizeof(float));

@@ -38,16 +38,23 @@ extern __shared__ __attribute__((aligned(16))) float hmc_smem[];
 // proposal, f the clamped force there, and the return value is E(x).
 //  * The clamped force at the end of a step is bit-identical to the one the reference
 //    recomputes at the start of the next step, so it is carried over.
-//  * torch's nan_to_num_ is the identity on finite values: the common path only *tests*
-//    x, p for non-finite values (one v_cmp_class each); the scrub itself, and the force
-//    re-evaluation the reference then performs on the scrubbed x, run only for lane groups
-//    that actually hold a NaN/inf.
+//  * torch's nan_to_num_ is the identity on finite values and clamp_ only differs from a plain
+//    median-of-three on NaN, so the common path never touches either: every energy here has the
+//    property "E(x) finite  =>  every x_i and every dE/dx_i is free of NaN, x is finite" (each
+//    coordinate enters E through sums and products only), which turns 2 x 4NV finiteness tests and
+//    4NV NaN-propagating clamps into ONE compare on the group-reduced energy plus v_med3 clamps.
+//    Momentum can still overflow on its own; sum(p_i * 0) is NaN exactly when some p_i is not
+//    finite (packed FMAs).  Lane groups that fail either test take the literal path: NaN-propagating
+//    clamp, scrub, and the force re-evaluation the reference then performs on the scrubbed x.
+//  * Energies with HAS_GRAD_ONLY (mixture) skip the energy on all but the last step; their
+//    grad_only() returns a value with the same "finite => clean" property.
 template <bool HAS_MASS, class En, class LaneT>
 __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Slice<LaneT::NV>& x,
                                                 Slice<LaneT::NV>& p, Slice<LaneT::NV>& f,
                                                 const Slice<LaneT::NV>& m_safe, float eps, float half_eps,
                                                 int n_steps, float e_in) {
   constexpr int NV = LaneT::NV;
+  typedef float v2f __attribute__((ext_vector_type(2)));
   float e = e_in;
   for (int l = 0; l < n_steps; ++l) {
 #pragma unroll
@@ -61,27 +68,54 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
         x.a[v][i] = L.ok(v, i) ? x.a[v][i] + step : 0.0f;
       }
     Slice<NV> g;
-    e = en.template eval<true>(L, x, g);
-    bool bad = false;
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float fn = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
-        const float pn = p.a[v][i] + half_eps * fn;
-        f.a[v][i] = fn;
-        p.a[v][i] = L.ok(v, i) ? pn : 0.0f;
-        bad |= !__builtin_isfinite(pn) | !__builtin_isfinite(x.a[v][i]);
+    float chk;  // group-uniform; finite => x finite, g free of NaN
+    bool have_e = true;
+    if constexpr (En::HAS_GRAD_ONLY) {
+      if (l + 1 < n_steps && en.grad_only_ready()) {
+        chk = en.grad_only(L, x, g);
+        have_e = false;
+      } else {
+        chk = e = en.template eval<true>(L, x, g);
       }
-    if (group_any<LaneT::G>(bad)) {  // rare: scrub, then re-evaluate on the scrubbed position
+    } else {
+      chk = e = en.template eval<true>(L, x, g);
+    }
+    if (__builtin_fabsf(chk) < __builtin_inff()) {
+      v2f pz = {0.0f, 0.0f};
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const float f0 = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
+          const float f1 = __builtin_amdgcn_fmed3f(-g.a[v][i + 1], -1e6f, 1e6f);
+          const float p0 = p.a[v][i] + half_eps * f0;
+          const float p1 = p.a[v][i + 1] + half_eps * f1;
+          f.a[v][i] = f0;
+          f.a[v][i + 1] = f1;
+          p.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
+          p.a[v][i + 1] = L.ok(v, i + 1) ? p1 : 0.0f;
+          pz = __builtin_elementwise_fma(v2f{p0, p1}, v2f{0.0f, 0.0f}, pz);
+        }
+      const float pchk = pz.x + pz.y;
+      if (group_any<LaneT::G>(pchk != pchk)) {  // momentum overflow: x is finite, so f stands
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) p.a[v][i] = nan_to_num0(p.a[v][i]);
+      }
+    } else {  // rare: literal semantics
+      if (!have_e) e = en.template eval<true>(L, x, g);
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          p.a[v][i] = nan_to_num0(p.a[v][i]);
+          const float fn = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+          const float pn = p.a[v][i] + half_eps * fn;
+          f.a[v][i] = fn;
+          p.a[v][i] = nan_to_num0(L.ok(v, i) ? pn : 0.0f);
           x.a[v][i] = nan_to_num0(x.a[v][i]);
         }
-      e = en.template eval<true>(L, x, g);
+      e = en.template eval<true>(L, x, g);  // the force the next step starts from, on the scrubbed x
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -95,7 +129,7 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 // per-slot forms kept in VGPRs).  XC_LDS: park the accepted state in a lane-private LDS slot
 // while the proposal is integrated (wide rows: frees 4*NV VGPRs).
 template <int KIND, int G, int NV, bool FULL, int MASS>
-__global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
+__device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   using LaneT = Lane<G, NV, FULL>;
   constexpr bool XC_LDS = NV >= 4;
   LaneT L;
@@ -234,6 +268,20 @@ __global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
   store_slice(L, a.x, row, xc);
 }
 
+template <int KIND, int G, int NV, bool FULL, int MASS>
+__global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
+  hmc_chain_body<KIND, G, NV, FULL, MASS>(a);
+}
+
+// Same body held to 256 VGPRs (two waves per SIMD).  For the one-lane-per-chain mixture kernel:
+// its leapfrog loop fits, only the cold paths (prologue, large-K fallback, scrub) spill, and the
+// second wave is worth 1.56 -> 1.22 ms on BASELINE config 3.  (A template-dependent expression in
+// __launch_bounds__ is silently ignored by hipcc 7.2, hence the second entry point.)
+template <int KIND, int G, int NV, bool FULL, int MASS>
+__global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
+  hmc_chain_body<KIND, G, NV, FULL, MASS>(a);
+}
+
 // KERNEL<KIND, G, NV, FULL, MASS> over the runtime geometry (see rows.h: EBM_GEO_LAUNCH)
 template <int KIND, int MASS>
 void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
@@ -257,6 +305,8 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
     EBM_HMC_G(4, 2, true);
   } else if (geo.G == 2 && geo.NV == 4) {
     EBM_HMC_G(2, 4, true);
+  } else if constexpr (KIND == EBM_ENERGY_GMM) {
+    hipLaunchKernelGGL((hmc_chain_kernel_w2<KIND, 1, 8, true, MASS>), grid, block, smem, st, a);
   } else {
     EBM_HMC_G(1, 8, true);
   }

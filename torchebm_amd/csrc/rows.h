@@ -207,6 +207,7 @@ struct Energy;
 template <class LaneT>
 struct Energy<EBM_ENERGY_DOUBLE_WELL, LaneT> {
   static constexpr int G = LaneT::G, NV = LaneT::NV;
+  static constexpr bool HAS_GRAD_ONLY = false;
   float h, b2;
   __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem&) {
     h = P.s0; b2 = P.s1;
@@ -232,6 +233,7 @@ struct Energy<EBM_ENERGY_DOUBLE_WELL, LaneT> {
 template <class LaneT>
 struct Energy<EBM_ENERGY_HARMONIC, LaneT> {
   static constexpr int G = LaneT::G, NV = LaneT::NV;
+  static constexpr bool HAS_GRAD_ONLY = false;
   float hk;
   __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem&) { hk = P.s0; }
   template <bool WANT_E>
@@ -256,6 +258,7 @@ struct Energy<EBM_ENERGY_HARMONIC, LaneT> {
 template <class LaneT>
 struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
   static constexpr int G = LaneT::G, NV = LaneT::NV;
+  static constexpr bool HAS_GRAD_ONLY = false;
   Slice<NV> mu;
   const float* P_lds;
   const float* P_glb;
@@ -284,8 +287,7 @@ struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (P_lds) {
-      for (int j = 0; j < L.dim; ++j) {
-        const float dj = xrow[j];
+      auto row_fma = [&](int j, float dj) {
         const float* row = P_lds + j * dim_pad;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -295,7 +297,19 @@ struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
           g.a[v][2] = __builtin_fmaf(pr.z, dj, g.a[v][2]);
           g.a[v][3] = __builtin_fmaf(pr.w, dj, g.a[v][3]);
         }
+      };
+      // four rows per trip (one 16-byte read of d, four independent row reads in flight): the
+      // one-row loop waited out a full LDS round trip per coordinate
+      int j = 0;
+#pragma unroll 2
+      for (; j + 4 <= L.dim; j += 4) {
+        const float4 d4 = *reinterpret_cast<const float4*>(xrow + j);
+        row_fma(j, d4.x);
+        row_fma(j + 1, d4.y);
+        row_fma(j + 2, d4.z);
+        row_fma(j + 3, d4.w);
       }
+      for (; j < L.dim; ++j) row_fma(j, xrow[j]);
     } else {  // precision matrix too large for LDS: stream rows from L2
       for (int j = 0; j < L.dim; ++j) {
         const float dj = xrow[j];
@@ -327,10 +341,12 @@ struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
 template <class LaneT>
 struct Energy<EBM_ENERGY_GMM, LaneT> {
   static constexpr int G = LaneT::G, NV = LaneT::NV;
+  static constexpr bool HAS_GRAD_ONLY = true;
   const float* mu_lds;
   const float* mu_glb;
   const float* logw;
   float lw8[8];
+  float c8[8];  // lw8[k] - |mu_k|^2 / (2 sigma^2): the x-independent part of the logit (grad_only)
   int K, dim_pad;
   float inv2s2, invs2;
   __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem& S) {
@@ -344,6 +360,177 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
     dim_pad = P.dim_pad;
     inv2s2 = P.s0;
     invs2 = P.s1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c8[k] = lw8[k];
+    if (K <= 8 && mu_lds) {  // staged rows are zero-padded to 8 components x dim_pad columns
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float nrm = 0.0f;
+        for (int d = 0; d < dim_pad; d += 4) {
+          const float4 m = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + d);
+          nrm = __builtin_fmaf(m.x, m.x, nrm);
+          nrm = __builtin_fmaf(m.y, m.y, nrm);
+          nrm = __builtin_fmaf(m.z, m.z, nrm);
+          nrm = __builtin_fmaf(m.w, m.w, nrm);
+        }
+        c8[k] = __builtin_fmaf(-nrm, inv2s2, lw8[k]);
+      }
+    }
+  }
+  __device__ __forceinline__ bool grad_only_ready() const { return K <= 8 && mu_lds != nullptr; }
+  // Gradient without the energy (K <= 8, staged): softmax is shift-invariant, so |x|^2 drops out of
+  // the logits and l_k = c8[k] + (x . mu_k) / sigma^2 -- one FMA per (component, coordinate) instead
+  // of a subtract and an FMA, and a dot product is better conditioned than the difference form.
+  // Returns sum_k exp(l_k - max): in [1, 8] for finite x, NaN as soon as one coordinate is not
+  // (inf * 0, inf - inf or exp(inf - inf) appear on every route), and then g is unspecified.
+  __device__ __forceinline__ float grad_only(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr int KM = 8;
+    if constexpr (G == 1 && LaneT::FULL && NV >= 4) return small_scalar_mu<false>(x, g);
+    float logit[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      v2f dot = {0.0f, 0.0f};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 m = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + L.col[v]);
+        // slots beyond the row hold no state (ragged dims): keep them out of the sum
+        const float x0 = L.ok(v, 0) ? x.a[v][0] : 0.0f, x1 = L.ok(v, 1) ? x.a[v][1] : 0.0f;
+        const float x2 = L.ok(v, 2) ? x.a[v][2] : 0.0f, x3 = L.ok(v, 3) ? x.a[v][3] : 0.0f;
+        // (their mu read lands in another row or in the -inf log-weight padding)
+        const float m0 = L.ok(v, 0) ? m.x : 0.0f, m1 = L.ok(v, 1) ? m.y : 0.0f;
+        const float m2 = L.ok(v, 2) ? m.z : 0.0f, m3 = L.ok(v, 3) ? m.w : 0.0f;
+        dot = __builtin_elementwise_fma(v2f{x0, x1}, v2f{m0, m1}, dot);
+        dot = __builtin_elementwise_fma(v2f{x2, x3}, v2f{m2, m3}, dot);
+      }
+      logit[k] = dot.x + dot.y;
+    }
+    float top = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      logit[k] = __builtin_fmaf(group_sum<G>(logit[k]), invs2, c8[k]);
+      top = logit[k] > top ? logit[k] : top;
+    }
+    float sum = 0.0f;
+    Slice<NV> acc;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc.a[v][i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      const float w = __expf(logit[k] - top);  // 0 for the padding components
+      sum += w;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 m = *reinterpret_cast<const float4*>(mu_lds + k * dim_pad + L.col[v]);
+        acc.a[v][0] = __builtin_fmaf(w, m.x, acc.a[v][0]);
+        acc.a[v][1] = __builtin_fmaf(w, m.y, acc.a[v][1]);
+        acc.a[v][2] = __builtin_fmaf(w, m.z, acc.a[v][2]);
+        acc.a[v][3] = __builtin_fmaf(w, m.w, acc.a[v][3]);
+      }
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        g.a[v][i] = L.ok(v, i) ? invs2 * (x.a[v][i] - acc.a[v][i] * inv) : 0.0f;
+    return sum;
+  }
+  // One lane per chain (G == 1, full rows): every lane of the wave needs the SAME mu[k][d], so the
+  // means are wave-uniform operands -- read through the scalar cache into SGPRs (constant address
+  // space => s_load), no LDS traffic and no cross-lane reduction at all.
+  // EXACT: logits in the reference's difference form -|x - mu_k|^2 / (2 sigma^2) and the energy as the
+  // return value (H0 / H1 and diagnostics); otherwise the dot-product form, returning the softmax sum.
+  template <bool EXACT>
+  __device__ __forceinline__ float small_scalar_mu(const Slice<NV>& x, Slice<NV>& g) const {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    constexpr int KM = 8, D = NV * 4, CH = 16, PER_ROW = D / CH, NCH = KM * PER_ROW;
+    static_assert(D % CH == 0, "rows stream in whole 16-float chunks");
+    // The means stream through SGPRs in 16-float chunks (s_load_dwordx16), one chunk in flight while
+    // the previous one is consumed.  The loads are volatile asm: left to itself the compiler hoists all
+    // 2 x 8 x D scalar loads to the top of the block and spills 8*D SGPRs.
+    const uint64_t base = (uint64_t)(uintptr_t)mu_glb;
+    auto issue = [&](int c, v16f& dst) {
+      const int k = c / PER_ROW, h = c % PER_ROW;
+      const uint64_t src = base + (uint64_t)(((k < K ? k : K - 1) * D + h * CH) * 4);  // padding re-reads the last row
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(src));
+    };
+    auto arrive = [](v16f& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); };
+    float logit[KM];
+    v16f buf[2];
+    issue(0, buf[0]);
+    v2f dot = {0.0f, 0.0f}, dot_b = {0.0f, 0.0f};  // two chains: a packed FMA cannot feed the next one back to back
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      arrive(buf[c & 1]);
+      if (c + 1 < NCH) issue(c + 1, buf[(c + 1) & 1]);
+      const v16f m = buf[c & 1];
+      const int h = c % PER_ROW;
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const int v = h * (CH / 4) + q;
+        if constexpr (EXACT) {
+          const v2f da = v2f{x.a[v][0], x.a[v][1]} - v2f{m[4 * q], m[4 * q + 1]};
+          const v2f db = v2f{x.a[v][2], x.a[v][3]} - v2f{m[4 * q + 2], m[4 * q + 3]};
+          dot = __builtin_elementwise_fma(da, da, dot);
+          dot_b = __builtin_elementwise_fma(db, db, dot_b);
+        } else {
+          dot = __builtin_elementwise_fma(v2f{x.a[v][0], x.a[v][1]}, v2f{m[4 * q], m[4 * q + 1]}, dot);
+          dot_b = __builtin_elementwise_fma(v2f{x.a[v][2], x.a[v][3]}, v2f{m[4 * q + 2], m[4 * q + 3]}, dot_b);
+        }
+      }
+      if (h == PER_ROW - 1) {
+        dot += dot_b;
+        if constexpr (EXACT) logit[c / PER_ROW] = __builtin_fmaf(-(dot.x + dot.y), inv2s2, lw8[c / PER_ROW]);
+        else logit[c / PER_ROW] = __builtin_fmaf(dot.x + dot.y, invs2, c8[c / PER_ROW]);
+        dot = dot_b = v2f{0.0f, 0.0f};
+      }
+      asm volatile("" : "+v"(dot), "+v"(dot_b));  // the chunk's FMAs stay between its load and the next one
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float top = logit[0];
+#pragma unroll
+    for (int k = 1; k < KM; ++k) top = __builtin_fmaxf(top, logit[k]);  // a NaN logit resurfaces in the sum
+    float w[KM];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      w[k] = __expf(logit[k] - top);
+      sum += w[k];
+    }
+    v2f acc[NV][2];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = v2f{0.0f, 0.0f};
+    issue(0, buf[0]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      arrive(buf[c & 1]);
+      if (c + 1 < NCH) issue(c + 1, buf[(c + 1) & 1]);
+      const v16f m = buf[c & 1];
+      const int h = c % PER_ROW;
+      const v2f wk = {w[c / PER_ROW], w[c / PER_ROW]};
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const int v = h * (CH / 4) + q;
+        acc[v][0] = __builtin_elementwise_fma(wk, v2f{m[4 * q], m[4 * q + 1]}, acc[v][0]);
+        acc[v][1] = __builtin_elementwise_fma(wk, v2f{m[4 * q + 2], m[4 * q + 3]}, acc[v][1]);
+        asm volatile("" : "+v"(acc[v][0]), "+v"(acc[v][1]));  // keep the FMAs with their chunk
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float inv = EXACT ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      g.a[v][0] = invs2 * (x.a[v][0] - acc[v][0].x * inv);
+      g.a[v][1] = invs2 * (x.a[v][1] - acc[v][0].y * inv);
+      g.a[v][2] = invs2 * (x.a[v][2] - acc[v][1].x * inv);
+      g.a[v][3] = invs2 * (x.a[v][3] - acc[v][1].y * inv);
+    }
+    if constexpr (EXACT) return -(top + logf(sum));
+    return sum;
   }
   __device__ __forceinline__ void load_mu(const LaneT& L, int k, int v, float (&m)[4]) const {
     if (mu_lds) {
@@ -362,6 +549,7 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
   template <bool WANT_E>
   __device__ __forceinline__ float eval_small(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
     constexpr int KM = 8;
+    if constexpr (G == 1 && LaneT::FULL && NV >= 4) return small_scalar_mu<true>(x, g);
     float logit[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
@@ -415,7 +603,14 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
 
   template <bool WANT_E>
   __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
-    if (K <= 8 && mu_lds) return eval_small<WANT_E>(L, x, g);
+    if (K <= 8 && mu_lds) {
+      if constexpr (!WANT_E) {
+        grad_only(L, x, g);
+        return 0.0f;
+      } else {
+        return eval_small<true>(L, x, g);
+      }
+    }
     float run_max = -__builtin_inff();
     float run_sum = 0.0f;
     Slice<NV> acc;
