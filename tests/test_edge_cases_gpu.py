@@ -43,7 +43,7 @@ def test_empty_inputs(cuda_device):
     assert diag["energy"].shape == (0,) and not torch.equal(out, x0)
 
 
-@pytest.mark.parametrize("dim,n", [(1, 1001), (3, 257), (5, 100), (6, 33), (30, 64), (100, 37), (250, 9)])
+@pytest.mark.parametrize("dim,n", [(1, 1001), (3, 257), (5, 100), (6, 33), (16, 129), (30, 64), (32, 65), (100, 37), (250, 9)])
 def test_native_rng_ragged_dims_langevin(cuda_device, dim, n):
     """dim % 4 != 0 (or tiny / ragged n): the fused chain with its own Philox draws equals the
     oracle fed with the field materialised by ebm_noise_fill_f32 -- element-wise energy (flat
@@ -65,7 +65,40 @@ def test_native_rng_ragged_dims_langevin(cuda_device, dim, n):
         torch.testing.assert_close(got2.cpu(), want2, rtol=3e-5, atol=3e-5)
 
 
-@pytest.mark.parametrize("dim,n,kind", [(6, 33, "gmm"), (3, 50, "dw"), (100, 40, "dw"), (250, 9, "har"), (1000, 5, "dw"), (1024, 3, "har")])
+@pytest.mark.parametrize("mass", [None, 2.0, "diag"])
+def test_lane_per_chain_mixture_hmc(cuda_device, mass):
+    """dim 32, K < 8: the one-lane-per-chain mixture kernel (means as scalar operands, padded
+    components re-reading the last row, two waves per SIMD) with every mass form, against the
+    oracle on the materialised Philox field."""
+    T, L, eps, n, dim = 5, 9, 0.08, 333, 32
+    x0 = torch.randn(n, dim).clamp_(-2.0, 2.0)
+    means = torch.randn(3, dim, generator=torch.Generator().manual_seed(4)) * 1.5
+    weights = torch.tensor([0.2, 0.5, 0.3])
+    model = ta.GaussianMixtureModel(means, sigma=0.9, weights=weights, device=cuda_device)
+    en = oracle.GaussianMixture(means, 0.9, log_weights=torch.log(weights))
+    if mass == "diag":
+        mass = torch.rand(dim, generator=torch.Generator().manual_seed(5)) + 0.5
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, mass=mass if mass is None or isinstance(mass, float) else mass.to(cuda_device),
+                                 device=cuda_device)
+    before = hip_calls("ebm_hmc_chain_f32")
+    got = s.sample(x=x0.to(cuda_device), n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(11))
+    assert hip_calls("ebm_hmc_chain_f32") == before + 1
+    p = _noise((T, n, dim), 11, 0, cuda_device, stride=2)
+    us = []
+    for t in range(T):
+        ut = torch.empty(n, device=cuda_device)
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 11, 2 * t + 1, _lib.stream_handle(cuda_device))
+        us.append(ut)
+    want = oracle.hmc_chain(en, x0, p.cpu(), torch.stack(us).cpu(), [eps] * T, L, mass=mass)
+    assert torch.isfinite(got).all()
+    close = ((got.cpu() - want["x"]).abs() / want["x"].abs().clamp(min=1.0)).amax(dim=1) <= 5e-4
+    if want["margin"] > 1e-4:
+        assert close.all()
+    else:  # an accept decision within round-off of u: only that chain may differ
+        assert close.float().mean().item() >= 0.99
+
+
+@pytest.mark.parametrize("dim,n,kind", [(6, 33, "gmm"), (32, 77, "gmm"), (3, 50, "dw"), (100, 40, "dw"), (250, 9, "har"), (1000, 5, "dw"), (1024, 3, "har")])
 def test_native_rng_ragged_dims_hmc(cuda_device, dim, n, kind):
     """HMC with in-kernel draws (momentum at step 2t, uniforms at 2t+1) vs the oracle on the
     materialised field, incl. the widest rows (G=64, NV=4, LDS-parked state)."""

@@ -192,14 +192,23 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
+  // small mixture, dim 16 / 32: one lane per chain, the means become wave-uniform scalar operands
+  // (rows.h: small_scalar_mu) -- no LDS traffic and no cross-lane reduction in the step loop
+  const bool lane_per_chain = e.kind == EBM_ENERGY_GMM && e.n_comp <= 8 && (dim == 16 || dim == 32);
+  if (lane_per_chain) geo = Geometry{1, dim / 4, true};
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  if (e.kind == EBM_ENERGY_GAUSSIAN)
-    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  const dim3 grid((unsigned)blocks), block(kBlock);
+  if (lane_per_chain && dim == 32)
+    hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 8, true>), grid, block, smem, st, a);
+  else if (lane_per_chain)
+    hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 4, true>), grid, block, smem, st, a);
+  else if (e.kind == EBM_ENERGY_GAUSSIAN)
+    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
   else
-    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
