@@ -61,11 +61,14 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
     for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float ph = p.a[v][i] + half_eps * f.a[v][i];
-        float step = eps * ph;
-        if constexpr (HAS_MASS) step = step / m_safe.a[v][i];
+        // fused multiply-adds: one rounding where the reference's eager ops take two -- HMC states are a
+        // tolerance tier anyway (energy and gradient sums run in another order than torch's)
+        const float ph = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);
+        float xn;
+        if constexpr (HAS_MASS) xn = x.a[v][i] + (eps * ph) / m_safe.a[v][i];
+        else xn = __builtin_fmaf(eps, ph, x.a[v][i]);
         p.a[v][i] = ph;
-        x.a[v][i] = L.ok(v, i) ? x.a[v][i] + step : 0.0f;
+        x.a[v][i] = L.ok(v, i) ? xn : 0.0f;
       }
     Slice<NV> g;
     float chk;  // group-uniform; finite => x finite, g free of NaN
@@ -88,8 +91,8 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
         for (int i = 0; i < 4; i += 2) {
           const float f0 = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
           const float f1 = __builtin_amdgcn_fmed3f(-g.a[v][i + 1], -1e6f, 1e6f);
-          const float p0 = p.a[v][i] + half_eps * f0;
-          const float p1 = p.a[v][i + 1] + half_eps * f1;
+          const float p0 = __builtin_fmaf(half_eps, f0, p.a[v][i]);
+          const float p1 = __builtin_fmaf(half_eps, f1, p.a[v][i + 1]);
           f.a[v][i] = f0;
           f.a[v][i + 1] = f1;
           p.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
@@ -110,7 +113,7 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float fn = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
-          const float pn = p.a[v][i] + half_eps * fn;
+          const float pn = __builtin_fmaf(half_eps, fn, p.a[v][i]);
           f.a[v][i] = fn;
           p.a[v][i] = nan_to_num0(L.ok(v, i) ? pn : 0.0f);
           x.a[v][i] = nan_to_num0(x.a[v][i]);
