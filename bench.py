@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: RCCL across processes needs this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -128,7 +131,10 @@ def main():
 
         if on_gpu:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl" if on_gpu else "gloo")
+            # device_id binds the communicator to this rank's GPU up front (no lazy guess at the first collective)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
