@@ -132,7 +132,12 @@ def main():
         if on_gpu:
             torch.cuda.set_device(local_rank)
             # device_id binds the communicator to this rank's GPU up front (no lazy guess at the first collective)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except (TypeError, RuntimeError):
+                if dist.is_initialized():
+                    raise
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
     if args.gpus != world and rank == 0 and world > 1:
