@@ -110,6 +110,22 @@ def cpu_baseline(dim: int, k_full: int):
     }
 
 
+def copy_ceiling_gbs(device, nbytes=1 << 28, reps=10):
+    """Measured device-to-device copy rate (read + write bytes / time) on this box: the practical HBM
+    ceiling quoted next to the 8 TB/s spec peak."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize(device)
+    return 2 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def read_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -222,6 +238,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "measured_copy_ceiling": copy_ceiling_gbs(device),
                 "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
                 "kernel": "langevin_chain_lean_kernel<DoubleWell> (ebm_langevin_chain_f32)",
                 "kernel_ms": kernel_ms,
