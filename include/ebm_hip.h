@@ -128,6 +128,22 @@ EBM_API int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t
                            uint64_t seed, uint64_t offset, void* stream);
 
 /*
+ * The same k fused steps with the reference's Heun (improved Euler) drift update,
+ * LangevinDynamics(integrator="heun"): tableau a = ((), (1,)), b = (1/2, 1/2) (integrators/heun.py)
+ * evaluated in the op order of BaseSDERungeKuttaIntegrator (core/base_integrator.py:387-397, 711-731):
+ *   k0 = -grad E(x);  x1 = x + eta*(1*k0);  k1 = -grad E(x1);
+ *   x' = x + eta*(0.5*k0 + 0.5*k1) + noise_coef*(eps*sqrt_eta)
+ * Two gradient evaluations per step, one noise draw (same Philox coordinates as the EM chain).
+ * Arguments as ebm_langevin_chain_f32; DoubleWell / Harmonic / Gaussian / mixture energies
+ * (EBM_ENERGY_MLP returns EBM_EKIND).
+ */
+EBM_API int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                           int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                           const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                           int32_t thin, float* traj, const float* noise,
+                           uint64_t seed, uint64_t offset, void* stream);
+
+/*
  * n_mh fused HMC transitions for an analytic energy: momentum draw, Hamiltonian,
  * L leapfrog steps (safe mode: force clamp +-1e6, NaN scrub), Metropolis accept.
  * Replaces the hot loop of HamiltonianMonteCarlo.sample (samplers/hmc.py:243-312),

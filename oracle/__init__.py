@@ -17,7 +17,7 @@ from .energies import (  # noqa: F401
     GaussianMixture,
     Harmonic,
 )
-from .langevin import em_step, langevin_chain  # noqa: F401
+from .langevin import em_step, heun_step, langevin_chain  # noqa: F401
 from .hmc import hmc_chain, leapfrog  # noqa: F401
 from .descent import descent_chain  # noqa: F401
 from .philox import normal_field, philox4x32_10, raw_field, uniform_field  # noqa: F401

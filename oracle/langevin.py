@@ -27,6 +27,27 @@ def em_step(x: torch.Tensor, grad: torch.Tensor, eps: Optional[torch.Tensor], et
     return x1 + (2.0 * sigma**2) ** 0.5 * dw
 
 
+def heun_step(energy, x: torch.Tensor, eps: Optional[torch.Tensor], eta: float, sigma: Optional[float]):
+    """One Heun-SDE step (torchebm/integrators/heun.py: a = ((), (1,)), b = (1/2, 1/2)), in the op order
+    of the generic tableau code (base_integrator.py:387-397), then the Euler-order noise (:728-729):
+        k0 = -grad(x)
+        x1 = x + eta * einsum([1.], [k0])                    stage input
+        k1 = -grad(x1)
+        xd = x + eta * einsum([.5, .5], [k0, k1])            drift update
+        x' = xd + (2 sigma^2)^0.5 * (eps * eta^0.5)
+    """
+    k0 = -energy.grad(x)
+    stages = torch.stack([k0])
+    x1 = x + eta * torch.einsum("i,i...->...", torch.tensor([1.0], dtype=x.dtype), stages)
+    k1 = -energy.grad(x1)
+    stages = torch.stack([k0, k1])
+    xd = x + eta * torch.einsum("i,i...->...", torch.tensor([0.5, 0.5], dtype=x.dtype), stages)
+    if sigma is None or eps is None:
+        return xd
+    dw = eps * (eta**0.5)
+    return xd + (2.0 * sigma**2) ** 0.5 * dw
+
+
 def langevin_chain(
     energy,
     x0: torch.Tensor,
@@ -37,8 +58,10 @@ def langevin_chain(
     thin: int = 1,
     want_traj: bool = False,
     want_diag: bool = False,
+    integrator: str = "euler_maruyama",
 ):
-    """k = len(etas) steps with ``noise[i]`` as the step-i Wiener draw.
+    """k = len(etas) steps with ``noise[i]`` as the step-i Wiener draw; ``integrator`` is
+    ``"euler_maruyama"`` (default) or ``"heun"``.
 
     Returns ``(x_final, trajectory_or_None, diagnostics_or_None)``; trajectory is
     ``[n, k // thin, dim]`` and diagnostics are ``mean``/``var``/``energy`` per kept step
@@ -59,7 +82,10 @@ def langevin_chain(
         }
     keep = 0
     for i in range(k):
-        x = em_step(x, energy.grad(x), noise[i], etas[i], sigmas[i])
+        if integrator == "heun":
+            x = heun_step(energy, x, noise[i], etas[i], sigmas[i])
+        else:
+            x = em_step(x, energy.grad(x), noise[i], etas[i], sigmas[i])
         if clamp is not None:
             x = x.clamp_(*clamp)
         if (i + 1) % thin == 0:

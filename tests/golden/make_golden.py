@@ -258,6 +258,7 @@ def main():
     langevin_case("ld_dw_1x8", dw, 1, 8, 8, 0.01, 1.0, seed=18)
     langevin_case("heun_dw_40x6", dw, 40, 6, 10, 0.01, 1.0, seed=19, integrator="heun", thin=2)
     langevin_case("heun_gauss2d_64", g2, 64, 2, 8, 0.05, 0.7, seed=20, integrator="heun")
+    heun_extra_cases()
     # SURVEY.md §8c checksum cases (noise is replayed from the seed, not stored)
     langevin_survey()
 
@@ -288,6 +289,22 @@ def main():
 
     # ---- Energy Matching negatives ---------------------------------
     energy_matching_cases()
+
+
+def heun_extra_cases():
+    """More Heun-SDE Langevin runs for the fused Heun kernel: schedulers + clamp, the mixture, wide rows."""
+    har = {"kind": "harmonic", "k": 1.5}
+    dw2 = {"kind": "double_well", "h": 0.7, "b": 1.3}
+    gmm6 = {"kind": "gmm", "means": ring_means(5, 6, radius=2.0), "sigma": 0.8}
+    gg = torch.Generator().manual_seed(5)
+    a = torch.randn(8, 8, generator=gg)
+    g8 = {"kind": "gaussian", "mean": torch.randn(8, generator=gg), "cov": a @ a.t() / 8 + 0.5 * torch.eye(8)}
+    langevin_case("heun_har_100x2_sched", har, 100, 2, 12, LinearScheduler(0.05, 0.005, 10),
+                  ExponentialDecayScheduler(1.0, 0.9, 0.3), seed=51, thin=2, integrator="heun")
+    langevin_case("heun_dw_37x3_clamp_thin3", dw2, 37, 3, 12, 0.02, 0.8, seed=52, clamp=(-1.25, 1.5), thin=3, integrator="heun")
+    langevin_case("heun_gmm5_50x6", gmm6, 50, 6, 10, 0.03, 0.9, seed=53, x0_scale=2.0, thin=5, integrator="heun")
+    langevin_case("heun_gauss8_64", g8, 64, 8, 10, 0.02, 1.0, seed=54, thin=2, integrator="heun")
+    langevin_case("heun_dw_64x64", {"kind": "double_well", "h": 2.0, "b": 1.0}, 64, 64, 10, 0.01, 1.0, seed=55, integrator="heun")
 
 
 def energy_matching_case(name, energy, n, dim, k, seed, noise_fraction, epsilon_max=0.15, tau_star=0.6, dt=0.01):

@@ -516,7 +516,10 @@ def test_heun_langevin_reproduces_reference(name):
     from torchebm_amd.integrators import HeunIntegrator
 
     fx = load_golden(name)
-    s = ta.LangevinDynamics(package_model(fx["energy"]), step_size=fx["etas"][0], noise_scale=fx["sigmas"][0], integrator="heun")
+    eta, sigma = fx["etas"][0], fx["sigmas"][0]
+    if name.endswith("_sched"):  # the schedulers tests/golden/make_golden.py used for this case
+        eta, sigma = LinearScheduler(0.05, 0.005, 10), ExponentialDecayScheduler(1.0, 0.9, 0.3)
+    s = ta.LangevinDynamics(package_model(fx["energy"]), step_size=eta, noise_scale=sigma, clamp=fx["clamp"], integrator="heun")
     assert type(s.integrator) is HeunIntegrator
     out = s.sample(x=fx["x0"].clone(), n_steps=fx["k"], generator=torch.Generator().manual_seed(fx["run_seed"]))
     _check(out, fx["ref"]["x"], fx["energy"]["kind"])

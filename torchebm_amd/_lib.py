@@ -32,6 +32,7 @@ EXPORTS = (
     "ebm_langevin_step_f32",
     "ebm_langevin_step_dev_f32",
     "ebm_langevin_chain_f32",
+    "ebm_langevin_heun_chain_f32",
     "ebm_hmc_chain_f32",
     "ebm_leapfrog_kick_drift_f32",
     "ebm_leapfrog_kick_f32",
@@ -72,6 +73,10 @@ _PROTOTYPES = {
     "ebm_langevin_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _u64, _u64, _p]),
     "ebm_langevin_step_dev_f32": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _p, _p]),
     "ebm_langevin_chain_f32": (
+        C.c_int,
+        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _u64, _u64, _p],
+    ),
+    "ebm_langevin_heun_chain_f32": (
         C.c_int,
         [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _u64, _u64, _p],
     ),

@@ -14,10 +14,10 @@ int launch_langevin_step(const float*, const float*, float*, const float*, int64
                          float, int, float, float, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
-                               const float*, uint64_t, uint64_t, hipStream_t);
+                               const float*, uint64_t, uint64_t, int heun, hipStream_t);
 int launch_langevin_chain_rows(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
-                               const float*, uint64_t, uint64_t, hipStream_t);
+                               const float*, uint64_t, uint64_t, int heun, hipStream_t);
 int launch_hmc_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float,
                      const float*, int32_t, double, const float*, int32_t, float*, uint8_t*,
                      uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
@@ -147,13 +147,15 @@ int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* out, int
                               rng_state, (hipStream_t)stream);
 }
 
-int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
-                           int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
-                           const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                           int32_t thin, float* traj, const float* noise, uint64_t seed,
-                           uint64_t offset, void* stream) {
-  const char* who = "ebm_langevin_chain_f32";
+static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* energy, float* x, int64_t n_chains,
+                               int32_t dim, int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                               const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                               int32_t thin, float* traj, const float* noise, uint64_t seed,
+                               uint64_t offset, void* stream) {
   if (int r = check_energy(energy, dim, who)) return r;
+  if (heun) {
+    if (int r = reject_mlp(energy, who)) return r;
+  }
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
   if (n_chains == 0 || k_steps == 0) return 0;
@@ -165,8 +167,8 @@ int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chain
   if (energy->kind == EBM_ENERGY_DOUBLE_WELL || energy->kind == EBM_ENERGY_HARMONIC)
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
-                                      cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
-  if (energy->kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim)) {
+                                      cmax, thin, traj, noise, seed, offset, heun, (hipStream_t)stream);
+  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim)) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
     if (!force_rows)
@@ -175,7 +177,25 @@ int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chain
   }
   return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef,
                                     coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
-                                    (hipStream_t)stream);
+                                    heun, (hipStream_t)stream);
+}
+
+int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                           int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                           const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                           int32_t thin, float* traj, const float* noise, uint64_t seed,
+                           uint64_t offset, void* stream) {
+  return langevin_chain_impl("ebm_langevin_chain_f32", 0, energy, x, n_chains, dim, k_steps, eta, sqrt_eta,
+                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset, stream);
+}
+
+int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                                int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                                const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                                int32_t thin, float* traj, const float* noise, uint64_t seed,
+                                uint64_t offset, void* stream) {
+  return langevin_chain_impl("ebm_langevin_heun_chain_f32", 1, energy, x, n_chains, dim, k_steps, eta, sqrt_eta,
+                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset, stream);
 }
 
 int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,

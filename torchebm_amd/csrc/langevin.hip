@@ -187,7 +187,11 @@ struct ChainArgs {
   uint64_t step0;
 };
 
-template <int KIND, bool NOISE_PTR>
+// HEUN: the reference's Heun tableau (integrators/heun.py: a = ((), (1,)), b = (1/2, 1/2)) in its
+// op order (base_integrator.py:387-397): k0 = -g(x); x1 = x + h*(1*k0); k1 = -g(x1);
+// x <- x + h*(0.5*k0 + 0.5*k1) + noise.  The halves are exact, the sum rounds once, so the update is
+// em_update() applied to the averaged gradient.
+template <int KIND, bool NOISE_PTR, bool HEUN>
 __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e0 = g * 4;
@@ -224,7 +228,11 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a
     else eps = normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gr = elem_grad<KIND>(x.v[j], a.s0, a.s1);
+      float gr = elem_grad<KIND>(x.v[j], a.s0, a.s1);
+      if constexpr (HEUN) {
+        const float x1 = x.v[j] - c.eta * gr;
+        gr = 0.5f * gr + 0.5f * elem_grad<KIND>(x1, a.s0, a.s1);
+      }
       float v = em_update(x.v[j], gr, eps.v[j], c);
       if (a.clamp_on) v = clamp_nanprop(v, a.cmin, a.cmax);
       x.v[j] = v;
@@ -322,7 +330,7 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
                                int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                const float* coef_table, int clamp_on, float cmin, float cmax,
                                int32_t thin, float* traj, const float* noise, uint64_t seed,
-                               uint64_t offset, hipStream_t st) {
+                               uint64_t offset, int heun, hipStream_t st) {
   ChainArgs a;
   a.x = x; a.n_elem = n_chains * (int64_t)dim; a.dim = dim; a.k_steps = k_steps;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
@@ -336,7 +344,7 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   const int64_t blocks = ceil_div64(n_groups, kBlock);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (!noise && !traj) {
+  if (!noise && !traj && !heun) {
 #define EBM_LEAN(KIND)                                                                                   \
   do {                                                                                                   \
     if (coef_table && clamp_on) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, true, true>), grid, block, 0, st, a);    \
@@ -351,13 +359,15 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   }
 #define EBM_LAUNCH(KIND)                                                                         \
   do {                                                                                           \
-    if (noise) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, true>), grid, block, 0, st, a);  \
-    else hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, false>), grid, block, 0, st, a);       \
+    if (heun && noise) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, true, true>), grid, block, 0, st, a);    \
+    else if (heun) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, false, true>), grid, block, 0, st, a);       \
+    else if (noise) hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, true, false>), grid, block, 0, st, a);      \
+    else hipLaunchKernelGGL((langevin_chain_elem_kernel<KIND, false, false>), grid, block, 0, st, a);                \
   } while (0)
   if (kind == EBM_ENERGY_DOUBLE_WELL) EBM_LAUNCH(EBM_ENERGY_DOUBLE_WELL);
   else EBM_LAUNCH(EBM_ENERGY_HARMONIC);
 #undef EBM_LAUNCH
-  return check_launch("ebm_langevin_chain_f32");
+  return check_launch(heun ? "ebm_langevin_heun_chain_f32" : "ebm_langevin_chain_f32");
 }
 
 }  // namespace ebm

@@ -29,8 +29,8 @@ struct RowChainArgs {
   int param_floats;
 };
 
-template <int KIND, int G, int NV, bool FULL>
-__global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArgs a) {
+template <int KIND, int G, int NV, bool FULL, bool HEUN>
+__device__ __forceinline__ void langevin_chain_rows_body(const RowChainArgs& a) {
   using LaneT = Lane<G, NV, FULL>;
   LaneT L;
   L.init(a.n_chains, a.dim);
@@ -54,6 +54,18 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArg
     }
     Slice<NV> g, eps;
     en.template eval<false>(L, x, g);
+    if constexpr (HEUN) {  // predictor x1 = x - eta*g0, corrector gradient 0.5*g0 + 0.5*g(x1)
+      Slice<NV> x1, g1;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x1.a[v][i] = L.ok(v, i) ? x.a[v][i] - eta * g.a[v][i] : 0.0f;
+      en.template eval<false>(L, x1, g1);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.a[v][i] = 0.5f * g.a[v][i] + 0.5f * g1.a[v][i];
+    }
     if (a.noise) load_slice(L, a.noise, ((int64_t)s * a.n_chains) * a.dim + row, eps);
     else normal_slice(L, a.key, a.step0 + (uint64_t)s, eps);
 #pragma unroll
@@ -74,6 +86,16 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArg
     }
   }
   store_slice(L, a.x, row, x);
+}
+
+template <int KIND, int G, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArgs a) {
+  langevin_chain_rows_body<KIND, G, NV, FULL, false>(a);
+}
+
+template <int KIND, int G, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void langevin_heun_rows_kernel(RowChainArgs a) {
+  langevin_chain_rows_body<KIND, G, NV, FULL, true>(a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -181,7 +203,7 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
                                int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                const float* coef_table, int clamp_on, float cmin, float cmax,
                                int32_t thin, float* traj, const float* noise, uint64_t seed,
-                               uint64_t offset, hipStream_t st) {
+                               uint64_t offset, int heun, hipStream_t st) {
   Geometry geo;
   if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: dim %d > 1024 is not supported for this energy", dim);
   RowChainArgs a;
@@ -194,14 +216,18 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
   a.step0 = offset;
   // small mixture, dim 16 / 32: one lane per chain, the means become wave-uniform scalar operands
   // (rows.h: small_scalar_mu) -- no LDS traffic and no cross-lane reduction in the step loop
-  const bool lane_per_chain = e.kind == EBM_ENERGY_GMM && e.n_comp <= 8 && (dim == 16 || dim == 32);
+  const bool lane_per_chain = !heun && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8 && (dim == 16 || dim == 32);
   if (lane_per_chain) geo = Geometry{1, dim / 4, true};
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (lane_per_chain && dim == 32)
+  if (heun && e.kind == EBM_ENERGY_GAUSSIAN)
+    EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
+  else if (heun)
+    EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
+  else if (lane_per_chain && dim == 32)
     hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 8, true>), grid, block, smem, st, a);
   else if (lane_per_chain)
     hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 4, true>), grid, block, smem, st, a);
@@ -209,7 +235,7 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
     EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
   else
     EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
-  return check_launch("ebm_langevin_chain_f32");
+  return check_launch(heun ? "ebm_langevin_heun_chain_f32" : "ebm_langevin_chain_f32");
 }
 
 int launch_descent_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,

@@ -30,7 +30,7 @@ from ..core.integrator_base import BaseSDERungeKuttaIntegrator
 from ..core.module import warn_once
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler, Schedulable
-from ..integrators.em import EulerMaruyamaIntegrator
+from ..integrators.em import EulerMaruyamaIntegrator, HeunIntegrator
 from ..integrators.registry import resolve_integrator
 
 
@@ -89,6 +89,12 @@ class LangevinDynamics(BaseSampler):
         if not x.is_cuda:
             return "eager", None
         plain_em = type(self.integrator) is EulerMaruyamaIntegrator
+        heun = type(self.integrator) is HeunIntegrator
+        if heun and x.dtype == torch.float32 and not (self.use_mixed_precision and self.autocast_available):
+            # Heun has a fused kernel for the analytic energies only; anything else keeps the eager loop
+            spec = self._fusable_spec(x, model_kwargs)
+            if spec is not None and not spec.langevin_only:
+                return "fused", spec
         if x.dtype != torch.float32 or not plain_em or (self.use_mixed_precision and self.autocast_available):
             warn_once(
                 "langevin-eager-cuda",
@@ -97,6 +103,10 @@ class LangevinDynamics(BaseSampler):
                 UserWarning,
             )
             return "eager", None
+        spec = self._fusable_spec(x, model_kwargs)
+        return ("fused", spec) if spec is not None else ("step", None)
+
+    def _fusable_spec(self, x: torch.Tensor, model_kwargs: Dict[str, Any]) -> Optional[FusedSpec]:
         spec = None
         if not model_kwargs and hasattr(self.model, "fused_spec") and not isinstance(self.model, Schedulable):
             spec = self.model.fused_spec()
@@ -106,7 +116,7 @@ class LangevinDynamics(BaseSampler):
                 t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)
             ):
                 spec = None
-        return ("fused", spec) if spec is not None else ("step", None)
+        return spec
 
     # ---------------------------------------------------------------------------------
     # public API
@@ -327,8 +337,9 @@ class LangevinDynamics(BaseSampler):
             a, sq, coef = rows[row0]
             host = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows[row0 : row0 + k]], dtype=torch.float32)
             table = host.to(x.device, non_blocking=True)
+        entry = "ebm_langevin_heun_chain_f32" if type(self.integrator) is HeunIntegrator else "ebm_langevin_chain_f32"
         _lib.call(
-            "ebm_langevin_chain_f32",
+            entry,
             spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(table),
             clamp_on, cmin, cmax, thin, _lib.ptr(traj), None, seed, step, stream,
         )
