@@ -192,6 +192,13 @@ EBM_API int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, c
                        const float* u, uint8_t* accept_mask, uint32_t* accept_count,
                        int64_t n_chains, int32_t dim, uint64_t seed, uint64_t offset, void* stream);
 
+/* The accept step with the RNG coordinates in DEVICE memory (rng_state = {seed, step}; the uniforms
+ * are drawn at step rng_state[1] + step_delta): the graph-capturable form, see
+ * ebm_langevin_step_dev_f32.  No injected-uniform form. */
+EBM_API int ebm_hmc_accept_dev_f32(float* x, const float* x_prop, const float* h0, const float* h1,
+                           uint8_t* accept_mask, uint32_t* accept_count, int64_t n_chains,
+                           int32_t dim, const uint64_t* rng_state, uint64_t step_delta, void* stream);
+
 /*
  * Noise-free descent samplers (reference: torchebm/samplers/gradient_descent.py).
  * torch.sub / torch.add with `alpha` are single-rounding FMAs on the CPU reference, and so are these:
@@ -239,6 +246,11 @@ EBM_API int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, f
  * BaseSampler._init_state-style draws): normals, uniforms in [0,1), or raw u32 bits. */
 EBM_API int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_t seed,
                        uint64_t offset, void* stream);
+
+/* The same field with {seed, step} read from DEVICE memory, at step rng_state[1] + step_delta (the
+ * momentum draw of a HMC transition captured in a HIP graph, samplers/hmc.py:92-134). */
+EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint64_t* rng_state,
+                           uint64_t step_delta, void* stream);
 
 #ifdef __cplusplus
 }

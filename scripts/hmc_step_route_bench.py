@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HMC on a neural energy (no fused kernel): eager step route vs one captured transition replayed."""
+import json, os, sys, time
+import torch
+from torch import nn
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchebm_amd as ta
+from torchebm_amd.utils.synthetic import two_moons
+dev = torch.device("cuda")
+
+
+class Net(ta.BaseModel):
+    def __init__(self):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(2, 128), nn.SiLU(), nn.Linear(128, 128), nn.SiLU(), nn.Linear(128, 1))
+
+    def forward(self, x):
+        return self.net(x).squeeze(-1)
+
+
+def wall(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+torch.manual_seed(0)
+model = Net().to(dev)
+n, T, L = 65536, 10, 10
+x = two_moons(n, 0.05, seed=0, device=dev)
+s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=dev)
+t_eager = wall(lambda: s.sample(x=x, n_steps=T))
+s.capture_graph = True
+t_graph = wall(lambda: s.sample(x=x, n_steps=T))
+print(json.dumps({"config": f"HMC step route, MLP 2-128-128-1, n={n}, L={L}, {T} transitions per call",
+                  "eager_s_per_call": t_eager, "graph_s_per_call": t_graph, "speedup": t_eager / t_graph,
+                  "mh_steps_per_s_graph": n * T / t_graph}))

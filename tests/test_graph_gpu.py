@@ -92,3 +92,48 @@ def test_scheduled_step_size_falls_back_to_the_eager_route(cuda_device):
     s0 = hip_calls("ebm_langevin_step_f32")
     out = s.sample(x=two_moons(256, 0.05, seed=0, device=cuda_device), n_steps=6)
     assert hip_calls("ebm_langevin_step_f32") == s0 + 6 and torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------------
+# HMC: one Metropolis transition per replay
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mass", [None, 1.7, "diag"])
+def test_hmc_graph_route_is_bit_identical_to_the_eager_step_route(cuda_device, mass):
+    torch.manual_seed(0)
+    model = Net(dim=3, hidden=32).to(cuda_device)
+    if mass == "diag":
+        mass = torch.tensor([0.5, 1.0, 2.0], device=cuda_device)
+    kw = dict(step_size=0.07, n_leapfrog_steps=4, mass=mass, device=cuda_device)
+    eager, graph = ta.HamiltonianMonteCarlo(model, **kw), ta.HamiltonianMonteCarlo(model, **kw)
+    graph.capture_graph = True
+    x0 = torch.randn(777, 3, device=cuda_device)
+    a0, d0 = hip_calls("ebm_hmc_accept_f32"), hip_calls("ebm_hmc_accept_dev_f32")
+    want, dw = eager.sample(x=x0, n_steps=6, thin=2, return_diagnostics=True, generator=_gen(cuda_device, 9))
+    got, dg = graph.sample(x=x0, n_steps=6, thin=2, return_diagnostics=True, generator=_gen(cuda_device, 9))
+    assert hip_calls("ebm_hmc_accept_f32") == a0 + 6
+    assert hip_calls("ebm_hmc_accept_dev_f32") == d0 + 3          # 2 warm-up transitions + the captured one
+    assert torch.equal(got, want)
+    assert torch.equal(dg["acceptance_rate"], dw["acceptance_rate"]) and 0.3 < dg["acceptance_rate"].mean().item() <= 1.0
+    torch.testing.assert_close(dg["energy"], dw["energy"], rtol=1e-6, atol=1e-6)
+    # continuing generators: fresh draws per call, same stream as the eager route, offset += 8 per transition
+    ge, gg = _gen(cuda_device, 4), _gen(cuda_device, 4)
+    e1, g1 = eager.sample(x=x0, n_steps=3, generator=ge), graph.sample(x=x0, n_steps=3, generator=gg)
+    e2, g2 = eager.sample(x=x0, n_steps=3, generator=ge), graph.sample(x=x0, n_steps=3, generator=gg)
+    assert hip_calls("ebm_hmc_accept_dev_f32") == d0 + 3          # graph re-used
+    assert torch.equal(e1, g1) and torch.equal(e2, g2) and not torch.equal(g1, g2)
+    assert ge.get_offset() == gg.get_offset() == 4 * 2 * 6
+    # in-place weight updates reach the next replay
+    with torch.no_grad():
+        model.net[0].weight.mul_(2.0)
+    assert torch.equal(graph.sample(x=x0, n_steps=2, generator=_gen(cuda_device, 5)),
+                       eager.sample(x=x0, n_steps=2, generator=_gen(cuda_device, 5)))
+
+
+def test_hmc_scheduled_step_size_falls_back_to_the_eager_route(cuda_device):
+    torch.manual_seed(0)
+    model = Net().to(cuda_device)
+    s = ta.HamiltonianMonteCarlo(model, step_size=LinearScheduler(0.05, 0.01, 10), n_leapfrog_steps=3, device=cuda_device)
+    s.capture_graph = True
+    a0 = hip_calls("ebm_hmc_accept_f32")
+    out = s.sample(x=two_moons(256, 0.05, seed=0, device=cuda_device), n_steps=4)
+    assert hip_calls("ebm_hmc_accept_f32") == a0 + 4 and torch.isfinite(out).all()

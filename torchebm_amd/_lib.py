@@ -37,6 +37,7 @@ EXPORTS = (
     "ebm_leapfrog_kick_drift_f32",
     "ebm_leapfrog_kick_f32",
     "ebm_hmc_accept_f32",
+    "ebm_hmc_accept_dev_f32",
     "ebm_descent_chain_f32",
     "ebm_descent_step_f32",
     "ebm_lookahead_f32",
@@ -45,6 +46,7 @@ EXPORTS = (
     "ebm_energy_grad_f32",
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
+    "ebm_noise_fill_dev_f32",
 )
 
 #: number of calls made through each entry point in this process (tests use it to
@@ -87,6 +89,7 @@ _PROTOTYPES = {
     "ebm_leapfrog_kick_drift_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _d, _p, _i32, _p]),
     "ebm_leapfrog_kick_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _i32, _p]),
     "ebm_hmc_accept_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _u64, _u64, _p]),
+    "ebm_hmc_accept_dev_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _u64, _p]),
     "ebm_descent_chain_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _i32, _f, _p, _i32, _f, _i32, _p, _p]),
     "ebm_descent_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _p]),
     "ebm_lookahead_f32": (C.c_int, [_p, _p, _p, _i64, _f, _p]),
@@ -95,6 +98,7 @@ _PROTOTYPES = {
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),
+    "ebm_noise_fill_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _u64, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

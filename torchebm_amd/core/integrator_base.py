@@ -216,7 +216,8 @@ class BaseSymplecticIntegrator(BaseIntegrator):
     def _unpack_state(state: Dict[str, torch.Tensor], step_size) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         x, p = state["x"], state["p"]
         if not torch.is_tensor(step_size):
-            step_size = torch.tensor(step_size, device=x.device, dtype=x.dtype)
+            # a fill kernel, not a host-to-device copy: legal inside HIP-graph capture, same fp32 value
+            step_size = torch.full((), float(step_size), device=x.device, dtype=x.dtype)
         t = torch.zeros(x.size(0), device=x.device, dtype=x.dtype)
         return x, p, step_size, t
 

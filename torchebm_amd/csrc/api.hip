@@ -26,7 +26,7 @@ int launch_leapfrog_kick_drift(const float*, const float*, const float*, float*,
 int launch_leapfrog_kick(float*, const float*, const float*, float*, int64_t, float, int32_t,
                          hipStream_t);
 int launch_hmc_accept(float*, const float*, const float*, const float*, const float*, uint8_t*,
-                      uint32_t*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
+                      uint32_t*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_energy_grad(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*,
                        hipStream_t);
 int launch_chain_stats(const float*, int64_t, int32_t, float*, float*, double*, hipStream_t);
@@ -37,7 +37,7 @@ int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStre
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
                       uint64_t, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
-int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, hipStream_t);
+int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
@@ -256,7 +256,18 @@ int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, const flo
   if (n_chains == 0) return 0;
   if (!x || !x_prop || !h0 || !h1) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   return launch_hmc_accept(x, x_prop, h0, h1, u, accept_mask, accept_count, n_chains, dim, seed,
-                           offset, (hipStream_t)stream);
+                           offset, nullptr, (hipStream_t)stream);
+}
+
+int ebm_hmc_accept_dev_f32(float* x, const float* x_prop, const float* h0, const float* h1,
+                           uint8_t* accept_mask, uint32_t* accept_count, int64_t n_chains, int32_t dim,
+                           const uint64_t* rng_state, uint64_t step_delta, void* stream) {
+  const char* who = "ebm_hmc_accept_dev_f32";
+  if (n_chains < 0 || dim < 1) return fail(EBM_EINVAL, "%s: bad shape", who);
+  if (n_chains == 0) return 0;
+  if (!x || !x_prop || !h0 || !h1 || !rng_state) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_hmc_accept(x, x_prop, h0, h1, nullptr, accept_mask, accept_count, n_chains, dim, 0,
+                           step_delta, rng_state, (hipStream_t)stream);
 }
 
 int ebm_descent_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
@@ -346,7 +357,18 @@ int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_t seed, 
   if (n_elem == 0) return 0;
   if (!out || !aligned16(out)) return fail(EBM_EINVAL, "%s: out must be a 16-byte aligned pointer", who);
   if (kind < EBM_NOISE_NORMAL || kind > EBM_NOISE_RAW_U32) return fail(EBM_EINVAL, "%s: bad kind %d", who, kind);
-  return launch_noise_fill(out, n_elem, kind, seed, offset, (hipStream_t)stream);
+  return launch_noise_fill(out, n_elem, kind, seed, offset, nullptr, (hipStream_t)stream);
+}
+
+int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint64_t* rng_state,
+                           uint64_t step_delta, void* stream) {
+  const char* who = "ebm_noise_fill_dev_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!out || !aligned16(out)) return fail(EBM_EINVAL, "%s: out must be a 16-byte aligned pointer", who);
+  if (!rng_state) return fail(EBM_EINVAL, "%s: rng_state is NULL", who);
+  if (kind < EBM_NOISE_NORMAL || kind > EBM_NOISE_RAW_U32) return fail(EBM_EINVAL, "%s: bad kind %d", who, kind);
+  return launch_noise_fill(out, n_elem, kind, 0, step_delta, rng_state, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -45,6 +45,9 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   // ONE lane per chain -- the means become wave-uniform scalar operands (no LDS traffic, no cross-lane
   // reduction): 1.22 ms per 10 transitions vs 1.76 for (2,4) and 2.3 for the generic (8,1)
   else if (dim == 32 && nv_env == 0 && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8) geo = Geometry{1, 8, true};
+  // element-wise energies at dim 32: two lanes x four vectors (one DPP level for E and K): 0.59 vs 0.70 ms
+  else if (dim == 32 && nv_env == 0 && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC))
+    geo = Geometry{2, 4, true};
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   a.park_offset_floats = (int)(smem / sizeof(float));

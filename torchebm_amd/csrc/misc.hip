@@ -17,8 +17,20 @@ int grid_for(int64_t n_threads) {
 }
 
 // ---------------------------------------------------------------------------------
+// rng_dev (optional): {seed, step} in device memory; the launch's own `step` is then an offset from
+// it -- what lets a launch captured in a HIP graph draw fresh numbers on every replay.
+__device__ __forceinline__ void resolve_rng(const uint64_t* rng_dev, RngKey& key, uint64_t& step) {
+  if (rng_dev) {
+    const uint64_t seed = rng_dev[0];
+    key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    step += rng_dev[1];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void noise_fill_kernel(float* __restrict__ out, int64_t n_elem,
-                                                            int kind, RngKey key, uint64_t step) {
+                                                            int kind, RngKey key, uint64_t step,
+                                                            const uint64_t* __restrict__ rng_dev) {
+  resolve_rng(rng_dev, key, step);
   const int64_t n_groups = ceil_div64(n_elem, 4);
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
        g += (int64_t)gridDim.x * kBlock) {
@@ -164,7 +176,9 @@ __global__ __launch_bounds__(kBlock) void pcd_scatter_kernel(float* __restrict__
 __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
     float* __restrict__ x, const float* __restrict__ x_prop, const float* __restrict__ h0,
     const float* __restrict__ h1, const float* __restrict__ u, uint8_t* __restrict__ mask,
-    uint32_t* __restrict__ count, int64_t n_chains, int32_t dim, RngKey key, uint64_t step) {
+    uint32_t* __restrict__ count, int64_t n_chains, int32_t dim, RngKey key, uint64_t step,
+    const uint64_t* __restrict__ rng_dev) {
+  resolve_rng(rng_dev, key, step);
   // phase 1: one lane per chain decides; phase 2: the block copies accepted rows.
   __shared__ uint8_t acc_s[kBlock];
   for (int64_t c0 = (int64_t)blockIdx.x * kBlock; c0 < n_chains; c0 += (int64_t)gridDim.x * kBlock) {
@@ -254,10 +268,10 @@ __global__ void chain_stats_finish_kernel(const float* __restrict__ x, const dou
 }  // namespace
 
 int launch_noise_fill(float* out, int64_t n_elem, int32_t kind, uint64_t seed, uint64_t offset,
-                      hipStream_t st) {
+                      const uint64_t* rng_dev, hipStream_t st) {
   const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
   hipLaunchKernelGGL(noise_fill_kernel, dim3(grid_for(ceil_div64(n_elem, 4))), dim3(kBlock), 0, st,
-                     out, n_elem, kind, key, offset);
+                     out, n_elem, kind, key, offset, rng_dev);
   return check_launch("ebm_noise_fill_f32");
 }
 
@@ -310,10 +324,10 @@ int launch_pcd_scatter(float* buffer, int64_t buffer_size, int32_t dim, const fl
 
 int launch_hmc_accept(float* x, const float* x_prop, const float* h0, const float* h1,
                       const float* u, uint8_t* mask, uint32_t* count, int64_t n_chains, int32_t dim,
-                      uint64_t seed, uint64_t offset, hipStream_t st) {
+                      uint64_t seed, uint64_t offset, const uint64_t* rng_dev, hipStream_t st) {
   const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
   hipLaunchKernelGGL(hmc_accept_kernel, dim3(grid_for(n_chains)), dim3(kBlock), 0, st, x, x_prop, h0,
-                     h1, u, mask, count, n_chains, dim, key, offset);
+                     h1, u, mask, count, n_chains, dim, key, offset, rng_dev);
   return check_launch("ebm_hmc_accept_f32");
 }
 

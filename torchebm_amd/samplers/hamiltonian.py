@@ -206,6 +206,8 @@ class HamiltonianMonteCarlo(BaseSampler):
         n_kept = n_steps // thin
         traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
         drift = lambda x_, t_: -self._model_gradient(x_, model_kwargs)  # noqa: E731
+        if hip and self.capture_graph and n > 0 and self._graph_eligible(model_kwargs):
+            return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
         if hip:
             x = _lib.dense_f32(x)
             seed, step0 = _rng.reserve(generator, x.device, 2 * n_steps)
@@ -271,6 +273,98 @@ class HamiltonianMonteCarlo(BaseSampler):
                     keep += 1
                 self.step_schedulers()
         out = traj if want_traj else x
+        return (out, diag) if want_diag else out
+
+    # ---------------------------------------------------------------------------------
+    # route: one transition of the step route captured in a HIP graph (opt-in: ``capture_graph = True``)
+    # ---------------------------------------------------------------------------------
+    #: Capture ONE Metropolis transition of the step route -- momentum draw, H0, L leapfrog steps (kick /
+    #: autograd gradient / kick), H1, accept -- into a HIP graph and replay it n_steps times.  With an
+    #: nn.Module energy a transition is ~15 small launches per leapfrog step; a replay is one submission.
+    #: The Philox coordinates live in a device buffer the graph advances by 2 per transition
+    #: (``ebm_noise_fill_dev_f32`` at +0, ``ebm_hmc_accept_dev_f32`` at +1), so the generator contract and
+    #: the noise field are those of the eager step route, bit for bit.  Requirements: constant step
+    #: size, no conditioning, a model whose forward is static-shape and free of host-side randomness.
+    capture_graph: bool = False
+
+    def _graph_eligible(self, model_kwargs: Dict[str, Any]) -> bool:
+        return not model_kwargs and not self.use_mixed_precision and self.schedulers["step_size"].is_constant()
+
+    def _graph_for(self, x: torch.Tensor):
+        eps = self.get_scheduled_value("step_size")
+        key = (
+            tuple(x.shape), x.device, eps, self.n_leapfrog_steps, id(self.integrator),
+            None if self.mass is None else (self.mass if isinstance(self.mass, float) else self.mass.data_ptr()),
+            tuple(p.data_ptr() for p in self.model.parameters()),
+        )
+        cached = getattr(self, "_step_graph", None)
+        if cached is not None and cached["key"] == key:
+            return cached
+        n = x.shape[0]
+        row_dim = x.numel() // n
+        state = torch.empty_like(x)                                        # static buffers of the graph
+        rng = torch.zeros(2, dtype=torch.int64, device=x.device)           # {seed, step} as raw 64-bit patterns
+        mask = torch.zeros(n, dtype=torch.uint8, device=x.device)
+        drift = lambda x_, t_: -self._model_gradient(x_, {})  # noqa: E731
+
+        def body():
+            stream = _lib.stream_handle(x.device)
+            p = torch.empty_like(state)
+            _lib.call("ebm_noise_fill_dev_f32", _lib.ptr(p), p.numel(), _lib.NOISE_NORMAL, _lib.ptr(rng), 0, stream)
+            p = self._scale_momentum_(p)
+            h0 = self._model_energy(state, {}).clamp_(min=-1e10, max=1e10) + self._compute_kinetic_energy(p).clamp_(
+                min=0.0, max=1e10)
+            prop = self.integrator.integrate(
+                {"x": state, "p": p}, step_size=eps, n_steps=self.n_leapfrog_steps, mass=self.mass, drift=drift, safe=True)
+            h1 = self._model_energy(prop["x"], {}).clamp_(min=-1e10, max=1e10) + self._compute_kinetic_energy(
+                prop["p"]).clamp_(min=0.0, max=1e10)
+            xp_d, h0_d, h1_d = _lib.dense_f32(prop["x"]), _lib.dense_f32(h0), _lib.dense_f32(h1)
+            _lib.call(
+                "ebm_hmc_accept_dev_f32",
+                _lib.ptr(state), _lib.ptr(xp_d), _lib.ptr(h0_d), _lib.ptr(h1_d), _lib.ptr(mask), None,
+                n, row_dim, _lib.ptr(rng), 1, stream,
+            )
+            rng[1:2].add_(2)
+
+        state.copy_(x)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                                      # warm-up off the capture stream
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        self._step_graph = {"key": key, "graph": graph, "state": state, "rng": rng, "mask": mask}
+        return self._step_graph
+
+    def _sample_graph(self, x, n_steps, thin, traj, diag, want_traj, want_diag, generator):
+        x = _lib.dense_f32(x)
+        n, dim = x.shape[0], x.shape[1]
+        g = self._graph_for(x)
+        seed, step0 = _rng.reserve(generator, x.device, 2 * n_steps)
+        as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v  # noqa: E731  (bit pattern of a uint64)
+        g["state"].copy_(x)
+        g["rng"].copy_(torch.tensor([as_i64(seed), as_i64(step0)], dtype=torch.int64), non_blocking=True)
+        state, keep = g["state"], 0
+        for i in range(n_steps):
+            g["graph"].replay()
+            if (i + 1) % thin == 0:
+                if traj is not None:
+                    traj[:, keep, :] = state
+                if diag is not None:
+                    diag["mean"][keep] = state.mean(dim=0)
+                    diag["var"][keep] = (
+                        state.var(dim=0, unbiased=False).clamp_(min=1e-10, max=1e10)
+                        if n > 1
+                        else torch.zeros(dim, dtype=self.dtype, device=self.device)
+                    )
+                    diag["energy"][keep] = self._model_energy(state, {}).clamp_(min=-1e10, max=1e10).mean()
+                    diag["acceptance_rate"][keep] = g["mask"].float().mean()
+                keep += 1
+        self.advance_schedulers(n_steps)
+        out = traj if want_traj else state.clone()
         return (out, diag) if want_diag else out
 
     # ---------------------------------------------------------------------------------
