@@ -256,14 +256,14 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a
 }
 
 // ---------------------------------------------------------------------------------
-// Lean variant (native RNG, no trajectory): nothing but Philox + Box-Muller + gradient + update
+// Lean variant (native RNG): nothing but Philox + Box-Muller + gradient + update
 // inside the loop.  The per-step coefficient table (schedulers, the Energy-Matching temperature
-// sweep) and the clamp are compile-time switches, so the headline case -- constant coefficients,
+// sweep), the clamp and the thinned trajectory store are compile-time switches, so the headline case -- constant coefficients,
 // no clamp -- carries neither a branch nor a live register for them.  One float4 group per lane:
 // 2 or 4 independent groups per lane were measured and change nothing (8.96 / 9.05 / 8.91 ms on
 // config 2; the loop is VALU-issue bound at 8 waves/SIMD either way).
 // ---------------------------------------------------------------------------------
-template <int KIND, bool TABLE, bool CLAMP>
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ>
 __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e0 = g * 4;
@@ -272,6 +272,14 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
   const int nv = left >= 4 ? 4 : (int)left;
   F4 x = load4(a.x, e0, nv, true);
   StepCoef c = a.c;
+  // TRAJ (dim % 4 == 0 only, so a lane's float4 never straddles two chains): traj[c, j, d..d+3]
+  float* tptr = nullptr;
+  int until_keep = a.thin;
+  if constexpr (TRAJ) {
+    const int64_t chain = e0 / a.dim;
+    tptr = a.traj + chain * (int64_t)a.n_kept * a.dim + (e0 - chain * a.dim);
+  }
+#pragma unroll 2  // measured: 9.00 -> 8.83 ms on config 2 (4 gives no more)
   for (int i = 0; i < a.k_steps; ++i) {
     if constexpr (TABLE) {  // wave-uniform: scalar loads
       const float4 t = a.table[i];
@@ -283,6 +291,13 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
       float v = em_update(x.v[q], elem_grad<KIND>(x.v[q], a.s0, a.s1), eps.v[q], c);
       if constexpr (CLAMP) v = clamp_nanprop(v, a.cmin, a.cmax);
       x.v[q] = v;
+    }
+    if constexpr (TRAJ) {
+      if (--until_keep == 0) {  // wave-uniform
+        until_keep = a.thin;
+        *reinterpret_cast<float4*>(tptr) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        tptr += a.dim;
+      }
     }
   }
   store4(a.x, e0, nv, true, x);
@@ -344,17 +359,23 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   const int64_t blocks = ceil_div64(n_groups, kBlock);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (!noise && !traj && !heun) {
-#define EBM_LEAN(KIND)                                                                                   \
+  if (!noise && !heun && (!traj || (dim & 3) == 0)) {
+#define EBM_LEAN_T(KIND, TB, CL)                                                                          \
   do {                                                                                                   \
-    if (coef_table && clamp_on) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, true, true>), grid, block, 0, st, a);    \
-    else if (coef_table) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, true, false>), grid, block, 0, st, a);         \
-    else if (clamp_on) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, false, true>), grid, block, 0, st, a);           \
-    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, false, false>), grid, block, 0, st, a);                        \
+    if (traj) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, TB, CL, true>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, TB, CL, false>), grid, block, 0, st, a);       \
+  } while (0)
+#define EBM_LEAN(KIND)                                                 \
+  do {                                                                 \
+    if (coef_table && clamp_on) EBM_LEAN_T(KIND, true, true);          \
+    else if (coef_table) EBM_LEAN_T(KIND, true, false);                \
+    else if (clamp_on) EBM_LEAN_T(KIND, false, true);                  \
+    else EBM_LEAN_T(KIND, false, false);                               \
   } while (0)
     if (kind == EBM_ENERGY_DOUBLE_WELL) EBM_LEAN(EBM_ENERGY_DOUBLE_WELL);
     else EBM_LEAN(EBM_ENERGY_HARMONIC);
 #undef EBM_LEAN
+#undef EBM_LEAN_T
     return check_launch("ebm_langevin_chain_f32");
   }
 #define EBM_LAUNCH(KIND)                                                                         \
