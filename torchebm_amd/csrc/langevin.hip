@@ -28,14 +28,18 @@ __device__ __forceinline__ float em_update(float x, float g, float eps, StepCoef
   return x1 + c.noise_coef * dw;
 }
 
-// Gradients in autograd's operation order.
+// Gradients with autograd's rounding.  Autograd evaluates (h*(2u))*(2x) and
+// (0.5k)*(2x); scaling by 2 is exact and commutes with rounding, so fl(fl(h*2u)*2x) == fl(fl(4h*u)*x)
+// and fl(s*2x) == fl(2s*x) bit for bit (overflow included: both sides reach inf together; the
+// intermediate never lies in the denormal range).  The doubled constants are wave-uniform: two
+// multiplies per element instead of four (DoubleWell), one instead of two (Harmonic).
 template <int KIND>
 __device__ __forceinline__ float elem_grad(float x, float s0, float s1) {
   if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) {
     const float u = x * x - s1;                // x.pow(2) - b**2
-    return (s0 * (2.0f * u)) * (2.0f * x);     // pow backward twice: (h*(2u)) * (2x)
+    return ((4.0f * s0) * u) * x;              // == (h*(2u)) * (2x), pow backward twice
   } else {
-    return s0 * (2.0f * x);                    // (0.5k) * (2x)
+    return (2.0f * s0) * x;                    // == (0.5k) * (2x)
   }
 }
 

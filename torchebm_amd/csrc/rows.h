@@ -222,7 +222,7 @@ struct Energy<EBM_ENERGY_DOUBLE_WELL, LaneT> {
         const float xv = x.a[v][i];
         const float u = xv * xv - b2;
         const bool ok = L.ok(v, i);
-        g.a[v][i] = ok ? (h * (2.0f * u)) * (2.0f * xv) : 0.0f;
+        g.a[v][i] = ok ? ((4.0f * h) * u) * xv : 0.0f;  // == (h*(2u))*(2x) bit for bit (see langevin.hip: elem_grad)
         if (WANT_E) acc += ok ? u * u : 0.0f;
       }
     if (!WANT_E) return 0.0f;
@@ -244,7 +244,7 @@ struct Energy<EBM_ENERGY_HARMONIC, LaneT> {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float xv = x.a[v][i];  // invalid slots are 0 and contribute 0
-        g.a[v][i] = hk * (2.0f * xv);
+        g.a[v][i] = (2.0f * hk) * xv;  // == hk*(2x) bit for bit
         if (WANT_E) acc += xv * xv;
       }
     if (!WANT_E) return 0.0f;
