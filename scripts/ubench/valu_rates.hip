@@ -85,6 +85,25 @@ __global__ void k_mad64_fma(float* out) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = __uint_as_float(s) + t;
 }
 
+// gfx950's three-input logic op (truth table 0x96 = a ^ b ^ c) + add, and a full Philox-round-shaped
+// mix: 2 x (mad_u64 + bitop3)
+__global__ void k_bitop3(float* out) {
+  uint32_t a[kUnroll];
+  for (int j = 0; j < kUnroll; ++j) a[j] = threadIdx.x * 2654435761u + j;
+  BODY_LOOP(a[j] = __builtin_amdgcn_bitop3_b32(a[j], 0x9E3779B9u, (uint32_t)threadIdx.x, 0x96) + 1u)
+  uint32_t s = 0; for (int j = 0; j < kUnroll; ++j) s += a[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = __uint_as_float(s);
+}
+__global__ void k_philox_round(float* out) {
+  uint32_t a[kUnroll], b[kUnroll];
+  for (int j = 0; j < kUnroll; ++j) { a[j] = threadIdx.x * 2654435761u + j; b[j] = a[j] ^ 0x55555555u; }
+  BODY_LOOP({ uint64_t p = (uint64_t)0xD2511F53u * a[j]; uint64_t q = (uint64_t)0xCD9E8D57u * b[j];
+              a[j] = __builtin_amdgcn_bitop3_b32((uint32_t)(q >> 32), (uint32_t)p, 0x9E3779B9u, 0x96);
+              b[j] = __builtin_amdgcn_bitop3_b32((uint32_t)(p >> 32), (uint32_t)q, 0xBB67AE85u, 0x96); })
+  uint32_t s = 0; for (int j = 0; j < kUnroll; ++j) s += a[j] + b[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = __uint_as_float(s);
+}
+
 template <class K>
 void run(const char* name, K kern, float* out, double ops_per_iter) {
   const int blocks = 256 * 8, threads = 256;
@@ -120,5 +139,7 @@ int main() {
   run("rcp+add", k_rcp, out, 2);
   run("log+add+2fma", k_log_fma, out, 4);
   run("mad64+xor+2fma", k_mad64_fma, out, 4);
+  run("bitop3+add", k_bitop3, out, 2);
+  run("philox round (2 mad64 + 2 bitop3)", k_philox_round, out, 4);
   return 0;
 }
