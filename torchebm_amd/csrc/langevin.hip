@@ -16,6 +16,8 @@ namespace {
 
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct StepCoef {
   float eta, sqrt_eta, noise_coef;
 };
@@ -290,11 +292,20 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
       c.eta = t.x; c.sqrt_eta = t.y; c.noise_coef = t.z;
     }
     const F4 eps = normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i);
+    // gradient + update on explicit 2-vectors (packed-f32 instructions); written out this way because
+    // the clamp's min/max would otherwise make the compiler fall back to scalar arithmetic for all of it
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v = em_update(x.v[q], elem_grad<KIND>(x.v[q], a.s0, a.s1), eps.v[q], c);
-      if constexpr (CLAMP) v = clamp_nanprop(v, a.cmin, a.cmax);
-      x.v[q] = v;
+    for (int q = 0; q < 4; q += 2) {
+      const v2f xv = {x.v[q], x.v[q + 1]}, ev = {eps.v[q], eps.v[q + 1]};
+      v2f gr;
+      if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) gr = ((4.0f * a.s0) * (xv * xv - a.s1)) * xv;  // see elem_grad
+      else gr = (2.0f * a.s0) * xv;
+      const v2f x1 = xv - c.eta * gr;
+      const v2f dw = ev * c.sqrt_eta;
+      v2f nv2 = x1 + c.noise_coef * dw;
+      if constexpr (CLAMP) nv2 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(nv2, v2f{a.cmin, a.cmin}), v2f{a.cmax, a.cmax});
+      x.v[q] = nv2.x;
+      x.v[q + 1] = nv2.y;
     }
     if constexpr (TRAJ) {
       if (--until_keep == 0) {  // wave-uniform
