@@ -277,6 +277,7 @@ def main():
     big[8:] = -1e6
     hmc_case("hmc_dw_extreme", dw, 16, 4, 4, 5, 0.01, seed=29, x0=big)
     hmc_survey()
+    hmc_wide_gaussian_cases()
     integrator_cases()
 
     # ---- noise-free descent ---------------------------------------
@@ -289,6 +290,16 @@ def main():
 
     # ---- Energy Matching negatives ---------------------------------
     energy_matching_cases()
+
+
+def hmc_wide_gaussian_cases():
+    """Correlated Gaussians at the dims the matrix-core HMC kernel covers (32, 64), no mass / scalar mass."""
+    for dim, n, L, eps, seed, mass in ((32, 96, 8, 0.45, 61, None), (64, 70, 6, 0.5, 62, 1.8), (64, 33, 5, 0.4, 63, None)):
+        gg = torch.Generator().manual_seed(100 + dim + seed)
+        a = torch.randn(dim, dim, generator=gg)
+        spec = {"kind": "gaussian", "mean": torch.randn(dim, generator=gg) * 0.5, "cov": a @ a.t() / dim + 0.5 * torch.eye(dim)}
+        tag = f"hmc_gauss{dim}_{n}" + ("_mass" if mass else "")
+        hmc_case(tag, spec, n, dim, 6, L, eps, seed=seed, mass=mass, thin=2 if mass else 1)
 
 
 def heun_extra_cases():

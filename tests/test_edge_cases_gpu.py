@@ -98,6 +98,40 @@ def test_lane_per_chain_mixture_hmc(cuda_device, mass):
         assert close.float().mean().item() >= 0.99
 
 
+@pytest.mark.parametrize("dim,n,mass", [(32, 129, None), (64, 70, None), (64, 33, 2.5), (32, 40, "diag")])
+def test_wide_gaussian_hmc_native_rng(cuda_device, dim, n, mass):
+    """Correlated Gaussian at dim 32 / 64: the matrix-core HMC kernel (state in the MFMA C/D layout; a
+    diagonal mass keeps the lane-group kernel) with in-kernel draws against the oracle on the
+    materialised Philox field -- ragged chain counts (partial waves), scalar mass, thinning."""
+    T, L, eps = 6, 7, 0.3
+    g = torch.Generator().manual_seed(dim + n)
+    a = torch.randn(dim, dim, generator=g)
+    mean, cov = torch.randn(dim, generator=g) * 0.5, a @ a.t() / dim + 0.5 * torch.eye(dim)
+    x0 = torch.randn(n, dim, generator=g)
+    if mass == "diag":
+        mass = torch.rand(dim, generator=g) + 0.5
+    model, en = ta.GaussianModel(mean, cov, device=cuda_device), oracle.Gaussian(mean, cov)
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L,
+                                 mass=mass if mass is None or isinstance(mass, float) else mass.to(cuda_device), device=cuda_device)
+    before = hip_calls("ebm_hmc_chain_f32")
+    traj = s.sample(x=x0.to(cuda_device), n_steps=T, thin=2, return_trajectory=True,
+                    generator=torch.Generator(device=cuda_device).manual_seed(13))
+    assert hip_calls("ebm_hmc_chain_f32") == before + 1 and traj.shape == (n, T // 2, dim)
+    p = _noise((T, n, dim), 13, 0, cuda_device, stride=2)
+    us = []
+    for t in range(T):
+        ut = torch.empty(n, device=cuda_device)
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 13, 2 * t + 1, _lib.stream_handle(cuda_device))
+        us.append(ut)
+    want = oracle.hmc_chain(en, x0, p.cpu(), torch.stack(us).cpu(), [eps] * T, L, mass=mass, thin=2, want_traj=True)
+    assert torch.isfinite(traj).all()
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).amax(dim=(1, 2))
+    if want["margin"] > 1e-4:
+        assert (err <= 5e-4).all()
+    else:  # an accept decision within round-off of u: only that chain may differ
+        assert (err <= 5e-4).float().mean().item() >= 0.97
+
+
 @pytest.mark.parametrize("dim,n,kind", [(6, 33, "gmm"), (32, 77, "gmm"), (3, 50, "dw"), (100, 40, "dw"), (250, 9, "har"), (1000, 5, "dw"), (1024, 3, "har")])
 def test_native_rng_ragged_dims_hmc(cuda_device, dim, n, kind):
     """HMC with in-kernel draws (momentum at step 2t, uniforms at 2t+1) vs the oracle on the

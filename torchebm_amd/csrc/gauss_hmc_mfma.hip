@@ -1,0 +1,290 @@
+// HMC transitions for the dense Gaussian energy on the matrix cores (dim 32 or 64, no mass or a scalar
+// mass): same mapping as gauss_mfma.hip -- a wavefront owns 32 chains, lane l = (m, h), the chain
+// state x, momentum p and force f all live in the C/D layout of v_mfma_f32_32x32x2_f32 tiles, so that
+// g^T = Ps (x - mu)^T takes its B-operand straight from the state registers and lands in the layout the
+// leapfrog arithmetic runs in.  The LDS mat-vec of the lane-group kernel (rows.h) is bound by LDS reads
+// (one 16-byte read per four FMAs); here the precision matrix is read once per K-step for 32 chains.
+//
+// Reference: samplers/hmc.py:201-315 (transition), integrators/leapfrog.py:116-187 (safe leapfrog),
+// core/base_model.py:181-210 (energy).  Semantics, RNG coordinates (momentum at step 2t, uniforms at
+// 2t+1, one Philox counter per four coordinates) and the fast/literal split of the safe mode are those
+// of hmc_kernel.h; the accepted state is "parked" in the x array itself (written on accept, re-read on
+// reject), which costs 256 B per chain and transition and no registers.
+#include "ebm_common.h"
+
+namespace ebm {
+namespace {
+
+constexpr int kBlock = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GaussHmcArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t n_mh, n_leapfrog;
+  float eps;
+  const float* eps_table;
+  int32_t has_mass;
+  float mass_raw, mass_sqrt, mass_safe;
+  int32_t thin, n_kept;
+  float* traj;
+  uint8_t* accept_mask;
+  uint32_t* accept_count;
+  const float* p_noise;
+  const float* u;
+  RngKey key;
+  uint64_t step0;
+  const float* mean;  // [dim]
+  const float* prec;  // [dim, dim], symmetric
+};
+
+extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
+
+template <int NT>
+struct Tile {
+  f32x16 t[NT];
+};
+
+// g^T = Ps (x - mu)^T and E = 0.5 (x - mu)^T Ps (x - mu) per chain (both halves of the wave hold E).
+template <int NT>
+__device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
+  constexpr int DIM = 32 * NT;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g.t[t][r] = 0.0f;
+  auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
+  float pa[NT], pb[NT], ma, mb;
+#pragma unroll
+  for (int it = 0; it < NT; ++it) pa[it] = Ps[k_of(0) * DIM + 32 * it + m];
+  ma = mus[k_of(0)];
+  float acc = 0.0f;
+  Tile<NT> d;
+#pragma unroll
+  for (int s = 0; s < 16 * NT; ++s) {  // operands of K-step s+1 are requested before the MFMAs of K-step s issue
+    if (s + 1 < 16 * NT) {
+      const int kn = k_of(s + 1);
+#pragma unroll
+      for (int it = 0; it < NT; ++it) pb[it] = Ps[kn * DIM + 32 * it + m];
+      mb = mus[kn];
+    }
+    const float dv = x.t[s >> 4][s & 15] - ma;
+    d.t[s >> 4][s & 15] = dv;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) g.t[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it], dv, g.t[it], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NT; ++it) pa[it] = pb[it];
+    ma = mb;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_fmaf(d.t[t][r], g.t[t][r], acc);
+  acc += __shfl_xor(acc, 32);
+  return 0.5f * acc;
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
+  constexpr int DIM = 32 * NT;
+  float* Ps = gauss_hmc_smem;
+  float* mus = gauss_hmc_smem + DIM * DIM;
+  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) Ps[i] = a.prec[i];
+  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = a.mean[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const bool active = chain < a.n_chains;
+  const int64_t row = active ? chain * (int64_t)DIM : 0;
+
+  // quad q of tile t = coordinates 32t + 8q + 4h .. +3  (one float4, one Philox counter)
+  auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) v = *reinterpret_cast<const float4*>(base + off + 32 * t + 8 * q + 4 * h);
+        dst.t[t][4 * q] = v.x; dst.t[t][4 * q + 1] = v.y; dst.t[t][4 * q + 2] = v.z; dst.t[t][4 * q + 3] = v.w;
+      }
+  };
+  auto store_rows = [&](float* base, int64_t off, const Tile<NT>& src) {
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(base + off + 32 * t + 8 * q + 4 * h) =
+            make_float4(src.t[t][4 * q], src.t[t][4 * q + 1], src.t[t][4 * q + 2], src.t[t][4 * q + 3]);
+  };
+  // K(p) = 0.5 p^T p [/ m], clamped to [0, 1e10]  (samplers/hmc.py:136-159, :251-254)
+  auto kinetic = [&](const Tile<NT>& q) -> float {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc += q.t[t][r] * q.t[t][r];
+    acc += __shfl_xor(acc, 32);
+    float k = 0.5f * acc;
+    if (a.has_mass) k = k / a.mass_raw;
+    return clamp_nanprop(k, 0.0f, 1e10f);
+  };
+
+  Tile<NT> x;
+  load_rows(a.x, row, x);
+  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * DIM : 0;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  float eps = a.eps;
+
+  for (int tr = 0; tr < a.n_mh; ++tr) {
+    if (a.eps_table) eps = a.eps_table[tr];
+    const float half_eps = 0.5f * eps;
+
+    // ---- momentum draw p ~ N(0, M)
+    Tile<NT> p;
+    if (a.p_noise) {
+      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * DIM + row, p);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const F4 n = normal4_at(a.key, ((uint64_t)chain * DIM + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2,
+                                  a.step0 + 2ull * (uint64_t)tr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = n.v[i];
+        }
+    }
+    if (a.has_mass) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.t[t][r] *= a.mass_sqrt;
+    }
+
+    // ---- H0 and the first (clamped) force
+    Tile<NT> f;
+    const float e0 = gauss_eval<NT>(Ps, mus, x, f, m, h);
+    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+
+    // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
+    float e1 = e0;
+    for (int l = 0; l < a.n_leapfrog; ++l) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ph = __builtin_fmaf(half_eps, f.t[t][r], p.t[t][r]);
+          p.t[t][r] = ph;
+          x.t[t][r] = a.has_mass ? x.t[t][r] + (eps * ph) / a.mass_safe : __builtin_fmaf(eps, ph, x.t[t][r]);
+        }
+      e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);  // f holds +g here
+      // E finite => x finite, g clean.  The decision is taken per WAVE: the literal path re-runs the
+      // MFMA evaluation, and an MFMA writes its result for every lane whatever EXEC says -- it must not
+      // run while other chains of the wave sit in the fast path.  (For a chain that is fine the literal
+      // path computes exactly what the fast path does.)
+      if (__all(__builtin_fabsf(e1) < __builtin_inff())) {
+        float pz = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float fn = __builtin_amdgcn_fmed3f(-f.t[t][r], -1e6f, 1e6f);
+            const float pn = __builtin_fmaf(half_eps, fn, p.t[t][r]);
+            f.t[t][r] = fn;
+            p.t[t][r] = pn;
+            pz = __builtin_fmaf(pn, 0.0f, pz);
+          }
+        pz += __shfl_xor(pz, 32);
+        if (pz != pz) {  // momentum overflow: x is finite, so f stands
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p.t[t][r] = nan_to_num0(p.t[t][r]);
+        }
+      } else {  // rare: literal semantics (NaN-propagating clamp, scrub, re-evaluate on the scrubbed x)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float fn = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+            p.t[t][r] = nan_to_num0(__builtin_fmaf(half_eps, fn, p.t[t][r]));
+            x.t[t][r] = nan_to_num0(x.t[t][r]);
+          }
+        e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+      }
+    }
+    const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
+
+    // ---- Metropolis accept (samplers/hmc.py:277-292)
+    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
+    float acc_p = expf(dlt);
+    acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
+    float uu;
+    if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + chain] : 2.0f;
+    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)chain >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(chain & 3)));
+    const bool accept = active && (uu < acc_p);
+    if (accept) store_rows(a.x, row, x);   // the x array always holds the accepted state ...
+    else load_rows(a.x, row, x);           // ... which a rejected proposal falls back to
+
+    const bool leader = active && h == 0;
+    if (a.accept_mask && leader) a.accept_mask[(int64_t)tr * a.n_chains + chain] = accept ? 1 : 0;
+    if (a.accept_count) {
+      const unsigned long long b = __ballot(accept && leader);
+      if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
+    }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      store_rows(a.traj, traj_row + keep_off, x);
+      keep_off += DIM;
+    }
+  }
+}
+
+template <int NT>
+int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)((32 * NT) * (32 * NT) + 32 * NT) * sizeof(float);
+  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL(gauss_hmc_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_hmc_chain_f32");
+}
+
+}  // namespace
+
+bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
+  return (dim == 32 || dim == 64) && mass_kind != EBM_MASS_DIAG;
+}
+
+int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
+                                int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
+                                double mass_scalar, int32_t thin, float* traj, uint8_t* accept_mask,
+                                uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
+                                uint64_t offset, hipStream_t st) {
+  GaussHmcArgs a;
+  a.x = x; a.n_chains = n_chains; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.eps = eps; a.eps_table = eps_table;
+  a.has_mass = mass_kind == EBM_MASS_SCALAR;
+  a.mass_raw = (float)mass_scalar;
+  a.mass_sqrt = (float)sqrt(mass_scalar);
+  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
+  a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
+  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
+  return dim == 32 ? launch_nt<1>(a, st) : launch_nt<2>(a, st);
+}
+
+}  // namespace ebm

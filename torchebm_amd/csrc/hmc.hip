@@ -18,11 +18,23 @@ void launch_gmm(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&
 }  // namespace hmc
 using hmc::HmcArgs;
 
+bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
+int launch_hmc_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
+                                int32_t, double, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
+                                uint64_t, uint64_t, hipStream_t);
+
 int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
                      int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
                      double mass_scalar, const float* mass_diag, int32_t thin, float* traj,
                      uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
                      const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
+  if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
+    // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
+    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+    if (!force_rows)
+      return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
+  }
   Geometry geo;
   if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
   HmcArgs a;
