@@ -270,9 +270,38 @@ struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
     P_glb = P.dev1;
     dim_pad = P.dim_pad;
     xrow = S.xchg + L.chain_in_wave * (G * NV * 4);
+    if constexpr (G == 1 && NV == 1) {  // dim <= 4: the whole precision matrix as 16 wave-uniform scalars
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tiny[j][i] = (j < L.dim && i < L.dim) ? P.dev1[j * L.dim + i] : 0.0f;
+    }
+  }
+  float tiny[(G == 1 && NV == 1) ? 4 : 1][4];  // Ps, zero-padded to 4x4 (dim <= 4 only)
+  // dim <= 4, one lane per chain: no exchange row, no wave barrier, no LDS read -- 16 FMAs on scalars
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval_tiny(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    float d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d[i] = L.ok(0, i) ? x.a[0][i] - mu.a[0][i] : 0.0f;
+      g.a[0][i] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // same j-ascending FMA order as the LDS mat-vec
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g.a[0][i] = __builtin_fmaf(tiny[j][i], d[j], g.a[0][i]);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!L.ok(0, i)) g.a[0][i] = 0.0f;
+      if (WANT_E) acc = __builtin_fmaf(d[i], g.a[0][i], acc);
+    }
+    return WANT_E ? 0.5f * acc : 0.0f;
   }
   template <bool WANT_E>
   __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    if constexpr (G == 1 && NV == 1) return eval_tiny<WANT_E>(L, x, g);
     Slice<NV> d;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
