@@ -259,7 +259,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"LangevinDynamics.sample on DoubleWell(h=2,b=1): n_chains={n} per GPU, dim={dim}, "
-                            f"k={k} steps per call, eta={ETA}, sigma={SIGMA} (BASELINE configs[1])",
+                            f"k={k} steps per call, eta={ETA}, sigma={SIGMA} "
+                            + ("(BASELINE configs[1])" if (n, dim, k) == (1 << 20, 64, 200) else "(shape overridden on the command line)"),
                 "n_chains_per_gpu": n,
                 "dim": dim,
                 "k_steps": k,
