@@ -19,7 +19,9 @@ import torchebm_amd as ta  # noqa: E402
 def best_threads(fn):
     ncpu = os.cpu_count() or 1
     best, best_t = 1, float("inf")
-    for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
+    # EBM_CPU_THREADS="16,64" restricts the probe (on a 256-core GPU host the full sweep takes minutes)
+    probe = [int(t) for t in os.environ.get("EBM_CPU_THREADS", "4,8,16,32,64,%d" % ncpu).split(",")]
+    for th in sorted({t for t in probe if t <= ncpu}):
         torch.set_num_threads(th)
         fn()
         t0 = time.perf_counter()
