@@ -13,8 +13,10 @@ The K timed steps continue the same chains (each call starts from the previous c
 
 N > 1: one process per GPU, chains sharded by rank (weak scaling: 2^20 chains per GPU, seed
 base+rank, no collective inside the k steps).  The only exchange on the path is the read-back
-of the final state: ONE RCCL all-gather of the [2^20, 64] shards after the last step, inside
-the timed region (and once during warm-up, so communicator set-up is not timed).
+of the final state: an RCCL all-gather of the [2^20, 64] shards, inside the timed region and
+pipelined with the last step (four row blocks; block i's gather is in flight while block i+1 is
+sampled -- utils.sample_and_gather).  It also runs once after the warm-up steps, untimed, so that
+communicator set-up is not timed.
 
 Output: one JSON line on rank 0 (see DESIGN.md §Measurement for the roofline accounting).
 """
@@ -167,7 +169,10 @@ def main():
     x0 = torch.randn(n, dim, device=device, generator=gen)
 
     gathered = None
-    readback = "none (single process)" if world == 1 else "one all_gather_into_tensor of the final state, inside the timed region"
+    pieces = 4 if n % 4 == 0 else 1
+    readback = ("none (single process)" if world == 1 else
+                f"final state all-gathered inside the timed region, pipelined with the last step: {pieces} row blocks, "
+                "the gather of block i in flight while block i+1 is sampled (utils.sample_and_gather)")
     state = x0
 
     def one_step():
@@ -175,19 +180,21 @@ def main():
         nonlocal state
         state = sampler.sample(x=state, n_steps=k, generator=gen)
 
-    def read_back():
-        """The path's only collective: rank-ordered all-gather of the final [n, dim] shards."""
-        nonlocal gathered, readback
+    def last_step_with_readback():
+        """The last step of the run together with the path's only collective -- the all-gather of the
+        final [n, dim] shards -- overlapped block by block (N > 1).  Falls back to a plain step if the
+        collective fails, and says so in config.readback."""
+        nonlocal gathered, readback, state
         if world == 1 or readback.startswith("disabled"):
+            one_step()
             return
-        import torch.distributed as dist
+        from torchebm_amd.utils import sample_and_gather
 
         try:
-            if gathered is None:
-                gathered = torch.empty((world * n, dim), dtype=state.dtype, device=device)
-            dist.all_gather_into_tensor(gathered, state.contiguous())
+            state, gathered = sample_and_gather(sampler, state, k, pieces=pieces, generator=gen)
         except Exception as exc:  # report it, keep measuring the sharded compute
             readback = f"disabled after error: {type(exc).__name__}: {exc}"[:300]
+            one_step()
 
     def fence():
         if world > 1:
@@ -199,15 +206,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    read_back()  # also creates the RCCL communicator outside the timed region
+    last_step_with_readback()  # untimed: also creates the RCCL communicator outside the timed region
     fence()
     state = x0
     if on_gpu:
         _lib.timed_events["ebm_langevin_chain_f32"] = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps - 1):
         one_step()
-    read_back()
+    last_step_with_readback()  # step K
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -221,8 +228,8 @@ def main():
     kernel_ms = None
     if on_gpu:
         pairs = _lib.timed_events.pop("ebm_langevin_chain_f32")
-        if pairs:
-            kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        if pairs:  # GPU time of the chain kernel per step (the pipelined last step of N > 1 is several launches)
+            kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
 
     if rank == 0:
         chain_steps = world * n * k * args.steps

@@ -45,8 +45,14 @@ def _worker(rank, world, init_file, out_dir):
         cd.get_start_points(torch.zeros(4, DIM))
         cd.replay_buffer.copy_((torch.arange(8.0) + 100 * rank)[:, None].expand(8, DIM))
         cd.mix_buffer_across_ranks(generator=torch.Generator().manual_seed(5))
+        # pipelined read-back: 4 row blocks, gather of block i overlapped with the sampling of block i+1
+        from torchebm_amd.utils import sample_and_gather
+
+        even = x_all[rank * 48 : (rank + 1) * 48]
+        loc, gat = sample_and_gather(sampler, even, K, pieces=4, generator=torch.Generator().manual_seed(BASE_SEED + rank))
         torch.save({"start": start, "count": count, "mine": mine, "gathered": gathered, "bcast": t,
-                    "mixed": cd.replay_buffer[:, 0].clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+                    "mixed": cd.replay_buffer[:, 0].clone(), "pipe_local": loc, "pipe_gathered": gat.clone()},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -76,6 +82,14 @@ def test_sharded_sampling_and_readback_gloo():
     # different ranks, different noise
     assert not torch.equal(res[0]["mine"][:50], res[1]["mine"][:50])
     assert torch.equal(res[0]["bcast"], torch.full((3,), 8.0)) and torch.equal(res[1]["bcast"], torch.full((3,), 8.0))
+    # pipelined read-back: every rank sees every rank's chains, in order; blocks = separate sample() calls
+    for r in range(world):
+        assert res[r]["pipe_gathered"].shape == (world, 4, 12, DIM)
+        for q in range(world):
+            assert torch.equal(res[r]["pipe_gathered"][q].reshape(48, DIM), res[q]["pipe_local"])
+        gen = torch.Generator().manual_seed(BASE_SEED + r)
+        want = torch.cat([sampler.sample(x=x_all[r * 48 + 12 * i : r * 48 + 12 * (i + 1)], n_steps=K, generator=gen) for i in range(4)])
+        assert torch.equal(res[r]["pipe_local"], want)
     union = torch.cat([res[0]["mixed"], res[1]["mixed"]]).sort().values
     assert torch.equal(union, torch.cat([torch.arange(8.0), torch.arange(8.0) + 100]))
     assert not torch.equal(res[0]["mixed"].sort().values, torch.arange(8.0))  # rows actually moved

@@ -1,3 +1,11 @@
-from .distributed import all_gather_cat, broadcast_tensor, get_rank, get_world_size, is_distributed, shard_rows
+from .distributed import (
+    all_gather_cat,
+    broadcast_tensor,
+    get_rank,
+    get_world_size,
+    is_distributed,
+    sample_and_gather,
+    shard_rows,
+)
 
-__all__ = ["all_gather_cat", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "shard_rows"]
+__all__ = ["all_gather_cat", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "sample_and_gather", "shard_rows"]

@@ -40,6 +40,39 @@ def all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: int = 4, generator=None, group=None):
+    """This rank's shard through ``sampler.sample`` AND the read-back all-gather, pipelined: the shard
+    is processed in ``pieces`` row blocks, and the all-gather of block i is in flight (RCCL's own
+    stream, ``async_op=True``) while block i+1 is being sampled, so only the last block's gather is
+    exposed.  Each block is still tens of thousands of workgroups at the sizes this matters for.
+
+    Returns ``(local, gathered)``: ``local`` is this rank's final ``[n, ...]`` state; ``gathered`` is a
+    view of shape ``[world, pieces, n // pieces, ...]`` -- ``gathered[r]`` are rank r's chains in order
+    (block-major storage; ``.reshape(world * n, ...)`` materialises the rank-ordered concatenation).
+    With one process it degenerates to ``sampler.sample`` (``gathered = local[None, None]``).
+    ``n`` must be divisible by ``pieces``."""
+    n = x.shape[0]
+    world = get_world_size(group)
+    if world == 1:
+        local = sampler.sample(x=x, n_steps=n_steps, generator=generator)
+        return local, local[None, None]
+    if pieces < 1 or n % pieces != 0:
+        raise ValueError(f"n = {n} chains cannot be split into {pieces} equal blocks")
+    block = n // pieces
+    tail = tuple(x.shape[1:])
+    local = torch.empty_like(x)
+    store = torch.empty((pieces, world, block) + tail, dtype=x.dtype, device=x.device)
+    pending = []
+    for i in range(pieces):
+        out = sampler.sample(x=x[i * block : (i + 1) * block], n_steps=n_steps, generator=generator)
+        local[i * block : (i + 1) * block] = out
+        pending.append(dist.all_gather_into_tensor(store[i].view((world * block,) + tail), out.contiguous(),
+                                                   group=group, async_op=True))
+    for work in pending:
+        work.wait()
+    return local, store.transpose(0, 1)
+
+
 def broadcast_tensor(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     """Broadcast ``x`` from ``src``; a CPU tensor hops through the GPU when the backend is
     NCCL/RCCL (which cannot move host memory)."""
