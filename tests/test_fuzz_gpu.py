@@ -1,0 +1,106 @@
+"""Seeded differential sweep: random (energy, n, dim, k, thin, clamp, schedule / mass, L) configurations
+of the fused Langevin and HMC kernels with in-kernel Philox draws against the oracle fed with the same
+field materialised by ebm_noise_fill_f32.  The named tests pin specific geometries; this one walks the
+lane-group geometries (G x NV, full and ragged rows, partial waves) that fall between them."""
+
+import os
+import random
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from torchebm_amd import _lib
+from torchebm_amd.core.schedules import ExponentialDecayScheduler, LinearScheduler
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("EBM_FUZZ_CASES", "0"))  # 0: the default sweep sizes below
+DIMS = [1, 2, 3, 4, 7, 8, 12, 16, 20, 31, 32, 33, 48, 64, 65, 96, 100, 128, 130, 200, 256, 300, 512, 700]
+
+
+def _field(shape, seed, steps, device, kind=None):
+    kind = _lib.NOISE_NORMAL if kind is None else kind
+    rows = []
+    for st in steps:
+        buf = torch.empty(shape, device=device)
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), buf.numel(), kind, seed, st, _lib.stream_handle(device))
+        rows.append(buf)
+    return torch.stack(rows)
+
+
+def _energy(rng, kind, dim, device):
+    g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    if kind == "dw":
+        h, b = rng.uniform(0.5, 2.5), rng.uniform(0.7, 1.4)
+        return ta.DoubleWellModel(barrier_height=h, b=b, device=device), oracle.DoubleWell(h, b)
+    if kind == "har":
+        k = rng.uniform(0.5, 2.0)
+        return ta.HarmonicModel(k=k, device=device), oracle.Harmonic(k)
+    if kind == "gauss":
+        a = torch.randn(dim, dim, generator=g)
+        mean, cov = torch.randn(dim, generator=g) * 0.5, a @ a.t() / dim + 0.5 * torch.eye(dim)
+        return ta.GaussianModel(mean, cov, device=device), oracle.Gaussian(mean, cov)
+    kk = rng.choice([2, 3, 5, 8, 11])
+    means, sigma = torch.randn(kk, dim, generator=g) * 1.5, rng.uniform(0.8, 1.3)
+    return ta.GaussianMixtureModel(means, sigma=sigma, device=device), oracle.GaussianMixture(means, sigma)
+
+
+@pytest.mark.parametrize("case", range(N_CASES or 28))
+def test_langevin_random_configuration(cuda_device, case):
+    rng = random.Random(1000 + case)
+    kind = rng.choice(["dw", "har", "gauss", "gmm"])
+    dim = rng.choice(DIMS if kind in ("dw", "har") else [d for d in DIMS if d <= 130])
+    n = rng.choice([1, 3, 17, 64, 65, 130, 257])
+    k, thin = rng.choice([1, 4, 9]), rng.choice([1, 2, 3])
+    clamp = rng.choice([None, (-2.0, 2.5)])
+    model, en = _energy(rng, kind, dim, cuda_device)
+    sched = rng.random() < 0.4
+    eta = LinearScheduler(0.02, 0.005, 6) if sched else 0.01
+    sig = ExponentialDecayScheduler(1.0, 0.9, 0.4) if sched else rng.choice([0.7, 1.0])
+    etas = LinearScheduler(0.02, 0.005, 6).preview(k) if sched else [0.01] * k
+    sigs = ExponentialDecayScheduler(1.0, 0.9, 0.4).preview(k) if sched else [sig] * k
+    heun = rng.random() < 0.25
+    s = ta.LangevinDynamics(model, step_size=eta, noise_scale=sig, clamp=clamp, integrator="heun" if heun else None, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(case)).clamp_(-2.0, 2.0)
+    seed = 500 + case
+    traj = s.sample(x=x0.to(cuda_device), n_steps=k, thin=thin, return_trajectory=True,
+                    generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    noise = _field((n, dim), seed, range(k), cuda_device).cpu()
+    _, want, _ = oracle.langevin_chain(en, x0, noise, etas, sigs, clamp=clamp, thin=thin, want_traj=True,
+                                       integrator="heun" if heun else "euler_maruyama")
+    assert traj.shape == want.shape
+    if kind in ("dw", "har"):
+        assert torch.equal(traj.cpu(), want), (kind, n, dim, k, thin, clamp, sched, heun)
+    else:
+        torch.testing.assert_close(traj.cpu(), want, rtol=5e-5, atol=5e-5, msg=lambda m: f"{m} {(kind, n, dim, k, thin, heun)}")
+
+
+@pytest.mark.parametrize("case", range(N_CASES or 20))
+def test_hmc_random_configuration(cuda_device, case):
+    rng = random.Random(2000 + case)
+    kind = rng.choice(["dw", "har", "gauss", "gmm"])
+    dim = rng.choice(DIMS if kind in ("dw", "har") else [d for d in DIMS if d <= 130])
+    n = rng.choice([1, 5, 33, 64, 100, 129])
+    T, L, thin = rng.choice([2, 3, 5]), rng.choice([1, 3, 6]), rng.choice([1, 2])
+    eps = 0.03 if kind == "dw" else 0.1
+    mass = rng.choice([None, None, 1.6, "diag"])
+    if mass == "diag":
+        mass = torch.rand(dim, generator=torch.Generator().manual_seed(case)) + 0.5
+    model, en = _energy(rng, kind, dim, cuda_device)
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L,
+                                 mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(case)).clamp_(-1.5, 1.5)
+    seed = 900 + case
+    traj = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True,
+                    generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    p = _field((n, dim), seed, range(0, 2 * T, 2), cuda_device).cpu()
+    u = _field((n,), seed, range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, mass=mass, thin=thin, want_traj=True)
+    assert torch.isfinite(traj).all() and traj.shape == want["trajectory"].shape
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    if want["margin"] > 1e-4:
+        assert (err <= 5e-4).all(), (kind, n, dim, T, L, thin, mass is not None, err.max().item())
+    else:  # an accept decision within round-off of u: only that chain may differ
+        assert (err <= 5e-4).float().mean().item() >= 0.9
