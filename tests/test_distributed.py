@@ -45,13 +45,19 @@ def _worker(rank, world, init_file, out_dir):
         cd.get_start_points(torch.zeros(4, DIM))
         cd.replay_buffer.copy_((torch.arange(8.0) + 100 * rank)[:, None].expand(8, DIM))
         cd.mix_buffer_across_ranks(generator=torch.Generator().manual_seed(5))
+        # sharded diagnostics: one all-reduce turns per-rank moments into the population's
+        from torchebm_amd.utils import all_reduce_diagnostics
+
+        _, dloc = sampler.sample(x=x_all[start : start + count], n_steps=6, thin=2, return_diagnostics=True,
+                                 generator=torch.Generator().manual_seed(BASE_SEED + rank))
+        dglob = all_reduce_diagnostics(dloc, count)
         # pipelined read-back: 4 row blocks, gather of block i overlapped with the sampling of block i+1
         from torchebm_amd.utils import sample_and_gather
 
         even = x_all[rank * 48 : (rank + 1) * 48]
         loc, gat = sample_and_gather(sampler, even, K, pieces=4, generator=torch.Generator().manual_seed(BASE_SEED + rank))
         torch.save({"start": start, "count": count, "mine": mine, "gathered": gathered, "bcast": t,
-                    "mixed": cd.replay_buffer[:, 0].clone(), "pipe_local": loc, "pipe_gathered": gat.clone()},
+                    "mixed": cd.replay_buffer[:, 0].clone(), "pipe_local": loc, "pipe_gathered": gat.clone(), "dglob": dglob},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -82,6 +88,19 @@ def test_sharded_sampling_and_readback_gloo():
     # different ranks, different noise
     assert not torch.equal(res[0]["mine"][:50], res[1]["mine"][:50])
     assert torch.equal(res[0]["bcast"], torch.full((3,), 8.0)) and torch.equal(res[1]["bcast"], torch.full((3,), 8.0))
+    # sharded diagnostics == diagnostics of the concatenated population
+    trajs = []
+    for r in range(world):
+        s_, c_ = res[r]["start"], res[r]["count"]
+        trajs.append(sampler.sample(x=x_all[s_ : s_ + c_], n_steps=6, thin=2, return_trajectory=True,
+                                    generator=torch.Generator().manual_seed(BASE_SEED + r)))
+    pop = torch.cat(trajs)                                   # [N_TOTAL, 3, DIM]
+    for r in range(world):
+        dg = res[r]["dglob"]
+        torch.testing.assert_close(dg["mean"], pop.mean(dim=0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(dg["var"], pop.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-6)
+        want_e = torch.stack([ta.DoubleWellModel()(pop[:, j]).mean() for j in range(3)])
+        torch.testing.assert_close(dg["energy"], want_e, rtol=1e-5, atol=1e-5)
     # pipelined read-back: every rank sees every rank's chains, in order; blocks = separate sample() calls
     for r in range(world):
         assert res[r]["pipe_gathered"].shape == (world, 4, 12, DIM)

@@ -1,5 +1,6 @@
 from .distributed import (
     all_gather_cat,
+    all_reduce_diagnostics,
     broadcast_tensor,
     get_rank,
     get_world_size,
@@ -8,4 +9,4 @@ from .distributed import (
     shard_rows,
 )
 
-__all__ = ["all_gather_cat", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "sample_and_gather", "shard_rows"]
+__all__ = ["all_gather_cat", "all_reduce_diagnostics", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "sample_and_gather", "shard_rows"]

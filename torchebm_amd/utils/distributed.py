@@ -73,6 +73,30 @@ def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: int = 4
     return local, store.transpose(0, 1)
 
 
+def all_reduce_diagnostics(diag: dict, n_local: int, group=None) -> dict:
+    """Combine per-rank sampler diagnostics (``mean`` / ``var`` ``[n_kept, dim]``, ``energy`` and, for HMC,
+    ``acceptance_rate`` ``[n_kept]``, each over this rank's ``n_local`` chains) into the statistics of the
+    whole sharded population: ONE all-reduce of the count-weighted first and second moments (a few
+    ``dim``-sized vectors -- negligible next to the sampling).  Identity with one process."""
+    world = get_world_size(group)
+    if world == 1:
+        return diag
+    w = float(n_local)
+    keys = [k for k in ("energy", "acceptance_rate") if k in diag]
+    parts = [diag["mean"] * w, (diag["var"] + diag["mean"] ** 2) * w] + [diag[k].unsqueeze(-1) * w for k in keys]
+    flat = torch.cat([p.reshape(p.shape[0], -1) for p in parts] + [torch.full_like(diag["energy"], w).unsqueeze(-1)], dim=1)
+    flat = flat.to(torch.float64)
+    dist.all_reduce(flat, group=group)
+    total = flat[:, -1:]
+    d = diag["mean"].reshape(diag["mean"].shape[0], -1).shape[1]
+    mean = flat[:, :d] / total
+    var = (flat[:, d : 2 * d] / total - mean**2).clamp_(min=1e-10, max=1e10)
+    out = {"mean": mean.to(diag["mean"].dtype).view_as(diag["mean"]), "var": var.to(diag["var"].dtype).view_as(diag["var"])}
+    for i, k in enumerate(keys):
+        out[k] = (flat[:, 2 * d + i] / total[:, 0]).to(diag[k].dtype)
+    return out
+
+
 def broadcast_tensor(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     """Broadcast ``x`` from ``src``; a CPU tensor hops through the GPU when the backend is
     NCCL/RCCL (which cannot move host memory)."""
