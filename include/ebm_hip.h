@@ -238,7 +238,9 @@ EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int6
                         int32_t dim, float* energy_out, float* grad_out, void* stream);
 
 /* Column statistics for the sampler diagnostics (samplers/langevin_dynamics.py:173-185):
- * mean[dim], biased var[dim] clamped to [1e-10, 1e10].  `work` = zeroed device double[2*dim]. */
+ * mean[dim], biased var[dim] clamped to [1e-10, 1e10].  `work` = device double[2*dim + 1], zeroed once by
+ * the caller: the kernel's last block finishes the statistics and leaves it zeroed again, so consecutive
+ * calls on one stream share it without a memset. */
 EBM_API int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, float* mean_out,
                         float* var_out, double* work, void* stream);
 

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
 // column statistics: one pass with shifted fp64 accumulators, per-block LDS partials, then one fp64
 // atomic per column per block.
 // ---------------------------------------------------------------------------------
-constexpr int kStatCols = 64;   // columns per block tile
+constexpr int kStatCols = 64;   // columns per block tile (== wave size: see the ticket logic)
 constexpr int kStatRows = 4;    // row lanes per block tile (kBlock / kStatCols)
 
 // One pass, shifted sums in fp64: with s_c = x[0, c] as the shift, S1 = sum (x - s), S2 = sum (x - s)^2;
@@ -222,7 +222,9 @@ constexpr int kStatRows = 4;    // row lanes per block tile (kBlock / kStatCols)
 // one-pass formula when |mean| >> std, fp64 accumulators remove the rest.
 __global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __restrict__ x,
                                                              int64_t n_chains, int32_t dim,
-                                                             double* __restrict__ work) {
+                                                             double* __restrict__ work,
+                                                             float* __restrict__ mean_out,
+                                                             float* __restrict__ var_out) {
   __shared__ double part1[kStatRows][kStatCols];
   __shared__ double part2[kStatRows][kStatCols];
   const int col = blockIdx.x * kStatCols + (threadIdx.x % kStatCols);
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __rest
   double s1 = 0.0, s2 = 0.0;
   if (col < dim) {
     const double shift = (double)x[col];
+#pragma unroll 8  // eight independent row loads in flight per lane
     for (int64_t r = (int64_t)blockIdx.y * kStatRows + rlane; r < n_chains;
          r += (int64_t)gridDim.y * kStatRows) {
       const double v = (double)x[r * dim + col] - shift;
@@ -247,22 +250,32 @@ __global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __rest
       a1 += part1[i][threadIdx.x];
       a2 += part2[i][threadIdx.x];
     }
-    atomicAdd(&work[col], a1);
-    atomicAdd(&work[dim + col], a2);
+    // returning atomics: once the returned values are here the adds have been performed at L2
+    const double r1 = atomicAdd(&work[col], a1);
+    const double r2 = atomicAdd(&work[dim + col], a2);
+    asm volatile("" ::"v"(r1), "v"(r2));
   }
-}
-
-__global__ void chain_stats_finish_kernel(const float* __restrict__ x, const double* __restrict__ work,
-                                          int64_t n_chains, int32_t dim, float* __restrict__ mean_out,
-                                          float* __restrict__ var_out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= dim) return;
+  // The last block to arrive turns the sums into mean / var and leaves `work` zeroed for the next call:
+  // one launch per diagnostics step, no memset and no finishing kernel.  All of a block's atomics and its
+  // ticket are issued by wave 0 (kStatCols == 64) in program order, the sums are read back with
+  // atomics at L2, so no device-wide fence (an L2 write-back on this chip) is needed.
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim);
+    const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+    last = atomicAdd(ticket, 1ull) == total - 1ull;
+  }
+  __syncthreads();
+  if (!last) return;
   const double n = (double)n_chains;
-  const double s1 = work[col], s2 = work[dim + col];
-  mean_out[col] = (float)((double)x[col] + s1 / n);
-  float v = (float)((s2 - s1 * s1 / n) / n);
-  v = clamp_nanprop(v, 1e-10f, 1e10f);  // langevin_dynamics.py:176-178
-  var_out[col] = v;
+  for (int c = threadIdx.x; c < dim; c += kBlock) {
+    const double s1 = atomicExch(&work[c], 0.0);          // read at L2 (where the atomics landed) and reset
+    const double s2 = atomicExch(&work[dim + c], 0.0);
+    mean_out[c] = (float)((double)x[c] + s1 / n);
+    float v = (float)((s2 - s1 * s1 / n) / n);
+    var_out[c] = clamp_nanprop(v, 1e-10f, 1e10f);  // langevin_dynamics.py:176-178
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim) = 0ull;
 }
 
 }  // namespace
@@ -339,9 +352,7 @@ int launch_chain_stats(const float* x, int64_t n_chains, int32_t dim, float* mea
   const int64_t cap = (256 * 8 + gx - 1) / gx;
   if (gy > cap) gy = cap;
   const dim3 grid(gx, (unsigned)gy);
-  hipLaunchKernelGGL(chain_stats_kernel, grid, dim3(kBlock), 0, st, x, n_chains, dim, work);
-  hipLaunchKernelGGL(chain_stats_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, x, work,
-                     n_chains, dim, mean_out, var_out);
+  hipLaunchKernelGGL(chain_stats_kernel, grid, dim3(kBlock), 0, st, x, n_chains, dim, work, mean_out, var_out);
   return check_launch("ebm_chain_stats_f32");
 }
 

@@ -401,7 +401,7 @@ class HamiltonianMonteCarlo(BaseSampler):
                 self._launch_hmc(spec_c, state, n, dim, eps_vals, 0, n_steps, thin, traj, None, seed, step0, stream)
             else:
                 counts = torch.zeros(n_steps, dtype=torch.int32, device=x.device)  # uint32 bit pattern
-                work = torch.empty(2 * dim, dtype=torch.float64, device=x.device)
+                work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=x.device)  # the kernel leaves it zeroed
                 energy = torch.empty(n, dtype=torch.float32, device=x.device)
                 done = 0
                 for keep in range(n_kept):
@@ -412,7 +412,6 @@ class HamiltonianMonteCarlo(BaseSampler):
                     if traj is not None:
                         traj[:, keep, :] = state
                     if n > 1:
-                        work.zero_()
                         _lib.call(
                             "ebm_chain_stats_f32",
                             _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),

@@ -365,7 +365,7 @@ class LangevinDynamics(BaseSampler):
             else:
                 # diagnostics need the whole population at every kept step: one launch per
                 # `thin` steps, then the column-statistics and energy kernels
-                work = torch.empty(2 * dim, dtype=torch.float64, device=x.device)
+                work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=x.device)  # the kernel leaves it zeroed
                 energy = torch.empty(n, dtype=torch.float32, device=x.device)
                 done = 0
                 for keep in range(n_kept):
@@ -374,7 +374,6 @@ class LangevinDynamics(BaseSampler):
                     if traj is not None:
                         traj[:, keep] = state.view(n, *shape)
                     if n > 1:
-                        work.zero_()
                         _lib.call(
                             "ebm_chain_stats_f32",
                             _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
