@@ -37,6 +37,11 @@ s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=d
 t_eager = wall(lambda: s.sample(x=x, n_steps=T))
 s.capture_graph = True
 t_graph = wall(lambda: s.sample(x=x, n_steps=T))
-print(json.dumps({"config": f"HMC step route, MLP 2-128-128-1, n={n}, L={L}, {T} transitions per call",
-                  "eager_s_per_call": t_eager, "graph_s_per_call": t_graph, "speedup": t_eager / t_graph,
-                  "mh_steps_per_s_graph": n * T / t_graph}))
+fused = ta.HamiltonianMonteCarlo(ta.MLPEnergy(2, device=dev), step_size=0.05, n_leapfrog_steps=L, device=dev)
+t_fused = wall(lambda: fused.sample(x=x, n_steps=T))
+flops = n * T * (L + 1) * 2 * (2 * 128 * 128 + 2 * 2 * 128)
+print(json.dumps({"config": f"HMC on an MLP energy 2-128-128-1, n={n}, L={L}, {T} transitions per call",
+                  "eager_step_route_s_per_call": t_eager, "graph_step_route_s_per_call": t_graph,
+                  "fused_mlp_kernel_s_per_call": t_fused, "graph_speedup": t_eager / t_graph,
+                  "fused_speedup_vs_eager": t_eager / t_fused, "mh_steps_per_s_fused": n * T / t_fused,
+                  "fused_fp32_TFLOPs": flops / t_fused / 1e12}))

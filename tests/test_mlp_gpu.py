@@ -124,3 +124,95 @@ def test_pcd_training_with_fused_mlp_sampler(cuda_device):
         model.net[4].weight.mul_(3.0)
     after = sampler.sample(x=data[:1024], n_steps=5, generator=torch.Generator(device=cuda_device).manual_seed(1))
     assert not torch.equal(before, after)
+
+
+# ------------------------------------------------------------------------------------------
+# HMC on the packaged MLP energy: one launch, the evaluation block inside a transition state machine
+# ------------------------------------------------------------------------------------------
+class _CpuMlpEnergy:
+    """Oracle adapter: the CPU autograd network as the energy object oracle.hmc_chain expects."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def energy(self, x):
+        return self.model(x).detach()
+
+    def grad(self, x):
+        return self.model.gradient(x)
+
+
+@pytest.mark.parametrize("in_dim,mass", [(2, None), (2, 1.7), (3, "diag"), (4, None), (1, None)])
+def test_fused_mlp_hmc_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, mass):
+    cpu, gpu = _models(cuda_device, in_dim, seed=10 + in_dim, scale=1.5)
+    n, T, L, eps = 515, 4, 6, 0.07
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(n, in_dim, generator=g)
+    p = torch.randn(T, n, in_dim, generator=g)
+    u = torch.rand(T, n, generator=g)
+    if mass == "diag":
+        mass = torch.rand(in_dim, generator=g) + 0.5
+    want = oracle.hmc_chain(_CpuMlpEnergy(cpu), x0, p, u, [eps] * T, L, mass=mass, thin=2, want_traj=True)
+    from torchebm_amd.integrators.symplectic import _mass_args
+
+    spec = gpu.fused_spec()
+    x = x0.to(cuda_device).clone()
+    kind, m_scalar, m_diag = _mass_args(mass.to(cuda_device) if torch.is_tensor(mass) else mass, x)
+    traj = torch.empty(n, T // 2, in_dim, device=cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    counts = torch.zeros(T, dtype=torch.int32, device=cuda_device)
+    p_d, u_d = p.to(cuda_device).contiguous(), u.to(cuda_device).contiguous()
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, in_dim, T, L, eps, None, kind, m_scalar, _lib.ptr(m_diag), 2,
+              traj.data_ptr(), mask.data_ptr(), counts.data_ptr(), p_d.data_ptr(), u_d.data_ptr(), 0, 0,
+              _lib.stream_handle(cuda_device))
+    got_mask = mask.cpu().bool()
+    agree = (got_mask == want["accepted"]).all(dim=0)           # per chain: every decision identical
+    # the kernel's sigmoid uses the hardware exp / rcp: H differs by ~1e-5, so a decision within that of u may flip
+    assert agree.float().mean().item() >= 0.99
+    assert torch.equal(counts.cpu().long(), got_mask.sum(dim=1))
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    assert (err[agree] <= 2e-3).all()
+    assert torch.equal(traj[:, -1], x)
+
+
+def test_sampler_hmc_on_mlp_energy_is_one_launch_and_tracks_the_step_route(cuda_device):
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    torch.manual_seed(4)
+    fused_model = ta.MLPEnergy(2, device=cuda_device)
+    step_model = Sub(2, device=cuda_device)
+    step_model.load_state_dict(fused_model.state_dict())
+    x0 = two_moons(4096, 0.05, seed=2, device=cuda_device)
+    kw = dict(step_size=0.05, n_leapfrog_steps=5, device=cuda_device)
+    hf, hs = ta.HamiltonianMonteCarlo(fused_model, **kw), ta.HamiltonianMonteCarlo(step_model, **kw)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    a, da = hf.sample(x=x0, n_steps=6, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(8))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 6            # diagnostics: one launch per kept transition
+    b, db = hs.sample(x=x0, n_steps=6, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(8))
+    # same Philox field: same momenta and uniforms; decisions agree except within round-off of u
+    same = ((a - b).abs().amax(dim=1) <= 5e-3).float().mean().item()
+    assert same >= 0.99
+    torch.testing.assert_close(da["acceptance_rate"], db["acceptance_rate"], rtol=0, atol=2e-3)
+    c1 = hip_calls("ebm_hmc_chain_f32")
+    out = hf.sample(x=x0, n_steps=10, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    assert hip_calls("ebm_hmc_chain_f32") == c1 + 1 and torch.isfinite(out).all()
+
+
+def test_fused_mlp_hmc_safe_mode_on_extreme_states(cuda_device):
+    """Huge / non-finite starts go through the literal path (re-evaluation on the scrubbed position in the
+    state machine) without hanging or leaking NaN into other chains of the wave."""
+    torch.manual_seed(1)
+    model = ta.MLPEnergy(2, device=cuda_device)
+    x0 = torch.randn(200, 2, device=cuda_device)
+    x0[5] = 1e30
+    x0[70] = float("inf")
+    x0[131] = float("nan")
+    h = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=4, device=cuda_device)
+    out = h.sample(x=x0, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    ok = torch.ones(200, dtype=torch.bool, device=cuda_device)
+    ok[[5, 70, 131]] = False
+    assert torch.isfinite(out[ok]).all()
+    clean = h.sample(x=x0[ok], n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    assert clean.shape == (197, 2)

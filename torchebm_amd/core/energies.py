@@ -37,7 +37,7 @@ class FusedSpec:
     dev0: Optional[torch.Tensor] = None
     dev1: Optional[torch.Tensor] = None
     elementwise: bool = False  # gradient of coordinate j depends on x_j only
-    langevin_only: bool = False  # fused for Langevin chains / energy-gradient evaluation, not HMC or descent
+    langevin_only: bool = False  # fused for Euler-Maruyama Langevin chains, HMC and energy/gradient evaluation; no Heun / descent kernel
 
     def to_c(self) -> "_lib.EnergyDesc":
         d = _lib.EnergyDesc()

@@ -18,6 +18,9 @@ int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int3
 int launch_langevin_chain_rows(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
                                const float*, uint64_t, uint64_t, int heun, hipStream_t);
+int launch_hmc_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
+                         double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
+                         uint64_t, uint64_t, hipStream_t);
 int launch_hmc_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float,
                      const float*, int32_t, double, const float*, int32_t, float*, uint8_t*,
                      uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
@@ -206,7 +209,6 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
                       void* stream) {
   const char* who = "ebm_hmc_chain_f32";
   if (int r = check_energy(energy, dim, who)) return r;
-  if (int r = reject_mlp(energy, who)) return r;
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (n_mh < 0 || thin < 1 || n_leapfrog < 1)
     return fail(EBM_EINVAL, "%s: n_mh=%d thin=%d n_leapfrog=%d", who, n_mh, thin, n_leapfrog);
@@ -217,6 +219,10 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
   if (n_chains == 0 || n_mh == 0) return 0;
   if ((traj && !aligned16(traj)) || (p_noise && !aligned16(p_noise)))
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  if (energy->kind == EBM_ENERGY_MLP)
+    return launch_hmc_chain_mlp(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset,
+                                (hipStream_t)stream);
   return launch_hmc_chain(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind,
                           mass_scalar, mass_diag, thin, traj, accept_mask, accept_count, p_noise, u,
                           seed, offset, (hipStream_t)stream);

@@ -96,101 +96,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_langevin_chain_kernel(MlpArgs a
   const int n_evals = a.k_steps > 0 ? a.k_steps : 1;
 
   for (int step = 0; step < n_evals; ++step) {
-    // ------------------------------------------------------------ forward: a2^T tiles
-    f32x16 acc[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    // software-pipelined: the LDS operands of K-step s+1 are requested before the MFMAs of K-step s
-    // issue, so their latency hides under 4 x 64 matrix-pipe cycles
-    float w2a[kTiles], w2b[kTiles];
-    float4 w1a = *reinterpret_cast<const float4*>(W1s + h * 8), w1b = w1a;
-    float b1a = W1s[h * 8 + 4], b1b = b1a;
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) w2a[t] = W2s[(t * 32 + m) * kW2Stride + h];
-    for (int s = 0; s < H / 2; ++s) {
-      const int in = 2 * (s + 1 < H / 2 ? s + 1 : s) + h;  // next K index (clamped on the last step)
-      w1b = *reinterpret_cast<const float4*>(W1s + in * 8);
-      b1b = W1s[in * 8 + 4];
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t) w2b[t] = W2s[(t * 32 + m) * kW2Stride + in];
-      float a1 = b1a;
-      a1 = __builtin_fmaf(w1a.x, x[0], a1);
-      a1 = __builtin_fmaf(w1a.y, x[1], a1);
-      a1 = __builtin_fmaf(w1a.z, x[2], a1);
-      a1 = __builtin_fmaf(w1a.w, x[3], a1);
-      const float h1 = a1 * sigmoidf_fast(a1);  // B[k = h][m]
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t)           // A[row = m][k = h] = W2[j = 32t + m][i]
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], h1, acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: next loads, this step's MFMAs
-      w1a = w1b; b1a = b1b;
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t) w2a[t] = w2b[t];
-    }
-    // ------------------------------------------------------------ energy, d2 = w3 * silu'(a2)
-    float e_part = 0.0f;
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = t * 32 + row_of(r, h);
-        const float a2 = acc[t][r] + b2s[j];
-        const float sg = sigmoidf_fast(a2);
-        const float w3 = w3s[j];
-        e_part = __builtin_fmaf(w3, a2 * sg, e_part);
-        acc[t][r] = w3 * (sg * (1.0f + a2 * (1.0f - sg)));
-      }
-    // ------------------------------------------------------------ backward: T^T tiles
-    f32x16 tac[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tac[t][r] = 0.0f;
-    {
-      float wa[kTiles], wb[kTiles];
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t) wa[t] = W2s[row_of(0, h) * kW2Stride + t * 32 + m];
-#pragma unroll
-      for (int s = 0; s < 16 * kTiles; ++s) {     // K-step s: tile jt = s >> 4, register r = s & 15
-        if (s + 1 < 16 * kTiles) {
-          const int jn = ((s + 1) >> 4) * 32 + row_of((s + 1) & 15, h);
-#pragma unroll
-          for (int t = 0; t < kTiles; ++t) wb[t] = W2s[jn * kW2Stride + t * 32 + m];
-        }
-        const float d2 = acc[s >> 4][s & 15];     // B[k = h][m]: the K index j this half holds in register s & 15
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t)          // A[row = m][k = h] = W2[j][i = 32t + m]
-          tac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], d2, tac[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) wa[t] = wb[t];
-      }
-    }
-    // ------------------------------------------------------------ g = W1^T (T^T * silu'(a1))
-    float g[kMaxDim] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = t * 32 + row_of(r, h);
-        const float4 w1 = *reinterpret_cast<const float4*>(W1s + i * 8);
-        float a1 = W1s[i * 8 + 4];
-        a1 = __builtin_fmaf(w1.x, x[0], a1);
-        a1 = __builtin_fmaf(w1.y, x[1], a1);
-        a1 = __builtin_fmaf(w1.z, x[2], a1);
-        a1 = __builtin_fmaf(w1.w, x[3], a1);
-        const float sg = sigmoidf_fast(a1);
-        const float d1 = tac[t][r] * (sg * (1.0f + a1 * (1.0f - sg)));
-        g[0] = __builtin_fmaf(w1.x, d1, g[0]);
-        g[1] = __builtin_fmaf(w1.y, d1, g[1]);
-        g[2] = __builtin_fmaf(w1.z, d1, g[2]);
-        g[3] = __builtin_fmaf(w1.w, d1, g[3]);
-      }
-#pragma unroll
-    for (int c = 0; c < kMaxDim; ++c) g[c] += __shfl_xor(g[c], 32);  // the two K-halves of a sample
-    const float energy = e_part + __shfl_xor(e_part, 32) + b3;
+#include "mlp_eval_body.inc"
 
     if (a.k_steps == 0) {  // evaluation only
       if (active && h == 0) {
@@ -242,6 +148,211 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_langevin_chain_kernel(MlpArgs a
     for (int c = 0; c < dim; ++c) a.x[sample * dim + c] = x[c];
 }
 
+// ---------------------------------------------------------------------------------
+// HMC transitions on the same energy (samplers/hmc.py:201-315 + integrators/leapfrog.py:116-187): the
+// evaluation block above sits ONCE in a small state machine -- mode 0: E and force at the current state,
+// mode 1: after a kick + drift, mode 2: re-evaluation on a scrubbed position (safe mode's literal path) --
+// so that every MFMA is reached by the whole wave whatever single chains do.  dim <= 4: a lane holds a
+// whole chain (x, p, f in 12 registers), both K-halves of a sample carry identical copies.
+// RNG coordinates as in hmc_kernel.h: momentum at step 2t, uniforms at 2t+1.
+// ---------------------------------------------------------------------------------
+struct MlpHmcArgs {
+  float* x;
+  int64_t n_chains;
+  int32_t dim, n_mh, n_leapfrog;
+  float eps;
+  const float* eps_table;
+  int32_t mass_kind;
+  float mass_raw, mass_sqrt, mass_safe;
+  const float* mass_diag;
+  int32_t thin, n_kept;
+  float* traj;
+  uint8_t* accept_mask;
+  uint32_t* accept_count;
+  const float* p_noise;
+  const float* u;
+  RngKey key;
+  uint64_t step0;
+  const float* params;
+};
+
+__global__ __launch_bounds__(kBlock, 2) void mlp_hmc_chain_kernel(MlpHmcArgs a) {
+  float* W2s = mlp_smem;
+  float* W1s = W2s + H * kW2Stride;
+  float* b2s = W1s + H * 8;
+  float* w3s = b2s + H;
+  const int dim = a.dim;
+  {  // stage the weights (once per launch)
+    const float* W1g = a.params;
+    const float* b1g = W1g + H * dim;
+    const float* W2g = b1g + H;
+    const float* b2g = W2g + H * H;
+    const float* w3g = b2g + H;
+    for (int i = threadIdx.x; i < H * H; i += kBlock) W2s[(i / H) * kW2Stride + (i % H)] = W2g[i];
+    for (int i = threadIdx.x; i < H; i += kBlock) {
+#pragma unroll
+      for (int c = 0; c < kMaxDim; ++c) W1s[i * 8 + c] = c < dim ? W1g[i * dim + c] : 0.0f;
+      W1s[i * 8 + 4] = b1g[i];
+      b2s[i] = b2g[i];
+      w3s[i] = w3g[i];
+    }
+    __syncthreads();
+  }
+  const float b3 = a.params[H * dim + H + H * H + H + H];
+
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t sample = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const bool active = sample < a.n_chains;
+
+  float xc[kMaxDim], m_raw[kMaxDim], m_sqrt[kMaxDim], m_safe[kMaxDim];
+#pragma unroll
+  for (int c = 0; c < kMaxDim; ++c) {
+    xc[c] = (active && c < dim) ? a.x[sample * dim + c] : 0.0f;
+    float mr = 1.0f;
+    if (a.mass_kind == EBM_MASS_SCALAR) mr = a.mass_raw;
+    else if (a.mass_kind == EBM_MASS_DIAG) mr = c < dim ? a.mass_diag[c] : 1.0f;
+    m_raw[c] = mr;
+    m_sqrt[c] = a.mass_kind == EBM_MASS_SCALAR ? a.mass_sqrt : sqrtf(mr);
+    m_safe[c] = a.mass_kind == EBM_MASS_SCALAR ? a.mass_safe : (mr < 1e-10f ? 1e-10f : mr);
+  }
+  const bool has_mass = a.mass_kind != EBM_MASS_NONE;
+  const bool diag_mass = a.mass_kind == EBM_MASS_DIAG;
+
+  auto kinetic = [&](const float (&q)[kMaxDim]) -> float {  // 0.5 p^T M^-1 p, clamped to [0, 1e10]
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxDim; ++c) {
+      float sq = q[c] * q[c];
+      if (diag_mass) sq = sq / m_raw[c];
+      acc += sq;
+    }
+    float k = 0.5f * acc;
+    if (has_mass && !diag_mass) k = k / a.mass_raw;
+    return clamp_nanprop(k, 0.0f, 1e10f);
+  };
+
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  float eps = a.eps;
+
+  for (int tr = 0; tr < a.n_mh; ++tr) {
+    if (a.eps_table) eps = a.eps_table[tr];
+    const float half_eps = 0.5f * eps;
+
+    // ---- momentum draw p ~ N(0, M)
+    float p[kMaxDim] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.p_noise) {
+      if (active)
+        for (int c = 0; c < dim; ++c) p[c] = a.p_noise[((int64_t)tr * a.n_chains + sample) * dim + c];
+    } else {
+      uint64_t have = ~0ull;
+      F4 nrm;
+      for (int c = 0; c < dim; ++c) {
+        const uint64_t e = (uint64_t)sample * (uint64_t)dim + (uint64_t)c;
+        if ((e >> 2) != have) {
+          have = e >> 2;
+          nrm = normal4_at(a.key, have, a.step0 + 2ull * (uint64_t)tr);
+        }
+        const int q = (int)(e & 3);
+        p[c] = q == 0 ? nrm.v[0] : (q == 1 ? nrm.v[1] : (q == 2 ? nrm.v[2] : nrm.v[3]));
+      }
+    }
+    if (has_mass) {
+#pragma unroll
+      for (int c = 0; c < kMaxDim; ++c) p[c] *= m_sqrt[c];
+    }
+
+    float x[kMaxDim], f[kMaxDim] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < kMaxDim; ++c) x[c] = xc[c];
+    float h0 = 0.0f, e_last = 0.0f;
+    int done = 0, mode = 0;  // wave-uniform
+    while (done <= a.n_leapfrog) {
+      if (mode == 1) {  // first half kick + drift
+#pragma unroll
+        for (int c = 0; c < kMaxDim; ++c) {
+          const float ph = __builtin_fmaf(half_eps, f[c], p[c]);
+          p[c] = ph;
+          const float xn = has_mass ? x[c] + (eps * ph) / m_safe[c] : __builtin_fmaf(eps, ph, x[c]);
+          x[c] = c < dim ? xn : 0.0f;
+        }
+      }
+#include "mlp_eval_body.inc"
+      if (mode == 0) {  // H0 and the first (clamped) force
+        h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
+#pragma unroll
+        for (int c = 0; c < kMaxDim; ++c) f[c] = clamp_nanprop(-g[c], -1e6f, 1e6f);
+        e_last = energy;
+        mode = 1;
+        ++done;
+      } else if (mode == 1) {
+        // E finite => x finite and the gradient free of NaN (hmc_kernel.h); decided per WAVE because the
+        // literal path re-runs the MFMA evaluation
+        if (__all(__builtin_fabsf(energy) < __builtin_inff())) {
+          float pz = 0.0f;
+#pragma unroll
+          for (int c = 0; c < kMaxDim; ++c) {
+            const float fn = __builtin_amdgcn_fmed3f(-g[c], -1e6f, 1e6f);
+            const float pn = __builtin_fmaf(half_eps, fn, p[c]);
+            f[c] = fn;
+            p[c] = pn;
+            pz = __builtin_fmaf(pn, 0.0f, pz);
+          }
+          if (pz != pz) {  // momentum overflow: x is finite, so f stands
+#pragma unroll
+            for (int c = 0; c < kMaxDim; ++c) p[c] = nan_to_num0(p[c]);
+          }
+          e_last = energy;
+          ++done;
+        } else {  // literal semantics: NaN-propagating clamp, scrub, then re-evaluate on the scrubbed x
+#pragma unroll
+          for (int c = 0; c < kMaxDim; ++c) {
+            const float fn = clamp_nanprop(-g[c], -1e6f, 1e6f);
+            p[c] = nan_to_num0(__builtin_fmaf(half_eps, fn, p[c]));
+            x[c] = nan_to_num0(x[c]);
+          }
+          mode = 2;
+        }
+      } else {  // mode 2: force and energy on the scrubbed position
+#pragma unroll
+        for (int c = 0; c < kMaxDim; ++c) f[c] = clamp_nanprop(-g[c], -1e6f, 1e6f);
+        e_last = energy;
+        mode = 1;
+        ++done;
+      }
+    }
+    const float h1 = clamp_nanprop(e_last, -1e10f, 1e10f) + kinetic(p);
+
+    // ---- Metropolis accept (samplers/hmc.py:277-292)
+    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
+    float acc_p = expf(dlt);
+    acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
+    float uu;
+    if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + sample] : 2.0f;
+    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)sample >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(sample & 3)));
+    const bool accept = active && (uu < acc_p);
+    if (accept) {
+#pragma unroll
+      for (int c = 0; c < kMaxDim; ++c) xc[c] = x[c];
+    }
+    const bool leader = active && h == 0;
+    if (a.accept_mask && leader) a.accept_mask[(int64_t)tr * a.n_chains + sample] = accept ? 1 : 0;
+    if (a.accept_count) {
+      const unsigned long long b = __ballot(accept && leader);
+      if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
+    }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      if (leader)
+        for (int c = 0; c < dim; ++c) a.traj[sample * (int64_t)a.n_kept * dim + keep_off + c] = xc[c];
+      keep_off += dim;
+    }
+  }
+  if (active && h == 0)
+    for (int c = 0; c < dim; ++c) a.x[sample * dim + c] = xc[c];
+}
+
 size_t mlp_smem_bytes() { return (size_t)(H * kW2Stride + H * 8 + 2 * H) * sizeof(float); }
 
 int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who) {
@@ -282,6 +393,35 @@ int launch_langevin_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains,
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.params = e.dev0; a.energy_out = nullptr; a.grad_out = nullptr;
   return mlp_launch(a, st, who);
+}
+
+int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh, int32_t n_leapfrog,
+                         float eps, const float* eps_table, int32_t mass_kind, double mass_scalar, const float* mass_diag,
+                         int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
+                         const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
+  const char* who = "ebm_hmc_chain_f32";
+  if (int r = mlp_check(e, dim, who)) return r;
+  MlpHmcArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
+  a.mass_raw = (float)mass_scalar;
+  a.mass_sqrt = (float)sqrt(mass_scalar);
+  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
+  a.mass_diag = mass_diag; a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
+  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset; a.params = e.dev0;
+  static bool attr_set = false;
+  const size_t smem = mlp_smem_bytes();
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_hmc_chain_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t blocks = ceil_div64(n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
+  hipLaunchKernelGGL(mlp_hmc_chain_kernel, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch(who);
 }
 
 int launch_energy_grad_mlp(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* e_out,

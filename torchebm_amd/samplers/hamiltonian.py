@@ -134,8 +134,6 @@ class HamiltonianMonteCarlo(BaseSampler):
             and not isinstance(self.model, Schedulable)
         ):
             spec = self.model.fused_spec()
-            if spec is not None and spec.langevin_only:
-                spec = None
             if spec is not None and any(t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)):
                 spec = None
         return ("fused", spec) if spec is not None else ("step", None)
