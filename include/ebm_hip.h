@@ -59,7 +59,7 @@ enum {
                                  examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31)
                                  n_comp = hidden width H (128), dim <= 4,
                                  dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
-                                 Supported by ebm_langevin_chain_f32 and ebm_energy_grad_f32 only.                          */
+                                 Supported by ebm_langevin_chain_f32, ebm_hmc_chain_f32 and ebm_energy_grad_f32.               */
 };
 
 typedef struct ebm_energy {
@@ -144,7 +144,7 @@ EBM_API int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, in
                            uint64_t seed, uint64_t offset, void* stream);
 
 /*
- * n_mh fused HMC transitions for an analytic energy: momentum draw, Hamiltonian,
+ * n_mh fused HMC transitions for an analytic energy (or EBM_ENERGY_MLP): momentum draw, Hamiltonian,
  * L leapfrog steps (safe mode: force clamp +-1e6, NaN scrub), Metropolis accept.
  * Replaces the hot loop of HamiltonianMonteCarlo.sample (samplers/hmc.py:243-312),
  * LeapfrogIntegrator.integrate (integrators/leapfrog.py:116-187) and the clamps of
