@@ -4,7 +4,8 @@ examples/20-training/01-mcmc-losses/02-persistent-cd/main.py; BASELINE config 5)
 The energy is the reference example's 2-128-128-1 SiLU MLP.  Defined by hand (as in the reference
 script) the sampler uses autograd for the gradient and one fused HIP launch per Langevin step;
 with the packaged `MLPEnergy` (same network) all k steps -- forward, input-gradient on the matrix
-cores, update, noise -- are ONE kernel launch.  Set TORCHEBM_HANDWRITTEN_MLP=1 for the former."""
+cores, update, noise -- are ONE kernel launch.  Set TORCHEBM_HANDWRITTEN_MLP=1 for the former;
+TORCHEBM_CAPTURE_GRAPH=1 additionally replays its per-step loop from a HIP graph."""
 
 import os
 import sys
@@ -37,6 +38,7 @@ torch.manual_seed(0)
 data = two_moons(n_samples=3000, noise=0.05, seed=0, device=device)
 energy = MLPEnergy().to(device) if os.getenv("TORCHEBM_HANDWRITTEN_MLP") == "1" else FusedMLPEnergy(2, device=device)
 sampler = LangevinDynamics(model=energy, step_size=0.1, noise_scale=1.0, device=device)
+sampler.capture_graph = device.type == "cuda" and os.getenv("TORCHEBM_CAPTURE_GRAPH") == "1"  # step route only
 pcd = ContrastiveDivergence(model=energy, sampler=sampler, k_steps=10, persistent=True, buffer_size=8192, device=device)
 opt = torch.optim.Adam(energy.parameters(), lr=1e-3)
 
