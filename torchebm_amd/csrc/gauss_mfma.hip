@@ -41,7 +41,9 @@ struct GaussArgs {
 extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 
 template <int NT>
-__global__ __launch_bounds__(kBlock, 2) void gauss_langevin_mfma_kernel(GaussArgs a) {
+// (no minimum-waves bound: at dim 128 the state alone is 128 VGPRs and the kernel needs 432 -- one wave per
+//  SIMD without spills is 4.6 ms on 2^18 x 128 x 50 where a 256-VGPR cap with spills was 6.9 ms)
+__global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a) {
   constexpr int DIM = 32 * NT;
   float* Ps = gauss_smem;            // [DIM][DIM]
   float* mus = gauss_smem + DIM * DIM;  // [DIM]
