@@ -59,7 +59,6 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   for (int it = 0; it < NT; ++it) pa[it] = Ps[k_of(0) * DIM + 32 * it + m];
   ma = mus[k_of(0)];
   float acc = 0.0f;
-  Tile<NT> d;
 #pragma unroll
   for (int s = 0; s < 16 * NT; ++s) {  // operands of K-step s+1 are requested before the MFMAs of K-step s issue
     if (s + 1 < 16 * NT) {
@@ -69,7 +68,6 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
       mb = mus[kn];
     }
     const float dv = x.t[s >> 4][s & 15] - ma;
-    d.t[s >> 4][s & 15] = dv;
 #pragma unroll
     for (int it = 0; it < NT; ++it) g.t[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it], dv, g.t[it], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -77,16 +75,16 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
     for (int it = 0; it < NT; ++it) pa[it] = pb[it];
     ma = mb;
   }
+  // E = 0.5 d.g with d = x - mu recomputed (a cheap LDS read of mu, two distinct addresses per wave) rather
+  // than kept: 16*NT fewer live registers across the MFMA loop
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc = __builtin_fmaf(d.t[t][r], g.t[t][r], acc);
+  for (int s = 0; s < 16 * NT; ++s) acc = __builtin_fmaf(x.t[s >> 4][s & 15] - mus[k_of(s)], g.t[s >> 4][s & 15], acc);
   acc += __shfl_xor(acc, 32);
   return 0.5f * acc;
 }
 
 template <int NT>
-__global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
+__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr int DIM = 32 * NT;
   float* Ps = gauss_hmc_smem;
   float* mus = gauss_hmc_smem + DIM * DIM;
@@ -253,19 +251,38 @@ __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel(GaussHmcArgs 
   }
 }
 
+// dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
+// need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
+// template-dependent __launch_bounds__ argument.)
+template <int NT>
+__global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
+  gauss_hmc_mfma_body<NT>(a);
+}
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
+  gauss_hmc_mfma_body<NT>(a);
+}
+
 template <int NT>
 int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
   const size_t smem = (size_t)((32 * NT) * (32 * NT) + 32 * NT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {  // dim 128: 64.5 KiB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL(gauss_hmc_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  if constexpr (NT <= 2) hipLaunchKernelGGL(gauss_hmc_mfma_kernel_w2<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else hipLaunchKernelGGL(gauss_hmc_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
 }
 
 }  // namespace
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
-  return (dim == 32 || dim == 64) && mass_kind != EBM_MASS_DIAG;
+  return dim >= 32 && dim <= 128 && (dim % 32) == 0 && mass_kind != EBM_MASS_DIAG;
 }
 
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
@@ -284,7 +301,12 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
   a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
-  return dim == 32 ? launch_nt<1>(a, st) : launch_nt<2>(a, st);
+  switch (dim / 32) {
+    case 1: return launch_nt<1>(a, st);
+    case 2: return launch_nt<2>(a, st);
+    case 3: return launch_nt<3>(a, st);
+    default: return launch_nt<4>(a, st);
+  }
 }
 
 }  // namespace ebm
