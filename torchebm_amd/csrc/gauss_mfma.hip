@@ -47,15 +47,21 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
   constexpr int DIM = 32 * NT;
   float* Ps = gauss_smem;            // [DIM][DIM]
   float* mus = gauss_smem + DIM * DIM;  // [DIM]
-  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) Ps[i] = a.prec[i];
-  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = a.mean[i];
+  // dim <= DIM, dim % 4 == 0: the tiles are zero-padded -- padded coordinates stay exactly 0 (d = 0, g = 0,
+  // no noise) and whole register quads beyond dim are never loaded, drawn or stored
+  const int dim = a.dim;
+  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+    const int r = i / DIM, c = i - r * DIM;
+    Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
   const bool active = chain < a.n_chains;
-  const int64_t row = active ? chain * (int64_t)DIM : 0;
+  const int64_t row = active ? chain * (int64_t)dim : 0;
 
   // state in the C/D layout; quad q of tile t = coordinates 32t + 8q + 4h .. +3
   f32x16 x[NT];
@@ -65,14 +71,14 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
     for (int q = 0; q < 4; ++q) {
       const int k0 = 32 * t + 8 * q + 4 * h;
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active) xv = *reinterpret_cast<const float4*>(a.x + row + k0);
+      if (active && k0 < dim) xv = *reinterpret_cast<const float4*>(a.x + row + k0);
       x[t][4 * q + 0] = xv.x; x[t][4 * q + 1] = xv.y; x[t][4 * q + 2] = xv.z; x[t][4 * q + 3] = xv.w;
     }
 
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
   int until_keep = a.thin;
   int64_t keep_off = 0;
-  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * DIM : 0;
+  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim : 0;
 
   for (int step = 0; step < a.k_steps; ++step) {
     if (a.table) {
@@ -121,11 +127,13 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
         F4 eps;
         if (a.noise) {
           float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (active) nv = *reinterpret_cast<const float4*>(a.noise + ((int64_t)step * a.n_chains) * DIM + row + k0);
+          if (active) nv = *reinterpret_cast<const float4*>(a.noise + ((int64_t)step * a.n_chains) * dim + row + k0);
           eps.v[0] = nv.x; eps.v[1] = nv.y; eps.v[2] = nv.z; eps.v[3] = nv.w;
         } else {
-          eps = normal4_at(a.key, ((uint64_t)chain * DIM + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
+          eps = normal4_at(a.key, ((uint64_t)chain * dim + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
         }
+        // (padding quads run the same straight-line code -- a branch here costs 160 VGPRs -- and whatever
+        //  they hold never reaches a real coordinate: their columns of Ps are zero and they are never stored)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
@@ -143,10 +151,11 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(a.traj + traj_row + keep_off + 32 * t + 8 * q + 4 * h) =
-                make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+            if (32 * t + 8 * q + 4 * h < dim)
+              *reinterpret_cast<float4*>(a.traj + traj_row + keep_off + 32 * t + 8 * q + 4 * h) =
+                  make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
       }
-      keep_off += DIM;
+      keep_off += dim;
     }
   }
   if (active) {
@@ -154,8 +163,9 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(a.x + row + 32 * t + 8 * q + 4 * h) =
-            make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+        if (32 * t + 8 * q + 4 * h < dim)
+          *reinterpret_cast<float4*>(a.x + row + 32 * t + 8 * q + 4 * h) =
+              make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
   }
 }
 
@@ -176,7 +186,9 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool gauss_mfma_supported(int32_t dim) { return dim >= 32 && dim <= 128 && (dim % 32) == 0; }
+// dims that are multiples of 4 run on zero-padded 32-wide tiles; below 20 the padding waste outweighs the
+// matrix cores (measured: scripts/bench_gauss_dims.py), those stay on the lane-group kernel
+bool gauss_mfma_supported(int32_t dim) { return dim >= 20 && dim <= 128 && (dim % 4) == 0; }
 
 int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                                      float eta, float sqrt_eta, float noise_coef, const float* coef_table,
@@ -190,7 +202,7 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
-  switch (dim / 32) {
+  switch ((dim + 31) / 32) {
     case 1: return launch_nt<1>(a, st);
     case 2: return launch_nt<2>(a, st);
     case 3: return launch_nt<3>(a, st);
