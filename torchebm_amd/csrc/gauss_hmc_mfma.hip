@@ -21,6 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GaussHmcArgs {
   float* x;
   int64_t n_chains;
+  int32_t dim;
   int32_t n_mh, n_leapfrog;
   float eps;
   const float* eps_table;
@@ -88,15 +89,21 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr int DIM = 32 * NT;
   float* Ps = gauss_hmc_smem;
   float* mus = gauss_hmc_smem + DIM * DIM;
-  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) Ps[i] = a.prec[i];
-  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = a.mean[i];
+  // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
+  // rows / columns of Ps are zero, their momentum draw is discarded) and are never loaded or stored
+  const int dim = a.dim;
+  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+    const int r = i / DIM, c = i - r * DIM;
+    Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
   const bool active = chain < a.n_chains;
-  const int64_t row = active ? chain * (int64_t)DIM : 0;
+  const int64_t row = active ? chain * (int64_t)dim : 0;
 
   // quad q of tile t = coordinates 32t + 8q + 4h .. +3  (one float4, one Philox counter)
   auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst) {
@@ -105,7 +112,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) v = *reinterpret_cast<const float4*>(base + off + 32 * t + 8 * q + 4 * h);
+        if (active && 32 * t + 8 * q + 4 * h < dim) v = *reinterpret_cast<const float4*>(base + off + 32 * t + 8 * q + 4 * h);
         dst.t[t][4 * q] = v.x; dst.t[t][4 * q + 1] = v.y; dst.t[t][4 * q + 2] = v.z; dst.t[t][4 * q + 3] = v.w;
       }
   };
@@ -115,8 +122,9 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(base + off + 32 * t + 8 * q + 4 * h) =
-            make_float4(src.t[t][4 * q], src.t[t][4 * q + 1], src.t[t][4 * q + 2], src.t[t][4 * q + 3]);
+        if (32 * t + 8 * q + 4 * h < dim)
+          *reinterpret_cast<float4*>(base + off + 32 * t + 8 * q + 4 * h) =
+              make_float4(src.t[t][4 * q], src.t[t][4 * q + 1], src.t[t][4 * q + 2], src.t[t][4 * q + 3]);
   };
   // K(p) = 0.5 p^T p [/ m], clamped to [0, 1e10]  (samplers/hmc.py:136-159, :251-254)
   auto kinetic = [&](const Tile<NT>& q) -> float {
@@ -133,7 +141,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 
   Tile<NT> x;
   load_rows(a.x, row, x);
-  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * DIM : 0;
+  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim : 0;
   int until_keep = a.thin;
   int64_t keep_off = 0;
   float eps = a.eps;
@@ -145,16 +153,16 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     // ---- momentum draw p ~ N(0, M)
     Tile<NT> p;
     if (a.p_noise) {
-      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * DIM + row, p);
+      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * dim + row, p);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const F4 n = normal4_at(a.key, ((uint64_t)chain * DIM + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2,
-                                  a.step0 + 2ull * (uint64_t)tr);
+          const int k0 = 32 * t + 8 * q + 4 * h;
+          const F4 n = normal4_at(a.key, ((uint64_t)chain * dim + (uint64_t)k0) >> 2, a.step0 + 2ull * (uint64_t)tr);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = n.v[i];
+          for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = k0 < dim ? n.v[i] : 0.0f;  // (straight-line: see gauss_mfma.hip)
         }
     }
     if (a.has_mass) {
@@ -246,7 +254,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     if (a.traj && --until_keep == 0) {
       until_keep = a.thin;
       store_rows(a.traj, traj_row + keep_off, x);
-      keep_off += DIM;
+      keep_off += dim;
     }
   }
 }
@@ -282,7 +290,9 @@ int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
-  return dim >= 32 && dim <= 128 && (dim % 32) == 0 && mass_kind != EBM_MASS_DIAG;
+  // four-tile kernels (dims 100..128) spill; measured against the lane-group kernel they win from ~112 up
+  // (dim 100: 4.4 vs 3.9 ms, dim 128: 4.5 vs 12.4 ms per 10 transitions; scripts/bench_gauss_hmc_dims.py)
+  return dim >= 20 && dim <= 128 && (dim <= 96 || dim >= 112) && (dim % 4) == 0 && mass_kind != EBM_MASS_DIAG;
 }
 
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
@@ -291,7 +301,7 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
                                 uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
                                 uint64_t offset, hipStream_t st) {
   GaussHmcArgs a;
-  a.x = x; a.n_chains = n_chains; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table;
   a.has_mass = mass_kind == EBM_MASS_SCALAR;
   a.mass_raw = (float)mass_scalar;
@@ -301,7 +311,7 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
   a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
-  switch (dim / 32) {
+  switch ((dim + 31) / 32) {
     case 1: return launch_nt<1>(a, st);
     case 2: return launch_nt<2>(a, st);
     case 3: return launch_nt<3>(a, st);
