@@ -133,3 +133,18 @@ if "c5" in want:
                       "sampler_speedup_vs_autograd_route": t_sample / tf_sample,
                       "sampler_fp32_TFLOPs": mlp_flops / tf_sample / 1e12},
     }), flush=True)
+
+if "ref" in want:
+    # the reference's own benchmark scales (benchmarks/conftest.py:35-39, registry.py:141-148,368-370,679-684):
+    # batch x dim x n_steps = 64x8x50 / 256x32x100 / 1024x128x200, DoubleWell(h=2), step 1e-3, HMC L=10.
+    # These are launch-latency sized on an MI355X: what counts is microseconds per sample() call.
+    for n, dim, k in ((64, 8, 50), (256, 32, 100), (1024, 128, 200)):
+        model = ta.DoubleWellModel(barrier_height=2.0, device=dev)
+        x0 = torch.randn(n, dim, device=dev)
+        ld = ta.LangevinDynamics(model, step_size=1e-3, noise_scale=1.0, device=dev)
+        hm = ta.HamiltonianMonteCarlo(model, step_size=1e-3, n_leapfrog_steps=10, device=dev)
+        t_ld = wall(lambda: ld.sample(x=x0, n_steps=k), reps=50, warm=5)
+        t_hm = wall(lambda: hm.sample(x=x0, n_steps=k), reps=20, warm=3)
+        print(json.dumps({"config": f"reference benchmark scale {n}x{dim}x{k} (DoubleWell, step 1e-3)",
+                          "langevin_us_per_call": t_ld * 1e6, "langevin_chain_steps_per_s": n * k / t_ld,
+                          "hmc_L10_us_per_call": t_hm * 1e6, "hmc_mh_steps_per_s": n * k / t_hm}), flush=True)
