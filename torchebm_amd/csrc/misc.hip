@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
 // column statistics: one pass with shifted fp64 accumulators, per-block LDS partials, then one fp64
 // atomic per column per block.
 // ---------------------------------------------------------------------------------
+typedef float v4f_stat __attribute__((ext_vector_type(4)));  // the vector form the non-temporal builtin accepts
 constexpr int kStatCols = 64;   // columns per block tile (== wave size: see the ticket logic)
 constexpr int kStatRows = 4;    // row lanes per block tile (kBlock / kStatCols)
 
@@ -274,6 +275,63 @@ __global__ __launch_bounds__(kBlock) void chain_stats_kernel(const float* __rest
     mean_out[c] = (float)((double)x[c] + s1 / n);
     float v = (float)((s2 - s1 * s1 / n) / n);
     var_out[c] = clamp_nanprop(v, 1e-10f, 1e10f);  // langevin_dynamics.py:176-178
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim) = 0ull;
+}
+
+// Fast path for dim a power of two in [4, 1024]: the matrix is walked as a flat float4 stream (a wave
+// reads 1 KiB contiguous, like the update kernels), a lane's four columns are fixed because a block tile
+// of 1024 elements is a whole number of rows, per-lane fp64 sums, LDS fp64 atomics across the lanes that
+// share columns, then the same global atomics + last-block finish as above.
+__global__ __launch_bounds__(kBlock) void chain_stats_wide_kernel(const float* __restrict__ x, int64_t n_chains,
+                                                                  int32_t dim, double* __restrict__ work,
+                                                                  float* __restrict__ mean_out,
+                                                                  float* __restrict__ var_out) {
+  __shared__ double acc1[1024];
+  __shared__ double acc2[1024];
+  for (int c = threadIdx.x; c < dim; c += kBlock) acc1[c] = acc2[c] = 0.0;
+  __syncthreads();
+  const int64_t n_groups = n_chains * (int64_t)dim / 4;
+  const int col0 = (threadIdx.x * 4) & (dim - 1);
+  const float4 sh4 = *reinterpret_cast<const float4*>(x + col0);  // row 0 of the lane's columns: the shift
+  const double sh[4] = {(double)sh4.x, (double)sh4.y, (double)sh4.z, (double)sh4.w};
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * kBlock) {
+    const v4f_stat v = __builtin_nontemporal_load(reinterpret_cast<const v4f_stat*>(x) + g);
+    const double d[4] = {(double)v.x - sh[0], (double)v.y - sh[1], (double)v.z - sh[2], (double)v.w - sh[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s1[i] += d[i];
+      s2[i] = __builtin_fma(d[i], d[i], s2[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    atomicAdd(&acc1[col0 + i], s1[i]);
+    atomicAdd(&acc2[col0 + i], s2[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim; c += kBlock) {
+    const double r1 = atomicAdd(&work[c], acc1[c]);
+    const double r2 = atomicAdd(&work[dim + c], acc2[c]);
+    asm volatile("" ::"v"(r1), "v"(r2));
+  }
+  __shared__ bool last;
+  __syncthreads();  // every wave's returning atomics have completed before the ticket is taken
+  if (threadIdx.x == 0) {
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim);
+    last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+  }
+  __syncthreads();
+  if (!last) return;
+  const double n = (double)n_chains;
+  for (int c = threadIdx.x; c < dim; c += kBlock) {
+    const double t1 = atomicExch(&work[c], 0.0);
+    const double t2 = atomicExch(&work[dim + c], 0.0);
+    mean_out[c] = (float)((double)x[c] + t1 / n);
+    float v = (float)((t2 - t1 * t1 / n) / n);
+    var_out[c] = clamp_nanprop(v, 1e-10f, 1e10f);
   }
   if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim) = 0ull;
 }
@@ -346,6 +404,14 @@ int launch_hmc_accept(float* x, const float* x_prop, const float* h0, const floa
 
 int launch_chain_stats(const float* x, int64_t n_chains, int32_t dim, float* mean_out,
                        float* var_out, double* work, hipStream_t st) {
+  if (dim >= 4 && dim <= 1024 && (dim & (dim - 1)) == 0 && n_chains * (int64_t)dim >= 1024) {
+    int64_t blocks = ceil_div64(n_chains * (int64_t)dim / 4, (int64_t)kBlock * 16);  // >= 16 float4 per lane
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(chain_stats_wide_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, n_chains, dim, work,
+                       mean_out, var_out);
+    return check_launch("ebm_chain_stats_f32");
+  }
   const int gx = (dim + kStatCols - 1) / kStatCols;
   int64_t gy = ceil_div64(n_chains, kStatRows * 64);  // >= 64 rows per row-lane
   if (gy < 1) gy = 1;
