@@ -526,3 +526,17 @@ def test_heun_langevin_reproduces_reference(name):
     traj = s.sample(x=fx["x0"].clone(), n_steps=fx["k"], thin=fx["thin"], return_trajectory=True,
                     generator=torch.Generator().manual_seed(fx["run_seed"]))
     _check(traj, fx["ref"]["trajectory"], fx["energy"]["kind"])
+
+
+def test_mlp_energy_adopts_an_existing_sequential_without_copying():
+    from torch import nn
+
+    net = nn.Sequential(nn.Linear(2, 128), nn.SiLU(), nn.Linear(128, 128), nn.SiLU(), nn.Linear(128, 1))
+    energy = ta.MLPEnergy.from_sequential(net)
+    assert energy.net is net and energy.in_dim == 2 and energy.hidden == 128
+    assert {id(p) for p in energy.parameters()} == {id(p) for p in net.parameters()}
+    x = torch.randn(7, 2)
+    assert torch.equal(energy(x), net(x).squeeze(-1))
+    assert energy.gradient(x).shape == (7, 2)
+    with pytest.raises(ValueError):
+        ta.MLPEnergy.from_sequential(nn.Sequential(nn.Linear(2, 8), nn.ReLU(), nn.Linear(8, 1)))

@@ -216,3 +216,26 @@ def test_fused_mlp_hmc_safe_mode_on_extreme_states(cuda_device):
     assert torch.isfinite(out[ok]).all()
     clean = h.sample(x=x0[ok], n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(2))
     assert clean.shape == (197, 2)
+
+
+def test_adopted_sequential_takes_the_fused_route_and_trains(cuda_device):
+    """MLPEnergy.from_sequential shares the user's network: the fused kernel sees the optimiser's updates."""
+    from torch import nn
+
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(2, 128), nn.SiLU(), nn.Linear(128, 128), nn.SiLU(), nn.Linear(128, 1)).to(cuda_device)
+    energy = ta.MLPEnergy.from_sequential(net)
+    assert energy.fused_spec() is not None
+    sampler = ta.LangevinDynamics(energy, step_size=0.1, device=cuda_device)
+    data = two_moons(2048, 0.05, seed=0, device=cuda_device)
+    pcd = ta.ContrastiveDivergence(energy, sampler, k_steps=5, persistent=True, buffer_size=2048, init_steps=0, device=cuda_device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)     # optimiser built on the ORIGINAL module
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    before = sampler.sample(x=data, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    for _ in range(3):
+        loss, _ = pcd(data)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    after = sampler.sample(x=data, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 5 and not torch.equal(before, after)

@@ -267,6 +267,30 @@ class MLPEnergy(BaseModel):
             nn.Linear(in_dim, hidden), nn.SiLU(), nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, 1)
         ).to(device=self._torchebm_probe.device, dtype=self._torchebm_probe.dtype)
 
+    @classmethod
+    def from_sequential(cls, net: "torch.nn.Sequential") -> "MLPEnergy":
+        """Adopt an existing ``Linear(d, H) - SiLU - Linear(H, H) - SiLU - Linear(H, 1)`` stack (the network
+        the reference's example writes by hand) WITHOUT copying it: the returned energy shares ``net``'s
+        parameters, so an optimiser built on either sees the same tensors, and sampling from it takes the
+        fused route when the shape qualifies (H = 128, d <= 4, CUDA fp32)."""
+        from torch import nn
+
+        layers = list(net)
+        ok = (
+            len(layers) == 5
+            and all(isinstance(layers[i], nn.Linear) for i in (0, 2, 4))
+            and all(isinstance(layers[i], nn.SiLU) for i in (1, 3))
+            and layers[0].out_features == layers[2].in_features == layers[2].out_features == layers[4].in_features
+            and layers[4].out_features == 1
+            and all(l.bias is not None for l in (layers[0], layers[2], layers[4]))
+        )
+        if not ok:
+            raise ValueError("expected nn.Sequential(Linear(d, H), SiLU(), Linear(H, H), SiLU(), Linear(H, 1)) with biases")
+        w = layers[0].weight
+        self = cls(in_dim=layers[0].in_features, hidden=layers[0].out_features, device=w.device, dtype=w.dtype)
+        self.net = net
+        return self
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.net(x).squeeze(-1)
 
