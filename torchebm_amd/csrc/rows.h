@@ -703,7 +703,11 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
 
   template <bool WANT_E>
   __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
-    if (K > 8 && mu_lds) return eval_blocks<WANT_E>(L, x, g);
+    // (not compiled into the one-lane-per-chain kernels: the launchers only pick that geometry for K <= 8,
+    //  and the extra code cost the config-3 kernel 12 % through register pressure)
+    if constexpr (!(G == 1 && LaneT::FULL && NV >= 4)) {
+      if (K > 8 && mu_lds) return eval_blocks<WANT_E>(L, x, g);
+    }
     if (K <= 8 && mu_lds) {
       if constexpr (!WANT_E) {
         grad_only(L, x, g);
