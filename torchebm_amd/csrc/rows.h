@@ -706,7 +706,7 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
     // (not compiled into the one-lane-per-chain kernels: the launchers only pick that geometry for K <= 8,
     //  and the extra code cost the config-3 kernel 12 % through register pressure)
     if constexpr (!(G == 1 && LaneT::FULL && NV >= 4)) {
-      if (K > 8 && mu_lds) return eval_blocks<WANT_E>(L, x, g);
+      if (K > 10 && mu_lds) return eval_blocks<WANT_E>(L, x, g);  // 9 or 10 components: two padded blocks cost more than the loop below
     }
     if (K <= 8 && mu_lds) {
       if constexpr (!WANT_E) {
