@@ -365,8 +365,12 @@ struct Energy<EBM_ENERGY_GAUSSIAN, LaneT> {
   }
 };
 
-// Gaussian mixture (isotropic, shared sigma): one pass over the K components with a
-// running max (online softmax).  g = s1 * (x - sum_k r_k mu_k), E = -(m + log sum_k e^{l_k-m}).
+// Gaussian mixture (isotropic, shared sigma):  g = s1 * (x - sum_k r_k mu_k),  E = -(m + log sum_k e^{l_k - m}).
+// Four evaluation paths, chosen by K, by where the parameters live and by the lane geometry:
+//   K <= 8, staged, one lane per chain (G == 1, NV >= 4)  small_scalar_mu: means as scalar operands
+//   K <= 8, staged, other geometries                      eval_small / grad_only: two branch-free passes
+//   K > 10, staged                                        eval_blocks: blocks of eight, one rescale per block
+//   otherwise (9-10 components, or parameters too large for LDS)  the per-component online-softmax loop
 template <class LaneT>
 struct Energy<EBM_ENERGY_GMM, LaneT> {
   static constexpr int G = LaneT::G, NV = LaneT::NV;
