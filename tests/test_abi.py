@@ -44,3 +44,22 @@ def test_argument_errors_do_not_need_a_gpu():
         _lib.call("ebm_langevin_chain_f32", desc, 16, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, 0, 0, None)
     with pytest.raises(ValueError, match="16-byte aligned"):
         _lib.call("ebm_noise_fill_f32", 4, 8, 0, 0, 0, None)
+
+
+@pytest.mark.gpu
+def test_plain_hip_program_drives_the_library_without_python(cuda_device, tmp_path):
+    """examples/c_abi_demo.cpp: hipMalloc'ed buffers, ebm_energy_t by value, no torch anywhere -- links
+    libebm_hip.so, runs the fused chain with native and with injected noise and finds them bit-identical."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "c_abi_demo")
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    build = subprocess.run(
+        [hipcc, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.cpp"),
+         "-L", lib_dir, "-lebm_hip", f"-Wl,-rpath,{lib_dir}", "-o", exe],
+        capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "c_abi_demo: OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
