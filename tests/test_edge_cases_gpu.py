@@ -271,3 +271,41 @@ def test_gaussian_mfma_chain_matches_oracle(cuda_device, dim, n):
     _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
               1, -2.5, 2.5, 1, None, noise.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
     torch.testing.assert_close(x.cpu(), wx, rtol=5e-5, atol=5e-5)
+
+
+def test_concurrent_streams_and_threads(cuda_device):
+    """Calls only enqueue on the stream they are given and share no mutable state (the last-error string is
+    thread-local): four host threads, each on its own stream, get exactly the results of sequential calls."""
+    import threading
+
+    model = ta.DoubleWellModel(device=cuda_device)
+    mix = ta.core.ring_mixture(8, 32, device=cuda_device)
+    x_dw = torch.randn(50_000, 16, device=cuda_device).clamp_(-2, 2)
+    x_mx = torch.randn(20_000, 32, device=cuda_device)
+
+    def job(i):
+        if i % 2 == 0:
+            s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
+            return s.sample(x=x_dw, n_steps=40, generator=torch.Generator(device=cuda_device).manual_seed(100 + i))
+        h = ta.HamiltonianMonteCarlo(mix, step_size=0.1, n_leapfrog_steps=8, device=cuda_device)
+        return h.sample(x=x_mx, n_steps=5, generator=torch.Generator(device=cuda_device).manual_seed(100 + i))
+
+    want = [job(i) for i in range(4)]
+    torch.cuda.synchronize()
+    got = [None] * 4
+
+    def worker(i):
+        stream = torch.cuda.Stream(device=cuda_device)
+        stream.wait_stream(torch.cuda.default_stream(cuda_device))
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                got[i] = job(i)
+        stream.synchronize()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(4):
+        assert torch.equal(got[i], want[i]), i
