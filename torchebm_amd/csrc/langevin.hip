@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_elem_kernel(ChainArgs a
 // 2 or 4 independent groups per lane were measured and change nothing (8.96 / 9.05 / 8.91 ms on
 // config 2; the loop is VALU-issue bound at 8 waves/SIMD either way).
 // ---------------------------------------------------------------------------------
-template <int KIND, bool TABLE, bool CLAMP, bool TRAJ>
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN = false>
 __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e0 = g * 4;
@@ -300,6 +300,13 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
       v2f gr;
       if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) gr = ((4.0f * a.s0) * (xv * xv - a.s1)) * xv;  // see elem_grad
       else gr = (2.0f * a.s0) * xv;
+      if constexpr (HEUN) {  // predictor x - eta*g0, corrector gradient 0.5*g0 + 0.5*g(predictor)
+        const v2f xp = xv - c.eta * gr;
+        v2f g1;
+        if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) g1 = ((4.0f * a.s0) * (xp * xp - a.s1)) * xp;
+        else g1 = (2.0f * a.s0) * xp;
+        gr = 0.5f * gr + 0.5f * g1;
+      }
       const v2f x1 = xv - c.eta * gr;
       const v2f dw = ev * c.sqrt_eta;
       v2f nv2 = x1 + c.noise_coef * dw;
@@ -374,6 +381,13 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
   const int64_t blocks = ceil_div64(n_groups, kBlock);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "state too large for one launch (%lld blocks)", (long long)blocks);
   const dim3 grid((unsigned)blocks), block(kBlock);
+  if (!noise && heun && !traj && !coef_table && !clamp_on) {  // plain Heun chain: the lean loop with a second gradient
+    if (kind == EBM_ENERGY_DOUBLE_WELL)
+      hipLaunchKernelGGL((langevin_chain_lean_kernel<EBM_ENERGY_DOUBLE_WELL, false, false, false, true>), grid, block, 0, st, a);
+    else
+      hipLaunchKernelGGL((langevin_chain_lean_kernel<EBM_ENERGY_HARMONIC, false, false, false, true>), grid, block, 0, st, a);
+    return check_launch("ebm_langevin_heun_chain_f32");
+  }
   if (!noise && !heun && (!traj || (dim & 3) == 0)) {
 #define EBM_LEAN_T(KIND, TB, CL)                                                                          \
   do {                                                                                                   \
