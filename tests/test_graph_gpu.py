@@ -137,3 +137,26 @@ def test_hmc_scheduled_step_size_falls_back_to_the_eager_route(cuda_device):
     a0 = hip_calls("ebm_hmc_accept_f32")
     out = s.sample(x=two_moons(256, 0.05, seed=0, device=cuda_device), n_steps=4)
     assert hip_calls("ebm_hmc_accept_f32") == a0 + 4 and torch.isfinite(out).all()
+
+
+def test_uncapturable_model_falls_back_to_the_eager_step_route(cuda_device):
+    """A forward with a host sync cannot be captured: the sampler warns once, clears the flag and runs eager."""
+
+    class Syncing(ta.BaseModel):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(2, 1)
+
+        def forward(self, x):
+            scale = float(x.detach().abs().max().item() > -1.0)   # .item(): a device-to-host sync
+            return scale * self.lin(x).squeeze(-1) + 0.5 * (x ** 2).sum(-1)
+
+    torch.manual_seed(0)
+    model = Syncing().to(cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    s.capture_graph = True
+    x0 = torch.randn(128, 2, device=cuda_device)
+    out = s.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 1))
+    assert s.capture_graph is False and torch.isfinite(out).all()
+    ref = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    assert torch.equal(out, ref.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 1)))

@@ -187,7 +187,15 @@ class LangevinDynamics(BaseSampler):
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         keep = 0
         if hip and self.capture_graph and self._graph_eligible(model_kwargs):
-            return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
+            try:
+                return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
+            except RuntimeError as exc:  # the model's forward cannot be captured (host sync, data-dependent control flow ...)
+                if "ebm_" in str(exc):
+                    raise
+                warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
+                          "continuing with the eager step route.", UserWarning)
+                self.capture_graph = False
+                self._step_graph = None
         if hip:
             x = _lib.dense_f32(x)
             seed, step0 = _rng.reserve(generator, x.device, n_steps)
