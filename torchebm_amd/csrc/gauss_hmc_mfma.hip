@@ -149,6 +149,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   for (int tr = 0; tr < a.n_mh; ++tr) {
     if (a.eps_table) eps = a.eps_table[tr];
     const float half_eps = 0.5f * eps;
+    const float drift_scale = a.has_mass ? eps / a.mass_safe : eps;  // x += eps * p / max(m, 1e-10), one FMA per step
 
     // ---- momentum draw p ~ N(0, M)
     Tile<NT> p;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
         for (int r = 0; r < 16; ++r) {
           const float ph = __builtin_fmaf(half_eps, f.t[t][r], p.t[t][r]);
           p.t[t][r] = ph;
-          x.t[t][r] = a.has_mass ? x.t[t][r] + (eps * ph) / a.mass_safe : __builtin_fmaf(eps, ph, x.t[t][r]);
+          x.t[t][r] = __builtin_fmaf(drift_scale, ph, x.t[t][r]);
         }
       e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);  // f holds +g here
       // E finite => x finite, g clean.  The decision is taken per WAVE: the literal path re-runs the

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_hmc_chain_kernel(MlpHmcArgs a) 
         for (int c = 0; c < kMaxDim; ++c) {
           const float ph = __builtin_fmaf(half_eps, f[c], p[c]);
           p[c] = ph;
-          const float xn = has_mass ? x[c] + (eps * ph) / m_safe[c] : __builtin_fmaf(eps, ph, x[c]);
+          const float xn = __builtin_fmaf(has_mass ? eps / m_safe[c] : eps, ph, x[c]);
           x[c] = c < dim ? xn : 0.0f;
         }
       }
