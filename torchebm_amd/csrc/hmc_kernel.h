@@ -313,6 +313,11 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
     EBM_HMC_G(64, 2, false);
   } else if (geo.G == 64 && geo.NV == 4) {
     EBM_HMC_G(64, 4, false);
+  } else if (geo.NV == 4 && geo.full && (geo.G == 4 || geo.G == 8)) {  // element-wise energies at dim 64 / 128
+    if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL || KIND == EBM_ENERGY_HARMONIC) {
+      if (geo.G == 4) EBM_HMC_G(4, 4, true);
+      else EBM_HMC_G(8, 4, true);
+    }
   } else if (geo.G == 4 && geo.NV == 2) {  // dim-32 alternatives (full rows only)
     EBM_HMC_G(4, 2, true);
   } else if (geo.G == 2 && geo.NV == 4) {
