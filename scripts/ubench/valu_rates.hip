@@ -104,6 +104,16 @@ __global__ void k_philox_round(float* out) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = __uint_as_float(s);
 }
 
+// packed fp32 FMA (2 FMAs per lane per instruction)
+__global__ void k_pk_fma(float* out) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f a[kUnroll];
+  for (int j = 0; j < kUnroll; ++j) a[j] = v2f{threadIdx.x * 1e-3f + j, 0.5f + j};
+  BODY_LOOP(a[j] = __builtin_elementwise_fma(a[j], v2f{1.0001f, 0.9999f}, v2f{0.5f, 0.25f}))
+  float s = 0; for (int j = 0; j < kUnroll; ++j) s += a[j].x + a[j].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class K>
 void run(const char* name, K kern, float* out, double ops_per_iter) {
   const int blocks = 256 * 8, threads = 256;
@@ -139,6 +149,7 @@ int main() {
   run("rcp+add", k_rcp, out, 2);
   run("log+add+2fma", k_log_fma, out, 4);
   run("mad64+xor+2fma", k_mad64_fma, out, 4);
+  run("pk_fma", k_pk_fma, out, 1);
   run("bitop3+add", k_bitop3, out, 2);
   run("philox round (2 mad64 + 2 bitop3)", k_philox_round, out, 4);
   return 0;
