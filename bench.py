@@ -9,6 +9,10 @@ of the fused kernel ``ebm_langevin_chain_f32`` = n_chains * k chain-steps.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+``--gpus N`` with N > 1 and no torchrun environment (``WORLD_SIZE`` unset) launches the N ranks
+ITSELF: the process re-executes this file under ``torch.distributed.run`` (127.0.0.1 rendezvous, a
+free port) and relays rank 0's JSON line; it fails loudly when fewer than N GPUs are visible.
+
 The K timed steps continue the same chains (each call starts from the previous call's state).
 
 N > 1: one process per GPU, chains sharded by rank (weak scaling: 2^20 chains per GPU, seed
@@ -18,12 +22,16 @@ pipelined with the last step (four row blocks; block i's gather is in flight whi
 sampled -- utils.sample_and_gather).  It also runs once after the warm-up steps, untimed, so that
 communicator set-up is not timed.
 
-Output: one JSON line on rank 0 (see DESIGN.md §Measurement for the roofline accounting).
+Output: one JSON line on rank 0 (see DESIGN.md §Measurement for the roofline accounting).  At N = 1
+the line also carries ``extra``: the other BASELINE configs and the genuinely HBM-bound per-step
+kernel, measured in the same run (``--no-extra`` skips them).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,8 +47,15 @@ if ROOT not in sys.path:
 import torchebm_amd as ta  # noqa: E402
 from torchebm_amd import _lib  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy ceiling is measured live next to it
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector (non-matrix) peak
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 ETA, SIGMA = 0.01, 1.0
+# Issue cost of one Euler-Maruyama step of one float4 group in the lean DoubleWell loop, in units of one plain
+# full-rate VALU op: 18 v_mad_u64_u32 x 2.6 + 20 v_bitop3_b32 + 8 transcendentals x 3.2 + 11 plain + 20 packed-f32 x 1.8
+# (static ISA count of langevin_chain_lean_kernel<DoubleWell>; per-class costs measured by scripts/ubench/valu_rates.hip,
+# profiles/r01_valu_rates.txt)
+LEAN_LOOP_ISSUE_UNITS = 140.0
 
 
 def parse():
@@ -54,9 +69,38 @@ def parse():
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = plumbing dry-run (gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (the `extra` array)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without torchrun
+# ---------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """Re-execute this file as N ranks under torch.distributed.run (what the driver's own N > 1 command
+    line does) and relay the children's output.  Returns the launcher's exit code."""
+    if args.device == "cuda":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible "
+                  f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}); refusing to report a "
+                  f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, EBM_BENCH_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only)
+# ---------------------------------------------------------------------------------------
 def cpu_baseline(dim: int, k_full: int):
     """The reference's CPU path, restated (oracle/), timed on this box's host cores on a bounded
     sample of the same workload: DoubleWell, dim=64, n = 2^16 chains, k sized to ~6 s per run, per-step
@@ -112,6 +156,9 @@ def cpu_baseline(dim: int, k_full: int):
     }
 
 
+# ---------------------------------------------------------------------------------------
+# live probes of the box
+# ---------------------------------------------------------------------------------------
 def copy_ceiling_gbs(device, nbytes=1 << 28, reps=10):
     """Measured device-to-device copy rate (read + write bytes / time) on this box: the practical HBM
     ceiling quoted next to the 8 TB/s spec peak."""
@@ -128,8 +175,24 @@ def copy_ceiling_gbs(device, nbytes=1 << 28, reps=10):
     return 2 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def plain_valu_rate(device, blocks=256 * 8, iters=4096, reps=5):
+    """Plain-VALU issue rate of this chip at its current clock, in wave-instructions per second (whole chip):
+    ``ebm_probe_valu_f32`` issues blocks * 4 waves * 8 * iters independent v_fma_f32."""
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=device)
+    st = _lib.stream_handle(device)
+    _lib.call("ebm_probe_valu_f32", out.data_ptr(), blocks, iters, st)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        _lib.call("ebm_probe_valu_f32", out.data_ptr(), blocks, iters, st)
+    b.record()
+    torch.cuda.synchronize(device)
+    return blocks * 4 * 8 * iters * reps / (a.elapsed_time(b) * 1e-3)
+
+
 def read_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json): counters cannot be
+    read from inside the timed process, so this figure is labelled with its source."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -138,12 +201,194 @@ def read_traffic():
         return None
 
 
+def timed(fn, reps, warm, device):
+    """Wall seconds per call, device-synchronised around the timed block."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) / reps
+
+
+def kernel_ms_of(entry, fn, reps, device):
+    """Mean GPU duration of the `entry` launches made by `fn` (events on the launch stream), per call of fn."""
+    _lib.timed_events[entry] = []
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize(device)
+    pairs = _lib.timed_events.pop(entry)
+    return sum(a.elapsed_time(b) for a, b in pairs) / reps if pairs else None
+
+
+# ---------------------------------------------------------------------------------------
+# the other BASELINE configs, measured in the same run (N = 1, rank 0): `extra`
+# ---------------------------------------------------------------------------------------
+def extra_measurements(device, valu_rate):
+    out = []
+
+    def guarded(name, fn):
+        try:
+            out.append(fn())
+        except Exception as exc:  # one failing extra must not take the headline line with it
+            out.append({"name": name, "error": f"{type(exc).__name__}: {exc}"[:300]})
+
+    def c3():
+        # BASELINE configs[2]: HMC, L = 20, 8-mode mixture on a radius-4 ring, n = 2^18, dim = 32, eps = 0.1, 50 MH steps per call
+        n, dim, T, L = 1 << 18, 32, 50, 20
+        model = ta.core.ring_mixture(8, dim, device=device)
+        s = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=L, device=device)
+        gen = torch.Generator(device=device).manual_seed(1234)
+        x0 = torch.randn(n, dim, device=device, generator=gen)
+        fn = lambda: s.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
+        t = timed(fn, reps=5, warm=2, device=device)
+        kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 3, device)
+        _, d = s.sample(x=x0, n_steps=T, thin=T, return_diagnostics=True, generator=gen)
+        evals = n * T * (L + 1)
+        # flops of one mixture gradient: two K x dim passes of FMAs (2 * 2 * 8 * 32) + the leapfrog's 6 per coordinate
+        flops = evals * (2 * 2 * 8 * dim) + n * T * L * 6 * dim
+        return {
+            "name": "config3_hmc_gmm8", "workload": "HamiltonianMonteCarlo.sample, L=20, 8-mode GaussianMixture, n_chains=2^18, dim=32, "
+            "eps=0.1, 50 MH steps per call (BASELINE configs[2])", "metric": "MH-steps/s", "value": n * T / t,
+            "ms_per_call": t * 1e3, "kernel_ms_per_call": kms, "leapfrog_steps_per_s": n * T * L / t,
+            "grad_evals_per_s": evals / t, "fp32_TFLOPs": flops / (kms * 1e-3 if kms else t) / 1e12,
+            "frac_of_fp32_vector_peak": flops / (kms * 1e-3 if kms else t) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "bound": "valu", "step_equivalent_GBps": n * T * 8 * dim / t / 1e9,
+            "acceptance_rate": float(d["acceptance_rate"][-1]),
+        }
+
+    def c4():
+        # one GPU's shard of BASELINE configs[3]: Langevin DoubleWell, 2^20 of 2^23 chains, dim = 128, k = 500
+        n, dim, k = 1 << 20, 128, 500
+        s = ta.LangevinDynamics(ta.DoubleWellModel(device=device), step_size=ETA, noise_scale=SIGMA, device=device)
+        gen = torch.Generator(device=device).manual_seed(1234)
+        x0 = torch.randn(n, dim, device=device, generator=gen)
+        fn = lambda: s.sample(x=x0, n_steps=k, generator=gen)  # noqa: E731
+        t = timed(fn, reps=3, warm=1, device=device)
+        kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 2, device)
+        limit_ms = (n * dim / 4 / 64) * k * LEAN_LOOP_ISSUE_UNITS / valu_rate * 1e3
+        return {
+            "name": "config4_shard", "workload": "LangevinDynamics.sample on DoubleWell, one GPU's shard of BASELINE configs[3]: "
+            "n_chains=2^20 (of 2^23 over 8 GPUs), dim=128, k=500", "metric": "chain-steps/s per GPU", "value": n * k / t,
+            "ms_per_call": t * 1e3, "kernel_ms_per_call": kms, "bound": "valu",
+            "frac_of_valu_issue_limit": (limit_ms / kms) if kms else None,
+            "step_equivalent_GBps": n * k * 8 * dim / t / 1e9, "step_equivalent_frac_of_8TBps": n * k * 8 * dim / t / 8e12,
+            "allgather_bytes_per_rank": n * dim * 4,
+        }
+
+    def c5():
+        # BASELINE configs[4]: PCD training of MLP 2-128-128-1 (SiLU) on two-moons, n_chains = batch = buffer = 65536, k = 20
+        from torch import nn
+
+        from torchebm_amd.utils.synthetic import two_moons
+
+        class AutogradMLP(ta.core.BaseModel):
+            def __init__(self):
+                super().__init__()
+                self.net = nn.Sequential(nn.Linear(2, 128), nn.SiLU(), nn.Linear(128, 128), nn.SiLU(), nn.Linear(128, 1))
+
+            def forward(self, x):
+                return self.net(x).squeeze(-1)
+
+        n, k = 65536, 20
+        data = two_moons(n, 0.05, seed=0, device=device)
+        res = {"name": "config5_pcd_mlp", "workload": "ContrastiveDivergence(persistent=True) training step, MLP 2-128-128-1 SiLU energy "
+               "on two-moons, n_chains=batch=buffer=65536, k=20, eta=0.1 (BASELINE configs[4])", "metric": "training steps/s"}
+
+        def train_loop(model, sampler):
+            pcd = ta.ContrastiveDivergence(model, sampler, k_steps=k, persistent=True, buffer_size=n, init_steps=0, device=device)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+            def step():
+                loss, _ = pcd(data)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+
+            return step
+
+        torch.manual_seed(0)
+        model = AutogradMLP().to(device)
+        s = ta.LangevinDynamics(model, step_size=0.1, noise_scale=1.0, device=device)
+        # as BASELINE prescribes it: autograd gradient + HIP fused update per Langevin step.  `capture_graph` toggles the
+        # HIP-graph replay of one such iteration (the default whenever the configuration is eligible).
+        default_graph = bool(getattr(s, "capture_graph", False))
+        s.capture_graph = False
+        t_eager = timed(train_loop(model, s), reps=5, warm=2, device=device)
+        t_eager_sample = timed(lambda: s.sample(x=data, n_steps=k), reps=5, warm=1, device=device)
+        s.capture_graph = True
+        t_graph = timed(train_loop(model, s), reps=10, warm=3, device=device)
+        t_graph_sample = timed(lambda: s.sample(x=data, n_steps=k), reps=10, warm=2, device=device)
+        res["autograd_plus_hip_update"] = {
+            "default_route": "hip-graph replay" if default_graph else "eager launches",
+            "eager_launches": {"training_steps_per_s": 1 / t_eager, "sampler_ms": t_eager_sample * 1e3},
+            "hip_graph_replay": {"training_steps_per_s": 1 / t_graph, "sampler_ms": t_graph_sample * 1e3},
+        }
+        # the same energy as the packaged MLPEnergy: forward + input gradient fused on fp32 MFMA (SURVEY 8f n4)
+        torch.manual_seed(0)
+        fmodel = ta.MLPEnergy(2, device=device)
+        fs = ta.LangevinDynamics(fmodel, step_size=0.1, noise_scale=1.0, device=device)
+        tf = timed(train_loop(fmodel, fs), reps=10, warm=3, device=device)
+        fn = lambda: fs.sample(x=data, n_steps=k)  # noqa: E731
+        tf_sample = timed(fn, reps=10, warm=2, device=device)
+        kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 5, device)
+        mlp_flops = n * k * 2 * (2 * 128 * 128 + 2 * 2 * 128)  # two HxH contractions + the two thin ones, per chain-step
+        res["fused_mlp_kernel"] = {
+            "training_steps_per_s": 1 / tf, "sampler_ms": tf_sample * 1e3, "kernel_ms": kms, "bound": "mfma",
+            "fp32_TFLOPs": mlp_flops / (kms * 1e-3 if kms else tf_sample) / 1e12,
+            "frac_of_fp32_matrix_peak": mlp_flops / (kms * 1e-3 if kms else tf_sample) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+        }
+        res["value"] = 1 / (t_graph if default_graph else t_eager)
+        res["chain_steps_per_s"] = n * k * res["value"]
+        return res
+
+    def step_kernel():
+        # the genuinely HBM-bound kernel of the path: one Euler-Maruyama step with an external gradient, 2^26 elements
+        n = 1 << 26
+        x = torch.randn(n, device=device)
+        g = torch.randn(n, device=device)
+        o = torch.empty_like(x)
+        st = _lib.stream_handle(device)
+        step = [0]
+
+        def fn():
+            step[0] += 1
+            _lib.call("ebm_langevin_step_f32", x.data_ptr(), g.data_ptr(), o.data_ptr(), None, n, ETA, ETA**0.5,
+                      (2.0 * SIGMA**2) ** 0.5, 0, 0.0, 0.0, 7, step[0], st)
+
+        for _ in range(3):
+            fn()
+        kms = kernel_ms_of("ebm_langevin_step_f32", lambda: [fn() for _ in range(10)], 3, device) / 10
+        gbs = 12 * n / (kms * 1e-3) / 1e9
+        return {"name": "langevin_step_kernel", "workload": "ebm_langevin_step_f32 (Integrator.step with an external gradient, in-kernel "
+                "Philox noise), 2^26 fp32 elements: reads x and grad, writes x'", "metric": "GB/s", "bound": "hbm",
+                "algorithmic_bytes_per_launch": 12 * n, "kernel_ms": kms, "value": gbs, "peak": HBM_PEAK_GBS,
+                "frac": gbs / HBM_PEAK_GBS}
+
+    guarded("config3_hmc_gmm8", c3)
+    guarded("config4_shard", c4)
+    guarded("config5_pcd_mlp", c5)
+    guarded("langevin_step_kernel", step_kernel)
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = args.device == "cuda"
+    if on_gpu and torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} (local {local_rank}) has no GPU: {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
@@ -158,8 +403,10 @@ def main():
                 dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        backend = dist.get_backend()
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}",
+              file=sys.stderr)
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
 
     n, dim, k = args.n_chains, args.dim, args.k
@@ -236,17 +483,38 @@ def main():
         value = chain_steps / elapsed
         algo_bytes = n * k * 8 * dim  # read x_t + write x_{t+1}, fp32, per chain-step
         roof = None
+        valu_rate = None
         if kernel_ms:
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             traffic = read_traffic()
+            valu_rate = plain_valu_rate(device)
+            physical = 2 * n * dim * 4  # what the k-fused launch has to move: the state in, the state out
+            issue_limit_ms = (n * dim / 4 / 64) * k * LEAN_LOOP_ISSUE_UNITS / valu_rate * 1e3
             roof = {
-                "bound": "hbm",
+                # The kernel keeps the state in registers for all k steps, so it is NOT memory-shaped: the physical
+                # limiter is VALU issue (Philox-10 + Box-Muller).  `achieved`/`peak`/`frac` keep BASELINE.json's
+                # definition -- step-equivalent bytes (8*dim per chain-step) over the kernel time against HBM peak --
+                # which for a k-fused kernel exceeds 1; the physical figures are in `hbm_physical` and `valu`.
+                "bound": "valu",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "definition": "step-equivalent: n_chains*k*8*dim bytes / kernel time (BASELINE.md section 3)",
+                "valu": {
+                    "issue_units_per_float4_group_step": LEAN_LOOP_ISSUE_UNITS,
+                    "plain_valu_wave_instr_per_s": valu_rate,
+                    "issue_limit_ms": issue_limit_ms,
+                    "frac_of_issue_limit": issue_limit_ms / kernel_ms,
+                },
+                "hbm_physical": {
+                    "bytes_per_launch": physical,
+                    "GBps": physical / (kernel_ms * 1e-3) / 1e9,
+                    "frac_of_peak": physical / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                },
                 "measured_copy_ceiling": copy_ceiling_gbs(device),
                 "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
+                "traffic_source": None if not traffic else traffic.get("source"),
                 "kernel": "langevin_chain_lean_kernel<DoubleWell> (ebm_langevin_chain_f32)",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -272,19 +540,26 @@ def main():
                 "dim": dim,
                 "k_steps": k,
                 "parallelism": f"chains sharded x{world}",
+                "ranks": world,
+                "backend": backend,
+                "launcher": ("bench.py self-launch (torch.distributed.run)" if os.environ.get("EBM_BENCH_SELF_LAUNCHED")
+                             else ("torch.distributed.run" if world > 1 else "single process")),
                 "readback": readback,
                 "device": args.device,
             },
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dim, k),
         }
+        if on_gpu and world == 1 and not args.no_extra:
+            line["extra"] = extra_measurements(device, valu_rate or plain_valu_rate(device))
         print(json.dumps(line), flush=True)
 
     if world > 1:
         import torch.distributed as dist
 
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -254,6 +254,12 @@ EBM_API int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_
 EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint64_t* rng_state,
                            uint64_t step_delta, void* stream);
 
+/* Measurement aid (bench.py, no counterpart in the reference): `blocks` x 256 lanes each issue
+ * 8 * iters independent v_fma_f32.  blocks * 4 * 8 * iters wave-instructions / elapsed time = the plain-VALU
+ * issue rate of this chip at its current clock, against which the VALU-bound chain kernels are priced.
+ * `out` = float[blocks * 256] (keeps the arithmetic alive). */
+EBM_API int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

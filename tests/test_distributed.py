@@ -146,3 +146,32 @@ def test_bench_contract_single_process_cpu():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec
     assert rec["n_gpus"] == 1 and rec["dtype"] == "f32" and rec["data"] == "synthetic" and rec["vs_baseline"] is None
+
+
+def test_bench_self_launches_n_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no torchrun environment must start the two ranks itself (VERDICT r1:
+    it used to run one process silently) -- same harness shape as the reference's
+    tests/distributed/dist_harness.py:72-84, on the gloo plumbing path."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--device", "cpu",
+           "--n-chains", "256", "--dim", "8", "--k", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2 and rec["config"]["backend"] == "gloo"
+    assert "self-launch" in rec["config"]["launcher"]
+    assert rec["value"] == pytest.approx(2 * 256 * 3 * 2 / (rec["ms_per_step"] * 2 / 1e3), rel=1e-6)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """Fewer visible GPUs than --gpus: no JSON line, a non-zero exit and a message -- never an N-GPU number from
+    fewer devices."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    have = torch.cuda.device_count()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--steps", "1", "--warmup", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "GPU(s) are visible" in out.stderr

@@ -47,6 +47,7 @@ EXPORTS = (
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
     "ebm_noise_fill_dev_f32",
+    "ebm_probe_valu_f32",
 )
 
 #: number of calls made through each entry point in this process (tests use it to
@@ -99,6 +100,7 @@ _PROTOTYPES = {
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),
     "ebm_noise_fill_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _u64, _p]),
+    "ebm_probe_valu_f32": (C.c_int, [_p, _i32, _i32, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

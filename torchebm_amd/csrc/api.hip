@@ -44,6 +44,7 @@ int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
+int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
 int launch_langevin_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                      const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
@@ -375,6 +376,12 @@ int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint6
   if (!rng_state) return fail(EBM_EINVAL, "%s: rng_state is NULL", who);
   if (kind < EBM_NOISE_NORMAL || kind > EBM_NOISE_RAW_U32) return fail(EBM_EINVAL, "%s: bad kind %d", who, kind);
   return launch_noise_fill(out, n_elem, kind, 0, step_delta, rng_state, (hipStream_t)stream);
+}
+
+int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream) {
+  const char* who = "ebm_probe_valu_f32";
+  if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
+  return launch_probe_valu(out, blocks, iters, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -352,7 +352,32 @@ __global__ __launch_bounds__(kBlock) void chain_stats_wide_kernel(const float* _
   if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(work + 2 * (int64_t)dim) = 0ull;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Calibration probe (bench.py): a dependent-free stream of plain full-rate VALU ops (v_fma_f32 on eight
+// independent registers per lane).  Its duration gives the chip's plain-VALU issue rate on THIS box at
+// THIS clock, which is what the VALU-bound chain kernels are priced against.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void probe_valu_kernel(float* __restrict__ out, int iters) {
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 1e-3f + j;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(a[j], 1.0001f, 0.5f);
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += a[j];
+  out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
+}
+
 }  // namespace
+
+int launch_probe_valu(float* out, int32_t blocks, int32_t iters, hipStream_t st) {
+  hipLaunchKernelGGL(probe_valu_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, out, iters);
+  return check_launch("ebm_probe_valu_f32");
+}
 
 int launch_noise_fill(float* out, int64_t n_elem, int32_t kind, uint64_t seed, uint64_t offset,
                       const uint64_t* rng_dev, hipStream_t st) {
