@@ -13,7 +13,7 @@ from torch import nn
 import oracle
 import torchebm_amd as ta
 from helpers import hip_calls
-from torchebm_amd import _lib
+from torchebm_amd import _lib, _rng
 from torchebm_amd.utils.synthetic import two_moons
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +47,7 @@ def test_cd_negatives_and_loss_match_cpu_restatement(cuda_device):
     x = data.clone()
     for i in range(k):
         eps = torch.empty(n, 2, device=cuda_device)
-        _lib.call("ebm_noise_fill_f32", eps.data_ptr(), eps.numel(), _lib.NOISE_NORMAL, 2024, off + i,
+        _lib.call("ebm_noise_fill_f32", eps.data_ptr(), eps.numel(), _lib.NOISE_NORMAL, _rng.kernel_seed(2024), off + i,
                   _lib.stream_handle(cuda_device))
         x = oracle.em_step(x, model_cpu.gradient(x), eps.cpu(), eta, sigma)
     # 20 steps of an MLP gradient: rocBLAS vs CPU GEMM round-off, amplified by the dynamics

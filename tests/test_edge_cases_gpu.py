@@ -8,7 +8,7 @@ import torch
 import oracle
 import torchebm_amd as ta
 from helpers import hip_calls
-from torchebm_amd import _lib
+from torchebm_amd import _lib, _rng
 from torchebm_amd.samplers.langevin import em_coefficients
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +53,7 @@ def test_native_rng_ragged_dims_langevin(cuda_device, dim, n):
     gen = torch.Generator(device=cuda_device).manual_seed(99)
     s = ta.LangevinDynamics(ta.DoubleWellModel(device=cuda_device), step_size=eta, device=cuda_device)
     got = s.sample(x=x0.to(cuda_device), n_steps=k, generator=gen)
-    noise = _noise((k, n, dim), 99, 0, cuda_device)
+    noise = _noise((k, n, dim), _rng.kernel_seed(99), 0, cuda_device)
     want, _, _ = oracle.langevin_chain(oracle.DoubleWell(), x0, noise.cpu(), [eta] * k, [1.0] * k)
     assert torch.equal(got.cpu(), want)
     if dim >= 2:
@@ -83,11 +83,11 @@ def test_lane_per_chain_mixture_hmc(cuda_device, mass):
     before = hip_calls("ebm_hmc_chain_f32")
     got = s.sample(x=x0.to(cuda_device), n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(11))
     assert hip_calls("ebm_hmc_chain_f32") == before + 1
-    p = _noise((T, n, dim), 11, 0, cuda_device, stride=2)
+    p = _noise((T, n, dim), _rng.kernel_seed(11), 0, cuda_device, stride=2)
     us = []
     for t in range(T):
         ut = torch.empty(n, device=cuda_device)
-        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 11, 2 * t + 1, _lib.stream_handle(cuda_device))
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, _rng.kernel_seed(11), 2 * t + 1, _lib.stream_handle(cuda_device))
         us.append(ut)
     want = oracle.hmc_chain(en, x0, p.cpu(), torch.stack(us).cpu(), [eps] * T, L, mass=mass)
     assert torch.isfinite(got).all()
@@ -117,11 +117,11 @@ def test_wide_gaussian_hmc_native_rng(cuda_device, dim, n, mass):
     traj = s.sample(x=x0.to(cuda_device), n_steps=T, thin=2, return_trajectory=True,
                     generator=torch.Generator(device=cuda_device).manual_seed(13))
     assert hip_calls("ebm_hmc_chain_f32") == before + 1 and traj.shape == (n, T // 2, dim)
-    p = _noise((T, n, dim), 13, 0, cuda_device, stride=2)
+    p = _noise((T, n, dim), _rng.kernel_seed(13), 0, cuda_device, stride=2)
     us = []
     for t in range(T):
         ut = torch.empty(n, device=cuda_device)
-        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 13, 2 * t + 1, _lib.stream_handle(cuda_device))
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, _rng.kernel_seed(13), 2 * t + 1, _lib.stream_handle(cuda_device))
         us.append(ut)
     want = oracle.hmc_chain(en, x0, p.cpu(), torch.stack(us).cpu(), [eps] * T, L, mass=mass, thin=2, want_traj=True)
     assert torch.isfinite(traj).all()
@@ -150,11 +150,11 @@ def test_native_rng_ragged_dims_hmc(cuda_device, dim, n, kind):
     got, diag = s.sample(x=x0.to(cuda_device), n_steps=T, return_diagnostics=True,
                          generator=torch.Generator(device=cuda_device).manual_seed(7))
     assert hip_calls("ebm_hmc_chain_f32") == before + T  # diagnostics: one launch per kept step
-    p = _noise((T, n, dim), 7, 0, cuda_device, stride=2)
+    p = _noise((T, n, dim), _rng.kernel_seed(7), 0, cuda_device, stride=2)
     us = []
     for t in range(T):
         ut = torch.empty(n, device=cuda_device)
-        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, 7, 2 * t + 1, _lib.stream_handle(cuda_device))
+        _lib.call("ebm_noise_fill_f32", ut.data_ptr(), n, _lib.NOISE_UNIFORM, _rng.kernel_seed(7), 2 * t + 1, _lib.stream_handle(cuda_device))
         us.append(ut)
     u = torch.stack(us)
     want = oracle.hmc_chain(en, x0, p.cpu(), u.cpu(), [eps] * T, L, want_diag=True)
@@ -188,6 +188,74 @@ def test_dim_limits_and_handover(cuda_device):
     s0 = hip_calls("ebm_langevin_step_f32")
     ta.LangevinDynamics(gm, step_size=0.01, device=cuda_device).sample(dim=4, n_samples=8, n_steps=2)
     assert hip_calls("ebm_langevin_step_f32") == s0 + 2
+
+
+def test_rows_wider_than_1024_on_every_sampler(cuda_device):
+    """the lane-group kernels take rows up to 1024 floats; wider states must keep working on every
+    sampler -- diagnostics of the (row-limit-free) element-wise Langevin chain, descent and the row-coupled
+    energies, which hand over to the per-step route like the reference's loop."""
+    m = ta.DoubleWellModel(device=cuda_device)
+    big = torch.randn(6, 5000, device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(0)).clamp_(-2, 2)
+    s = ta.LangevinDynamics(m, step_size=0.001, device=cuda_device)
+    traj, diag = s.sample(x=big, n_steps=6, thin=3, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert traj.shape == (6, 2, 5000) and diag["mean"].shape == (2, 5000) and diag["energy"].shape == (2,)
+    for j in range(2):
+        torch.testing.assert_close(diag["mean"][j], traj[:, j].mean(dim=0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(diag["var"][j], traj[:, j].var(dim=0, unbiased=False).clamp(1e-10, 1e10), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(diag["energy"][j], m(traj[:, j]).mean(), rtol=1e-5, atol=1e-3)
+    # stand-alone energy / gradient of a wide element-wise row (one wave per chain)
+    e, g = torch.empty(6, device=cuda_device), torch.empty(6, 5000, device=cuda_device)
+    _lib.call("ebm_energy_grad_f32", m.fused_spec().to_c(), big.data_ptr(), 6, 5000, e.data_ptr(), g.data_ptr(), _lib.stream_handle(cuda_device))
+    torch.testing.assert_close(e, m(big), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(g, m.gradient(big), rtol=1e-6, atol=1e-6)
+    # descent: analytic energy, dim > 1024 -> per-step HIP updates around model.gradient
+    d0 = hip_calls("ebm_descent_step_f32")
+    for cls in (ta.samplers.GradientDescentSampler, ta.samplers.NesterovSampler):
+        out, dd = cls(m, step_size=0.01, device=cuda_device).sample(x=big[:, :1500].contiguous(), n_steps=3, return_diagnostics=True)
+        assert out.shape == (6, 1500) and torch.isfinite(out).all() and dd["energy"].shape == (3,)
+    assert hip_calls("ebm_descent_step_f32") == d0 + 6
+    # a 1100-dimensional Gaussian / mixture: per-step route (autograd gradient + the HIP update)
+    dim = 1100
+    g_model = ta.GaussianModel(torch.zeros(dim), torch.eye(dim) * 2.0, device=cuda_device)
+    mix = ta.GaussianMixtureModel(torch.randn(3, dim, generator=torch.Generator().manual_seed(2)), device=cuda_device)
+    s0, c0 = hip_calls("ebm_langevin_step_f32"), hip_calls("ebm_langevin_chain_f32")
+    for model in (g_model, mix):
+        out = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device).sample(dim=dim, n_samples=5, n_steps=2)
+        assert out.shape == (5, dim) and torch.isfinite(out).all()
+    assert hip_calls("ebm_langevin_step_f32") == s0 + 4 and hip_calls("ebm_langevin_chain_f32") == c0
+
+
+def test_state_width_must_match_the_model_on_the_gpu(cuda_device):
+    """x narrower / wider than the model's own dimension raises the reference's ValueError
+    (core/base_model.py:185-188) instead of reading mean / P / the means with x.shape[1]."""
+    g = ta.GaussianModel(torch.zeros(8), torch.eye(8), device=cuda_device)
+    mix = ta.GaussianMixtureModel(torch.zeros(3, 8), device=cuda_device)
+    for model in (g, mix):
+        for sampler in (ta.LangevinDynamics(model, step_size=0.01, device=cuda_device),
+                        ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=2, device=cuda_device),
+                        ta.samplers.GradientDescentSampler(model, step_size=0.05, device=cuda_device)):
+            for width in (4, 12):
+                with pytest.raises(ValueError, match="expected"):
+                    sampler.sample(x=torch.zeros(5, width, device=cuda_device), n_steps=2)
+    mlp = ta.MLPEnergy(2, device=cuda_device)
+    with pytest.raises(RuntimeError):  # nn.Linear's own shape error, as with any torch module
+        ta.LangevinDynamics(mlp, step_size=0.01, device=cuda_device).sample(x=torch.zeros(5, 3, device=cuda_device), n_steps=2)
+
+
+def test_launches_follow_the_tensor_device_not_the_current_one(cuda_device):
+    """with >= 2 GPUs, a state on cuda:1 while cuda:0 is current must be launched on cuda:1's stream
+    with cuda:1 current (and give the same chains as running there directly)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d1 = torch.device("cuda", 1)
+    x0 = torch.randn(512, 16, generator=torch.Generator().manual_seed(0)).clamp_(-2, 2)
+    s1 = ta.LangevinDynamics(ta.DoubleWellModel(device=d1), step_size=0.01, device=d1)
+    assert torch.cuda.current_device() == 0
+    a = s1.sample(x=x0.to(d1), n_steps=5, generator=torch.Generator(device=d1).manual_seed(3))
+    with torch.cuda.device(1):
+        b = s1.sample(x=x0.to(d1), n_steps=5, generator=torch.Generator(device=d1).manual_seed(3))
+    assert a.device == d1 and torch.equal(a, b)
 
 
 def test_large_mixture_and_large_precision_matrix(cuda_device):
@@ -260,7 +328,7 @@ def test_gaussian_mfma_chain_matches_oracle(cuda_device, dim, n):
                             device=cuda_device)
     gen = torch.Generator(device=cuda_device).manual_seed(31)
     traj = s.sample(x=x0.to(cuda_device), n_steps=k, thin=2, return_trajectory=True, generator=gen)
-    noise = _noise((k, n, dim), 31, 0, cuda_device)
+    noise = _noise((k, n, dim), _rng.kernel_seed(31), 0, cuda_device)
     wx, wtraj, _ = oracle.langevin_chain(en, x0, noise.cpu(), etas, [0.8] * k, clamp=(-2.5, 2.5), thin=2, want_traj=True)
     torch.testing.assert_close(traj.cpu(), wtraj, rtol=5e-5, atol=5e-5)
     # injected-noise entry and final state

@@ -11,7 +11,7 @@ import torch
 
 import oracle
 import torchebm_amd as ta
-from torchebm_amd import _lib
+from torchebm_amd import _lib, _rng
 from torchebm_amd.core.schedules import ExponentialDecayScheduler, LinearScheduler
 
 pytestmark = pytest.mark.gpu
@@ -67,7 +67,7 @@ def test_langevin_random_configuration(cuda_device, case):
     seed = 500 + case
     traj = s.sample(x=x0.to(cuda_device), n_steps=k, thin=thin, return_trajectory=True,
                     generator=torch.Generator(device=cuda_device).manual_seed(seed))
-    noise = _field((n, dim), seed, range(k), cuda_device).cpu()
+    noise = _field((n, dim), _rng.kernel_seed(seed), range(k), cuda_device).cpu()
     _, want, _ = oracle.langevin_chain(en, x0, noise, etas, sigs, clamp=clamp, thin=thin, want_traj=True,
                                        integrator="heun" if heun else "euler_maruyama")
     assert traj.shape == want.shape
@@ -102,8 +102,8 @@ def test_hmc_random_configuration(cuda_device, case):
     seed = 900 + case
     traj = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True,
                     generator=torch.Generator(device=cuda_device).manual_seed(seed))
-    p = _field((n, dim), seed, range(0, 2 * T, 2), cuda_device).cpu()
-    u = _field((n,), seed, range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
+    p = _field((n, dim), _rng.kernel_seed(seed), range(0, 2 * T, 2), cuda_device).cpu()
+    u = _field((n,), _rng.kernel_seed(seed), range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
     want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, mass=mass, thin=thin, want_traj=True)
     assert torch.isfinite(traj).all() and traj.shape == want["trajectory"].shape
     err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)

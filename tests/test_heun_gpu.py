@@ -11,7 +11,7 @@ import torch
 import oracle
 import torchebm_amd as ta
 from helpers import golden_names, hip_calls, load_golden, oracle_energy, package_model
-from torchebm_amd import _lib
+from torchebm_amd import _lib, _rng
 from torchebm_amd.samplers.langevin import em_coefficients
 
 pytestmark = pytest.mark.gpu
@@ -73,7 +73,7 @@ def test_sampler_heun_fused_route_native_rng(cuda_device, kind):
     noise = []
     for i in range(k):
         buf = torch.empty(n, dim, device=cuda_device)
-        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n * dim, _lib.NOISE_NORMAL, 21, i, _lib.stream_handle(cuda_device))
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n * dim, _lib.NOISE_NORMAL, _rng.kernel_seed(21), i, _lib.stream_handle(cuda_device))
         noise.append(buf)
     want, _, _ = oracle.langevin_chain(en, x0, torch.stack(noise).cpu(), [eta] * k, [0.8] * k, clamp=(-3.0, 3.0), integrator="heun")
     if kind == "dw":

@@ -540,3 +540,51 @@ def test_mlp_energy_adopts_an_existing_sequential_without_copying():
     assert energy.gradient(x).shape == (7, 2)
     with pytest.raises(ValueError):
         ta.MLPEnergy.from_sequential(nn.Sequential(nn.Linear(2, 8), nn.ReLU(), nn.Linear(8, 1)))
+
+
+def test_sample_and_gather_single_process_contract():
+    """ADVICE r1: with one process the result is indexed [world=1, pieces, n // pieces, ...] exactly like the
+    multi-rank result, `n % pieces` is validated, and the chains are those of `pieces` sample() calls."""
+    from torchebm_amd.utils import sample_and_gather
+
+    s = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+    x = torch.randn(12, 3, generator=torch.Generator().manual_seed(0))
+    loc, gat = sample_and_gather(s, x, 4, pieces=3, generator=torch.Generator().manual_seed(1))
+    assert gat.shape == (1, 3, 4, 3) and torch.equal(gat.reshape(12, 3), loc)
+    gen = torch.Generator().manual_seed(1)
+    want = torch.cat([s.sample(x=x[4 * i : 4 * (i + 1)], n_steps=4, generator=gen) for i in range(3)])
+    assert torch.equal(loc, want)
+    with pytest.raises(ValueError, match="equal blocks"):
+        sample_and_gather(s, x, 4, pieces=5)
+
+
+def test_width_mismatch_raises_like_the_reference():
+    """a state narrower / wider than the model's own dimension must raise the reference's
+    ValueError (core/base_model.py:185-188) on every sampler, never index the parameters with x.shape[1]."""
+    g = ta.GaussianModel(torch.zeros(8), torch.eye(8))
+    for sampler in (ta.LangevinDynamics(g, step_size=0.01), ta.HamiltonianMonteCarlo(g, step_size=0.05, n_leapfrog_steps=2),
+                    ta.samplers.GradientDescentSampler(g, step_size=0.05)):
+        for width in (4, 12):
+            with pytest.raises(ValueError, match="expected"):
+                sampler.sample(x=torch.zeros(5, width), n_steps=2)
+    from torchebm_amd.core.energies import fused_spec_for
+
+    assert fused_spec_for(g, torch.zeros(5, 8), {}) is not None       # the model's own width: fusable
+    assert fused_spec_for(g, torch.zeros(5, 4), {}) is None           # narrower: step route -> forward raises
+    assert fused_spec_for(g, torch.zeros(5, 12), {}) is None          # wider: never read past mean / P
+    assert fused_spec_for(ta.DoubleWellModel(), torch.zeros(2, 5000), {}) is None                         # lane-group kernels cap rows at 1024
+    assert fused_spec_for(ta.DoubleWellModel(), torch.zeros(2, 5000), {}, cap_elementwise=False) is not None  # the flat Langevin kernel does not
+    spec = g.fused_spec()
+    assert spec.dim == 8
+    mix = ta.GaussianMixtureModel(torch.zeros(3, 6))
+    assert mix.fused_spec().dim == 6 and ta.DoubleWellModel().fused_spec().dim is None
+
+
+def test_three_d_state_of_an_analytic_energy_raises_like_the_reference():
+    """The reference's BaseModel.gradient rejects an energy of shape (n, a) for a [n, a, b] state
+    (core/base_model.py:95-99; verified against /root/reference when the fixtures were made): so do we, on
+    every route -- such states are never flattened onto the fused kernels."""
+    s = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=0.01)
+    with pytest.raises(ValueError, match="expected shape"):
+        s.sample(n_samples=3, dim=(2, 3), n_steps=2)
+    assert s.sample(n_samples=3, dim=(2,), n_steps=2).shape == (3, 2)

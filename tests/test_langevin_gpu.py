@@ -15,7 +15,7 @@ import torch
 import oracle
 import torchebm_amd as ta
 from helpers import golden_names, hip_calls, load_golden, oracle_energy, package_model
-from torchebm_amd import _lib
+from torchebm_amd import _lib, _rng
 from torchebm_amd.samplers.langevin import em_coefficients
 
 pytestmark = pytest.mark.gpu
@@ -189,7 +189,7 @@ def test_schedulers_thin_trajectory_diagnostics_fused(cuda_device):
     assert s.schedulers["step_size"].step_count == k and s.schedulers["noise_scale"].step_count == k
     noise = torch.empty(k, n, dim, device=cuda_device)
     for i in range(k):
-        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * dim, _lib.NOISE_NORMAL, 77, off // 4 + i,
+        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * dim, _lib.NOISE_NORMAL, _rng.kernel_seed(77), off // 4 + i,
                   _lib.stream_handle(cuda_device))
     etas = ta.core.LinearScheduler(0.01, 0.002, 10).preview(k)
     sigmas = ta.core.CosineScheduler(1.0, 0.2, 12).preview(k)

@@ -148,8 +148,17 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class _StreamArg(int):
+    """A ``hipStream_t`` value that remembers which device it belongs to (see ``call``)."""
+
+    device_index: int = -1
+
+
 def stream_handle(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """The current stream of ``device`` as the ``void* stream`` argument of the entry points."""
+    h = _StreamArg(torch.cuda.current_stream(device).cuda_stream)
+    h.device_index = device.index if device.index is not None else torch.cuda.current_device()
+    return h
 
 
 def dense_f32(t: torch.Tensor) -> torch.Tensor:
@@ -169,15 +178,28 @@ timed_events: dict = {}
 
 
 def call(name: str, *args) -> None:
-    """Invoke an int-returning entry point and raise on a non-zero status."""
+    """Invoke an int-returning entry point and raise on a non-zero status.
+
+    The launch is made with the stream's own device current: a kernel enqueued on a stream of ``cuda:1``
+    while ``cuda:0`` is current would go to a foreign-device stream, and ``hipGetLastError`` /
+    the timing events would look at the wrong device."""
     fn = getattr(lib(), name)
     call_counts[name] += 1
+    st = args[-1] if args else None
+    if isinstance(st, _StreamArg) and st.device_index != torch.cuda.current_device():
+        with torch.cuda.device(st.device_index):
+            _call_here(fn, name, args)
+        return
+    _call_here(fn, name, args)
+
+
+def _call_here(fn, name: str, args) -> None:
     pairs = timed_events.get(name)
     if pairs is None:
         check(fn(*args), name)
         return
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()  # current stream == the stream handed to the kernel (stream_handle)
+    start.record()  # current stream of the current device == the stream handed to the kernel (stream_handle)
     check(fn(*args), name)
     stop.record()
     pairs.append((start, stop))

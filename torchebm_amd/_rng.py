@@ -47,11 +47,25 @@ def _set_offset(gen: torch.Generator, offset: int) -> None:
     gen.set_state(state)
 
 
+#: XORed into the high word of the Philox key.  torch's own CUDA draws from the same generator use
+#: key = seed with counter (offset/4, 0, thread, 0); the kernels' counter space (element group, step)
+#: overlaps that index space, so with the bare seed as key e.g. `randn`'s thread `tid` at offset 0 and the
+#: kernel's group 0 at step `tid` would read the same 128 random bits.  A distinct key is an independent
+#: Philox stream.  ("EBM1")
+STREAM_TAG = 0x45424D31
+
+
+def kernel_seed(seed: int) -> int:
+    """The Philox key the kernels use for a generator seeded with ``seed`` (tests use it to materialise
+    the field a sampler call drew with ``ebm_noise_fill_f32``)."""
+    return (int(seed) ^ (STREAM_TAG << 32)) & 0xFFFFFFFFFFFFFFFF
+
+
 def reserve(generator: Optional[torch.Generator], device: torch.device, n_steps: int) -> Tuple[int, int]:
     """Return ``(seed, first_step)`` for a kernel call that consumes ``n_steps`` RNG steps
     and advance the generator past them."""
     gen = _resolve(generator, device)
-    seed = int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    seed = kernel_seed(gen.initial_seed())
     offset = _get_offset(gen)
     _set_offset(gen, offset + 4 * int(n_steps))
     return seed, offset // 4

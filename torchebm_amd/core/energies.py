@@ -37,6 +37,7 @@ class FusedSpec:
     dev0: Optional[torch.Tensor] = None
     dev1: Optional[torch.Tensor] = None
     elementwise: bool = False  # gradient of coordinate j depends on x_j only
+    dim: Optional[int] = None  # the model's own state width (None: any width, e.g. element-wise energies)
     langevin_only: bool = False  # fused for Euler-Maruyama Langevin chains, HMC and energy/gradient evaluation; no Heun / descent kernel
 
     def to_c(self) -> "_lib.EnergyDesc":
@@ -177,7 +178,7 @@ class GaussianModel(BaseModel):
         if self._sym_cache is None or self._sym_cache[0] != key:
             sym = (0.5 * (self.cov_inv + self.cov_inv.t())).contiguous()
             self._sym_cache = (key, sym)
-        return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1])
+        return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1], dim=int(self.mean.shape[0]))
 
 
 class GaussianMixtureModel(BaseModel):
@@ -241,6 +242,7 @@ class GaussianMixtureModel(BaseModel):
             n_comp=int(self.means.shape[0]),
             dev0=self.means,
             dev1=self.log_weights,
+            dim=int(self.means.shape[1]),
         )
 
 
@@ -304,7 +306,45 @@ class MLPEnergy(BaseModel):
             packed = torch.cat([p.detach().reshape(-1) for p in (
                 self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
                 self.net[4].weight, self.net[4].bias)])
-        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True)
+        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True, dim=int(self.in_dim))
+
+
+#: widest chain row the lane-group kernels (csrc/rows.h: pick_geometry) take
+FUSED_MAX_ROW = 1024
+
+
+def fused_spec_for(model, x: torch.Tensor, model_kwargs: Optional[dict], *, cap_elementwise: bool = True) -> Optional[FusedSpec]:
+    """The descriptor the fused kernels need for sampling ``model`` on the state ``x`` -- or ``None`` when
+    the configuration must take the per-step route (``model.gradient`` + update kernel):
+
+    * conditioning kwargs, a model that carries schedulers, parameters on another device;
+    * a state whose trailing width differs from the model's own (``GaussianModel.mean``, the mixture's
+      ``means``, the MLP's ``in_dim``): the kernels index the parameters with ``x.shape[1]``, so a mismatch
+      would read them with the wrong stride or out of bounds -- on the step route the model's ``forward``
+      raises the reference's ``ValueError`` instead (core/base_model.py:185-188);
+    * rows wider than ``FUSED_MAX_ROW`` for the row-coupled kernels (``cap_elementwise=False`` lifts the cap
+      for element-wise energies where the caller uses the flat kernel, which has no row limit);
+    * a state that is not ``[n, dim]``: the analytic energies reduce over the last axis only, so for a
+      ``[n, a, b]`` state the reference's ``BaseModel.gradient`` raises ``ValueError`` (energy shape
+      ``(n, a)`` is not ``(n,)``, core/base_model.py:95-99) -- and so does the step route here.
+    """
+    from .schedules import Schedulable
+
+    if model_kwargs or not hasattr(model, "fused_spec") or isinstance(model, Schedulable):
+        return None
+    spec = model.fused_spec()
+    if spec is None:
+        return None
+    if x.ndim != 2:
+        return None
+    if any(t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)):
+        return None
+    width = x.shape[1]
+    if spec.dim is not None and width != spec.dim:
+        return None
+    if width > FUSED_MAX_ROW and (cap_elementwise or not spec.elementwise):
+        return None
+    return spec
 
 
 def ring_mixture(

@@ -197,6 +197,33 @@ __global__ __launch_bounds__(kBlock) void energy_grad_kernel(EgArgs a) {
   if (a.g_out) store_slice(L, a.g_out, row, g);
 }
 
+// Element-wise energies on rows wider than the lane-group geometries take (dim > 1024): one wave per chain,
+// lanes stride over the row.  Only the diagnostics / stand-alone evaluation of very wide element-wise
+// states come here; the chain kernels for those energies are flat and have no row limit.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void energy_grad_wide_row_kernel(const float* __restrict__ x, int64_t n_chains,
+                                                                      int32_t dim, float s0, float s1,
+                                                                      float* __restrict__ e_out, float* __restrict__ g_out) {
+  const int64_t chain = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (chain >= n_chains) return;
+  const int lane = threadIdx.x & 63;
+  const float* row = x + chain * (int64_t)dim;
+  float acc = 0.0f;
+  for (int d = lane; d < dim; d += 64) {
+    const float xv = row[d];
+    if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) {
+      const float u = xv * xv - s1;
+      acc += u * u;
+      if (g_out) g_out[chain * (int64_t)dim + d] = ((4.0f * s0) * u) * xv;
+    } else {
+      acc += xv * xv;
+      if (g_out) g_out[chain * (int64_t)dim + d] = (2.0f * s0) * xv;
+    }
+  }
+  acc = group_sum<64>(acc);
+  if (e_out && lane == 0) e_out[chain] = s0 * acc;
+}
+
 }  // namespace
 
 int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim,
@@ -258,7 +285,19 @@ int launch_descent_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int3
 int launch_energy_grad(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim,
                        float* e_out, float* g_out, hipStream_t st) {
   Geometry geo;
-  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_energy_grad_f32: dim %d > 1024 is not supported", dim);
+  if (!pick_geometry(dim, geo)) {
+    if (e.kind != EBM_ENERGY_DOUBLE_WELL && e.kind != EBM_ENERGY_HARMONIC)
+      return fail(EBM_EDIM, "ebm_energy_grad_f32: dim %d > 1024 is not supported for this energy", dim);
+    const int64_t wide_blocks = ceil_div64(n_chains, kWavesPerBlock);
+    if (wide_blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_energy_grad_f32: too many chains for one launch");
+    if (e.kind == EBM_ENERGY_DOUBLE_WELL)
+      hipLaunchKernelGGL(energy_grad_wide_row_kernel<EBM_ENERGY_DOUBLE_WELL>, dim3((unsigned)wide_blocks), dim3(kBlock), 0, st,
+                         x, n_chains, dim, e.s[0], e.s[1], e_out, g_out);
+    else
+      hipLaunchKernelGGL(energy_grad_wide_row_kernel<EBM_ENERGY_HARMONIC>, dim3((unsigned)wide_blocks), dim3(kBlock), 0, st,
+                         x, n_chains, dim, e.s[0], e.s[1], e_out, g_out);
+    return check_launch("ebm_energy_grad_f32");
+  }
   geo.full = false;  // one evaluation per launch: the masked form is as fast, and halves the variants
   EgArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.e_out = e_out; a.g_out = g_out;

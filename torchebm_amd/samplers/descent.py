@@ -17,9 +17,9 @@ from typing import Any, Dict, Optional, Tuple, Union
 import torch
 
 from .. import _lib
-from ..core.energies import BaseModel
+from ..core.energies import BaseModel, fused_spec_for
 from ..core.sampler_base import BaseSampler
-from ..core.schedules import BaseScheduler, Schedulable
+from ..core.schedules import BaseScheduler
 
 
 class _DescentBase(BaseSampler):
@@ -29,13 +29,9 @@ class _DescentBase(BaseSampler):
     def _route(self, x: torch.Tensor, model_kwargs: Dict[str, Any]):
         if not x.is_cuda or x.dtype != torch.float32 or (self.use_mixed_precision and self.autocast_available):
             return "eager", None
-        spec = None
-        if not model_kwargs and x.ndim == 2 and hasattr(self.model, "fused_spec") and not isinstance(self.model, Schedulable):
-            spec = self.model.fused_spec()
-            if spec is not None and spec.langevin_only:
-                spec = None
-            if spec is not None and any(t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)):
-                spec = None
+        spec = fused_spec_for(self.model, x, model_kwargs)
+        if spec is not None and spec.langevin_only:
+            spec = None
         return ("fused", spec) if spec is not None else ("step", None)
 
     @torch.no_grad()

@@ -24,11 +24,11 @@ from typing import Any, Dict, Optional, Tuple, Union
 import torch
 
 from .. import _lib, _rng
-from ..core.energies import BaseModel, FusedSpec
+from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSymplecticIntegrator
 from ..core.module import warn_once
 from ..core.sampler_base import BaseSampler
-from ..core.schedules import BaseScheduler, Schedulable
+from ..core.schedules import BaseScheduler
 from ..integrators.registry import resolve_integrator
 from ..integrators.symplectic import LeapfrogIntegrator, _mass_args
 
@@ -125,17 +125,8 @@ class HamiltonianMonteCarlo(BaseSampler):
         mass_ok = self.mass is None or isinstance(self.mass, float) or (
             torch.is_tensor(self.mass) and self.mass.ndim == 1 and self.mass.numel() == x.shape[-1]
         )
-        if (
-            not model_kwargs
-            and x.ndim == 2
-            and x.shape[1] <= 1024
-            and mass_ok
-            and hasattr(self.model, "fused_spec")
-            and not isinstance(self.model, Schedulable)
-        ):
-            spec = self.model.fused_spec()
-            if spec is not None and any(t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)):
-                spec = None
+        if mass_ok:
+            spec = fused_spec_for(self.model, x, model_kwargs)
         return ("fused", spec) if spec is not None else ("step", None)
 
     # ---------------------------------------------------------------------------------

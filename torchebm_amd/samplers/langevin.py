@@ -25,7 +25,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import torch
 
 from .. import _lib, _rng
-from ..core.energies import BaseModel, FusedSpec
+from ..core.energies import FUSED_MAX_ROW, BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSDERungeKuttaIntegrator
 from ..core.module import warn_once
 from ..core.sampler_base import BaseSampler
@@ -107,16 +107,8 @@ class LangevinDynamics(BaseSampler):
         return ("fused", spec) if spec is not None else ("step", None)
 
     def _fusable_spec(self, x: torch.Tensor, model_kwargs: Dict[str, Any]) -> Optional[FusedSpec]:
-        spec = None
-        if not model_kwargs and hasattr(self.model, "fused_spec") and not isinstance(self.model, Schedulable):
-            spec = self.model.fused_spec()
-            if spec is not None and x.ndim != 2:
-                spec = None  # the analytic energies reduce over the last axis only: [n, dim] states
-            if spec is not None and any(
-                t is not None and t.device != x.device for t in (spec.dev0, spec.dev1)
-            ):
-                spec = None
-        return spec
+        # element-wise energies run on the flat kernel, which has no row-width limit
+        return fused_spec_for(self.model, x, model_kwargs, cap_elementwise=False)
 
     # ---------------------------------------------------------------------------------
     # public API

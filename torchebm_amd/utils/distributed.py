@@ -49,18 +49,24 @@ def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: int = 4
     Returns ``(local, gathered)``: ``local`` is this rank's final ``[n, ...]`` state; ``gathered`` is a
     view of shape ``[world, pieces, n // pieces, ...]`` -- ``gathered[r]`` are rank r's chains in order
     (block-major storage; ``.reshape(world * n, ...)`` materialises the rank-ordered concatenation).
-    With one process it degenerates to ``sampler.sample`` (``gathered = local[None, None]``).
-    ``n`` must be divisible by ``pieces``."""
+    The rank-ordered concatenation is one device copy away (4 GiB at BASELINE config-4 size: ~1.6 ms at the
+    chip's copy rate, against 282 ms of sampling per call).
+    With one process the same ``pieces`` ``sampler.sample`` calls are made (so a rank's chains do not depend
+    on how many other ranks exist) and ``gathered`` is the ``[1, pieces, n // pieces, ...]`` view of the
+    local result -- the indexing contract does not depend on the world size.  ``n`` must be divisible by
+    ``pieces`` in every case."""
     n = x.shape[0]
     world = get_world_size(group)
-    if world == 1:
-        local = sampler.sample(x=x, n_steps=n_steps, generator=generator)
-        return local, local[None, None]
     if pieces < 1 or n % pieces != 0:
         raise ValueError(f"n = {n} chains cannot be split into {pieces} equal blocks")
     block = n // pieces
     tail = tuple(x.shape[1:])
     local = torch.empty_like(x)
+    if world == 1:
+        for i in range(pieces):
+            local[i * block : (i + 1) * block] = sampler.sample(x=x[i * block : (i + 1) * block], n_steps=n_steps,
+                                                                generator=generator)
+        return local, local.view((1, pieces, block) + tail)
     store = torch.empty((pieces, world, block) + tail, dtype=x.dtype, device=x.device)
     pending = []
     for i in range(pieces):
