@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 1
+#define EBM_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -119,12 +119,17 @@ EBM_API int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* 
  *                (pre-expanded schedulers, core/schedulable.py:55-75); when NULL the three
  *                scalars are used for every step
  *   traj         NULL, or [n_chains, k_steps/thin, dim]; row j is the state after step (j+1)*thin
+ *   diag_partials NULL, or the per-block diagnostics records of the k_steps/thin kept steps (see
+ *                ebm_diag_layout / ebm_diag_finish_f32 below): the sampler diagnostics of
+ *                samplers/langevin_dynamics.py:170-185 (population mean / var, mean energy) without leaving
+ *                the launch.  EBM_EDIM / EBM_EKIND when this energy / dim has no in-kernel form (ask
+ *                ebm_diag_layout first).
  *   noise        NULL (native RNG, steps offset .. offset+k-1), or [k_steps, n_chains, dim]
  */
 EBM_API int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                            int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                            const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                           int32_t thin, float* traj, const float* noise,
+                           int32_t thin, float* traj, float* diag_partials, const float* noise,
                            uint64_t seed, uint64_t offset, void* stream);
 
 /*
@@ -140,7 +145,7 @@ EBM_API int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t
 EBM_API int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                            int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                            const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                           int32_t thin, float* traj, const float* noise,
+                           int32_t thin, float* traj, float* diag_partials, const float* noise,
                            uint64_t seed, uint64_t offset, void* stream);
 
 /*
@@ -155,6 +160,8 @@ EBM_API int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, in
  *                (float)sqrt(m) for the momentum draw, (float)m for the kinetic energy and
  *                (float)max(m,1e-10) in the drift) / device float[dim]
  *   traj         NULL, or [n_chains, n_mh/thin, dim]
+ *   diag_partials NULL, or the per-block diagnostics records of the n_mh/thin kept transitions (samplers/hmc.py:294-310:
+ *                population mean / var, mean clamped energy, acceptance rate), see ebm_diag_layout below
  *   accept_mask  NULL, or uint8[n_mh, n_chains]   (1 = proposal accepted)
  *   accept_count NULL, or uint32[n_mh], must be zeroed by the caller; receives the number
  *                of accepted chains per MH step (wavefront ballot + one atomic per wave)
@@ -165,7 +172,7 @@ EBM_API int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, in
 EBM_API int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                       int32_t n_mh, int32_t n_leapfrog, float eps, const float* eps_table,
                       int32_t mass_kind, double mass_scalar, const float* mass_diag,
-                      int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                      int32_t thin, float* traj, float* diag_partials, uint8_t* accept_mask, uint32_t* accept_count,
                       const float* p_noise, const float* u,
                       uint64_t seed, uint64_t offset, void* stream);
 
@@ -253,6 +260,32 @@ EBM_API int ebm_noise_fill_f32(float* out, int64_t n_elem, int32_t kind, uint64_
  * momentum draw of a HMC transition captured in a HIP graph, samplers/hmc.py:92-134). */
 EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint64_t* rng_state,
                            uint64_t step_delta, void* stream);
+
+/*
+ * In-kernel sampler diagnostics (SURVEY.md section 8b `diag_partials`, section 5 "kernels emit per-block partial sums").
+ * At every kept step each workgroup of a chain launch stores ONE record of its chains' per-column partials
+ * (sum, M2 about the block mean), its energy sum and its accept count; ebm_diag_finish_f32 merges the records of
+ * all kept steps into the reference's diagnostics tensors.  return_diagnostics=True is therefore one chain launch
+ * plus one small merge launch, with no extra pass over the state.
+ *
+ * ebm_diag_layout: the record geometry the chain entry WOULD use for this energy / shape --
+ *   sampler: EBM_DIAG_LANGEVIN / EBM_DIAG_LANGEVIN_HEUN / EBM_DIAG_HMC;  injected_noise / with_traj: whether the
+ *   chain call will pass a noise / trajectory pointer (they select the kernel family);
+ *   outputs: n_blocks (records per kept step), slots S and block_elems E.  The caller allocates
+ *   diag_partials = float[n_kept][n_blocks][2*S + 2] and work = double[n_kept][3*dim + 3] (zeroed once; the merge
+ *   leaves it zeroed).  Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
+ *   statistics from the state with ebm_chain_stats_f32 / ebm_energy_grad_f32 between launches).
+ * ebm_diag_finish_f32: mean_out / var_out = float[n_kept][dim] (biased variance clamped to [1e-10, 1e10], zero for a
+ *   single chain), energy_out = float[n_kept] (mean per-chain energy), accept_out = NULL or float[n_kept]
+ *   (accepted fraction of the kept transition).  fp64 merge by the pairwise-variance identity.
+ */
+enum { EBM_DIAG_LANGEVIN = 0, EBM_DIAG_LANGEVIN_HEUN = 1, EBM_DIAG_HMC = 2 };
+EBM_API int ebm_diag_layout(const ebm_energy_t* energy, int32_t sampler, int64_t n_chains, int32_t dim,
+                            int32_t injected_noise, int32_t with_traj, int64_t* n_blocks, int32_t* slots,
+                            int32_t* block_elems);
+EBM_API int ebm_diag_finish_f32(const float* diag_partials, int32_t n_kept, int64_t n_blocks, int32_t slots,
+                                int32_t block_elems, int64_t n_chains, int32_t dim, float* mean_out, float* var_out,
+                                float* energy_out, float* accept_out, double* work, void* stream);
 
 /* Measurement aid (bench.py, no counterpart in the reference): `blocks` x 256 lanes each issue
  * 8 * iters independent v_fma_f32.  blocks * 4 * 8 * iters wave-instructions / elapsed time = the plain-VALU

@@ -19,5 +19,5 @@ for dim in (8, 12, 16, 20, 24, 32, 48, 64, 96, 100, 128):
     spec = model.fused_spec().to_c()
     aa, sq, coef = em_coefficients(0.01, 1.0)
     st = _lib.stream_handle(dev)
-    ms = timeit(lambda: _lib.call("ebm_langevin_chain_f32", spec, x.data_ptr(), n, dim, k, aa, sq, coef, None, 0, 0.0, 0.0, 1, None, None, 1, 0, st))
+    ms = timeit(lambda: _lib.call("ebm_langevin_chain_f32", spec, x.data_ptr(), n, dim, k, aa, sq, coef, None, 0, 0.0, 0.0, 1, None, None, None, 1, 0, st))
     print(json.dumps({"dim": dim, "ms": ms, "chain_steps_per_s": n*k/ms*1e3, "frac": n*k*8*dim/ms*1e3/8e12}))

@@ -68,7 +68,7 @@ def chain_case(name, model, n, dim, k, clamp=None, thin=1, traj=False, table=Fal
 
     def run():
         _lib.call("ebm_langevin_chain_f32", c, x.data_ptr(), n, dim, k, a, sq, coef, _lib.ptr(tab), c_on, cmin, cmax,
-                  thin, _lib.ptr(tr), None, 1, 0, st)
+                  thin, _lib.ptr(tr), None, None, 1, 0, st)
 
     ms, best = timeit(run)
     report(name, ms, best, n * k, "chain_steps", n * k * 8 * dim, n=n, dim=dim, k=k)
@@ -105,7 +105,7 @@ def hmc_case(name, model, n, dim, T, L, eps, mass=None):
     c = spec.to_c()
 
     def run():
-        _lib.call("ebm_hmc_chain_f32", c, x.data_ptr(), n, dim, T, L, eps, None, kind, ms_, _lib.ptr(md), 1, None, None,
+        _lib.call("ebm_hmc_chain_f32", c, x.data_ptr(), n, dim, T, L, eps, None, kind, ms_, _lib.ptr(md), 1, None, None, None,
                   None, None, None, 1, 0, st)
 
     ms, best = timeit(run, reps=5, warm=1)

@@ -38,10 +38,10 @@ def test_argument_errors_do_not_need_a_gpu():
     desc = _lib.EnergyDesc()
     desc.kind = _lib.ENERGY_DOUBLE_WELL
     with pytest.raises(ValueError, match="state pointer is NULL"):
-        _lib.call("ebm_langevin_chain_f32", desc, None, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, 0, 0, None)
+        _lib.call("ebm_langevin_chain_f32", desc, None, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, None, 0, 0, None)
     desc.kind = 77
     with pytest.raises(RuntimeError, match="unknown energy kind"):
-        _lib.call("ebm_langevin_chain_f32", desc, 16, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, 0, 0, None)
+        _lib.call("ebm_langevin_chain_f32", desc, 16, 8, 4, 3, 0.1, 0.3, 1.0, None, 0, 0.0, 0.0, 1, None, None, None, 0, 0, None)
     with pytest.raises(ValueError, match="16-byte aligned"):
         _lib.call("ebm_noise_fill_f32", 4, 8, 0, 0, 0, None)
 

@@ -149,7 +149,7 @@ def test_native_rng_ragged_dims_hmc(cuda_device, dim, n, kind):
     before = hip_calls("ebm_hmc_chain_f32")
     got, diag = s.sample(x=x0.to(cuda_device), n_steps=T, return_diagnostics=True,
                          generator=torch.Generator(device=cuda_device).manual_seed(7))
-    assert hip_calls("ebm_hmc_chain_f32") == before + T  # diagnostics: one launch per kept step
+    assert hip_calls("ebm_hmc_chain_f32") == before + 1  # diagnostics are taken inside the one launch
     p = _noise((T, n, dim), _rng.kernel_seed(7), 0, cuda_device, stride=2)
     us = []
     for t in range(T):
@@ -175,7 +175,7 @@ def test_dim_limits_and_handover(cuda_device):
     assert out.shape == (4, 1025) and torch.isfinite(out).all()
     desc = m.fused_spec().to_c()
     with pytest.raises(RuntimeError, match="dim 1025"):
-        _lib.call("ebm_hmc_chain_f32", desc, x.data_ptr(), 4, 1025, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None, None,
+        _lib.call("ebm_hmc_chain_f32", desc, x.data_ptr(), 4, 1025, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None, None, None,
                   0, 0, _lib.stream_handle(cuda_device))
     # the element-wise Langevin chain has no dim limit
     s = ta.LangevinDynamics(m, step_size=0.001, device=cuda_device)
@@ -337,7 +337,7 @@ def test_gaussian_mfma_chain_matches_oracle(cuda_device, dim, n):
     rows = [em_coefficients(e, 0.8) for e in etas]
     table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=cuda_device)
     _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
-              1, -2.5, 2.5, 1, None, noise.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+              1, -2.5, 2.5, 1, None, None, noise.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
     torch.testing.assert_close(x.cpu(), wx, rtol=5e-5, atol=5e-5)
 
 

@@ -18,7 +18,7 @@ from torchebm_amd.integrators.symplectic import _mass_args
 pytestmark = pytest.mark.gpu
 
 
-def _hmc_call(spec, x, eps_vals, L, mass, thin, traj, mask, counts, p_noise, u, seed=0, step=0):
+def _hmc_call(spec, x, eps_vals, L, mass, thin, traj, mask, counts, p_noise, u, seed=0, step=0, records=None):
     n, dim = x.shape
     T = len(eps_vals)
     table = None
@@ -27,7 +27,7 @@ def _hmc_call(spec, x, eps_vals, L, mass, thin, traj, mask, counts, p_noise, u, 
     kind, ms, md = _mass_args(mass, x)
     _lib.call(
         "ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, dim, T, L, eps_vals[0], _lib.ptr(table),
-        kind, ms, _lib.ptr(md), thin, _lib.ptr(traj), _lib.ptr(mask), _lib.ptr(counts),
+        kind, ms, _lib.ptr(md), thin, _lib.ptr(traj), _lib.ptr(records), _lib.ptr(mask), _lib.ptr(counts),
         _lib.ptr(p_noise), _lib.ptr(u), seed, step, _lib.stream_handle(x.device),
     )
 

@@ -21,7 +21,7 @@ from torchebm_amd.samplers.langevin import em_coefficients
 pytestmark = pytest.mark.gpu
 
 
-def _chain_call(spec, x, k, rows, clamp, thin, traj, noise, seed=0, step=0):
+def _chain_call(spec, x, k, rows, clamp, thin, traj, noise, seed=0, step=0, records=None):
     n, dim = x.shape
     a, sq, coef = rows[0]
     table = None
@@ -30,7 +30,7 @@ def _chain_call(spec, x, k, rows, clamp, thin, traj, noise, seed=0, step=0):
     clamp_on, cmin, cmax = (0, 0.0, 0.0) if clamp is None else (1, clamp[0], clamp[1])
     _lib.call(
         "ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, a, sq, coef, _lib.ptr(table),
-        clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(noise), seed, step, _lib.stream_handle(x.device),
+        clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(records), _lib.ptr(noise), seed, step, _lib.stream_handle(x.device),
     )
 
 

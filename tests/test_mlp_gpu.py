@@ -63,7 +63,7 @@ def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device)
     traj = torch.empty(n, k // 4, 2, device=cuda_device)
     noise_d = noise.to(cuda_device)
     _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, 2, k, a, sq, coef, None, 0, 0.0, 0.0, 4, traj.data_ptr(),
-              noise_d.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+              None, noise_d.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
     torch.testing.assert_close(x.cpu(), want, rtol=1e-3, atol=1e-3)
     assert torch.equal(traj[:, -1], x)
 
@@ -163,7 +163,7 @@ def test_fused_mlp_hmc_matches_cpu_autograd_chain_with_injected_noise(cuda_devic
     counts = torch.zeros(T, dtype=torch.int32, device=cuda_device)
     p_d, u_d = p.to(cuda_device).contiguous(), u.to(cuda_device).contiguous()
     _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, in_dim, T, L, eps, None, kind, m_scalar, _lib.ptr(m_diag), 2,
-              traj.data_ptr(), mask.data_ptr(), counts.data_ptr(), p_d.data_ptr(), u_d.data_ptr(), 0, 0,
+              traj.data_ptr(), None, mask.data_ptr(), counts.data_ptr(), p_d.data_ptr(), u_d.data_ptr(), 0, 0,
               _lib.stream_handle(cuda_device))
     got_mask = mask.cpu().bool()
     agree = (got_mask == want["accepted"]).all(dim=0)           # per chain: every decision identical

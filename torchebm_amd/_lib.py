@@ -18,12 +18,13 @@ import torch  # imported first on purpose: it loads the HIP runtime (libamdhip64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # energy kinds / enums: keep in sync with include/ebm_hip.h
 ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM, ENERGY_MLP = 0, 1, 2, 3, 4
 NOISE_NORMAL, NOISE_UNIFORM, NOISE_RAW_U32 = 0, 1, 2
 MASS_NONE, MASS_SCALAR, MASS_DIAG = 0, 1, 2
+DIAG_LANGEVIN, DIAG_LANGEVIN_HEUN, DIAG_HMC = 0, 1, 2
 
 #: entry points declared in include/ebm_hip.h (tests check the library exports every one)
 EXPORTS = (
@@ -47,6 +48,8 @@ EXPORTS = (
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
     "ebm_noise_fill_dev_f32",
+    "ebm_diag_layout",
+    "ebm_diag_finish_f32",
     "ebm_probe_valu_f32",
 )
 
@@ -77,16 +80,19 @@ _PROTOTYPES = {
     "ebm_langevin_step_dev_f32": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _p, _p]),
     "ebm_langevin_chain_f32": (
         C.c_int,
-        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _u64, _u64, _p],
+        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _p, _u64, _u64, _p],
     ),
     "ebm_langevin_heun_chain_f32": (
         C.c_int,
-        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _u64, _u64, _p],
+        [_ENERGY_P, _p, _i64, _i32, _i32, _f, _f, _f, _p, _i32, _f, _f, _i32, _p, _p, _p, _u64, _u64, _p],
     ),
     "ebm_hmc_chain_f32": (
         C.c_int,
-        [_ENERGY_P, _p, _i64, _i32, _i32, _i32, _f, _p, _i32, _d, _p, _i32, _p, _p, _p, _p, _p, _u64, _u64, _p],
+        [_ENERGY_P, _p, _i64, _i32, _i32, _i32, _f, _p, _i32, _d, _p, _i32, _p, _p, _p, _p, _p, _p, _u64, _u64, _p],
     ),
+    "ebm_diag_layout": (C.c_int, [_ENERGY_P, _i32, _i64, _i32, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]),
+    "ebm_diag_finish_f32": (C.c_int, [_p, _i32, _i64, _i32, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "ebm_leapfrog_kick_drift_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _d, _p, _i32, _p]),
     "ebm_leapfrog_kick_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _i32, _p]),
     "ebm_hmc_accept_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _u64, _u64, _p]),
@@ -170,6 +176,19 @@ def dense_f32(t: torch.Tensor) -> torch.Tensor:
     if t.data_ptr() % 16:
         t = t.clone()
     return t
+
+
+def diag_layout(energy: "EnergyDesc", sampler: int, n_chains: int, dim: int, injected_noise: bool = False,
+                with_traj: bool = False) -> Optional[tuple]:
+    """``(n_blocks, slots, block_elems)`` of the in-kernel diagnostics records for this chain call, or ``None``
+    when the configuration has no in-kernel form (``ebm_diag_layout`` returned EBM_EDIM / EBM_EKIND)."""
+    nb, sl, be = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    rc = lib().ebm_diag_layout(energy, sampler, n_chains, dim, int(injected_noise), int(with_traj), C.byref(nb), C.byref(sl),
+                               C.byref(be))
+    if rc in (-2, -3):
+        return None
+    check(rc, "ebm_diag_layout")
+    return nb.value, sl.value, be.value
 
 
 #: when an entry-point name is a key here, every call to it is bracketed by a pair of

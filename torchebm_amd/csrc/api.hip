@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "diag.h"
 #include "ebm_common.h"
 
 namespace ebm {
@@ -17,13 +18,22 @@ int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int3
                                const float*, uint64_t, uint64_t, int heun, hipStream_t);
 int launch_langevin_chain_rows(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
-                               const float*, uint64_t, uint64_t, int heun, hipStream_t);
+                               const float*, uint64_t, uint64_t, int heun, float* diag_partials, hipStream_t);
+int launch_langevin_chain_elem_diag(int, float, float, float*, int64_t, int32_t, int32_t, float, float, float,
+                                    const float*, int, float, float, int32_t, float*, uint64_t, uint64_t, int heun,
+                                    float* diag_partials, hipStream_t);
+bool elem_diag_supported(int32_t dim, bool has_noise, bool has_traj);
+bool elem_diag_plan(int64_t n_chains, int32_t dim, diag::DiagArgs&);
+bool rows_langevin_diag_plan(const ebm_energy_t&, int heun, int64_t n_chains, int32_t dim, diag::DiagArgs&);
+bool hmc_diag_plan(const ebm_energy_t&, int64_t n_chains, int32_t dim, diag::DiagArgs&);
+int launch_diag_finish(const float*, int32_t, int64_t, int32_t, int32_t, int64_t, int32_t, float*, float*, float*, float*,
+                       double*, hipStream_t);
 int launch_hmc_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
                          double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
                          uint64_t, uint64_t, hipStream_t);
 int launch_hmc_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float,
                      const float*, int32_t, double, const float*, int32_t, float*, uint8_t*,
-                     uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
+                     uint32_t*, const float*, const float*, uint64_t, uint64_t, float* diag_partials, hipStream_t);
 int launch_leapfrog_kick_drift(const float*, const float*, const float*, float*, float*, int64_t,
                                int32_t, float, int32_t, double, const float*, int32_t, hipStream_t);
 int launch_leapfrog_kick(float*, const float*, const float*, float*, int64_t, float, int32_t,
@@ -106,6 +116,20 @@ int reject_mlp(const ebm_energy_t* en, const char* who) {
   return 0;
 }
 
+// Which kernel family serves a chain call that asks for diagnostics records, and with what record geometry.
+// One function for the layout query and for the dispatch, so the two cannot disagree.
+enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows };
+
+DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32_t dim, bool has_noise, bool has_traj,
+                     diag::DiagArgs& d) {
+  if (e.kind == EBM_ENERGY_MLP) return kDiagNone;  // matrix-layout kernels: statistics from the state between launches
+  const bool elementwise = e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC;
+  if (sampler == EBM_DIAG_HMC) return hmc_diag_plan(e, n_chains, dim, d) ? kDiagHmcRows : kDiagNone;
+  const int heun = sampler == EBM_DIAG_LANGEVIN_HEUN;
+  if (elementwise && elem_diag_supported(dim, has_noise, has_traj) && elem_diag_plan(n_chains, dim, d)) return kDiagElemFlat;
+  return rows_langevin_diag_plan(e, heun, n_chains, dim, d) ? kDiagRows : kDiagNone;
+}
+
 int check_state(const void* x, int64_t n_chains, int32_t dim, const char* who) {
   if (!x) return fail(EBM_EINVAL, "%s: state pointer is NULL", who);
   if (n_chains < 0 || dim < 1) return fail(EBM_EINVAL, "%s: bad shape [%lld, %d]", who, (long long)n_chains, dim);
@@ -154,7 +178,7 @@ int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* out, int
 static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* energy, float* x, int64_t n_chains,
                                int32_t dim, int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                               int32_t thin, float* traj, const float* noise, uint64_t seed,
+                               int32_t thin, float* traj, float* diag_partials, const float* noise, uint64_t seed,
                                uint64_t offset, void* stream) {
   if (int r = check_energy(energy, dim, who)) return r;
   if (heun) {
@@ -163,8 +187,23 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
   if (int r = check_state(x, n_chains, dim, who)) return r;
   if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
   if (n_chains == 0 || k_steps == 0) return 0;
-  if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)) || (noise && !aligned16(noise)))
+  if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)) || (noise && !aligned16(noise)) ||
+      (diag_partials && !aligned16(diag_partials)))
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  if (diag_partials && k_steps / thin > 0) {
+    diag::DiagArgs d;
+    const DiagFamily fam = plan_diag(*energy, heun ? EBM_DIAG_LANGEVIN_HEUN : EBM_DIAG_LANGEVIN, n_chains, dim, noise != nullptr,
+                                     traj != nullptr, d);
+    if (fam == kDiagElemFlat)
+      return launch_langevin_chain_elem_diag(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim, k_steps, eta, sqrt_eta,
+                                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, seed, offset, heun,
+                                             diag_partials, (hipStream_t)stream);
+    if (fam == kDiagRows)
+      return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
+                                        cmax, thin, traj, noise, seed, offset, heun, diag_partials, (hipStream_t)stream);
+    return fail(energy->kind == EBM_ENERGY_MLP ? EBM_EKIND : EBM_EDIM,
+                "%s: no in-kernel diagnostics for this energy / dim %d (see ebm_diag_layout)", who, dim);
+  }
   if (energy->kind == EBM_ENERGY_MLP)
     return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                      clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
@@ -181,31 +220,31 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
   }
   return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef,
                                     coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
-                                    heun, (hipStream_t)stream);
+                                    heun, nullptr, (hipStream_t)stream);
 }
 
 int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                            int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                            const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                           int32_t thin, float* traj, const float* noise, uint64_t seed,
+                           int32_t thin, float* traj, float* diag_partials, const float* noise, uint64_t seed,
                            uint64_t offset, void* stream) {
   return langevin_chain_impl("ebm_langevin_chain_f32", 0, energy, x, n_chains, dim, k_steps, eta, sqrt_eta,
-                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset, stream);
+                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, diag_partials, noise, seed, offset, stream);
 }
 
 int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                                 int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                 const float* coef_table, int32_t clamp_on, float cmin, float cmax,
-                                int32_t thin, float* traj, const float* noise, uint64_t seed,
+                                int32_t thin, float* traj, float* diag_partials, const float* noise, uint64_t seed,
                                 uint64_t offset, void* stream) {
   return langevin_chain_impl("ebm_langevin_heun_chain_f32", 1, energy, x, n_chains, dim, k_steps, eta, sqrt_eta,
-                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset, stream);
+                             noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, diag_partials, noise, seed, offset, stream);
 }
 
 int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                       int32_t n_mh, int32_t n_leapfrog, float eps, const float* eps_table,
                       int32_t mass_kind, double mass_scalar, const float* mass_diag, int32_t thin,
-                      float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                      float* traj, float* diag_partials, uint8_t* accept_mask, uint32_t* accept_count,
                       const float* p_noise, const float* u, uint64_t seed, uint64_t offset,
                       void* stream) {
   const char* who = "ebm_hmc_chain_f32";
@@ -218,15 +257,22 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
   if ((p_noise == nullptr) != (u == nullptr))
     return fail(EBM_EINVAL, "%s: p_noise and u must be given together", who);
   if (n_chains == 0 || n_mh == 0) return 0;
-  if ((traj && !aligned16(traj)) || (p_noise && !aligned16(p_noise)))
+  if ((traj && !aligned16(traj)) || (p_noise && !aligned16(p_noise)) || (diag_partials && !aligned16(diag_partials)))
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  if (n_mh / thin == 0) diag_partials = nullptr;
+  if (diag_partials) {
+    diag::DiagArgs d;
+    if (plan_diag(*energy, EBM_DIAG_HMC, n_chains, dim, p_noise != nullptr, traj != nullptr, d) != kDiagHmcRows)
+      return fail(energy->kind == EBM_ENERGY_MLP ? EBM_EKIND : EBM_EDIM,
+                  "%s: no in-kernel diagnostics for this energy / dim %d (see ebm_diag_layout)", who, dim);
+  }
   if (energy->kind == EBM_ENERGY_MLP)
     return launch_hmc_chain_mlp(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
                                 mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset,
                                 (hipStream_t)stream);
   return launch_hmc_chain(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind,
                           mass_scalar, mass_diag, thin, traj, accept_mask, accept_count, p_noise, u,
-                          seed, offset, (hipStream_t)stream);
+                          seed, offset, diag_partials, (hipStream_t)stream);
 }
 
 int ebm_leapfrog_kick_drift_f32(const float* x, const float* p, const float* force, float* x_new,
@@ -376,6 +422,38 @@ int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, const uint6
   if (!rng_state) return fail(EBM_EINVAL, "%s: rng_state is NULL", who);
   if (kind < EBM_NOISE_NORMAL || kind > EBM_NOISE_RAW_U32) return fail(EBM_EINVAL, "%s: bad kind %d", who, kind);
   return launch_noise_fill(out, n_elem, kind, 0, step_delta, rng_state, (hipStream_t)stream);
+}
+
+int ebm_diag_layout(const ebm_energy_t* energy, int32_t sampler, int64_t n_chains, int32_t dim, int32_t injected_noise,
+                    int32_t with_traj, int64_t* n_blocks, int32_t* slots, int32_t* block_elems) {
+  const char* who = "ebm_diag_layout";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (sampler < EBM_DIAG_LANGEVIN || sampler > EBM_DIAG_HMC) return fail(EBM_EINVAL, "%s: unknown sampler kind %d", who, sampler);
+  if (n_chains < 1 || dim < 1 || !n_blocks || !slots || !block_elems)
+    return fail(EBM_EINVAL, "%s: bad shape [%lld, %d] or NULL output", who, (long long)n_chains, dim);
+  diag::DiagArgs d;
+  if (plan_diag(*energy, sampler, n_chains, dim, injected_noise != 0, with_traj != 0, d) == kDiagNone)
+    return fail(energy->kind == EBM_ENERGY_MLP ? EBM_EKIND : EBM_EDIM, "%s: no in-kernel diagnostics for this energy / dim %d", who,
+                dim);
+  *n_blocks = d.n_blocks;
+  *slots = d.S;
+  *block_elems = d.E;
+  return 0;
+}
+
+int ebm_diag_finish_f32(const float* diag_partials, int32_t n_kept, int64_t n_blocks, int32_t slots, int32_t block_elems,
+                        int64_t n_chains, int32_t dim, float* mean_out, float* var_out, float* energy_out, float* accept_out,
+                        double* work, void* stream) {
+  const char* who = "ebm_diag_finish_f32";
+  if (n_kept < 0) return fail(EBM_EINVAL, "%s: n_kept < 0", who);
+  if (n_kept == 0) return 0;
+  if (!diag_partials || !mean_out || !var_out || !work) return fail(EBM_EINVAL, "%s: NULL records / outputs / workspace", who);
+  if (n_chains < 1 || dim < 1 || n_blocks < 1 || slots < 1 || block_elems < 1 || slots != (dim < block_elems ? dim : block_elems) ||
+      (block_elems % dim != 0 && dim % block_elems != 0) || n_blocks != ceil_div64(n_chains * (int64_t)dim, block_elems))
+    return fail(EBM_EINVAL, "%s: inconsistent layout (n_blocks %lld, slots %d, block_elems %d for [%lld, %d])", who,
+                (long long)n_blocks, slots, block_elems, (long long)n_chains, dim);
+  return launch_diag_finish(diag_partials, n_kept, n_blocks, slots, block_elems, n_chains, dim, mean_out, var_out, energy_out,
+                            accept_out, work, (hipStream_t)stream);
 }
 
 int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream) {

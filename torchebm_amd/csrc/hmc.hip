@@ -23,30 +23,10 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, i
                                 int32_t, double, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
                                 uint64_t, uint64_t, hipStream_t);
 
-int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
-                     int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
-                     double mass_scalar, const float* mass_diag, int32_t thin, float* traj,
-                     uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
-                     const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
-  if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
-    // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
-    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
-    if (!force_rows)
-      return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
-  }
-  Geometry geo;
-  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
-  HmcArgs a;
-  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
-  a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
-  a.mass_raw = (float)mass_scalar;
-  a.mass_sqrt = (float)sqrt(mass_scalar);
-  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
-  a.mass_diag = mass_diag; a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
-  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
-  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  a.step0 = offset;
+// Lane geometry of the transition kernel for this energy / row width (shared by the launcher and the
+// diagnostics layout query, which must agree).
+static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
+  if (!pick_geometry(dim, geo)) return false;
   // dim-32 full rows can be re-shaped to (G, NV) = (4,2) | (2,4) | (1,8); EBM_HMC_NV overrides
   static const int nv_env = [] {
     const char* s = getenv("EBM_HMC_NV");
@@ -63,10 +43,52 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   // ... and at dim 64 / 128 four vectors per lane on 4 / 8 lanes (0.32 vs 0.36 ms at dim 128)
   else if ((dim == 64 || dim == 128) && nv_env == 0 && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC))
     geo = Geometry{dim / 16, 4, true};
+  return true;
+}
+
+bool hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  Geometry geo;
+  if (!hmc_geometry(e, dim, geo)) return false;
+  return diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, d);
+}
+
+int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
+                     int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
+                     double mass_scalar, const float* mass_diag, int32_t thin, float* traj,
+                     uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
+                     const float* u, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
+  // (with diagnostics records the lane-group kernel runs: the MFMA kernel keeps the state in the matrix layout)
+  if (!diag_partials && e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
+    // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
+    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+    if (!force_rows)
+      return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
+  }
+  Geometry geo;
+  if (!hmc_geometry(e, dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
+  HmcArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
+  a.mass_raw = (float)mass_scalar;
+  a.mass_sqrt = (float)sqrt(mass_scalar);
+  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
+  a.mass_diag = mass_diag; a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
+  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   a.park_offset_floats = (int)(smem / sizeof(float));
   if (geo.NV >= 4) smem += (size_t)kBlock * geo.NV * 16;
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  a.diag_offset_floats = (int)(smem / sizeof(float));
+  if (diag_partials) {
+    if (!diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, a.diag))
+      return fail(EBM_EDIM, "ebm_hmc_chain_f32: diagnostics records are not available for dim %d", dim);
+    a.diag.partials = diag_partials;
+    smem += (size_t)diag::lds_floats(a.diag.E, a.diag.S) * sizeof(float);
+  }
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks);

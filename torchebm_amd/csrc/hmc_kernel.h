@@ -30,6 +30,8 @@ struct HmcArgs {
   EnergyParams energy;
   int param_floats;
   int park_offset_floats;  // start of the lane-private parking slots in dynamic LDS
+  diag::DiagArgs diag;     // per-block diagnostics records at the kept transitions (null: off)
+  int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
 };
 
 extern __shared__ __attribute__((aligned(16))) float hmc_smem[];
@@ -192,6 +194,8 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * a.dim : 0;
   int until_keep = a.thin;
   int64_t keep_off = 0;
+  int keep = 0;
+  const bool keeping = a.traj != nullptr || a.diag.partials != nullptr;
   float eps = a.eps;
 
   for (int t = 0; t < a.n_mh; ++t) {
@@ -271,10 +275,22 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
       if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.accept_count + t, (uint32_t)__popcll(b));
     }
 
-    if (a.traj && --until_keep == 0) {
+    if (keeping && --until_keep == 0) {
       until_keep = a.thin;
-      store_slice(L, a.traj, traj_row + keep_off, xc);
-      keep_off += a.dim;
+      if (a.traj) {
+        store_slice(L, a.traj, traj_row + keep_off, xc);
+        keep_off += a.dim;
+      }
+      if (a.diag.partials) {
+        // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain
+        // holds now (its accepted proposal's E1, else E0 -- what the reference re-evaluates), acceptance rate
+        float* tile = hmc_smem + a.diag_offset_floats;
+        tile_store(L, tile, xc);
+        const float e_now = clamp_nanprop(accept ? e1 : e0, -1e10f, 1e10f);
+        diag::emit(a.diag, keep, tile, tile_valid<G>(a.n_chains, a.dim), a.dim, leader ? e_now : 0.0f,
+                   (accept && leader) ? 1.0f : 0.0f);
+        ++keep;
+      }
     }
   }
   store_slice(L, a.x, row, xc);

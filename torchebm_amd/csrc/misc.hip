@@ -1,6 +1,7 @@
 // Small streaming kernels around the hot path: native-RNG fill, the leapfrog sub-steps and
 // Metropolis accept used when the force comes from an opaque drift closure (autograd
 // models), and the column statistics behind the sampler diagnostics.
+#include "diag.h"
 #include "ebm_common.h"
 
 namespace ebm {
@@ -372,7 +373,125 @@ __global__ __launch_bounds__(kBlock) void probe_valu_kernel(float* __restrict__ 
   out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Merge of the per-block diagnostics records the chain kernels emit (diag.h) into the sampler
+// diagnostics: mean[n_kept, dim], biased var[n_kept, dim] clamped to [1e-10, 1e10] (0 for a single chain),
+// energy[n_kept] = mean per-chain energy, accept[n_kept] = accepted fraction.
+//
+// grid = (n_kept, W, Q): W = column windows (1 when a block holds whole rows, dim / E when a row spans several
+// blocks: block b then covers columns (b % W) * E + slot), Q splits the block range.  Every workgroup adds its
+// share of three plain sums per column to the fp64 work row of its kept step --
+//   A = sum_b sum_x,   B = sum_b M2_b,   C = sum_b cnt_b (mean_b - shift)^2,   shift = mean of the window's first block
+// -- and M2_total = B + C - n (mean - shift)^2 (pairwise-variance identity about a common shift; exact in
+// exact arithmetic, and in fp64 conditioned by |mean_b - shift| ~ the spread of block means, not by |mean|).
+// The last workgroup of a kept step (ticket) turns the sums into the outputs and leaves the work row zeroed.
+// work: double[n_kept][3 * dim + 3] = {A[dim], B[dim], C[dim], energy sum, accept sum, ticket}, zeroed by the caller.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t diag_block_len(int64_t b, int E, int64_t n_elem) {
+  const int64_t left = n_elem - b * (int64_t)E;
+  return left >= E ? E : (left > 0 ? left : 0);
+}
+
+__global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __restrict__ partials, int64_t n_blocks,
+                                                             int32_t S, int32_t E, int64_t n_chains, int32_t dim,
+                                                             float* __restrict__ mean_out, float* __restrict__ var_out,
+                                                             float* __restrict__ energy_out, float* __restrict__ accept_out,
+                                                             double* __restrict__ work) {
+  const int j = blockIdx.x;
+  const int W = gridDim.y, w = blockIdx.y, Q = gridDim.z, q = blockIdx.z;
+  const int R = 2 * S + 2;
+  const int64_t n_elem = n_chains * (int64_t)dim;
+  const float* base = partials + (int64_t)j * n_blocks * R;
+  double* wrow = work + (int64_t)j * (3 * (int64_t)dim + 3);
+  // blocks of this window: b = w, w + W, ...; this workgroup takes the q-th chunk of them
+  const int64_t n_win = (n_blocks - w + W - 1) / W;
+  const int64_t per = (n_win + Q - 1) / Q;
+  const int64_t i0 = (int64_t)q * per, i1 = (i0 + per < n_win) ? i0 + per : n_win;
+  const int64_t len_first = diag_block_len(w, E, n_elem);
+  for (int s = threadIdx.x; s < S; s += kBlock) {
+    const int cnt0 = s < len_first ? (int)((len_first - s + dim - 1) / dim) : 0;
+    const double shift = cnt0 > 0 ? (double)base[(int64_t)w * R + s] / (double)cnt0 : 0.0;
+    double A = 0.0, B = 0.0, C = 0.0;
+    for (int64_t i = i0; i < i1; ++i) {
+      const int64_t b = w + i * W;
+      const int64_t len = diag_block_len(b, E, n_elem);
+      if (s >= len) continue;
+      const double cnt = (double)((len - s + dim - 1) / dim);
+      const float* rec = base + b * R;
+      const double sx = (double)rec[s];
+      const double dm = sx / cnt - shift;
+      A += sx;
+      B += (double)rec[S + s];
+      C += cnt * dm * dm;
+    }
+    const int col = w * E + s;  // W == 1: col = s
+    const double r0 = atomicAdd(&wrow[col], A);
+    const double r1 = atomicAdd(&wrow[dim + col], B);
+    const double r2 = atomicAdd(&wrow[2 * dim + col], C);
+    asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));  // the adds have been performed at L2 once their old values are back
+  }
+  if (threadIdx.x == 0) {  // energy / accept sums of this workgroup's blocks
+    double es = 0.0, as = 0.0;
+    for (int64_t i = i0; i < i1; ++i) {
+      const float* rec = base + (w + i * W) * R;
+      es += (double)rec[2 * S];
+      as += (double)rec[2 * S + 1];
+    }
+    const double r0 = atomicAdd(&wrow[3 * dim], es);
+    const double r1 = atomicAdd(&wrow[3 * dim + 1], as);
+    asm volatile("" ::"v"(r0), "v"(r1));
+  }
+  __shared__ bool last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(wrow + 3 * dim + 2);
+    last = atomicAdd(ticket, 1ull) == (unsigned long long)W * Q - 1ull;
+  }
+  __syncthreads();
+  if (!last) return;
+  const double n = (double)n_chains;
+  for (int c = threadIdx.x; c < dim; c += kBlock) {
+    const double A = atomicExch(&wrow[c], 0.0);  // read at L2 (where the atomics landed) and reset
+    const double B = atomicExch(&wrow[dim + c], 0.0);
+    const double C = atomicExch(&wrow[2 * dim + c], 0.0);
+    const int wc = c / E, sc = c - wc * E;       // the shift this column's sums were taken about
+    const int64_t lf = diag_block_len(wc, E, n_elem);
+    const int cnt0 = sc < lf ? (int)((lf - sc + dim - 1) / dim) : 0;
+    const double shift = cnt0 > 0 ? (double)base[(int64_t)wc * R + sc] / (double)cnt0 : 0.0;
+    const double mean = A / n;
+    const double dm = mean - shift;
+    double m2 = B + C - n * dm * dm;
+    if (m2 < 0.0) m2 = 0.0;
+    mean_out[(int64_t)j * dim + c] = (float)mean;
+    // biased variance clamped like langevin_dynamics.py:176-178; a single chain has none (:179-181, hmc.py:300-303)
+    var_out[(int64_t)j * dim + c] = n_chains > 1 ? clamp_nanprop((float)(m2 / n), 1e-10f, 1e10f) : 0.0f;
+  }
+  if (threadIdx.x == 0) {
+    const double es = atomicExch(&wrow[3 * dim], 0.0);
+    const double as = atomicExch(&wrow[3 * dim + 1], 0.0);
+    if (energy_out) energy_out[j] = (float)(es / n);
+    if (accept_out) accept_out[j] = (float)(as / n);
+    *reinterpret_cast<unsigned long long*>(wrow + 3 * dim + 2) = 0ull;
+  }
+}
+
 }  // namespace
+
+int launch_diag_finish(const float* partials, int32_t n_kept, int64_t n_blocks, int32_t S, int32_t E, int64_t n_chains,
+                       int32_t dim, float* mean_out, float* var_out, float* energy_out, float* accept_out, double* work,
+                       hipStream_t st) {
+  const int W = E % dim == 0 ? 1 : dim / E;
+  const int64_t n_win = ceil_div64(n_blocks, W);
+  int64_t Q = ceil_div64(n_win, 64);  // >= 64 records per workgroup and slot
+  const int64_t cap = ceil_div64(256 * 8, (int64_t)n_kept * W);  // ~ 8 workgroups per CU in total
+  if (Q > cap) Q = cap;
+  if (Q < 1) Q = 1;
+  if (Q > 65535) Q = 65535;
+  hipLaunchKernelGGL(diag_finish_kernel, dim3((unsigned)n_kept, (unsigned)W, (unsigned)Q), dim3(kBlock), 0, st, partials,
+                     n_blocks, S, E, n_chains, dim, mean_out, var_out, energy_out, accept_out, work);
+  return check_launch("ebm_diag_finish_f32");
+}
 
 int launch_probe_valu(float* out, int32_t blocks, int32_t iters, hipStream_t st) {
   hipLaunchKernelGGL(probe_valu_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, out, iters);

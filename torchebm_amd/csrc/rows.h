@@ -15,6 +15,7 @@
 // validity selects disappear from the inner loops; lanes of chains past n_chains then
 // compute on zeros and are only prevented from loading/storing.
 #pragma once
+#include "diag.h"
 #include "ebm_common.h"
 
 namespace ebm {
@@ -138,6 +139,26 @@ __device__ __forceinline__ void store_slice(const LaneT& L, float* __restrict__ 
         if (L.mem_ok(v, i)) base[row_off + L.col[v] + i] = s.a[v][i];
     }
   }
+}
+
+// Diagnostics tile (diag.h): the block's chains in flat order, chain_in_block * dim + column.
+template <class LaneT>
+__device__ __forceinline__ void tile_store(const LaneT& L, float* __restrict__ tile, const Slice<LaneT::NV>& s) {
+  float* row = tile + (int)(threadIdx.x / LaneT::G) * L.dim;
+#pragma unroll
+  for (int v = 0; v < LaneT::NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (L.mem_ok(v, i)) row[L.col[v] + i] = s.a[v][i];
+}
+
+// valid flat elements of this workgroup's tile: its active chains x dim
+template <int G>
+__device__ __forceinline__ int tile_valid(int64_t n_chains, int dim) {
+  const int64_t first = (int64_t)blockIdx.x * (kBlock / G);
+  const int64_t left = n_chains - first;
+  const int c = left >= kBlock / G ? kBlock / G : (left > 0 ? (int)left : 0);
+  return c * dim;
 }
 
 // Load a [dim] parameter vector slice (mean, diagonal mass); `fill` in invalid slots.

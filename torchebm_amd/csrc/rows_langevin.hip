@@ -27,6 +27,8 @@ struct RowChainArgs {
   uint64_t step0;
   EnergyParams energy;
   int param_floats;
+  diag::DiagArgs diag;     // per-block diagnostics records at the kept steps (null: off)
+  int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
 };
 
 template <int KIND, int G, int NV, bool FULL, bool HEUN>
@@ -45,6 +47,8 @@ __device__ __forceinline__ void langevin_chain_rows_body(const RowChainArgs& a) 
   const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * a.dim : 0;
   int until_keep = a.thin;
   int64_t keep_off = 0;
+  int keep = 0;
+  const bool keeping = a.traj != nullptr || a.diag.partials != nullptr;
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
 
   for (int s = 0; s < a.k_steps; ++s) {
@@ -79,10 +83,20 @@ __device__ __forceinline__ void langevin_chain_rows_body(const RowChainArgs& a) 
         if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
         x.a[v][i] = L.ok(v, i) ? nv : 0.0f;
       }
-    if (a.traj && --until_keep == 0) {
+    if (keeping && --until_keep == 0) {
       until_keep = a.thin;
-      store_slice(L, a.traj, traj_row + keep_off, x);
-      keep_off += a.dim;
+      if (a.traj) {
+        store_slice(L, a.traj, traj_row + keep_off, x);
+        keep_off += a.dim;
+      }
+      if (a.diag.partials) {  // langevin_dynamics.py:170-185: mean / var of the population, mean energy
+        float* tile = rows_smem + a.diag_offset_floats;
+        tile_store(L, tile, x);
+        Slice<NV> g_unused;
+        const float e_now = en.template eval<true>(L, x, g_unused);
+        diag::emit(a.diag, keep, tile, tile_valid<G>(a.n_chains, a.dim), a.dim, (L.active && L.lg == 0) ? e_now : 0.0f, 0.0f);
+        ++keep;
+      }
     }
   }
   store_slice(L, a.x, row, x);
@@ -226,13 +240,34 @@ __global__ __launch_bounds__(kBlock) void energy_grad_wide_row_kernel(const floa
 
 }  // namespace
 
+// Lane geometry of the row-coupled Langevin chain for this energy / row width (shared by the launcher and the
+// diagnostics layout query, which must agree).
+static bool rows_langevin_geometry(const ebm_energy_t& e, int32_t dim, int heun, Geometry& geo, bool& lane_per_chain) {
+  if (!pick_geometry(dim, geo)) return false;
+  // small mixture, dim 16 / 32: one lane per chain, the means become wave-uniform scalar operands
+  // (rows.h: small_scalar_mu) -- no LDS traffic and no cross-lane reduction in the step loop
+  lane_per_chain = !heun && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8 && (dim == 16 || dim == 32);
+  if (lane_per_chain) geo = Geometry{1, dim / 4, true};
+  return true;
+}
+
+bool rows_langevin_diag_plan(const ebm_energy_t& e, int heun, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  Geometry geo;
+  bool lpc;
+  if (!rows_langevin_geometry(e, dim, heun, geo, lpc)) return false;
+  if (heun && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC)) return false;  // Heun element-wise: flat kernel only
+  return diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, d);
+}
+
 int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim,
                                int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                const float* coef_table, int clamp_on, float cmin, float cmax,
                                int32_t thin, float* traj, const float* noise, uint64_t seed,
-                               uint64_t offset, int heun, hipStream_t st) {
+                               uint64_t offset, int heun, float* diag_partials, hipStream_t st) {
   Geometry geo;
-  if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: dim %d > 1024 is not supported for this energy", dim);
+  bool lane_per_chain;
+  if (!rows_langevin_geometry(e, dim, heun, geo, lane_per_chain))
+    return fail(EBM_EDIM, "ebm_langevin_chain_f32: dim %d > 1024 is not supported for this energy", dim);
   RowChainArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
@@ -241,27 +276,31 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
-  // small mixture, dim 16 / 32: one lane per chain, the means become wave-uniform scalar operands
-  // (rows.h: small_scalar_mu) -- no LDS traffic and no cross-lane reduction in the step loop
-  const bool lane_per_chain = !heun && e.kind == EBM_ENERGY_GMM && e.n_comp <= 8 && (dim == 16 || dim == 32);
-  if (lane_per_chain) geo = Geometry{1, dim / 4, true};
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  a.diag_offset_floats = (int)(smem / sizeof(float));
+  if (diag_partials) {
+    if (!rows_langevin_diag_plan(e, heun, n_chains, dim, a.diag))
+      return fail(EBM_EDIM, "ebm_langevin_chain_f32: diagnostics records are not available for this energy / dim %d", dim);
+    a.diag.partials = diag_partials;
+    smem += (size_t)diag::lds_floats(a.diag.E, a.diag.S) * sizeof(float);
+  }
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks), block(kBlock);
   if (heun && e.kind == EBM_ENERGY_GAUSSIAN)
     EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
-  else if (heun)
+  else if (heun && e.kind == EBM_ENERGY_GMM)
     EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
+  else if (heun)
+    return fail(EBM_EKIND, "ebm_langevin_heun_chain_f32: element-wise energies run on the flat kernel");
   else if (lane_per_chain && dim == 32)
     hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 8, true>), grid, block, smem, st, a);
   else if (lane_per_chain)
     hipLaunchKernelGGL((langevin_chain_rows_kernel<EBM_ENERGY_GMM, 1, 4, true>), grid, block, smem, st, a);
-  else if (e.kind == EBM_ENERGY_GAUSSIAN)
-    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
   else
-    EBM_GEO_LAUNCH(langevin_chain_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
+    EBM_KIND_LAUNCH(langevin_chain_rows_kernel, e.kind, geo, grid, block, smem, st, a);
   return check_launch(heun ? "ebm_langevin_heun_chain_f32" : "ebm_langevin_chain_f32");
 }
 

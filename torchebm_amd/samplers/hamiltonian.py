@@ -367,25 +367,41 @@ class HamiltonianMonteCarlo(BaseSampler):
     # ---------------------------------------------------------------------------------
     # route: fused HIP kernel
     # ---------------------------------------------------------------------------------
-    def _launch_hmc(self, spec_c, state, n, dim, eps_vals, t0, n_mh, thin, traj, counts, seed, step, stream):
+    def _eps_table(self, eps_vals, device) -> Optional[torch.Tensor]:
+        if len(eps_vals) == 1:
+            return None
+        key = (device, tuple(eps_vals))
+        cached = getattr(self, "_table_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.tensor(eps_vals, dtype=torch.float32).to(device, non_blocking=True))
+            self._table_cache = cached
+        return cached[1]
+
+    def _launch_hmc(self, spec_c, state, n, dim, eps_vals, t0, n_mh, thin, traj, counts, seed, step, stream, records=None):
         kind, m_scalar, m_diag = _mass_args(self.mass, state)
         if len(eps_vals) == 1:
             eps, table = eps_vals[0], None
         else:
             eps = eps_vals[t0]
-            table = torch.tensor(eps_vals[t0 : t0 + n_mh], dtype=torch.float32).to(state.device, non_blocking=True)
+            table = self._eps_table(eps_vals, state.device)[t0 : t0 + n_mh]
         cptr = None if counts is None else counts.data_ptr() + 4 * t0
         _lib.call(
             "ebm_hmc_chain_f32",
             spec_c, _lib.ptr(state), n, dim, n_mh, self.n_leapfrog_steps, eps, _lib.ptr(table),
-            kind, m_scalar, _lib.ptr(m_diag), thin, _lib.ptr(traj), None, cptr, None, None,
+            kind, m_scalar, _lib.ptr(m_diag), thin, _lib.ptr(traj), _lib.ptr(records), None, cptr, None, None,
             seed, step, stream,
         )
+
+    #: see LangevinDynamics.donate_input / DIAG_RECORD_BYTES
+    donate_input: bool = False
+    DIAG_RECORD_BYTES = 1 << 30
 
     def _sample_fused(self, x, spec: FusedSpec, n_steps, thin, want_traj, want_diag, generator):
         n, dim = x.shape
         n_kept = n_steps // thin
-        state = _lib.dense_f32(x).clone()
+        state = _lib.dense_f32(x)
+        if state.data_ptr() == x.data_ptr() and not self.donate_input:
+            state = state.clone()  # the kernel updates in place; never touch the caller's tensor unless it was donated
         traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
         sched = self.schedulers["step_size"]
         eps_vals = [sched.get_value()] if sched.is_constant() else sched.preview(n_steps)
@@ -394,37 +410,73 @@ class HamiltonianMonteCarlo(BaseSampler):
         spec_c = spec.to_c()
 
         if n_steps > 0 and n > 0:
-            if not want_diag:
+            layout = _lib.diag_layout(spec_c, _lib.DIAG_HMC, n, dim, False, want_traj) if (want_diag and n_kept > 0) else None
+            if not want_diag or n_kept == 0:
                 self._launch_hmc(spec_c, state, n, dim, eps_vals, 0, n_steps, thin, traj, None, seed, step0, stream)
+            elif layout is not None:
+                self._fused_with_records(spec_c, state, n, dim, eps_vals, n_steps, thin, traj, diag, layout, seed, step0, stream)
             else:
-                counts = torch.zeros(n_steps, dtype=torch.int32, device=x.device)  # uint32 bit pattern
-                work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=x.device)  # the kernel leaves it zeroed
-                energy = torch.empty(n, dtype=torch.float32, device=x.device)
-                done = 0
-                for keep in range(n_kept):
-                    self._launch_hmc(
-                        spec_c, state, n, dim, eps_vals, done, thin, thin, None, counts, seed, step0 + 2 * done, stream
-                    )
-                    done += thin
-                    if traj is not None:
-                        traj[:, keep, :] = state
-                    if n > 1:
-                        _lib.call(
-                            "ebm_chain_stats_f32",
-                            _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
-                            _lib.ptr(work), stream,
-                        )
-                    else:
-                        diag["mean"][keep] = state[0]
-                        diag["var"][keep].zero_()
-                    _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
-                    diag["energy"][keep] = energy.clamp_(min=-1e10, max=1e10).mean()
-                    diag["acceptance_rate"][keep] = counts[done - 1].to(torch.float32) / n
-                if done < n_steps:
-                    self._launch_hmc(
-                        spec_c, state, n, dim, eps_vals, done, n_steps - done, thin, None, None, seed,
-                        step0 + 2 * done, stream,
-                    )
+                self._fused_with_state_passes(spec_c, state, n, dim, eps_vals, n_steps, thin, traj, diag, seed, step0, stream)
         self.advance_schedulers(n_steps)
         out = traj if want_traj else state
         return (out, diag) if want_diag else out
+
+    def _fused_with_records(self, spec_c, state, n, dim, eps_vals, n_steps, thin, traj, diag, layout, seed, step0, stream):
+        """Diagnostics from inside the transition kernel (include/ebm_hip.h: ``diag_partials``): at every kept
+        transition each workgroup stores one record (column sums / M2, the energy of the states its chains hold,
+        its accept count); ``ebm_diag_finish_f32`` merges them.  One chain launch + one merge launch per call."""
+        n_blocks, slots, block_elems = layout
+        n_kept = n_steps // thin
+        rec_floats = n_blocks * (2 * slots + 2)
+        chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
+        records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
+        work = torch.zeros(chunk * (3 * dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        done_keep, done = 0, 0
+        while done_keep < n_kept:
+            kk = min(chunk, n_kept - done_keep)
+            n_mh = kk * thin
+            if done_keep + kk == n_kept:
+                n_mh = n_steps - done  # trailing n_steps % thin transitions ride along
+            whole = traj is not None and kk == n_kept
+            piece = traj if (traj is None or whole) else torch.empty(n, kk, dim, dtype=torch.float32, device=state.device)
+            self._launch_hmc(spec_c, state, n, dim, eps_vals, done, n_mh, thin, piece, None, seed, step0 + 2 * done, stream,
+                             records=records)
+            if traj is not None and not whole:
+                traj[:, done_keep : done_keep + kk] = piece
+            sl = slice(done_keep, done_keep + kk)
+            _lib.call(
+                "ebm_diag_finish_f32", _lib.ptr(records), kk, n_blocks, slots, block_elems, n, dim,
+                _lib.ptr(diag["mean"][sl]), _lib.ptr(diag["var"][sl]), _lib.ptr(diag["energy"][sl]),
+                _lib.ptr(diag["acceptance_rate"][sl]), _lib.ptr(work), stream,
+            )
+            done_keep += kk
+            done += n_mh
+
+    def _fused_with_state_passes(self, spec_c, state, n, dim, eps_vals, n_steps, thin, traj, diag, seed, step0, stream):
+        """Diagnostics for energies without in-kernel records (the MLP energy's matrix-layout kernel): one launch
+        per ``thin`` transitions, then the column-statistics and energy kernels on the state."""
+        n_kept = n_steps // thin
+        counts = torch.zeros(n_steps, dtype=torch.int32, device=state.device)  # uint32 bit pattern
+        work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=state.device)  # the kernel leaves it zeroed
+        energy = torch.empty(n, dtype=torch.float32, device=state.device)
+        done = 0
+        for keep in range(n_kept):
+            self._launch_hmc(spec_c, state, n, dim, eps_vals, done, thin, thin, None, counts, seed, step0 + 2 * done, stream)
+            done += thin
+            if traj is not None:
+                traj[:, keep, :] = state
+            if n > 1:
+                _lib.call(
+                    "ebm_chain_stats_f32",
+                    _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
+                    _lib.ptr(work), stream,
+                )
+            else:
+                diag["mean"][keep] = state[0]
+                diag["var"][keep].zero_()
+            _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
+            diag["energy"][keep] = energy.clamp_(min=-1e10, max=1e10).mean()
+            diag["acceptance_rate"][keep] = counts[done - 1].to(torch.float32) / n
+        if done < n_steps:
+            self._launch_hmc(spec_c, state, n, dim, eps_vals, done, n_steps - done, thin, None, None, seed,
+                             step0 + 2 * done, stream)

@@ -25,11 +25,11 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import torch
 
 from .. import _lib, _rng
-from ..core.energies import FUSED_MAX_ROW, BaseModel, FusedSpec, fused_spec_for
+from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSDERungeKuttaIntegrator
 from ..core.module import warn_once
 from ..core.sampler_base import BaseSampler
-from ..core.schedules import BaseScheduler, Schedulable
+from ..core.schedules import BaseScheduler
 from ..integrators.em import EulerMaruyamaIntegrator, HeunIntegrator
 from ..integrators.registry import resolve_integrator
 
@@ -327,71 +327,125 @@ class LangevinDynamics(BaseSampler):
         etas, sigmas = s_eta.preview(k), s_sig.preview(k)
         return False, [em_coefficients(e, s) for e, s in zip(etas, sigmas)]
 
-    def _launch_chain(self, spec_c, x, n, dim, rows, row0, k, thin, traj, seed, step, stream):
+    def _coef_table(self, rows, device) -> Optional[torch.Tensor]:
+        """Device table ``float[k][4]`` of a non-constant schedule, kept for the next call with the same schedule
+        (a training loop calls ``sample`` with an unchanged scheduler thousands of times)."""
+        if len(rows) == 1:
+            return None
+        key = (device, tuple(rows))
+        cached = getattr(self, "_table_cache", None)
+        if cached is None or cached[0] != key:
+            host = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32)
+            cached = (key, host.to(device, non_blocking=True))
+            self._table_cache = cached
+        return cached[1]
+
+    def _launch_chain(self, spec_c, x, n, dim, rows, row0, k, thin, traj, seed, step, stream, table=None, records=None):
         """One ``ebm_langevin_chain_f32`` launch for steps [row0, row0+k) of ``rows``."""
         clamp_on, cmin, cmax = self._clamp_args()
         if len(rows) == 1:  # constant schedule: scalars, no table
             a, sq, coef = rows[0]
-            table = None
+            tab = None
         else:
             a, sq, coef = rows[row0]
-            host = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows[row0 : row0 + k]], dtype=torch.float32)
-            table = host.to(x.device, non_blocking=True)
+            tab = (self._coef_table(rows, x.device) if table is None else table)[row0 : row0 + k]
         entry = "ebm_langevin_heun_chain_f32" if type(self.integrator) is HeunIntegrator else "ebm_langevin_chain_f32"
         _lib.call(
             entry,
-            spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(table),
-            clamp_on, cmin, cmax, thin, _lib.ptr(traj), None, seed, step, stream,
+            spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(tab),
+            clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(records), None, seed, step, stream,
         )
 
+    #: Opt-in: let the fused route update the caller's ``x`` in place and return it (no defensive copy of the
+    #: state -- 256 MiB per call at BASELINE config 2).  Off by default: the reference never mutates its input.
+    donate_input: bool = False
+
+    #: upper bound on the bytes of per-block diagnostics records held at once; longer runs are cut into several
+    #: launches at kept-step boundaries (the state is re-read once per cut)
+    DIAG_RECORD_BYTES = 1 << 30
+
     def _sample_fused(self, x, spec: FusedSpec, n_steps, thin, want_traj, want_diag, generator):
-        shape = tuple(x.shape[1:])
-        n = x.shape[0]
-        dim = 1
-        for s in shape:
-            dim *= s
+        n, dim = x.shape
         n_kept = n_steps // thin
-        state = _lib.dense_f32(x).clone()  # the kernel updates in place; never touch the caller's tensor
+        state = _lib.dense_f32(x)
+        if state.data_ptr() == x.data_ptr() and not self.donate_input:
+            state = state.clone()  # the kernel updates in place; never touch the caller's tensor unless it was donated
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         _, rows = self._coef_rows(n_steps)
         seed, step0 = _rng.reserve(generator, x.device, n_steps)
         stream = _lib.stream_handle(x.device)
         spec_c = spec.to_c()
+        heun = type(self.integrator) is HeunIntegrator
 
         if n_steps > 0 and n > 0:
-            if not want_diag:
+            layout = None
+            if want_diag and n_kept > 0:
+                layout = _lib.diag_layout(spec_c, _lib.DIAG_LANGEVIN_HEUN if heun else _lib.DIAG_LANGEVIN, n, dim, False, want_traj)
+            if not want_diag or n_kept == 0:
                 # one launch for the whole call; thinned rows are stored by the kernel
                 self._launch_chain(spec_c, state, n, dim, rows, 0, n_steps, thin, traj, seed, step0, stream)
+            elif layout is not None:
+                self._fused_with_records(spec_c, state, n, dim, rows, n_steps, thin, traj, diag, layout, seed, step0, stream)
             else:
-                # diagnostics need the whole population at every kept step: one launch per
-                # `thin` steps, then the column-statistics and energy kernels
-                work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=x.device)  # the kernel leaves it zeroed
-                energy = torch.empty(n, dtype=torch.float32, device=x.device)
-                done = 0
-                for keep in range(n_kept):
-                    self._launch_chain(spec_c, state, n, dim, rows, done, thin, thin, None, seed, step0 + done, stream)
-                    done += thin
-                    if traj is not None:
-                        traj[:, keep] = state.view(n, *shape)
-                    if n > 1:
-                        _lib.call(
-                            "ebm_chain_stats_f32",
-                            _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
-                            _lib.ptr(work), stream,
-                        )
-                    else:
-                        diag["mean"][keep] = state.view(*shape)
-                        diag["var"][keep].zero_()
-                    if state.ndim == 2:
-                        _lib.call(
-                            "ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream
-                        )
-                        diag["energy"][keep] = energy.mean()
-                    else:  # >2-D state: the model's own reduction over the last axis defines "energy"
-                        diag["energy"][keep] = self._model_energy(state, {}).mean()
-                if done < n_steps:
-                    self._launch_chain(spec_c, state, n, dim, rows, done, n_steps - done, thin, None, seed, step0 + done, stream)
+                self._fused_with_state_passes(spec_c, state, n, dim, rows, n_steps, thin, traj, diag, seed, step0, stream)
         self.advance_schedulers(n_steps)
-        final = state.view(n, *shape)
-        out = traj if want_traj else final
+        out = traj if want_traj else state
         return (out, diag) if want_diag else out
+
+    def _fused_with_records(self, spec_c, state, n, dim, rows, n_steps, thin, traj, diag, layout, seed, step0, stream):
+        """Diagnostics from inside the chain launch (include/ebm_hip.h: ``diag_partials``): every workgroup stores
+        one record of its chains' partial sums per kept step, ``ebm_diag_finish_f32`` merges them.  One chain
+        launch + one merge launch per call (several only when the records of all kept steps would not fit
+        ``DIAG_RECORD_BYTES``)."""
+        n_blocks, slots, block_elems = layout
+        n_kept = n_steps // thin
+        rec_floats = n_blocks * (2 * slots + 2)
+        chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
+        records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
+        work = torch.zeros(chunk * (3 * dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        done_keep, done_steps = 0, 0
+        while done_keep < n_kept:
+            kk = min(chunk, n_kept - done_keep)
+            steps = kk * thin
+            if done_keep + kk == n_kept:
+                steps = n_steps - done_steps  # the trailing n_steps % thin steps ride along (no kept step among them)
+            whole = traj is not None and kk == n_kept
+            piece = traj if (traj is None or whole) else torch.empty(n, kk, dim, dtype=torch.float32, device=state.device)
+            self._launch_chain(spec_c, state, n, dim, rows, done_steps, steps, thin, piece, seed, step0 + done_steps, stream,
+                               records=records)
+            if traj is not None and not whole:
+                traj[:, done_keep : done_keep + kk] = piece
+            _lib.call(
+                "ebm_diag_finish_f32", _lib.ptr(records), kk, n_blocks, slots, block_elems, n, dim,
+                _lib.ptr(diag["mean"][done_keep : done_keep + kk]), _lib.ptr(diag["var"][done_keep : done_keep + kk]),
+                _lib.ptr(diag["energy"][done_keep : done_keep + kk]), None, _lib.ptr(work), stream,
+            )
+            done_keep += kk
+            done_steps += steps
+
+    def _fused_with_state_passes(self, spec_c, state, n, dim, rows, n_steps, thin, traj, diag, seed, step0, stream):
+        """Diagnostics for the configurations without in-kernel records (the matrix-layout kernels of the MLP
+        energy, rows that neither divide nor are divided by the flat kernel's 1024-element blocks): one launch per
+        ``thin`` steps, then the column-statistics and energy kernels on the state."""
+        n_kept = n_steps // thin
+        work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=state.device)  # the kernel leaves it zeroed
+        energy = torch.empty(n, dtype=torch.float32, device=state.device)
+        done = 0
+        for keep in range(n_kept):
+            self._launch_chain(spec_c, state, n, dim, rows, done, thin, thin, None, seed, step0 + done, stream)
+            done += thin
+            if traj is not None:
+                traj[:, keep] = state
+            if n > 1:
+                _lib.call(
+                    "ebm_chain_stats_f32",
+                    _lib.ptr(state), n, dim, _lib.ptr(diag["mean"][keep]), _lib.ptr(diag["var"][keep]),
+                    _lib.ptr(work), stream,
+                )
+            else:
+                diag["mean"][keep] = state[0]
+                diag["var"][keep].zero_()
+            _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
+            diag["energy"][keep] = energy.mean()
+        if done < n_steps:
+            self._launch_chain(spec_c, state, n, dim, rows, done, n_steps - done, thin, None, seed, step0 + done, stream)
