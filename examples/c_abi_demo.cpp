@@ -70,7 +70,7 @@ int main() {
   EBM_OK(ebm_diag_layout(&e, EBM_DIAG_LANGEVIN, n, dim, 0, 0, &n_blocks, &slots, &block_elems));
   float *records, *d_mean, *d_var, *d_energy;
   double* work;
-  HIP_OK(hipMalloc(&records, (size_t)n_blocks * (2 * slots + 2) * sizeof(float)));
+  HIP_OK(hipMalloc(&records, (size_t)n_blocks * (2 * slots + 8) * sizeof(float)));
   HIP_OK(hipMalloc(&d_mean, dim * sizeof(float)));
   HIP_OK(hipMalloc(&d_var, dim * sizeof(float)));
   HIP_OK(hipMalloc(&d_energy, sizeof(float)));

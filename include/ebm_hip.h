@@ -272,7 +272,7 @@ EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, con
  *   sampler: EBM_DIAG_LANGEVIN / EBM_DIAG_LANGEVIN_HEUN / EBM_DIAG_HMC;  injected_noise / with_traj: whether the
  *   chain call will pass a noise / trajectory pointer (they select the kernel family);
  *   outputs: n_blocks (records per kept step), slots S and block_elems E.  The caller allocates
- *   diag_partials = float[n_kept][n_blocks][2*S + 2] and work = double[n_kept][3*dim + 3] (zeroed once; the merge
+ *   diag_partials = float[n_kept][n_blocks][2*S + 8] and work = double[n_kept][3*dim + 3] (zeroed once; the merge
  *   leaves it zeroed).  Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
  *   statistics from the state with ebm_chain_stats_f32 / ebm_energy_grad_f32 between launches).
  * ebm_diag_finish_f32: mean_out / var_out = float[n_kept][dim] (biased variance clamped to [1e-10, 1e10], zero for a

@@ -202,7 +202,7 @@ def test_c_abi_layout_and_injected_noise_records(cuda_device):
     layout = _lib.diag_layout(c, _lib.DIAG_LANGEVIN, n, dim, True, False)
     assert layout == (32, 64, 1024)  # injected noise: lane-group kernel, 16 lanes per chain -> 16 rows per block
     nb, S, E = layout
-    rec = torch.empty(3 * nb * (2 * S + 2), device=cuda_device)
+    rec = torch.empty(3 * nb * (2 * S + 8), device=cuda_device)
     work = torch.zeros(3 * (3 * dim + 3), dtype=torch.float64, device=cuda_device)
     x, nz = x0.to(cuda_device), noise.to(cuda_device)
     st = _lib.stream_handle(cuda_device)

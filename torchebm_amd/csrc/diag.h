@@ -12,13 +12,16 @@
 // (whole rows) or dim % E == 0 (a row is several blocks).  S = min(dim, E) slots; slot s collects the block's
 // elements s, s + dim, s + 2 dim, ... (the block's rows of one column; exactly one element when dim >= E).
 //
-// Record of block b at kept step j:  rec = partials + (j * n_blocks + b) * (2 S + 2)
-//   rec[s]        sum of the slot's elements
-//   rec[S + s]    M2 = sum (x - slot mean)^2      (two-pass inside the block: no cancellation)
-//   rec[2 S]      sum of the block's per-chain energies      rec[2 S + 1]  number of accepted chains (HMC)
+// Record of block b at kept step j:  rec = partials + (j * n_blocks + b) * (2 S + 8)
+//   rec[s]             sum of the slot's elements
+//   rec[S + s]         M2 = sum (x - slot mean)^2      (two-pass inside the block: no cancellation)
+//   rec[2 S + 0 .. 3]  four shares of the block's energy sum (one per wave on the fast path; share 0 otherwise)
+//   rec[2 S + 4 .. 7]  four shares of the block's accept count (HMC)
 // The finishing kernel merges (count, sum, M2) triples with the pairwise-variance identity in fp64, so the
 // result does not depend on how far the population mean is from zero.  Deterministic: same launch, same bits.
 #pragma once
+#include <type_traits>
+
 #include "ebm_common.h"
 
 namespace ebm {
@@ -34,6 +37,7 @@ struct DiagArgs {
 constexpr int kBlock = 256;
 constexpr int kMaxPart = 16;  // row partitions per slot (small dims: several threads share a slot)
 
+__host__ __device__ inline int record_floats(int S) { return 2 * S + 8; }
 __host__ __device__ inline int scratch_floats(int S) { return 2 * (S > kBlock ? S : kBlock) + 8; }
 // LDS floats emit() needs behind the caller's own LDS: the tile, two scratch rows, eight wave partials
 __host__ __device__ inline int lds_floats(int E, int S) { return E + scratch_floats(S); }
@@ -91,7 +95,7 @@ __device__ __noinline__ void emit(const DiagArgs d, int keep, float* tile, int L
     }
   }
   __syncthreads();
-  float* rec = d.partials + ((int64_t)keep * d.n_blocks + blockIdx.x) * (int64_t)(2 * S + 2);
+  float* rec = d.partials + ((int64_t)keep * d.n_blocks + blockIdx.x) * (int64_t)record_floats(S);
   if (p == 0) {
     for (int s = s0; s < S; s += SP) {
       float tot = 0.0f, m2 = 0.0f;
@@ -103,11 +107,75 @@ __device__ __noinline__ void emit(const DiagArgs d, int keep, float* tile, int L
       rec[S + s] = m2;
     }
   }
-  if (tid == 0) {
-    rec[2 * S] = (red[0] + red[1]) + (red[2] + red[3]);
-    rec[2 * S + 1] = (red[4] + red[5]) + (red[6] + red[7]);
-  }
+  if (tid < 8) rec[2 * S + tid] = red[tid];  // the four waves' energy shares, then their accept shares
   __syncthreads();  // everyone is done with the tile and the scratch rows
+}
+
+// Fast path of the flat element-wise kernel for dim = 4 .. 256, a power of two (1024 % dim == 0).  Every lane drops
+// its float4 into an LDS tile, ONE barrier (two alternating tiles), then every wave reduces its own QUARTER OF THE
+// COLUMNS over all rows of the tile: wave w owns columns [w dim/4, (w+1) dim/4), 64 / (dim/4) lanes share a
+// column and each reads 4 rows; sum, xor-shuffle across the sharing lanes, mean, squared deviations, shuffle
+// again; the first dim/4 lanes store the wave's part of the record.  All four waves do the same ~70 instructions,
+// so none of them lags at the next barrier (a reduction left to ONE wave is time-sliced with the seven other
+// waves of its SIMD and holds its workgroup back eight times its own length).
+//   x4: the lane's elements; L: valid flat elements of this workgroup; rows_b = L / dim;
+//   lds: 2 * fast_lds_floats() floats.
+__host__ __device__ inline bool fast_flat_ok(int dim) { return dim >= 4 && dim <= 256 && (dim & (dim - 1)) == 0; }
+__host__ __device__ inline int fast_lds_floats() { return 1024; }
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // total in every lane of rows 0 / 2; used from lane 0
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ void emit_flat_fast(const DiagArgs d, int keep, float* lds, int dim, float4 x4, int L, int rows_b,
+                                               float e_part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* tile = lds + (keep & 1) * fast_lds_floats();
+  *reinterpret_cast<float4*>(tile + 4 * tid) = x4;
+  // ONE barrier: the tiles alternate with the kept step, and no wave can reach the barrier of the step after next
+  // (behind which this tile is written again) before it has finished reading here
+  __syncthreads();
+  const int cw = dim >> 2;        // columns per wave (1 .. 64)
+  const int lpc = 64 / cw;        // lanes per column; each takes rows lane / cw + lpc * i, i < 4
+  const int col = wave * cw + (lane & (cw - 1));
+  const int r0 = lane / cw;
+  float v[4];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = (r0 + lpc * i) * dim + col;
+    ok[i] = e < L;
+    v[i] = ok[i] ? tile[e] : 0.0f;
+  }
+  float sum = (v[0] + v[1]) + (v[2] + v[3]);
+  for (int m = cw; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+  const float mu = rows_b > 0 ? sum / (float)rows_b : 0.0f;
+  float m2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float dv = ok[i] ? v[i] - mu : 0.0f;
+    m2 = __builtin_fmaf(dv, dv, m2);
+  }
+  for (int m = cw; m < 64; m <<= 1) m2 += __shfl_xor(m2, m);
+  float* rec = d.partials + ((int64_t)keep * d.n_blocks + blockIdx.x) * (int64_t)record_floats(d.S);
+  if (lane < cw) {
+    rec[col] = sum;
+    rec[d.S + col] = m2;
+  }
+  const float e = wave_sum_dpp(e_part);
+  if (lane == 0) {  // tail: four per-wave energy shares, four accept shares
+    rec[2 * d.S + wave] = e;
+    rec[2 * d.S + 4 + wave] = 0.0f;
+  }
 }
 
 // host side: the layout of a launch that covers `block_elems` flat elements per workgroup

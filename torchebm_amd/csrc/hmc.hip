@@ -15,6 +15,11 @@ void launch_double_well(const rows::Geometry&, dim3, size_t, hipStream_t, const 
 void launch_harmonic(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 void launch_gaussian(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 void launch_gmm(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+// ... and the variants that emit diagnostics records at the kept transitions (hmc_*_diag.hip)
+void launch_double_well_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+void launch_harmonic_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+void launch_gaussian_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+void launch_gmm_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 }  // namespace hmc
 using hmc::HmcArgs;
 
@@ -92,6 +97,15 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks);
+  if (diag_partials) {
+    switch (e.kind) {
+      case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well_diag(geo, grid, smem, st, a); break;
+      case EBM_ENERGY_HARMONIC:    hmc::launch_harmonic_diag(geo, grid, smem, st, a); break;
+      case EBM_ENERGY_GAUSSIAN:    hmc::launch_gaussian_diag(geo, grid, smem, st, a); break;
+      default:                     hmc::launch_gmm_diag(geo, grid, smem, st, a); break;
+    }
+    return check_launch("ebm_hmc_chain_f32");
+  }
   switch (e.kind) {
     case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well(geo, grid, smem, st, a); break;
     case EBM_ENERGY_HARMONIC:    hmc::launch_harmonic(geo, grid, smem, st, a); break;

@@ -4,7 +4,7 @@
 namespace ebm {
 namespace hmc {
 void launch_gmm(const rows::Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
-  launch_kind<EBM_ENERGY_GMM>(geo, grid, smem, st, a);
+  launch_kind<EBM_ENERGY_GMM, false>(geo, grid, smem, st, a);
 }
 }  // namespace hmc
 }  // namespace ebm

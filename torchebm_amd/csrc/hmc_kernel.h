@@ -133,7 +133,9 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 // MASS: 0 = identity mass (no mass registers at all), 1 = scalar or diagonal mass (three
 // per-slot forms kept in VGPRs).  XC_LDS: park the accepted state in a lane-private LDS slot
 // while the proposal is integrated (wide rows: frees 4*NV VGPRs).
-template <int KIND, int G, int NV, bool FULL, int MASS>
+// DIAG: emit the per-block diagnostics records at the kept transitions (a compile-time switch: the call into
+// diag::emit cost the one-lane-per-chain mixture kernel 4 % through register pressure even when never taken).
+template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   using LaneT = Lane<G, NV, FULL>;
   constexpr bool XC_LDS = NV >= 4;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   int until_keep = a.thin;
   int64_t keep_off = 0;
   int keep = 0;
-  const bool keeping = a.traj != nullptr || a.diag.partials != nullptr;
+  const bool keeping = a.traj != nullptr || DIAG;
   float eps = a.eps;
 
   for (int t = 0; t < a.n_mh; ++t) {
@@ -281,7 +283,7 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
         store_slice(L, a.traj, traj_row + keep_off, xc);
         keep_off += a.dim;
       }
-      if (a.diag.partials) {
+      if constexpr (DIAG) {
         // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain
         // holds now (its accepted proposal's E1, else E0 -- what the reference re-evaluates), acceptance rate
         float* tile = hmc_smem + a.diag_offset_floats;
@@ -296,25 +298,25 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   store_slice(L, a.x, row, xc);
 }
 
-template <int KIND, int G, int NV, bool FULL, int MASS>
+template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
-  hmc_chain_body<KIND, G, NV, FULL, MASS>(a);
+  hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG>(a);
 }
 
 // Same body held to 256 VGPRs (two waves per SIMD).  For the one-lane-per-chain mixture kernel:
 // its leapfrog loop fits, only the cold paths (prologue, large-K fallback, scrub) spill, and the
 // second wave is worth 1.56 -> 1.22 ms on BASELINE config 3.  (A template-dependent expression in
 // __launch_bounds__ is silently ignored by hipcc 7.2, hence the second entry point.)
-template <int KIND, int G, int NV, bool FULL, int MASS>
+template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
-  hmc_chain_body<KIND, G, NV, FULL, MASS>(a);
+  hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG>(a);
 }
 
-// KERNEL<KIND, G, NV, FULL, MASS> over the runtime geometry (see rows.h: EBM_GEO_LAUNCH)
-template <int KIND, int MASS>
+// KERNEL<KIND, G, NV, FULL, MASS, DIAG> over the runtime geometry (see rows.h: EBM_GEO_LAUNCH)
+template <int KIND, int MASS, bool DIAG>
 void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
   const dim3 block(kBlock);
-#define EBM_HMC_G(GV, NVV, FULLV) hipLaunchKernelGGL((hmc_chain_kernel<KIND, GV, NVV, FULLV, MASS>), grid, block, smem, st, a)
+#define EBM_HMC_G(GV, NVV, FULLV) hipLaunchKernelGGL((hmc_chain_kernel<KIND, GV, NVV, FULLV, MASS, DIAG>), grid, block, smem, st, a)
   if (geo.NV == 1) {
     switch (geo.G) {
       case 1:  if (geo.full) EBM_HMC_G(1, 1, true);  else EBM_HMC_G(1, 1, false);  break;
@@ -339,17 +341,17 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
   } else if (geo.G == 2 && geo.NV == 4) {
     EBM_HMC_G(2, 4, true);
   } else if constexpr (KIND == EBM_ENERGY_GMM) {
-    hipLaunchKernelGGL((hmc_chain_kernel_w2<KIND, 1, 8, true, MASS>), grid, block, smem, st, a);
+    hipLaunchKernelGGL((hmc_chain_kernel_w2<KIND, 1, 8, true, MASS, DIAG>), grid, block, smem, st, a);
   } else {
     EBM_HMC_G(1, 8, true);
   }
 #undef EBM_HMC_G
 }
 
-template <int KIND>
+template <int KIND, bool DIAG>
 void launch_kind(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
-  if (a.mass_kind == EBM_MASS_NONE) launch_geo<KIND, 0>(geo, grid, smem, st, a);
-  else launch_geo<KIND, 1>(geo, grid, smem, st, a);
+  if (a.mass_kind == EBM_MASS_NONE) launch_geo<KIND, 0, DIAG>(geo, grid, smem, st, a);
+  else launch_geo<KIND, 1, DIAG>(geo, grid, smem, st, a);
 }
 
 }  // namespace hmc

@@ -33,11 +33,12 @@ int launch_langevin_chain_elem_diag(int kind, float s0, float s1, float* x, int6
   a.diag.partials = diag_partials;
   if (a.diag.n_blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: state too large for one launch", who);
   const dim3 grid((unsigned)a.diag.n_blocks), block(kBlock);
-  const size_t smem = (size_t)diag::lds_floats(a.diag.E, a.diag.S) * sizeof(float);
+  const int lds_generic = diag::lds_floats(a.diag.E, a.diag.S), lds_fast = 2 * diag::fast_lds_floats();
+  const size_t smem = (size_t)(diag::fast_flat_ok(dim) ? lds_fast : lds_generic) * sizeof(float);
 #define EBM_D_T(KIND, TB, CL, HE)                                                                                     \
   do {                                                                                                               \
-    if (traj) hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, TB, CL, true, HE, true>), grid, block, smem, st, a);   \
-    else hipLaunchKernelGGL((langevin_chain_lean_kernel<KIND, TB, CL, false, HE, true>), grid, block, smem, st, a);       \
+    if (traj) hipLaunchKernelGGL((langevin_chain_lean_diag_kernel<KIND, TB, CL, true, HE>), grid, block, smem, st, a);   \
+    else hipLaunchKernelGGL((langevin_chain_lean_diag_kernel<KIND, TB, CL, false, HE>), grid, block, smem, st, a);       \
   } while (0)
 #define EBM_D_H(KIND, HE)                                       \
   do {                                                          \

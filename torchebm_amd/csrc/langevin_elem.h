@@ -94,11 +94,12 @@ extern __shared__ __attribute__((aligned(16))) float elem_smem[];
 // config 2; the loop is VALU-issue bound at 8 waves/SIMD either way).
 // ---------------------------------------------------------------------------------
 // DIAG: at every kept step the workgroup also reduces its 1024 elements to one diagnostics record (diag.h):
-// the lane's float4 goes to an LDS tile, the block's column sums / M2 and its energy sum are stored -- the
-// population statistics of return_diagnostics=True without leaving the k-step launch.  Lanes past the end of
-// the state stay in the loop (they take part in the workgroup barriers) with nothing to load or store.
-template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN = false, bool DIAG = false>
-__global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
+// the block's column sums / M2 and its energy sum are stored -- the population statistics of
+// return_diagnostics=True without leaving the k-step launch.  Lanes past the end of the state stay in the
+// loop (they take part in the workgroup barriers) with nothing to load or store.  The k steps are then walked
+// as n_kept runs of `thin` steps (the hot inner loop is the plain one, unrolled by two).
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN, bool DIAG>
+__device__ __forceinline__ void lean_body(const ChainArgs& a) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e0 = g * 4;
   if constexpr (!DIAG) {
@@ -108,17 +109,13 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
   const int nv = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
   F4 x = load4(a.x, e0 < a.n_elem ? e0 : 0, nv, true);
   StepCoef c = a.c;
-  // TRAJ / DIAG (dim % 4 == 0 or dim < 4 dividing 4: a lane's float4 never straddles two kept rows unevenly):
-  // traj[c, j, d..d+3]
+  // TRAJ (dim % 4 == 0 only, so a lane's float4 never straddles two chains): traj[c, j, d..d+3]
   float* tptr = nullptr;
-  int until_keep = a.thin;
-  int keep = 0;
   if constexpr (TRAJ) {
     const int64_t chain = e0 / a.dim;
     tptr = a.traj + chain * (int64_t)a.n_kept * a.dim + (e0 - chain * a.dim);
   }
-#pragma unroll 2  // measured: 9.00 -> 8.83 ms on config 2 (4 gives no more)
-  for (int i = 0; i < a.k_steps; ++i) {
+  auto one_step = [&](int i) {
     if constexpr (TABLE) {  // wave-uniform: scalar loads
       const float4 t = a.table[i];
       c.eta = t.x; c.sqrt_eta = t.y; c.noise_coef = t.z;
@@ -146,32 +143,67 @@ __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a
       x.v[q] = nv2.x;
       x.v[q + 1] = nv2.y;
     }
-    if constexpr (TRAJ || DIAG) {
-      if (--until_keep == 0) {  // wave-uniform
-        until_keep = a.thin;
-        if constexpr (TRAJ) {
-          if (nv == 4) *reinterpret_cast<float4*>(tptr) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  };
+  if constexpr (!DIAG) {
+    int until_keep = a.thin;
+#pragma unroll 2  // measured: 9.00 -> 8.83 ms on config 2 (4 gives no more)
+    for (int i = 0; i < a.k_steps; ++i) {
+      one_step(i);
+      if constexpr (TRAJ) {
+        if (--until_keep == 0) {  // wave-uniform
+          until_keep = a.thin;
+          *reinterpret_cast<float4*>(tptr) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
           tptr += a.dim;
-        }
-        if constexpr (DIAG) {
-          *reinterpret_cast<float4*>(elem_smem + 4 * threadIdx.x) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
-          float e_part = 0.0f;  // sum over the lane's elements of the per-coordinate energy term
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float t;
-            if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) { const float u = x.v[q] * x.v[q] - a.s1; t = u * u; }
-            else t = x.v[q] * x.v[q];
-            e_part += (q < nv) ? t : 0.0f;
-          }
-          const int64_t block_e0 = (int64_t)blockIdx.x * (kBlock * 4);
-          const int64_t rest = a.n_elem - block_e0;
-          diag::emit(a.diag, keep, elem_smem, rest >= kBlock * 4 ? kBlock * 4 : (int)rest, a.dim, a.s0 * e_part, 0.0f);
-          ++keep;
         }
       }
     }
+  } else {
+    const int64_t block_e0 = (int64_t)blockIdx.x * (kBlock * 4);
+    const int64_t rest = a.n_elem - block_e0;
+    const int L = rest >= kBlock * 4 ? kBlock * 4 : (int)rest;  // valid elements of this workgroup
+    const bool fast = diag::fast_flat_ok(a.dim);
+    const int rows_b = L / a.dim;
+    int i = 0;
+    for (int keep = 0; keep < a.n_kept; ++keep) {
+      const int stop = i + a.thin;
+#pragma unroll 2
+      for (; i < stop; ++i) one_step(i);
+      if constexpr (TRAJ) {
+        if (nv == 4) *reinterpret_cast<float4*>(tptr) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        tptr += a.dim;
+      }
+      float e_part = 0.0f;  // sum over the lane's elements of the per-coordinate energy term
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t;
+        if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) { const float u = x.v[q] * x.v[q] - a.s1; t = u * u; }
+        else t = x.v[q] * x.v[q];
+        e_part += (q < nv) ? t : 0.0f;
+      }
+      if (fast) {
+        diag::emit_flat_fast(a.diag, keep, elem_smem, a.dim, make_float4(x.v[0], x.v[1], x.v[2], x.v[3]), L, rows_b, a.s0 * e_part);
+      } else {
+        *reinterpret_cast<float4*>(elem_smem + 4 * threadIdx.x) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        diag::emit(a.diag, keep, elem_smem, L, a.dim, a.s0 * e_part, 0.0f);
+      }
+    }
+#pragma unroll 2
+    for (; i < a.k_steps; ++i) one_step(i);  // the trailing k % thin steps
   }
   if (nv > 0) store4(a.x, e0, nv, true, x);
+}
+
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN = false>
+__global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
+  lean_body<KIND, TABLE, CLAMP, TRAJ, HEUN, false>(a);
+}
+
+// The DIAG form, held to 64 VGPRs (8 waves per SIMD like the plain kernel: the out-of-line generic emit() would
+// otherwise set the kernel's register count to 80 and cost the step loop 4 %).  A template-dependent expression in
+// __launch_bounds__ is ignored by hipcc 7.2, hence the second entry point.
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN>
+__global__ __launch_bounds__(kBlock, 8) void langevin_chain_lean_diag_kernel(ChainArgs a) {
+  lean_body<KIND, TABLE, CLAMP, TRAJ, HEUN, true>(a);
 }
 
 }  // namespace

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
                                                              double* __restrict__ work) {
   const int j = blockIdx.x;
   const int W = gridDim.y, w = blockIdx.y, Q = gridDim.z, q = blockIdx.z;
-  const int R = 2 * S + 2;
+  const int R = diag::record_floats(S);
   const int64_t n_elem = n_chains * (int64_t)dim;
   const float* base = partials + (int64_t)j * n_blocks * R;
   double* wrow = work + (int64_t)j * (3 * (int64_t)dim + 3);
@@ -409,34 +409,60 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
   const int64_t per = (n_win + Q - 1) / Q;
   const int64_t i0 = (int64_t)q * per, i1 = (i0 + per < n_win) ? i0 + per : n_win;
   const int64_t len_first = diag_block_len(w, E, n_elem);
-  for (int s = threadIdx.x; s < S; s += kBlock) {
-    const int cnt0 = s < len_first ? (int)((len_first - s + dim - 1) / dim) : 0;
-    const double shift = cnt0 > 0 ? (double)base[(int64_t)w * R + s] / (double)cnt0 : 0.0;
+  // lanes: slot s = t % SP, record lane p = t / SP of P (small S: several lanes walk the same slot over
+  // interleaved records); their partial sums meet in LDS before the atomics
+  __shared__ double red[3][kBlock];
+  const int SP = S < kBlock ? S : kBlock;
+  const int P = kBlock / SP;
+  const int p = threadIdx.x / SP;
+  const double inv_full = 1.0 / (double)((E + dim - 1) / dim);  // 1 / rows of a full block's slot (E % dim == 0), or 1
+  for (int s0 = 0; s0 < S; s0 += SP) {
+    const int s = s0 + (threadIdx.x - p * SP);
     double A = 0.0, B = 0.0, C = 0.0;
-    for (int64_t i = i0; i < i1; ++i) {
-      const int64_t b = w + i * W;
-      const int64_t len = diag_block_len(b, E, n_elem);
-      if (s >= len) continue;
-      const double cnt = (double)((len - s + dim - 1) / dim);
-      const float* rec = base + b * R;
-      const double sx = (double)rec[s];
-      const double dm = sx / cnt - shift;
-      A += sx;
-      B += (double)rec[S + s];
-      C += cnt * dm * dm;
+    double shift = 0.0;
+    if (p < P && s < S) {
+      const int cnt0 = s < len_first ? (int)((len_first - s + dim - 1) / dim) : 0;
+      shift = cnt0 > 0 ? (double)base[(int64_t)w * R + s] / (double)cnt0 : 0.0;
+      for (int64_t i = i0 + p; i < i1; i += P) {
+        const int64_t b = w + i * W;
+        const int64_t len = diag_block_len(b, E, n_elem);
+        if (s >= len) continue;
+        const float* rec = base + b * R;
+        const double sx = (double)rec[s];
+        double cnt, inv;
+        if (len == E) {
+          cnt = (double)((E + dim - 1) / dim);
+          inv = inv_full;
+        } else {
+          cnt = (double)((len - s + dim - 1) / dim);
+          inv = 1.0 / cnt;
+        }
+        const double dm = sx * inv - shift;
+        A += sx;
+        B += (double)rec[S + s];
+        C += cnt * dm * dm;
+      }
     }
-    const int col = w * E + s;  // W == 1: col = s
-    const double r0 = atomicAdd(&wrow[col], A);
-    const double r1 = atomicAdd(&wrow[dim + col], B);
-    const double r2 = atomicAdd(&wrow[2 * dim + col], C);
-    asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));  // the adds have been performed at L2 once their old values are back
+    red[0][threadIdx.x] = A; red[1][threadIdx.x] = B; red[2][threadIdx.x] = C;
+    __syncthreads();
+    if (p == 0 && s < S) {
+      for (int k = 1; k < P; ++k) {
+        A += red[0][threadIdx.x + k * SP]; B += red[1][threadIdx.x + k * SP]; C += red[2][threadIdx.x + k * SP];
+      }
+      const int col = w * E + s;  // W == 1: col = s
+      const double r0 = atomicAdd(&wrow[col], A);
+      const double r1 = atomicAdd(&wrow[dim + col], B);
+      const double r2 = atomicAdd(&wrow[2 * dim + col], C);
+      asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));  // the adds have been performed at L2 once their old values are back
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0) {  // energy / accept sums of this workgroup's blocks
     double es = 0.0, as = 0.0;
     for (int64_t i = i0; i < i1; ++i) {
       const float* rec = base + (w + i * W) * R;
-      es += (double)rec[2 * S];
-      as += (double)rec[2 * S + 1];
+      es += ((double)rec[2 * S] + (double)rec[2 * S + 1]) + ((double)rec[2 * S + 2] + (double)rec[2 * S + 3]);
+      as += ((double)rec[2 * S + 4] + (double)rec[2 * S + 5]) + ((double)rec[2 * S + 6] + (double)rec[2 * S + 7]);
     }
     const double r0 = atomicAdd(&wrow[3 * dim], es);
     const double r1 = atomicAdd(&wrow[3 * dim + 1], as);

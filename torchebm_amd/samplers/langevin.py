@@ -399,7 +399,7 @@ class LangevinDynamics(BaseSampler):
         ``DIAG_RECORD_BYTES``)."""
         n_blocks, slots, block_elems = layout
         n_kept = n_steps // thin
-        rec_floats = n_blocks * (2 * slots + 2)
+        rec_floats = n_blocks * (2 * slots + 8)
         chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
         records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
         work = torch.zeros(chunk * (3 * dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
