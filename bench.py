@@ -314,7 +314,7 @@ def extra_measurements(device, valu_rate):
         s = ta.LangevinDynamics(model, step_size=0.1, noise_scale=1.0, device=device)
         # as BASELINE prescribes it: autograd gradient + HIP fused update per Langevin step.  `capture_graph` toggles the
         # HIP-graph replay of one such iteration (the default whenever the configuration is eligible).
-        default_graph = bool(getattr(s, "capture_graph", False))
+        default_graph = s.capture_graph is not False and s._use_graph({}, k)  # None = replay whenever eligible
         s.capture_graph = False
         t_eager = timed(train_loop(model, s), reps=5, warm=2, device=device)
         t_eager_sample = timed(lambda: s.sample(x=data, n_steps=k), reps=5, warm=1, device=device)

@@ -38,9 +38,11 @@ def test_cd_negatives_and_loss_match_cpu_restatement(cuda_device):
     cd = ta.ContrastiveDivergence(model, sampler, k_steps=k, persistent=False, device=cuda_device)
     gen = torch.Generator(device=cuda_device).manual_seed(2024)
     off = gen.get_offset() // 4
-    before = hip_calls("ebm_langevin_step_f32")
+    before, dev0 = hip_calls("ebm_langevin_step_f32"), hip_calls("ebm_langevin_step_dev_f32")
     loss, neg = cd(data.to(cuda_device), generator=gen)
-    assert hip_calls("ebm_langevin_step_f32") == before + k  # the HIP per-step kernel did the updates
+    # the HIP per-step kernel did the updates -- replayed from a HIP graph by default (3 warm-up launches + the
+    # captured one pass through the binding, the k replays do not); same Philox field as eager launches
+    assert hip_calls("ebm_langevin_step_dev_f32") == dev0 + 4 and hip_calls("ebm_langevin_step_f32") == before
     assert neg.is_cuda and not neg.requires_grad and neg.shape == (n, 2)
 
     # the same chain on the CPU, with the kernel's own noise
@@ -71,7 +73,7 @@ def test_pcd_training_config5_shape(cuda_device):
                                    device=cuda_device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     before = [p.detach().clone() for p in model.parameters()]
-    calls0 = hip_calls("ebm_langevin_step_f32")
+    calls0, dev0 = hip_calls("ebm_langevin_step_f32"), hip_calls("ebm_langevin_step_dev_f32")
     losses = []
     for _ in range(3):
         loss, neg = pcd(data)
@@ -79,7 +81,8 @@ def test_pcd_training_config5_shape(cuda_device):
         loss.backward()
         opt.step()
         losses.append(loss.detach())
-    assert hip_calls("ebm_langevin_step_f32") == calls0 + 3 * k
+    # one capture, then every training step replays it (the optimiser's in-place updates are seen by the replays)
+    assert hip_calls("ebm_langevin_step_dev_f32") == dev0 + 4 and hip_calls("ebm_langevin_step_f32") == calls0
     assert all(torch.isfinite(l) for l in losses)
     assert pcd.replay_buffer.shape == (n, 2) and torch.isfinite(pcd.replay_buffer).all()
     assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))

@@ -32,6 +32,8 @@ def _pair(cuda_device, **kw):
     model = Net().to(cuda_device)
     eager = ta.LangevinDynamics(model, step_size=0.05, noise_scale=1.0, device=cuda_device, **kw)
     graph = ta.LangevinDynamics(model, step_size=0.05, noise_scale=1.0, device=cuda_device, **kw)
+    assert eager.capture_graph is None  # the default: replay whenever eligible and the call has >= GRAPH_MIN_STEPS steps
+    eager.capture_graph = False
     graph.capture_graph = True
     return model, eager, graph
 
@@ -105,6 +107,7 @@ def test_hmc_graph_route_is_bit_identical_to_the_eager_step_route(cuda_device, m
         mass = torch.tensor([0.5, 1.0, 2.0], device=cuda_device)
     kw = dict(step_size=0.07, n_leapfrog_steps=4, mass=mass, device=cuda_device)
     eager, graph = ta.HamiltonianMonteCarlo(model, **kw), ta.HamiltonianMonteCarlo(model, **kw)
+    eager.capture_graph = False
     graph.capture_graph = True
     x0 = torch.randn(777, 3, device=cuda_device)
     a0, d0 = hip_calls("ebm_hmc_accept_f32"), hip_calls("ebm_hmc_accept_dev_f32")
@@ -160,3 +163,37 @@ def test_uncapturable_model_falls_back_to_the_eager_step_route(cuda_device):
     assert s.capture_graph is False and torch.isfinite(out).all()
     ref = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
     assert torch.equal(out, ref.sample(x=x0, n_steps=4, generator=_gen(cuda_device, 1)))
+
+
+def test_default_is_replay_and_python_state_changes_recapture(cuda_device):
+    """replay is the DEFAULT when eligible.  A replay cannot see a changed Python attribute
+    of the model, so the model's state key (core.module.graph_state_key) is part of the cache key."""
+
+    class Tempered(ta.BaseModel):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(2, 1)
+            self.temperature = 1.0
+
+        def forward(self, x):
+            return (self.lin(x).squeeze(-1) + 0.5 * (x ** 2).sum(-1)) / self.temperature
+
+    torch.manual_seed(0)
+    model = Tempered().to(cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    e = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    e.capture_graph = False
+    x0 = torch.randn(512, 2, device=cuda_device)
+    d0, s0 = hip_calls("ebm_langevin_step_dev_f32"), hip_calls("ebm_langevin_step_f32")
+    a = s.sample(x=x0, n_steps=10, generator=_gen(cuda_device, 1))
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 4 and hip_calls("ebm_langevin_step_f32") == s0  # replayed by default
+    assert torch.equal(a, e.sample(x=x0, n_steps=10, generator=_gen(cuda_device, 1)))
+    short = s.sample(x=x0, n_steps=3, generator=_gen(cuda_device, 1))  # below GRAPH_MIN_STEPS: eager launches
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 4 and torch.equal(short, e.sample(x=x0, n_steps=3, generator=_gen(cuda_device, 1)))
+    model.temperature = 4.0  # a plain attribute the captured graph has frozen: must re-capture
+    b = s.sample(x=x0, n_steps=10, generator=_gen(cuda_device, 1))
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 8
+    assert torch.equal(b, e.sample(x=x0, n_steps=10, generator=_gen(cuda_device, 1))) and not torch.equal(a, b)
+    model.eval()  # so does train / eval
+    s.sample(x=x0, n_steps=10, generator=_gen(cuda_device, 1))
+    assert hip_calls("ebm_langevin_step_dev_f32") == d0 + 12

@@ -104,3 +104,24 @@ class TorchEBMModule(nn.Module):
         if self.use_mixed_precision and self.autocast_available:
             return torch.amp.autocast(device_type=self.device.type, dtype=self._amp_dtype)
         return contextlib.nullcontext()
+
+
+def graph_state_key(model) -> tuple:
+    """What a captured HIP graph of ``model``'s forward / backward has frozen, as a hashable key: the storage of
+    every parameter and buffer (in-place updates -- an optimiser step -- are seen by a replay, a REPLACED tensor is
+    not) and every plain Python attribute of every submodule (``training``, a temperature, a flag: a replay cannot
+    see a changed value).  The samplers re-capture when the key of the model they are about to replay differs."""
+    import torch
+
+    items = []
+    for name, mod in model.named_modules():
+        for attr, val in vars(mod).items():
+            if attr.startswith("_"):
+                continue
+            if isinstance(val, (bool, int, float, str, type(None))):
+                items.append((name, attr, val))
+            elif isinstance(val, (tuple, list)) and all(isinstance(v, (bool, int, float, str)) for v in val):
+                items.append((name, attr, tuple(val)))
+        items.append((name, "training", mod.training))
+    tensors = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in list(model.parameters()) + list(model.buffers()))
+    return (tuple(items), tensors)

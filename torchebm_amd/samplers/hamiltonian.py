@@ -26,7 +26,7 @@ import torch
 from .. import _lib, _rng
 from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSymplecticIntegrator
-from ..core.module import warn_once
+from ..core.module import graph_state_key, warn_once
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler
 from ..integrators.registry import resolve_integrator
@@ -195,7 +195,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         n_kept = n_steps // thin
         traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
         drift = lambda x_, t_: -self._model_gradient(x_, model_kwargs)  # noqa: E731
-        if hip and self.capture_graph and n > 0 and self._graph_eligible(model_kwargs):
+        if hip and n > 0 and self._use_graph(model_kwargs, n_steps):
             try:
                 return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
             except RuntimeError as exc:  # the model's forward cannot be captured (host sync, data-dependent control flow ...)
@@ -273,7 +273,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         return (out, diag) if want_diag else out
 
     # ---------------------------------------------------------------------------------
-    # route: one transition of the step route captured in a HIP graph (opt-in: ``capture_graph = True``)
+    # route: one transition of the step route captured in a HIP graph (the default whenever eligible)
     # ---------------------------------------------------------------------------------
     #: Capture ONE Metropolis transition of the step route -- momentum draw, H0, L leapfrog steps (kick /
     #: autograd gradient / kick), H1, accept -- into a HIP graph and replay it n_steps times.  With an
@@ -282,17 +282,25 @@ class HamiltonianMonteCarlo(BaseSampler):
     #: (``ebm_noise_fill_dev_f32`` at +0, ``ebm_hmc_accept_dev_f32`` at +1), so the generator contract and
     #: the noise field are those of the eager step route, bit for bit.  Requirements: constant step
     #: size, no conditioning, a model whose forward is static-shape and free of host-side randomness.
-    capture_graph: bool = False
+    #: ``None`` (default): replay whenever eligible and the call has at least ``GRAPH_MIN_STEPS`` transitions;
+    #: ``True``: whenever eligible; ``False``: never.  See ``LangevinDynamics.capture_graph`` for the rules.
+    capture_graph: Optional[bool] = None
+    GRAPH_MIN_STEPS = 4
 
     def _graph_eligible(self, model_kwargs: Dict[str, Any]) -> bool:
         return not model_kwargs and not self.use_mixed_precision and self.schedulers["step_size"].is_constant()
+
+    def _use_graph(self, model_kwargs: Dict[str, Any], n_steps: int) -> bool:
+        if self.capture_graph is False or not self._graph_eligible(model_kwargs):
+            return False
+        return self.capture_graph is True or n_steps >= self.GRAPH_MIN_STEPS
 
     def _graph_for(self, x: torch.Tensor):
         eps = self.get_scheduled_value("step_size")
         key = (
             tuple(x.shape), x.device, eps, self.n_leapfrog_steps, id(self.integrator),
             None if self.mass is None else (self.mass if isinstance(self.mass, float) else self.mass.data_ptr()),
-            tuple(p.data_ptr() for p in self.model.parameters()),
+            graph_state_key(self.model),
         )
         cached = getattr(self, "_step_graph", None)
         if cached is not None and cached["key"] == key:

@@ -27,7 +27,7 @@ import torch
 from .. import _lib, _rng
 from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSDERungeKuttaIntegrator
-from ..core.module import warn_once
+from ..core.module import graph_state_key, warn_once
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler
 from ..integrators.em import EulerMaruyamaIntegrator, HeunIntegrator
@@ -178,7 +178,7 @@ class LangevinDynamics(BaseSampler):
         n_kept = n_steps // thin
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         keep = 0
-        if hip and self.capture_graph and self._graph_eligible(model_kwargs):
+        if hip and self._use_graph(model_kwargs, n_steps):
             try:
                 return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
             except RuntimeError as exc:  # the model's forward cannot be captured (host sync, data-dependent control flow ...)
@@ -233,16 +233,31 @@ class LangevinDynamics(BaseSampler):
         return (out, diag) if want_diag else out
 
     # ---------------------------------------------------------------------------------
-    # route: per-step loop replayed from a HIP graph (opt-in: ``sampler.capture_graph = True``)
+    # route: per-step loop replayed from a HIP graph (the default whenever the configuration is eligible)
     # ---------------------------------------------------------------------------------
     #: Capture one "autograd gradient + fused update" iteration of the step route into a HIP graph and
-    #: replay it n_steps times per call.  The step route is launch-bound (BASELINE config 5: ~13 small
+    #: replay it n_steps times.  The step route is launch-bound (BASELINE config 5: ~13 small
     #: kernels per Langevin step): a replay costs one submission instead of 13.  The Philox
     #: coordinates live in a device buffer advanced inside the graph (``ebm_langevin_step_dev_f32``), so
-    #: every replay draws fresh noise and the generator contract is unchanged.  Requirements: constant
-    #: step size / noise scale, no conditioning, a model whose forward is static-shape and free of
-    #: host-side randomness or data-dependent control flow (the usual CUDA-graph rules).
-    capture_graph: bool = False
+    #: every replay draws fresh noise and the generator contract is unchanged; the result is bit-identical
+    #: to the eager step route.
+    #:   ``None`` (default)  replay whenever the call is eligible: constant step size / noise scale, no
+    #:                       conditioning, no autocast, at least ``GRAPH_MIN_STEPS`` steps.  The graph is kept
+    #:                       for the next call and re-captured when the batch shape, the coefficients or the
+    #:                       model's state key (``core.module.graph_state_key``: parameter / buffer storages and
+    #:                       plain Python attributes of every submodule) change.  A forward that cannot be
+    #:                       captured (host sync, data-dependent control flow) falls back to eager launches
+    #:                       with a one-time warning.
+    #:   ``True``            as above, without the minimum step count.
+    #:   ``False``           always eager launches (what a model with host-side randomness, or with state a
+    #:                       replay cannot see, needs).
+    capture_graph: Optional[bool] = None
+    GRAPH_MIN_STEPS = 8
+
+    def _use_graph(self, model_kwargs: Dict[str, Any], n_steps: int) -> bool:
+        if self.capture_graph is False or not self._graph_eligible(model_kwargs):
+            return False
+        return self.capture_graph is True or n_steps >= self.GRAPH_MIN_STEPS
 
     def _graph_eligible(self, model_kwargs: Dict[str, Any]) -> bool:
         return (
@@ -256,7 +271,7 @@ class LangevinDynamics(BaseSampler):
         a, sq, coef = em_coefficients(self.get_scheduled_value("step_size"), self.get_scheduled_value("noise_scale"))
         key = (
             tuple(x.shape), x.device, (a, sq, coef), self._clamp_args(),
-            tuple(p.data_ptr() for p in self.model.parameters()),
+            graph_state_key(self.model),
         )
         cached = getattr(self, "_step_graph", None)
         if cached is not None and cached["key"] == key:
