@@ -85,7 +85,8 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
   a.park_offset_floats = (int)(smem / sizeof(float));
-  if (geo.NV >= 4) smem += (size_t)kBlock * geo.NV * 16;
+  // the accepted state and its force (two force slots for NV == 4: hmc_kernel.h F_TWO), one float4 slot per lane and vector
+  if (geo.NV >= 4) smem += (size_t)kBlock * geo.NV * 16 * (geo.NV <= 4 ? 3 : 2);
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
   a.diag_offset_floats = (int)(smem / sizeof(float));
   if (diag_partials) {

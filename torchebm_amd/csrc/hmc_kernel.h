@@ -50,6 +50,12 @@ extern __shared__ __attribute__((aligned(16))) float hmc_smem[];
 //    clamp, scrub, and the force re-evaluation the reference then performs on the scrubbed x.
 //  * Energies with HAS_GRAD_ONLY (mixture) skip the energy on all but the last step; their
 //    grad_only() returns a value with the same "finite => clean" property.
+//  * Merged kicks.  The second half kick of step l and the first half kick of step l + 1 use the SAME clamped
+//    force, so between two evaluations the momentum moves by ONE fused multiply-add with the whole step size
+//    (p + eps f instead of (p + eps/2 f) + eps/2 f: one rounding less, in the tolerance tier like every FMA of
+//    this kernel); the trajectory starts and ends with a half kick.  4 NV operations per step and -- the force is
+//    consumed as soon as it exists -- 4 NV registers less across the evaluation.  If the merged kick leaves the
+//    finite range the step is redone literally (half kick, scrub, half kick).
 template <bool HAS_MASS, class En, class LaneT>
 __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Slice<LaneT::NV>& x,
                                                 Slice<LaneT::NV>& p, Slice<LaneT::NV>& f,
@@ -58,25 +64,29 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
   constexpr int NV = LaneT::NV;
   typedef float v2f __attribute__((ext_vector_type(2)));
   float e = e_in;
+  // first half kick (fused multiply-adds: one rounding where the reference's eager ops take two -- HMC states are
+  // a tolerance tier anyway: energy and gradient sums run in another order than torch's)
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p.a[v][i] = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);
   for (int l = 0; l < n_steps; ++l) {
+    const bool last = l + 1 >= n_steps;
+    const float kick = last ? half_eps : eps;  // the next step's first half kick rides along
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        // fused multiply-adds: one rounding where the reference's eager ops take two -- HMC states are a
-        // tolerance tier anyway (energy and gradient sums run in another order than torch's)
-        const float ph = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);
         float xn;
-        if constexpr (HAS_MASS) xn = __builtin_fmaf(m_safe.a[v][i], ph, x.a[v][i]);  // m_safe holds eps / max(m, 1e-10) here
-        else xn = __builtin_fmaf(eps, ph, x.a[v][i]);
-        p.a[v][i] = ph;
+        if constexpr (HAS_MASS) xn = __builtin_fmaf(m_safe.a[v][i], p.a[v][i], x.a[v][i]);  // m_safe holds eps / max(m, 1e-10) here
+        else xn = __builtin_fmaf(eps, p.a[v][i], x.a[v][i]);
         x.a[v][i] = L.ok(v, i) ? xn : 0.0f;
       }
     Slice<NV> g;
     float chk;  // group-uniform; finite => x finite, g free of NaN
     bool have_e = true;
     if constexpr (En::HAS_GRAD_ONLY) {
-      if (l + 1 < n_steps && en.grad_only_ready()) {
+      if (!last && en.grad_only_ready()) {
         chk = en.grad_only(L, x, g);
         have_e = false;
       } else {
@@ -85,28 +95,36 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
     } else {
       chk = e = en.template eval<true>(L, x, g);
     }
-    if (__builtin_fabsf(chk) < __builtin_inff()) {
+    bool literal = !(__builtin_fabsf(chk) < __builtin_inff());
+    if (!literal) {
       v2f pz = {0.0f, 0.0f};
+      Slice<NV> pn;
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
           const float f0 = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
           const float f1 = __builtin_amdgcn_fmed3f(-g.a[v][i + 1], -1e6f, 1e6f);
-          const float p0 = __builtin_fmaf(half_eps, f0, p.a[v][i]);
-          const float p1 = __builtin_fmaf(half_eps, f1, p.a[v][i + 1]);
+          const float p0 = __builtin_fmaf(kick, f0, p.a[v][i]);
+          const float p1 = __builtin_fmaf(kick, f1, p.a[v][i + 1]);
           f.a[v][i] = f0;
           f.a[v][i + 1] = f1;
-          p.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
-          p.a[v][i + 1] = L.ok(v, i + 1) ? p1 : 0.0f;
+          pn.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
+          pn.a[v][i + 1] = L.ok(v, i + 1) ? p1 : 0.0f;
           pz = __builtin_elementwise_fma(v2f{p0, p1}, v2f{0.0f, 0.0f}, pz);
         }
       const float pchk = pz.x + pz.y;
-      if (group_any<LaneT::G>(pchk != pchk)) {  // momentum overflow: x is finite, so f stands
-#pragma unroll
+      if (group_any<LaneT::G>(pchk != pchk)) {  // momentum left the finite range (x is finite, so f stands):
+#pragma unroll                                  // the literal sequence -- half kick, scrub, the next step's half kick
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) p.a[v][i] = nan_to_num0(p.a[v][i]);
+          for (int i = 0; i < 4; ++i) {
+            float q = nan_to_num0(L.ok(v, i) ? __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]) : 0.0f);
+            if (!last) q = __builtin_fmaf(half_eps, f.a[v][i], q);
+            p.a[v][i] = q;
+          }
+      } else {
+        p = pn;
       }
     } else {  // rare: literal semantics
       if (!have_e) e = en.template eval<true>(L, x, g);
@@ -115,16 +133,18 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float fn = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
-          const float pn = __builtin_fmaf(half_eps, fn, p.a[v][i]);
-          f.a[v][i] = fn;
-          p.a[v][i] = nan_to_num0(L.ok(v, i) ? pn : 0.0f);
+          const float pl = __builtin_fmaf(half_eps, fn, p.a[v][i]);
+          p.a[v][i] = nan_to_num0(L.ok(v, i) ? pl : 0.0f);
           x.a[v][i] = nan_to_num0(x.a[v][i]);
         }
       e = en.template eval<true>(L, x, g);  // the force the next step starts from, on the scrubbed x
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+        for (int i = 0; i < 4; ++i) {
+          f.a[v][i] = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+          if (!last) p.a[v][i] = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);  // the next step's first half kick
+        }
     }
   }
   return e;
@@ -135,7 +155,9 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 // while the proposal is integrated (wide rows: frees 4*NV VGPRs).
 // DIAG: emit the per-block diagnostics records at the kept transitions (a compile-time switch: the call into
 // diag::emit cost the one-lane-per-chain mixture kernel 4 % through register pressure even when never taken).
-template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
+// CARRY: carry energy and force from transition to transition (see below); false re-evaluates both at the top of
+// every transition, the reference's own sequence (kept for A/B measurements).
+template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG, bool CARRY = true>
 __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   using LaneT = Lane<G, NV, FULL>;
   constexpr bool XC_LDS = NV >= 4;
@@ -146,7 +168,16 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   Energy<KIND, LaneT> en;
   en.init(a.energy, L, S);
   // lane-private parking slots sit behind the parameter / exchange area: [v][thread] float4
-  float4* park = reinterpret_cast<float4*>(hmc_smem + a.park_offset_floats) + threadIdx.x;
+  // (indexed straight off the LDS array: a generic pointer into it made hipcc 7.2 emit an illegal
+  //  V_CMP_NE_U32 against src_shared_base for the null check of the address-space cast)
+  const int park0 = a.park_offset_floats + 4 * (int)threadIdx.x;
+  auto park_put = [&](int slot, const float (&q)[4]) {
+    *reinterpret_cast<float4*>(&hmc_smem[park0 + slot * (4 * kBlock)]) = make_float4(q[0], q[1], q[2], q[3]);
+  };
+  auto park_get = [&](int slot, float (&q)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(&hmc_smem[park0 + slot * (4 * kBlock)]);
+    q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+  };
 
   const int64_t row = L.active ? L.chain * (int64_t)a.dim : 0;
   Slice<NV> xc;  // current (accepted) state
@@ -200,41 +231,95 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
   const bool keeping = a.traj != nullptr || DIAG;
   float eps = a.eps;
 
-  for (int t = 0; t < a.n_mh; ++t) {
-    if (a.eps_table) eps = a.eps_table[t];
-    const float half_eps = 0.5f * eps;
+  // Energy and clamped force of the state the chain holds are CARRIED from transition to transition: an accepted
+  // proposal brings its own E1 and end-of-trajectory force (what the reference recomputes at the top of the next
+  // transition on the same x: bit-identical), a rejected one keeps the saved pair.  A transition costs L
+  // evaluations instead of L + 1.  The pair of the INITIAL state comes out of the same code: the loop starts with
+  // a pseudo-transition t = -1 -- zero momentum, zero step size, one leapfrog step (x + 0 * p is x bit for bit,
+  // the step's last evaluation is E(x), dE/dx), always "accepted", nothing written -- so the energy is inlined
+  // at ONE call site (a second one in front of the loop trips an instruction-selection bug of hipcc 7.2 and costs
+  // the register allocation of the hot loop).
+  Slice<NV> f;  // clamped force -dE/dx: at the current state between trajectories, then along the trajectory
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[v][i] = 0.0f;
+  float e_cur = 0.0f;
+  // wide rows: the carried force lives in LDS between trajectories (frees 4*NV VGPRs across the momentum draw and
+  // the accept step).  F_TWO (NV == 4): TWO force slots -- the end-of-trajectory force is parked in the spare one
+  // right behind the last leapfrog step, before H1 and the accept arithmetic (holding it in registers until the
+  // decision costs the element-wise kernels their third wave per SIMD); accepting flips which slot is current.
+  constexpr bool F_TWO = CARRY && XC_LDS && NV <= 4;
+  int fcur = 0;
+  if constexpr (CARRY && XC_LDS) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) park_put(NV + v, f.a[v]);
+  }
+
+  for (int t = CARRY ? -1 : 0; t < a.n_mh; ++t) {
+    const bool init = CARRY && t < 0;
+    if constexpr (!CARRY) {  // re-evaluate at the top of every transition (the reference's own sequence)
+      e_cur = en.template eval<true>(L, xc, f);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-f.a[v][i], -1e6f, 1e6f);
+    }
+    if (a.eps_table && !init) eps = a.eps_table[t];
+    const float eps_t = init ? 0.0f : eps;
+    const float half_eps = 0.5f * eps_t;
 
     // ---- momentum draw: p ~ N(0, M)  (samplers/hmc.py:92-134)
     Slice<NV> p;
-    if (a.p_noise) load_slice(L, a.p_noise, ((int64_t)t * a.n_chains) * a.dim + row, p);
-    else normal_slice(L, a.key, a.step0 + 2ull * (uint64_t)t, p);
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float pv = p.a[v][i];
-        if constexpr (has_mass) pv = pv * m_sqrt.a[v][i];
-        p.a[v][i] = L.ok(v, i) ? pv : 0.0f;
-      }
-
-    // ---- H0 and the first (clamped) force
-    Slice<NV> f;
-    const float e0 = en.template eval<true>(L, xc, f);
-    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-f.a[v][i], -1e6f, 1e6f);
-
-    // ---- proposal (integrated in place in xc's registers when the old state is parked in LDS)
-    if constexpr (XC_LDS) {
+    if (init) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        park[v * kBlock] = make_float4(xc.a[v][0], xc.a[v][1], xc.a[v][2], xc.a[v][3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p.a[v][i] = 0.0f;
+    } else {
+      if (a.p_noise) load_slice(L, a.p_noise, ((int64_t)t * a.n_chains) * a.dim + row, p);
+      else normal_slice(L, a.key, a.step0 + 2ull * (uint64_t)t, p);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float pv = p.a[v][i];
+          if constexpr (has_mass) pv = pv * m_sqrt.a[v][i];
+          p.a[v][i] = L.ok(v, i) ? pv : 0.0f;
+        }
+    }
+
+    // ---- the accept uniform, drawn here (one register across the trajectory) rather than after it: behind the
+    //      trajectory the Philox temporaries would sit on top of the live end-of-trajectory force
+    float uu;
+    if (init) uu = -1.0f;
+    else if (a.u) uu = L.active ? a.u[(int64_t)t * a.n_chains + L.chain] : 2.0f;
+    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)L.chain >> 2, a.step0 + 2ull * (uint64_t)t + 1ull),
+                                 (int)(L.chain & 3)));
+
+    // ---- H0 from the carried energy
+    const float e0 = e_cur;
+    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
+
+    // ---- proposal (integrated in place in xc's registers when the old state is parked in LDS; its force is
+    //      parked next to it); narrow rows keep both in registers
+    Slice<XC_LDS ? 1 : NV> f_keep;
+    if constexpr (XC_LDS) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        park_put(v, xc.a[v]);
+        if constexpr (CARRY) park_get(NV * (1 + fcur) + v, f.a[v]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f_keep.a[v][i] = f.a[v][i];
     }
     Slice<NV> xprop_store;
     Slice<NV>& x = XC_LDS ? xc : xprop_store;
     if constexpr (!XC_LDS) x = xc;
+    const int n_lf = init ? 1 : a.n_leapfrog;
     float e1;
     if constexpr (has_mass) {
       // drift x += eps * p / max(m, 1e-10): the quotient eps / m is formed once per transition (an IEEE
@@ -243,32 +328,46 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) drift_scale.a[v][i] = eps / m_safe.a[v][i];
-      e1 = leapfrog_steps<true>(en, L, x, p, f, drift_scale, eps, half_eps, a.n_leapfrog, e0);
+        for (int i = 0; i < 4; ++i) drift_scale.a[v][i] = eps_t / m_safe.a[v][i];
+      e1 = leapfrog_steps<true>(en, L, x, p, f, drift_scale, eps_t, half_eps, n_lf, e0);
     }
-    else e1 = leapfrog_steps<false>(en, L, x, p, f, x, eps, half_eps, a.n_leapfrog, e0);
+    else e1 = leapfrog_steps<false>(en, L, x, p, f, x, eps_t, half_eps, n_lf, e0);
+    if constexpr (F_TWO) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) park_put(NV * (2 - fcur) + v, f.a[v]);
+    }
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
 
     // ---- Metropolis accept (samplers/hmc.py:277-292)
     const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
     float acc_p = expf(dlt);
     acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
-    float uu;
-    if (a.u) uu = L.active ? a.u[(int64_t)t * a.n_chains + L.chain] : 2.0f;
-    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)L.chain >> 2, a.step0 + 2ull * (uint64_t)t + 1ull),
-                                 (int)(L.chain & 3)));
-    const bool accept = L.active && (uu < acc_p);
+    // (the pseudo-transition always takes its "proposal": the unchanged state with its energy and force)
+    const bool accept = init || (L.active && (uu < acc_p));
+    if (accept) e_cur = e1;
     if constexpr (XC_LDS) {
-      if (!accept) {  // rejected: bring the parked state back
+      if (accept) {  // the proposal's force becomes the carried one
+        if constexpr (F_TWO) {
+          fcur ^= 1;
+        } else if constexpr (CARRY) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const float4 q = park[v * kBlock];
-          xc.a[v][0] = q.x; xc.a[v][1] = q.y; xc.a[v][2] = q.z; xc.a[v][3] = q.w;
+          for (int v = 0; v < NV; ++v) park_put(NV + v, f.a[v]);
         }
+      } else {       // rejected: bring the parked state back (its force is still parked)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) park_get(v, xc.a[v]);
       }
     } else {
-      if (accept) xc = x;
+      if (accept) {
+        xc = x;
+      } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f.a[v][i] = f_keep.a[v][i];
+      }
     }
+    if (init) continue;
 
     const bool leader = L.active && L.lg == 0;
     if (a.accept_mask && leader) a.accept_mask[(int64_t)t * a.n_chains + L.chain] = accept ? 1 : 0;
@@ -288,7 +387,7 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
         // holds now (its accepted proposal's E1, else E0 -- what the reference re-evaluates), acceptance rate
         float* tile = hmc_smem + a.diag_offset_floats;
         tile_store(L, tile, xc);
-        const float e_now = clamp_nanprop(accept ? e1 : e0, -1e10f, 1e10f);
+        const float e_now = clamp_nanprop(e_cur, -1e10f, 1e10f);
         diag::emit(a.diag, keep, tile, tile_valid<G>(a.n_chains, a.dim), a.dim, leader ? e_now : 0.0f,
                    (accept && leader) ? 1.0f : 0.0f);
         ++keep;
@@ -307,9 +406,12 @@ __global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
 // its leapfrog loop fits, only the cold paths (prologue, large-K fallback, scrub) spill, and the
 // second wave is worth 1.56 -> 1.22 ms on BASELINE config 3.  (A template-dependent expression in
 // __launch_bounds__ is silently ignored by hipcc 7.2, hence the second entry point.)
+// Measured and NOT taken (round 2, profiles/r02_hmc_c3_experiments.txt): three waves per SIMD at 168 VGPRs without
+// the carried force (1.06 ms per 10 transitions against 1.00: the cold-path spills grow and the third wave does
+// not buy back the scalar-load waits), and two waves without the carried force (1.05).
 template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
-  hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG>(a);
+  hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG, true>(a);
 }
 
 // KERNEL<KIND, G, NV, FULL, MASS, DIAG> over the runtime geometry (see rows.h: EBM_GEO_LAUNCH)

@@ -175,7 +175,11 @@ __device__ __forceinline__ void load_param_slice(const LaneT& L, const float* __
 template <class LaneT>
 __device__ __forceinline__ void normal_slice(const LaneT& L, RngKey key, uint64_t step,
                                              Slice<LaneT::NV>& s) {
-  const uint64_t row0 = (uint64_t)L.chain * (uint64_t)L.dim;
+  uint64_t row0 = (uint64_t)L.chain * (uint64_t)L.dim;
+  // wide rows: hide the (loop-invariant) counter from the optimiser -- it otherwise hoists the counter words and the
+  // first Philox multiply of all NV calls out of the caller's transition loop: 3 * NV registers that live through the
+  // whole kernel, are spilled by the register-capped kernels and reloaded at every transition
+  if constexpr (LaneT::NV >= 8) asm volatile("" : "+v"(row0));
 #pragma unroll
   for (int v = 0; v < LaneT::NV; ++v) {
     if (L.vec_ok) {  // e % 4 == 0: the slice vector is exactly one Philox counter
@@ -427,7 +431,9 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
           nrm = __builtin_fmaf(m.z, m.z, nrm);
           nrm = __builtin_fmaf(m.w, m.w, nrm);
         }
-        c8[k] = __builtin_fmaf(-nrm, inv2s2, lw8[k]);
+        // wave-uniform (every lane read the same LDS words): keep it on the scalar side -- as a vector
+        // register it is spilled by the register-capped kernels and reloaded at every transition
+        c8[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_fmaf(-nrm, inv2s2, lw8[k]))));
       }
     }
   }
