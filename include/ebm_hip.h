@@ -54,7 +54,13 @@ enum {
   EBM_ENERGY_HARMONIC    = 1, /* E = (0.5*k) * sum_j x_j^2       base_model.py:213-229  s[0]=(float)(0.5*k)                 */
   EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1) */
   EBM_ENERGY_GMM         = 3, /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
-                                 s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]                   */
+                                 s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]
+                                 aux = NULL, or device int32[1]: bit v set <=> the component means differ somewhere in
+                                 columns 4v..4v+3 (v < 8).  A hint, read by the kernel itself: columns all components
+                                 share drop out of the responsibilities, and when the mask is 1 (a mixture of a plane
+                                 embedded in the first coordinates, e.g. BASELINE config 3's ring) the one-lane-per-chain
+                                 kernels (dim 16 / 32, K <= 8) run their K x dim passes over four columns only.
+                                 A wrong mask gives wrong samples; NULL is always safe.                                    */
   EBM_ENERGY_MLP         = 4  /* E = w3 . silu(W2 silu(W1 x + b1) + b2) + b3   (the energy of the reference's
                                  examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31)
                                  n_comp = hidden width H (128), dim <= 4,
@@ -68,6 +74,7 @@ typedef struct ebm_energy {
   float   s[4];        /* scalar parameters, see the enum           */
   const float* dev0;   /* device parameter arrays, see the enum     */
   const float* dev1;
+  const int32_t* aux;  /* optional device hints, see the enum (NULL: none) */
 } ebm_energy_t;
 
 /* noise kinds for ebm_noise_fill_f32 */

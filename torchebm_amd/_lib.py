@@ -67,6 +67,7 @@ class EnergyDesc(C.Structure):
         ("s", C.c_float * 4),
         ("dev0", C.c_void_p),
         ("dev1", C.c_void_p),
+        ("aux", C.c_void_p),
     ]
 
 

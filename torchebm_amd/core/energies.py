@@ -36,6 +36,7 @@ class FusedSpec:
     n_comp: int = 0
     dev0: Optional[torch.Tensor] = None
     dev1: Optional[torch.Tensor] = None
+    aux: Optional[torch.Tensor] = None  # device int32 hints (mixture: active-column mask), see include/ebm_hip.h
     elementwise: bool = False  # gradient of coordinate j depends on x_j only
     dim: Optional[int] = None  # the model's own state width (None: any width, e.g. element-wise energies)
     langevin_only: bool = False  # fused for Euler-Maruyama Langevin chains, HMC and energy/gradient evaluation; no Heun / descent kernel
@@ -48,6 +49,7 @@ class FusedSpec:
             d.s[i] = float(v)
         d.dev0 = _lib.ptr(self.dev0)
         d.dev1 = _lib.ptr(self.dev1)
+        d.aux = _lib.ptr(self.aux)
         return d
 
 
@@ -230,6 +232,22 @@ class GaussianMixtureModel(BaseModel):
         logits = self.log_weights - sq_dist / (2.0 * self.sigma**2)
         return -torch.logsumexp(logits, dim=1)
 
+    def _active_column_mask(self) -> Optional[torch.Tensor]:
+        """Device int32[1]: bit v set when the component means differ somewhere in columns 4v..4v+3 (the `aux` hint
+        of EBM_ENERGY_GMM).  Computed on the device -- no host read -- and kept until the means change."""
+        m = self.means
+        k, d = m.shape
+        if not m.is_cuda or d % 4 != 0 or d // 4 > 8:
+            return None
+        key = (m.data_ptr(), m._version)
+        cached = getattr(self, "_mask_cache", None)
+        if cached is None or cached[0] != key:
+            differs = (m != m[:1]).any(dim=0).view(d // 4, 4).any(dim=1)
+            weights = torch.ones(d // 4, dtype=torch.int32, device=m.device) << torch.arange(d // 4, dtype=torch.int32, device=m.device)
+            cached = (key, (differs.to(torch.int32) * weights).sum().to(torch.int32).reshape(1))
+            self._mask_cache = cached
+        return cached[1]
+
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(GaussianMixtureModel) or self.means.dtype != torch.float32:
             return None
@@ -239,6 +257,7 @@ class GaussianMixtureModel(BaseModel):
         return FusedSpec(
             _lib.ENERGY_GMM,
             (1.0 / (2.0 * s2), 1.0 / s2, 0.0, 0.0),
+            aux=self._active_column_mask(),
             n_comp=int(self.means.shape[0]),
             dev0=self.means,
             dev1=self.log_weights,

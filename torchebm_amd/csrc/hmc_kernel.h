@@ -409,8 +409,16 @@ __global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
 // Measured and NOT taken (round 2, profiles/r02_hmc_c3_experiments.txt): three waves per SIMD at 168 VGPRs without
 // the carried force (1.06 ms per 10 transitions against 1.00: the cold-path spills grow and the third wave does
 // not buy back the scalar-load waits), and two waves without the carried force (1.05).
+// For the mixture this kernel looks at the active-column mask first: means that differ in columns 0..3 only take the
+// body built on Energy<kGmmSlot1> (rows.h) -- a wave-uniform branch, both bodies share the register budget.
 template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
+  if constexpr (KIND == EBM_ENERGY_GMM && G == 1 && FULL && NV >= 4) {
+    if (gmm_is_slot1(a.energy)) {
+      hmc_chain_body<kGmmSlot1, G, NV, FULL, MASS, DIAG, true>(a);
+      return;
+    }
+  }
   hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG, true>(a);
 }
 

@@ -216,7 +216,21 @@ struct EnergyParams {
   const float* dev1;
   int param_in_lds;   // shared parameters were staged into LDS
   int dim_pad;        // row stride of the staged parameters (dim rounded up to 4)
+  const int32_t* aux; // mixture: NULL or device int32[1], bit v = the component means differ somewhere in columns 4v..4v+3
 };
+
+// Internal energy kind (not part of the ABI): a mixture whose component means differ ONLY in the first four columns
+// (bit mask == 1 in EnergyParams::aux) -- a K-mode mixture of a plane embedded in a higher-dimensional state, like the
+// eight-mode ring of BASELINE config 3.  Columns all components share drop out of the responsibilities (softmax is
+// shift-invariant) and their gradient is that of ONE Gaussian, so the two K x dim passes of the dense kernel shrink to
+// K x 4: see Energy<kGmmSlot1>.  The one-lane-per-chain kernels look at the mask and pick the body themselves
+// (a wave-uniform branch at the top of the kernel: no host read of device memory).
+constexpr int kGmmSlot1 = 100;
+
+__device__ __forceinline__ bool gmm_is_slot1(const EnergyParams& P) {
+  if (P.aux == nullptr || P.n_comp > 8 || P.n_comp < 1) return false;
+  return __builtin_amdgcn_readfirstlane(P.aux[0]) == 1;
+}
 
 // LDS carve-up (dynamic shared memory, 16-byte aligned):
 //   [0, param_floats)                      shared parameters (P rows / mixture means + log-weights)
@@ -790,6 +804,127 @@ struct Energy<EBM_ENERGY_GMM, LaneT> {
   }
 };
 
+// Mixture with the component means differing in columns 0..3 only (kGmmSlot1; one lane per chain, full rows).
+//   logits  l_k = c_k + (x[0:4] . mu_k[0:4]) / sigma^2        (the |x|^2 term and every shared column cancel in softmax)
+//   gradient    g[0:4] = (x[0:4] - sum_k r_k mu_k[0:4]) / sigma^2,   g[d] = (x[d] - mu_0[d]) / sigma^2 for d >= 4
+//   energy      E = sum_{d >= 4} (x[d] - mu_0[d])^2 / (2 sigma^2)  -  logsumexp_k(logw_k - |x[0:4] - mu_k[0:4]|^2 / (2 sigma^2))
+// The 8 x 4 active means stay RESIDENT in 32 SGPRs for the whole kernel (no load in the step loop); the shared
+// row mu_0 streams through 16 SGPRs per chunk, one wait per 16 columns.  ~140 VALU instructions per gradient
+// where the dense passes take ~380 plus 32 scalar-load round trips.
+template <class LaneT>
+struct Energy<kGmmSlot1, LaneT> {
+  static constexpr int G = LaneT::G, NV = LaneT::NV;
+  static constexpr bool HAS_GRAD_ONLY = true;
+  static_assert(G == 1 && LaneT::FULL && NV >= 4 && NV % 4 == 0, "one lane per chain, rows in whole 16-float chunks");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  float mact[8][4];  // wave-uniform: scalar registers
+  float lw8[8], c8[8];
+  const float* mu_glb;
+  float inv2s2, invs2;
+  __device__ __forceinline__ void init(const EnergyParams& P, const LaneT&, const Smem&) {
+    constexpr int D = NV * 4;
+    mu_glb = P.dev0;
+    inv2s2 = P.s0;
+    invs2 = P.s1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kk = k < P.n_comp ? k : P.n_comp - 1;  // padding re-reads the last row, its log-weight is -inf
+      lw8[k] = (k < P.n_comp) ? P.dev1[kk] : -__builtin_inff();
+      float nrm = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        mact[k][i] = P.dev0[kk * D + i];
+        nrm = __builtin_fmaf(mact[k][i], mact[k][i], nrm);
+      }
+      c8[k] = __builtin_fmaf(-nrm, inv2s2, lw8[k]);
+    }
+  }
+  __device__ __forceinline__ bool grad_only_ready() const { return true; }
+  // the shared columns: g = (x - mu_0) / sigma^2, and (WANT_E) sum (x - mu_0)^2
+  template <bool WANT_E>
+  __device__ __forceinline__ float shared_columns(const Slice<NV>& x, Slice<NV>& g) const {
+    constexpr int NCH = NV / 4;  // 16-float chunks of row 0
+    const uint64_t base = (uint64_t)(uintptr_t)mu_glb;
+    v2f sq = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      v16f m;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(m) : "s"(base + (uint64_t)(c * 64)));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int v = c * 4 + q;
+        if (v == 0) continue;  // the active slot
+        const v2f da = v2f{x.a[v][0], x.a[v][1]} - v2f{m[4 * q], m[4 * q + 1]};
+        const v2f db = v2f{x.a[v][2], x.a[v][3]} - v2f{m[4 * q + 2], m[4 * q + 3]};
+        if (WANT_E) {
+          sq = __builtin_elementwise_fma(da, da, sq);
+          sq = __builtin_elementwise_fma(db, db, sq);
+        }
+        g.a[v][0] = invs2 * da.x; g.a[v][1] = invs2 * da.y;
+        g.a[v][2] = invs2 * db.x; g.a[v][3] = invs2 * db.y;
+      }
+    }
+    return sq.x + sq.y;
+  }
+  template <bool EXACT>
+  __device__ __forceinline__ float active_slot(const Slice<NV>& x, Slice<NV>& g, float common_sq) const {
+    const v2f xa = {x.a[0][0], x.a[0][1]}, xb = {x.a[0][2], x.a[0][3]};
+    float logit[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const v2f ma = {mact[k][0], mact[k][1]}, mb = {mact[k][2], mact[k][3]};
+      if constexpr (EXACT) {
+        const v2f da = xa - ma, db = xb - mb;
+        const v2f d2 = __builtin_elementwise_fma(db, db, da * da);
+        logit[k] = __builtin_fmaf(-(d2.x + d2.y), inv2s2, lw8[k]);
+      } else {
+        const v2f dt = __builtin_elementwise_fma(xb, mb, xa * ma);
+        logit[k] = __builtin_fmaf(dt.x + dt.y, invs2, c8[k]);
+      }
+    }
+    float top = logit[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) top = __builtin_fmaxf(top, logit[k]);  // a NaN logit resurfaces in the sum
+    float w[8], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      w[k] = __expf(logit[k] - top);
+      sum += w[k];
+    }
+    v2f acc_a = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const v2f wk = {w[k], w[k]};
+      acc_a = __builtin_elementwise_fma(wk, v2f{mact[k][0], mact[k][1]}, acc_a);
+      acc_b = __builtin_elementwise_fma(wk, v2f{mact[k][2], mact[k][3]}, acc_b);
+    }
+    const float inv = EXACT ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
+    g.a[0][0] = invs2 * (x.a[0][0] - acc_a.x * inv);
+    g.a[0][1] = invs2 * (x.a[0][1] - acc_a.y * inv);
+    g.a[0][2] = invs2 * (x.a[0][2] - acc_b.x * inv);
+    g.a[0][3] = invs2 * (x.a[0][3] - acc_b.y * inv);
+    if constexpr (EXACT) return __builtin_fmaf(common_sq, inv2s2, -(top + logf(sum)));
+    // a non-finite shared coordinate must resurface in the check value as it does on the dense path
+    return sum + 0.0f * common_sq;
+  }
+  __device__ __forceinline__ float grad_only(const LaneT&, const Slice<NV>& x, Slice<NV>& g) const {
+    // (the squared sum of the shared columns is only taken to carry a NaN / inf into the check value)
+    const float sq = shared_columns<true>(x, g);
+    return active_slot<false>(x, g, sq);
+  }
+  template <bool WANT_E>
+  __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+    if constexpr (!WANT_E) {
+      grad_only(L, x, g);
+      return 0.0f;
+    } else {
+      const float sq = shared_columns<true>(x, g);
+      return active_slot<true>(x, g, sq);
+    }
+  }
+};
+
 // Stage the shared parameters into LDS (all threads of the block), zero-padded rows.
 __device__ __forceinline__ void stage_params(const EnergyParams& P, int dim, float* dst) {
   if (!P.param_in_lds) return;
@@ -849,7 +984,7 @@ inline void plan_params(const ebm_energy_t& e, int dim, const Geometry& geo, Ene
                         int& param_floats, size_t& smem_bytes) {
   P.kind = e.kind; P.n_comp = e.n_comp; P.s0 = e.s[0]; P.s1 = e.s[1];
   P.n_comp_pad = e.n_comp < 8 ? 8 : ((e.n_comp + 7) & ~7);  // whole blocks of eight (see Energy<GMM>::eval_blocks)
-  P.dev0 = e.dev0; P.dev1 = e.dev1;
+  P.dev0 = e.dev0; P.dev1 = e.dev1; P.aux = e.aux;
   P.dim_pad = (dim + 3) & ~3;
   P.param_in_lds = 0;
   param_floats = 0;

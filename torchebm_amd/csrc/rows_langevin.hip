@@ -104,6 +104,12 @@ __device__ __forceinline__ void langevin_chain_rows_body(const RowChainArgs& a) 
 
 template <int KIND, int G, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void langevin_chain_rows_kernel(RowChainArgs a) {
+  if constexpr (KIND == EBM_ENERGY_GMM && G == 1 && FULL && NV >= 4) {  // means that differ in columns 0..3 only: rows.h kGmmSlot1
+    if (gmm_is_slot1(a.energy)) {
+      langevin_chain_rows_body<kGmmSlot1, G, NV, FULL, false>(a);
+      return;
+    }
+  }
   langevin_chain_rows_body<KIND, G, NV, FULL, false>(a);
 }
 
