@@ -66,10 +66,18 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
   float e = e_in;
   // first half kick (fused multiply-adds: one rounding where the reference's eager ops take two -- HMC states are
   // a tolerance tier anyway: energy and gradient sums run in another order than torch's)
+  bool tame = true;  // every |p_i| < 1e30 on entry
 #pragma unroll
   for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p.a[v][i] = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);
+    for (int i = 0; i < 4; ++i) {
+      p.a[v][i] = __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]);
+      tame = tame && (__builtin_fabsf(p.a[v][i]) < 1e30f);  // false for NaN / inf too
+    }
+  // Momentum moves by at most eps * 1e6 per step (the force is clamped), so a momentum that starts below 1e30
+  // cannot leave the finite range within any trajectory a float step count can express: the per-step finiteness
+  // test of the momentum (the reference's nan_to_num_ on p) is only kept for lane groups that start outside.
+  const bool watch_p = group_any<LaneT::G>(!tame);
   for (int l = 0; l < n_steps; ++l) {
     const bool last = l + 1 >= n_steps;
     const float kick = last ? half_eps : eps;  // the next step's first half kick rides along
@@ -97,34 +105,46 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
     }
     bool literal = !(__builtin_fabsf(chk) < __builtin_inff());
     if (!literal) {
-      v2f pz = {0.0f, 0.0f};
-      Slice<NV> pn;
+      if (!watch_p) {
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-          const float f0 = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
-          const float f1 = __builtin_amdgcn_fmed3f(-g.a[v][i + 1], -1e6f, 1e6f);
-          const float p0 = __builtin_fmaf(kick, f0, p.a[v][i]);
-          const float p1 = __builtin_fmaf(kick, f1, p.a[v][i + 1]);
-          f.a[v][i] = f0;
-          f.a[v][i + 1] = f1;
-          pn.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
-          pn.a[v][i + 1] = L.ok(v, i + 1) ? p1 : 0.0f;
-          pz = __builtin_elementwise_fma(v2f{p0, p1}, v2f{0.0f, 0.0f}, pz);
-        }
-      const float pchk = pz.x + pz.y;
-      if (group_any<LaneT::G>(pchk != pchk)) {  // momentum left the finite range (x is finite, so f stands):
-#pragma unroll                                  // the literal sequence -- half kick, scrub, the next step's half kick
         for (int v = 0; v < NV; ++v)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float q = nan_to_num0(L.ok(v, i) ? __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]) : 0.0f);
-            if (!last) q = __builtin_fmaf(half_eps, f.a[v][i], q);
-            p.a[v][i] = q;
+            const float fc = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
+            const float pc = __builtin_fmaf(kick, fc, p.a[v][i]);
+            f.a[v][i] = fc;
+            p.a[v][i] = L.ok(v, i) ? pc : 0.0f;
           }
       } else {
-        p = pn;
+        v2f pz = {0.0f, 0.0f};
+        Slice<NV> pn;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {
+            const float f0 = __builtin_amdgcn_fmed3f(-g.a[v][i], -1e6f, 1e6f);
+            const float f1 = __builtin_amdgcn_fmed3f(-g.a[v][i + 1], -1e6f, 1e6f);
+            const float p0 = __builtin_fmaf(kick, f0, p.a[v][i]);
+            const float p1 = __builtin_fmaf(kick, f1, p.a[v][i + 1]);
+            f.a[v][i] = f0;
+            f.a[v][i + 1] = f1;
+            pn.a[v][i] = L.ok(v, i) ? p0 : 0.0f;
+            pn.a[v][i + 1] = L.ok(v, i + 1) ? p1 : 0.0f;
+            pz = __builtin_elementwise_fma(v2f{p0, p1}, v2f{0.0f, 0.0f}, pz);
+          }
+        const float pchk = pz.x + pz.y;
+        if (group_any<LaneT::G>(pchk != pchk)) {  // momentum left the finite range (x is finite, so f stands):
+#pragma unroll                                    // the literal sequence -- half kick, scrub, the next step's half kick
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float q = nan_to_num0(L.ok(v, i) ? __builtin_fmaf(half_eps, f.a[v][i], p.a[v][i]) : 0.0f);
+              if (!last) q = __builtin_fmaf(half_eps, f.a[v][i], q);
+              p.a[v][i] = q;
+            }
+        } else {
+          p = pn;
+        }
       }
     } else {  // rare: literal semantics
       if (!have_e) e = en.template eval<true>(L, x, g);

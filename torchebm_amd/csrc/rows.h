@@ -841,34 +841,20 @@ struct Energy<kGmmSlot1, LaneT> {
     }
   }
   __device__ __forceinline__ bool grad_only_ready() const { return true; }
-  // the shared columns: g = (x - mu_0) / sigma^2, and (WANT_E) sum (x - mu_0)^2
-  template <bool WANT_E>
-  __device__ __forceinline__ float shared_columns(const Slice<NV>& x, Slice<NV>& g) const {
+  // One evaluation.  Row 0 of the means (the shared columns) is requested FIRST, the active slot is worked out
+  // while the scalar loads are in flight (~100 instructions), then the shared columns: g = (x - mu_0) / sigma^2 and,
+  // with the energy, sum (x - mu_0)^2.  The gradient-only form returns the softmax sum of the active slot: finite
+  // => the active coordinates are finite.  A shared coordinate cannot turn NaN inside a trajectory (x + eps p with
+  // finite p), only +-inf, and that is absorbing: it surfaces in the energy of the trajectory's last evaluation,
+  // whose literal path scrubs it -- the proposal is rejected either way (H1 at its clamp).
+  template <bool EXACT>
+  __device__ __forceinline__ float evaluate(const Slice<NV>& x, Slice<NV>& g) const {
     constexpr int NCH = NV / 4;  // 16-float chunks of row 0
     const uint64_t base = (uint64_t)(uintptr_t)mu_glb;
-    v2f sq = {0.0f, 0.0f};
+    v16f row0[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      v16f m;
-      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(m) : "s"(base + (uint64_t)(c * 64)));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int v = c * 4 + q;
-        if (v == 0) continue;  // the active slot
-        const v2f da = v2f{x.a[v][0], x.a[v][1]} - v2f{m[4 * q], m[4 * q + 1]};
-        const v2f db = v2f{x.a[v][2], x.a[v][3]} - v2f{m[4 * q + 2], m[4 * q + 3]};
-        if (WANT_E) {
-          sq = __builtin_elementwise_fma(da, da, sq);
-          sq = __builtin_elementwise_fma(db, db, sq);
-        }
-        g.a[v][0] = invs2 * da.x; g.a[v][1] = invs2 * da.y;
-        g.a[v][2] = invs2 * db.x; g.a[v][3] = invs2 * db.y;
-      }
-    }
-    return sq.x + sq.y;
-  }
-  template <bool EXACT>
-  __device__ __forceinline__ float active_slot(const Slice<NV>& x, Slice<NV>& g, float common_sq) const {
+    for (int c = 0; c < NCH; ++c) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(row0[c]) : "s"(base + (uint64_t)(c * 64)));
+
     const v2f xa = {x.a[0][0], x.a[0][1]}, xb = {x.a[0][2], x.a[0][3]};
     float logit[8];
 #pragma unroll
@@ -904,23 +890,40 @@ struct Energy<kGmmSlot1, LaneT> {
     g.a[0][1] = invs2 * (x.a[0][1] - acc_a.y * inv);
     g.a[0][2] = invs2 * (x.a[0][2] - acc_b.x * inv);
     g.a[0][3] = invs2 * (x.a[0][3] - acc_b.y * inv);
+
+    // the shared columns
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(row0[c]));
+    v2f sq = {0.0f, 0.0f}, sq_b = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int v = c * 4 + q;
+        if (v == 0) continue;  // the active slot
+        const v2f da = v2f{x.a[v][0], x.a[v][1]} - v2f{row0[c][4 * q], row0[c][4 * q + 1]};
+        const v2f db = v2f{x.a[v][2], x.a[v][3]} - v2f{row0[c][4 * q + 2], row0[c][4 * q + 3]};
+        if constexpr (EXACT) {
+          sq = __builtin_elementwise_fma(da, da, sq);
+          sq_b = __builtin_elementwise_fma(db, db, sq_b);
+        }
+        g.a[v][0] = invs2 * da.x; g.a[v][1] = invs2 * da.y;
+        g.a[v][2] = invs2 * db.x; g.a[v][3] = invs2 * db.y;
+      }
+    }
+    sq += sq_b;
+    const float common_sq = sq.x + sq.y;
     if constexpr (EXACT) return __builtin_fmaf(common_sq, inv2s2, -(top + logf(sum)));
-    // a non-finite shared coordinate must resurface in the check value as it does on the dense path
-    return sum + 0.0f * common_sq;
+    return sum;
   }
-  __device__ __forceinline__ float grad_only(const LaneT&, const Slice<NV>& x, Slice<NV>& g) const {
-    // (the squared sum of the shared columns is only taken to carry a NaN / inf into the check value)
-    const float sq = shared_columns<true>(x, g);
-    return active_slot<false>(x, g, sq);
-  }
+  __device__ __forceinline__ float grad_only(const LaneT&, const Slice<NV>& x, Slice<NV>& g) const { return evaluate<false>(x, g); }
   template <bool WANT_E>
-  __device__ __forceinline__ float eval(const LaneT& L, const Slice<NV>& x, Slice<NV>& g) const {
+  __device__ __forceinline__ float eval(const LaneT&, const Slice<NV>& x, Slice<NV>& g) const {
     if constexpr (!WANT_E) {
-      grad_only(L, x, g);
+      evaluate<false>(x, g);
       return 0.0f;
     } else {
-      const float sq = shared_columns<true>(x, g);
-      return active_slot<true>(x, g, sq);
+      return evaluate<true>(x, g);
     }
   }
 };
