@@ -367,9 +367,27 @@ def extra_measurements(device, valu_rate):
                 "algorithmic_bytes_per_launch": 12 * n, "kernel_ms": kms, "value": gbs, "peak": HBM_PEAK_GBS,
                 "frac": gbs / HBM_PEAK_GBS}
 
+    def mlp_bench_net():
+        # the reference's benchmark network (benchmarks/registry.py:372-387) at dim 32: Langevin chain fused on fp32 MFMA
+        n, k, dim, hidden = 65536, 20, 32, 128
+        torch.manual_seed(0)
+        m = ta.MLPEnergy(dim, hidden, device=device)
+        s = ta.LangevinDynamics(m, step_size=0.05, device=device)
+        x0 = torch.randn(n, dim, device=device)
+        fn = lambda: s.sample(x=x0, n_steps=k)  # noqa: E731
+        timed(fn, reps=2, warm=2, device=device)
+        kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 5, device)
+        flops = n * k * 2 * (2 * hidden * hidden + 2 * dim * hidden)
+        return {"name": "mlp_benchmark_network_dim32", "workload": "LangevinDynamics.sample on MLPEnergy Linear(32,128)-SiLU-Linear(128,128)-"
+                "SiLU-Linear(128,1) (the reference's benchmarks/registry.py network), n_chains=65536, k=20: forward + input gradient + "
+                "update fused, four contractions on v_mfma_f32_32x32x2_f32", "metric": "TFLOP/s (exact fp32 matrix)", "bound": "mfma",
+                "kernel_ms": kms, "value": flops / (kms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "frac": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3)}
+
     guarded("config3_hmc_gmm8", c3)
     guarded("config4_shard", c4)
     guarded("config5_pcd_mlp", c5)
+    guarded("mlp_benchmark_network_dim32", mlp_bench_net)
     guarded("langevin_step_kernel", step_kernel)
     return out
 

@@ -1,0 +1,112 @@
+"""The fused MLP energy beyond the two-moons shape (csrc/mlp_wide.hip): hidden width 64 / 128, input dim up to 128 --
+the reference's benchmark network (benchmarks/registry.py:372-387: Linear(dim,128)-SiLU-Linear(128,128)-SiLU-
+Linear(128,1) at dim 8 / 32 / 128).  One evaluation against autograd (and against the fp64 network), the k-fused
+chain against the CPU autograd chain on injected noise, the sampler's routes, and the native-RNG field."""
+
+import copy
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd import _lib, _rng
+from torchebm_amd.samplers.langevin import em_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(cuda_device, in_dim, hidden, seed=0, scale=1.0):
+    torch.manual_seed(seed)
+    cpu = ta.MLPEnergy(in_dim, hidden)
+    with torch.no_grad():
+        for p in cpu.parameters():
+            p.mul_(scale)
+    return cpu, copy.deepcopy(cpu).to(cuda_device)
+
+
+@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (5, 128), (33, 128), (100, 128), (64, 64), (7, 64),
+                                           (128, 64), (2, 64)])
+def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
+    cpu, gpu = _models(cuda_device, in_dim, hidden, seed=in_dim + hidden, scale=1.5)
+    spec = gpu.fused_spec()
+    assert spec is not None and spec.dim == in_dim and spec.hmc is False
+    n = 333  # not a multiple of the 32-chain tile
+    x = torch.randn(n, in_dim, generator=torch.Generator().manual_seed(1)) * 1.5
+    x_d = x.to(cuda_device)
+    e, g = torch.empty(n, device=cuda_device), torch.empty(n, in_dim, device=cuda_device)
+    _lib.call("ebm_energy_grad_f32", spec.to_c(), x_d.data_ptr(), n, in_dim, e.data_ptr(), g.data_ptr(), _lib.stream_handle(cuda_device))
+    want_e, want_g = cpu(x), cpu.gradient(x)
+    # both are fp32 evaluations in different summation orders: compare with the fp64 network as the referee
+    cpu64 = copy.deepcopy(cpu).double()
+    x64 = x.double().requires_grad_(True)
+    e64 = cpu64(x64)
+    (g64,) = torch.autograd.grad(e64.sum(), x64)
+    err_hip = (g.cpu().double() - g64).abs().max().item()
+    err_torch = (want_g.double() - g64).abs().max().item()
+    scale = g64.abs().max().item()
+    assert err_hip <= max(4.0 * err_torch, 2e-6 * scale), (err_hip, err_torch, scale)
+    torch.testing.assert_close(e.cpu(), want_e.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(g.cpu(), want_g, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (30, 64)])
+def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden):
+    cpu, gpu = _models(cuda_device, in_dim, hidden, seed=5)
+    n, k, eta, sigma = 200, 12, 0.05, 0.7
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(n, in_dim, generator=g)
+    noise = torch.randn(k, n, in_dim, generator=g)
+    want = x0
+    rows = []
+    for i in range(k):
+        want = oracle.em_step(want, cpu.gradient(want), noise[i], eta, sigma)
+        if (i + 1) % 4 == 0:
+            rows.append(want)
+    x = x0.to(cuda_device)
+    a, sq, coef = em_coefficients(eta, sigma)
+    traj = torch.empty(n, k // 4, in_dim, device=cuda_device)
+    nz = noise.to(cuda_device)
+    _lib.call("ebm_langevin_chain_f32", gpu.fused_spec().to_c(), x.data_ptr(), n, in_dim, k, a, sq, coef, None, 0, 0.0, 0.0, 4,
+              traj.data_ptr(), None, nz.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    torch.testing.assert_close(x.cpu(), want, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(traj.cpu(), torch.stack(rows, dim=1), rtol=1e-3, atol=1e-3)
+
+
+def test_sampler_routes_and_native_rng_field(cuda_device):
+    """LangevinDynamics on the benchmark MLP is ONE launch; its Philox field is the (seed, step, element) field of
+    every other kernel, so the step route (autograd gradient + ebm_langevin_step_f32) lands on the same chains."""
+
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    for in_dim in (8, 30, 128):
+        torch.manual_seed(in_dim)
+        fused_model = ta.MLPEnergy(in_dim, 128, device=cuda_device)
+        step_model = Sub(in_dim, 128, device=cuda_device)
+        step_model.load_state_dict(fused_model.state_dict())
+        assert step_model.fused_spec() is None
+        x0 = torch.randn(1000, in_dim, device=cuda_device)
+        sf = ta.LangevinDynamics(fused_model, step_size=0.05, clamp=(-3.0, 3.0), device=cuda_device)
+        ss = ta.LangevinDynamics(step_model, step_size=0.05, clamp=(-3.0, 3.0), device=cuda_device)
+        c0 = hip_calls("ebm_langevin_chain_f32")
+        a = sf.sample(x=x0, n_steps=10, generator=torch.Generator(device=cuda_device).manual_seed(4))
+        b = ss.sample(x=x0, n_steps=10, generator=torch.Generator(device=cuda_device).manual_seed(4))
+        assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+        # trajectory + diagnostics (statistics from the state between launches for this energy)
+        traj, diag = sf.sample(x=x0, n_steps=6, thin=2, return_trajectory=True, return_diagnostics=True)
+        assert traj.shape == (1000, 3, in_dim) and torch.isfinite(traj).all()
+        torch.testing.assert_close(diag["energy"][-1], fused_model(traj[:, -1]).mean(), rtol=1e-4, atol=1e-4)
+    # HMC on a wide MLP: the per-transition route (HIP kicks around autograd), never the 2-D kernel
+    h = ta.HamiltonianMonteCarlo(ta.MLPEnergy(8, 128, device=cuda_device), step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    out = h.sample(x=torch.randn(64, 8, device=cuda_device), n_steps=2)
+    assert hip_calls("ebm_hmc_chain_f32") == c0 and torch.isfinite(out).all()
+    with pytest.raises(RuntimeError, match="HMC on the fused MLP"):
+        spec = ta.MLPEnergy(8, 128, device=cuda_device).fused_spec()
+        xx = torch.zeros(4, 8, device=cuda_device)
+        _lib.call("ebm_hmc_chain_f32", spec.to_c(), xx.data_ptr(), 4, 8, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
+                  None, None, 0, 0, _lib.stream_handle(cuda_device))

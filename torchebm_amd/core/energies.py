@@ -40,6 +40,7 @@ class FusedSpec:
     elementwise: bool = False  # gradient of coordinate j depends on x_j only
     dim: Optional[int] = None  # the model's own state width (None: any width, e.g. element-wise energies)
     langevin_only: bool = False  # fused for Euler-Maruyama Langevin chains, HMC and energy/gradient evaluation; no Heun / descent kernel
+    hmc: bool = True  # ebm_hmc_chain_f32 takes this energy at this shape
 
     def to_c(self) -> "_lib.EnergyDesc":
         d = _lib.EnergyDesc()
@@ -270,14 +271,19 @@ class MLPEnergy(BaseModel):
     -- the trainable energy of the reference's PCD example
     (examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).
 
-    With ``hidden == 128`` and ``in_dim <= 4`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
+    With ``hidden`` 64 or 128 and ``in_dim <= 128`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
     forward, input-gradient on the matrix cores, update, noise -- in one ``ebm_langevin_chain_f32``
-    launch instead of one autograd round trip per step.  Training is unaffected:
-    the parameters are ordinary ``nn.Linear`` weights and are re-read at every ``sample()`` call.
+    launch instead of one autograd round trip per step: the reference's benchmark network
+    ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
+    (benchmarks/registry.py:372-387) as well as the 2-D two-moons energy of its PCD example, which has a kernel
+    of its own (``hidden == 128``, ``in_dim <= 4``; that shape is also fused for ``HamiltonianMonteCarlo``).
+    Training is unaffected: the parameters are ordinary ``nn.Linear`` weights and are re-read at every
+    ``sample()`` call.
     """
 
-    FUSED_HIDDEN = 128
-    FUSED_MAX_DIM = 4
+    FUSED_HIDDEN = (64, 128)
+    FUSED_MAX_DIM = 128
+    HMC_HIDDEN, HMC_MAX_DIM = 128, 4
 
     def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -293,7 +299,7 @@ class MLPEnergy(BaseModel):
         """Adopt an existing ``Linear(d, H) - SiLU - Linear(H, H) - SiLU - Linear(H, 1)`` stack (the network
         the reference's example writes by hand) WITHOUT copying it: the returned energy shares ``net``'s
         parameters, so an optimiser built on either sees the same tensors, and sampling from it takes the
-        fused route when the shape qualifies (H = 128, d <= 4, CUDA fp32)."""
+        fused route when the shape qualifies (H = 64 or 128, d <= 128, CUDA fp32)."""
         from torch import nn
 
         layers = list(net)
@@ -316,7 +322,7 @@ class MLPEnergy(BaseModel):
         return self.net(x).squeeze(-1)
 
     def fused_spec(self) -> Optional[FusedSpec]:
-        if not self._is_exactly(MLPEnergy) or self.hidden != self.FUSED_HIDDEN or self.in_dim > self.FUSED_MAX_DIM:
+        if not self._is_exactly(MLPEnergy) or self.hidden not in self.FUSED_HIDDEN or self.in_dim > self.FUSED_MAX_DIM:
             return None
         w = self.net[0].weight
         if not w.is_cuda or w.dtype != torch.float32:
@@ -325,7 +331,8 @@ class MLPEnergy(BaseModel):
             packed = torch.cat([p.detach().reshape(-1) for p in (
                 self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
                 self.net[4].weight, self.net[4].bias)])
-        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True, dim=int(self.in_dim))
+        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True, dim=int(self.in_dim),
+                         hmc=(self.hidden == self.HMC_HIDDEN and self.in_dim <= self.HMC_MAX_DIM))
 
 
 #: widest chain row the lane-group kernels (csrc/rows.h: pick_geometry) take

@@ -22,6 +22,13 @@
 #include "ebm_common.h"
 
 namespace ebm {
+
+bool mlp_wide_supported(int32_t hidden, int32_t dim);
+int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
+                    float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
+                    int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
+                    float* grad_out, hipStream_t st, const char* who);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -355,10 +362,17 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_hmc_chain_kernel(MlpHmcArgs a) 
 
 size_t mlp_smem_bytes() { return (size_t)(H * kW2Stride + H * 8 + 2 * H) * sizeof(float); }
 
-int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who) {
-  if (e.n_comp != H) return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width %d (got %d)", who, H, e.n_comp);
-  if (dim < 1 || dim > kMaxDim) return fail(EBM_EDIM, "%s: the fused MLP energy supports 1 <= dim <= %d (got %d)", who, kMaxDim, dim);
+// the two-moons shape this file specialises (layer 1 on the VALU); everything else: mlp_wide.hip
+bool mlp_small(const ebm_energy_t& e, int32_t dim) { return e.n_comp == H && dim >= 1 && dim <= kMaxDim; }
+
+int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool small_only) {
   if (!e.dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
+  if (mlp_small(e, dim)) return 0;
+  if (small_only)
+    return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width %d and 1 <= dim <= %d (got %d, %d)", who, H, kMaxDim,
+                e.n_comp, dim);
+  if (!mlp_wide_supported(e.n_comp, dim))
+    return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64 or 128 and 1 <= dim <= 128 (got %d, %d)", who, e.n_comp, dim);
   return 0;
 }
 
@@ -383,7 +397,10 @@ int launch_langevin_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains,
                               float cmin, float cmax, int32_t thin, float* traj, const float* noise, uint64_t seed,
                               uint64_t offset, hipStream_t st) {
   const char* who = "ebm_langevin_chain_f32";
-  if (int r = mlp_check(e, dim, who)) return r;
+  if (int r = mlp_check(e, dim, who, false)) return r;
+  if (!mlp_small(e, dim))
+    return launch_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
+                           thin, traj, noise, seed, offset, nullptr, nullptr, st, who);
   MlpArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
@@ -400,7 +417,7 @@ int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int3
                          int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
                          const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
   const char* who = "ebm_hmc_chain_f32";
-  if (int r = mlp_check(e, dim, who)) return r;
+  if (int r = mlp_check(e, dim, who, true)) return r;
   MlpHmcArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
@@ -427,7 +444,10 @@ int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int3
 int launch_energy_grad_mlp(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* e_out,
                            float* g_out, hipStream_t st) {
   const char* who = "ebm_energy_grad_f32";
-  if (int r = mlp_check(e, dim, who)) return r;
+  if (int r = mlp_check(e, dim, who, false)) return r;
+  if (!mlp_small(e, dim))
+    return launch_mlp_wide(e.n_comp, e.dev0, const_cast<float*>(x), n_chains, dim, 0, 0.0f, 0.0f, 0.0f, nullptr, 0, 0.0f, 0.0f, 1,
+                           nullptr, nullptr, 0, 0, e_out, g_out, st, who);
   MlpArgs a{};
   a.x = const_cast<float*>(x); a.n_chains = n_chains; a.dim = dim; a.k_steps = 0;
   a.thin = 1; a.n_kept = 0; a.params = e.dev0; a.energy_out = e_out; a.grad_out = g_out;

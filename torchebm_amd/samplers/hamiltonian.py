@@ -127,6 +127,8 @@ class HamiltonianMonteCarlo(BaseSampler):
         )
         if mass_ok:
             spec = fused_spec_for(self.model, x, model_kwargs)
+            if spec is not None and not spec.hmc:
+                spec = None  # (a wide MLP energy: fused for Langevin only)
         return ("fused", spec) if spec is not None else ("step", None)
 
     # ---------------------------------------------------------------------------------
