@@ -53,3 +53,36 @@ def hip_calls(name):
     from torchebm_amd import _lib
 
     return _lib.call_counts[name]
+
+
+# ---- SURVEY 8c fixture grid (tests/golden/grid, made by tests/golden/make_grid.py) ---------------------------
+GRID = os.path.join(GOLDEN, "grid")
+
+
+def grid_names(prefix=""):
+    return sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GRID, prefix + "*.pt")))
+
+
+def load_grid(name):
+    return torch.load(os.path.join(GRID, name + ".pt"), weights_only=False)
+
+
+def grid_inputs(fx):
+    """x0 and the draws the reference consumed, replayed from the fixture's seeds in the reference's draw order
+    (Langevin: one randn per step; HMC: momentum normal_ then torch.rand per transition)."""
+    n, dim = fx["n"], fx["dim"]
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(fx["seed"])) * fx["x0_scale"]
+    g = torch.Generator().manual_seed(fx["run_seed"])
+    if fx["sampler"] == "langevin":
+        return x0, torch.stack([torch.randn(n, dim, generator=g) for _ in range(fx["k"])])
+    ps, us = [], []
+    for _ in range(fx["T"]):
+        ps.append(torch.empty(n, dim).normal_(generator=g))
+        us.append(torch.rand(n, generator=g))
+    return x0, torch.stack(ps), torch.stack(us)
+
+
+def sha16(t):
+    import hashlib
+
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()[:16]

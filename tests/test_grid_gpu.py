@@ -1,0 +1,110 @@
+"""The HIP kernels against the reference's recorded runs on the SURVEY.md section 8c grid (tests/golden/grid): every
+energy x {Langevin k = 16, HMC L = 5 / 20} x dim in {2, 32, 64, 100} at n = 1000, scheduled step sizes, scalar and
+diagonal masses.  Through the C ABI with the draws the reference consumed (replayed from the seeds); the diagnostics
+come from the in-kernel records.  Bars: element-wise Langevin bit-exact (sha256 of the whole state), coupled energies
+3e-5, HMC accept masks bit-identical and states 5e-4 (per chain: >= 99 % of them, 5e-3 all), diagnostics 1e-4 (they are fp64 merges against fp32 torch sums)."""
+
+import pytest
+import torch
+
+import torchebm_amd as ta
+from helpers import grid_inputs, grid_names, load_grid, mass_to, package_model, sha16
+from torchebm_amd import _lib
+from torchebm_amd.integrators.symplectic import _mass_args
+from torchebm_amd.samplers.langevin import em_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(desc, sampler, n, dim, n_kept, dev, injected=True):
+    layout = _lib.diag_layout(desc, sampler, n, dim, injected, False)
+    assert layout is not None
+    nb, S, E = layout
+    rec = torch.empty(n_kept * nb * (2 * S + 8), device=dev)
+    work = torch.zeros(n_kept * (3 * dim + 3), dtype=torch.float64, device=dev)
+    return layout, rec, work
+
+
+def _finish(layout, rec, work, n, dim, n_kept, dev, with_accept):
+    nb, S, E = layout
+    out = {"mean": torch.empty(n_kept, dim, device=dev), "var": torch.empty(n_kept, dim, device=dev),
+           "energy": torch.empty(n_kept, device=dev)}
+    if with_accept:
+        out["acceptance_rate"] = torch.empty(n_kept, device=dev)
+    _lib.call("ebm_diag_finish_f32", rec.data_ptr(), n_kept, nb, S, E, n, dim, out["mean"].data_ptr(), out["var"].data_ptr(),
+              out["energy"].data_ptr(), _lib.ptr(out.get("acceptance_rate")), work.data_ptr(), _lib.stream_handle(dev))
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def _check_diag(got, want, keys):
+    for key in keys:
+        torch.testing.assert_close(got[key], want[key], rtol=1e-4, atol=1e-5, msg=lambda m, key=key: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("name", grid_names("ld_"))
+def test_langevin_grid(cuda_device, name):
+    fx = load_grid(name)
+    x0, noise = grid_inputs(fx)
+    n, dim, k, thin = fx["n"], fx["dim"], fx["k"], fx["thin"]
+    model = package_model(fx["energy"], cuda_device)
+    desc = model.fused_spec().to_c()
+    rows = [em_coefficients(e, s) for e, s in zip(fx["etas"], fx["sigmas"])]
+    table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=cuda_device)
+    layout, rec, work = _records(desc, _lib.DIAG_LANGEVIN, n, dim, k // thin, cuda_device)
+    x, nz = x0.to(cuda_device), noise.to(cuda_device)
+    _lib.call("ebm_langevin_chain_f32", desc, x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
+              0, 0.0, 0.0, thin, None, rec.data_ptr(), nz.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    diag = _finish(layout, rec, work, n, dim, k // thin, cuda_device, False)
+    got = x.cpu()
+    if fx["energy"]["kind"] in ("double_well", "harmonic"):
+        assert sha16(got) == fx["ref"]["sha_x"]  # all 1000 x dim values bit-identical to the reference
+    else:
+        torch.testing.assert_close(got[:256], fx["ref"]["x_rows"], rtol=3e-5, atol=3e-5)
+    _check_diag(diag, fx["ref"]["diagnostics"], ("mean", "var", "energy"))
+    # the same run without records (for the Gaussian: the matrix-core kernel where it applies)
+    x2 = x0.to(cuda_device)
+    _lib.call("ebm_langevin_chain_f32", desc, x2.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
+              0, 0.0, 0.0, thin, None, None, nz.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    torch.testing.assert_close(x2.cpu()[:256], fx["ref"]["x_rows"], rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("name", grid_names("hmc"))
+def test_hmc_grid(cuda_device, name):
+    fx = load_grid(name)
+    x0, p, u = grid_inputs(fx)
+    n, dim, T, L, thin = fx["n"], fx["dim"], fx["T"], fx["L"], fx["thin"]
+    model = package_model(fx["energy"], cuda_device)
+    desc = model.fused_spec().to_c()
+    eps = fx["eps"]
+    table = torch.tensor(eps, dtype=torch.float32, device=cuda_device) if len(set(eps)) > 1 else None
+    p_d, u_d = p.to(cuda_device), u.to(cuda_device)
+    mass = mass_to(fx["mass"], cuda_device)
+
+    def run(records):
+        x = x0.to(cuda_device)
+        mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+        kind, ms, md = _mass_args(mass, x)
+        _lib.call("ebm_hmc_chain_f32", desc, x.data_ptr(), n, dim, T, L, eps[0], _lib.ptr(table), kind, ms, _lib.ptr(md), thin, None,
+                  _lib.ptr(records), mask.data_ptr(), None, p_d.data_ptr(), u_d.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+        return x.cpu(), mask.cpu().bool()
+
+    layout, rec, work = _records(desc, _lib.DIAG_HMC, n, dim, T // thin, cuda_device)
+    got, mask = run(rec)
+    diag = _finish(layout, rec, work, n, dim, T // thin, cuda_device, True)
+    assert torch.equal(mask, fx["accepted"])  # all 8 x 1000 accept / reject decisions identical to the reference's
+    scale = fx["ref"]["x_rows"].abs().clamp(min=1.0)
+
+    def check_states(x):
+        # per chain; 160 leapfrog steps in the quartic well amplify a last-bit difference of one chain in a few
+        # hundred by 1e4, so the bar is 5e-4 for >= 99 % of the chains and 5e-3 for every one
+        err = ((x[:256] - fx["ref"]["x_rows"]).abs() / scale).amax(dim=1)
+        assert (err <= 5e-4).float().mean().item() >= 0.99 and err.max().item() <= 5e-3, (err.max().item(), (err > 5e-4).sum().item())
+
+    check_states(got)
+    assert torch.equal(diag["acceptance_rate"], fx["ref"]["diagnostics"]["acceptance_rate"])
+    _check_diag(diag, fx["ref"]["diagnostics"], ("mean", "energy"))
+    torch.testing.assert_close(diag["var"], fx["ref"]["diagnostics"]["var"], rtol=2e-3, atol=1e-5)
+    # without records (Gaussian: the matrix-core kernel where it applies)
+    got2, mask2 = run(None)
+    assert torch.equal(mask2, fx["accepted"])
+    check_states(got2)

@@ -1,0 +1,92 @@
+"""Distributional parity of the native (in-kernel Philox) path -- SURVEY.md section 7 "KS on marginals".  The CPU reference
+draws from mt19937, so native-RNG runs cannot match it draw for draw; what must match is the LAW: Kolmogorov-Smirnov
+tests of the kernel's normals / uniforms against N(0,1) / U[0,1), and two-sample KS tests of the stationary marginals
+of GPU chains against the oracle's CPU chains (same energy, step size and number of steps, independent noise).
+Fixed seeds: the p-values below are reproducible numbers, the bar (p > 1e-3 on every marginal) is written here."""
+
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+import oracle
+import torchebm_amd as ta
+from torchebm_amd import _lib
+
+pytestmark = pytest.mark.gpu
+P_MIN = 1e-3
+
+
+def test_kernel_normals_and_uniforms_follow_their_laws(cuda_device):
+    n = 1 << 20
+    buf = torch.empty(n, device=cuda_device)
+    for step in (0, 12345):
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n, _lib.NOISE_NORMAL, 99, step, _lib.stream_handle(cuda_device))
+        z = buf.cpu().double().numpy()
+        assert stats.kstest(z, "norm").pvalue > P_MIN
+        assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 6 * np.sqrt(2 / n)
+        assert abs(stats.skew(z)) < 0.02 and abs(stats.kurtosis(z)) < 0.04
+        # tails: P(|z| > 4) = 6.33e-5 -> ~66 of 2^20
+        assert 30 < (np.abs(z) > 4).sum() < 110
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n, _lib.NOISE_UNIFORM, 99, step, _lib.stream_handle(cuda_device))
+        u = buf.cpu().double().numpy()
+        assert stats.kstest(u, "uniform").pvalue > P_MIN and u.min() >= 0.0 and u.max() < 1.0
+    # consecutive elements and consecutive steps are uncorrelated
+    _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n, _lib.NOISE_NORMAL, 99, 7, _lib.stream_handle(cuda_device))
+    a = buf.cpu().double().numpy()
+    _lib.call("ebm_noise_fill_f32", buf.data_ptr(), n, _lib.NOISE_NORMAL, 99, 8, _lib.stream_handle(cuda_device))
+    b = buf.cpu().double().numpy()
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5 / np.sqrt(n) and abs(np.corrcoef(a, b)[0, 1]) < 5 / np.sqrt(n)
+
+
+def _cpu_langevin(energy, n, dim, k, eta, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, dim, generator=g)
+    noise = torch.randn(k, n, dim, generator=g)
+    out, _, _ = oracle.langevin_chain(energy, x, noise, [eta] * k, [1.0] * k)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["gauss2d", "double_well", "gmm"])
+def test_langevin_stationary_marginals_match_the_oracle(cuda_device, kind):
+    n, k = 8192, 300
+    if kind == "gauss2d":
+        mean, cov = torch.tensor([0.5, -0.25]), torch.tensor([[1.0, 0.8], [0.8, 1.0]])
+        model, en, dim, eta = ta.GaussianModel(mean, cov, device=cuda_device), oracle.Gaussian(mean, cov), 2, 0.05
+    elif kind == "double_well":
+        model, en, dim, eta = ta.DoubleWellModel(device=cuda_device), oracle.DoubleWell(), 4, 0.01
+    else:
+        means = ta.core.ring_mixture(8, 16).means.cpu() * 0.5  # radius 2: the modes mix within 300 steps
+        model, en, dim, eta = ta.GaussianMixtureModel(means, device=cuda_device), oracle.GaussianMixture(means, 1.0), 16, 0.05
+    want = _cpu_langevin(en, n, dim, k, eta, seed=1).double().numpy()
+    s = ta.LangevinDynamics(model, step_size=eta, device=cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(2)
+    got = s.sample(dim=dim, n_samples=n, n_steps=k, generator=gen).cpu().double().numpy()
+    for c in range(min(dim, 4)):
+        p = stats.ks_2samp(got[:, c], want[:, c]).pvalue
+        assert p > P_MIN, (kind, c, p)
+    if kind == "gauss2d":  # ... and against the closed-form law of the discretised chain: x' = x - eta P (x - mu) + sqrt(2 eta) eps
+        prec = np.linalg.inv(cov.double().numpy())
+        w, v = np.linalg.eigh(prec)
+        var_modes = 1.0 / (w * (1.0 - eta * w / 2.0))          # stationary variance of each eigen-direction
+        proj = (got - mean.double().numpy()) @ v
+        for c in range(2):
+            assert stats.kstest(proj[:, c] / np.sqrt(var_modes[c]), "norm").pvalue > P_MIN
+
+
+def test_hmc_marginals_and_acceptance_match_the_oracle(cuda_device):
+    n, T, L, eps = 4096, 30, 8, 0.2
+    mean, cov = torch.tensor([0.5, -0.25]), torch.tensor([[1.0, 0.8], [0.8, 1.0]])
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(n, 2, generator=g)
+    p, u = torch.randn(T, n, 2, generator=g), torch.rand(T, n, generator=g)
+    want = oracle.hmc_chain(oracle.Gaussian(mean, cov), x0, p, u, [eps] * T, L, want_diag=True)
+    s = ta.HamiltonianMonteCarlo(ta.GaussianModel(mean, cov, device=cuda_device), step_size=eps, n_leapfrog_steps=L, device=cuda_device)
+    got, diag = s.sample(x=x0.to(cuda_device), n_steps=T, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(4))
+    gx, wx = got.cpu().double().numpy(), want["x"].double().numpy()
+    for c in range(2):
+        assert stats.ks_2samp(gx[:, c], wx[:, c]).pvalue > P_MIN
+        # HMC is exact: the target's own marginal N(mean_c, cov_cc)
+        assert stats.kstest((gx[:, c] - mean[c].item()) / np.sqrt(cov[c, c].item()), "norm").pvalue > P_MIN
+    acc_gpu, acc_cpu = diag["acceptance_rate"].mean().item(), want["diagnostics"]["acceptance_rate"].mean().item()
+    assert abs(acc_gpu - acc_cpu) < 0.01, (acc_gpu, acc_cpu)
