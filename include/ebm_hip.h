@@ -107,6 +107,18 @@ EBM_API int ebm_langevin_step_f32(const float* x, const float* grad, float* out,
                           uint64_t seed, uint64_t offset, void* stream);
 
 /*
+ * The same step with a TENSOR diffusion coefficient D instead of the scalar noise scale
+ * (BaseSDERungeKuttaIntegrator.step(..., diffusion=D), core/base_integrator.py:652-671, 724-729):
+ *     out = (x - eta * grad) + sqrt(2 * D_e) * (eps * sqrt_eta),      D_e = diffusion[e % diffusion_period]
+ * with (2.0 * D) ** 0.5 evaluated as torch does (fp32 product, correctly rounded fp32 square root).
+ * diffusion_period = 1 (a 0-dim tensor), the row width (one value per coordinate) or n_elem (a full field); it must
+ * divide n_elem.  No clamp (the integrator has none).  `out` may alias `x`, `grad` may be NULL.
+ */
+EBM_API int ebm_langevin_step_diffusion_f32(const float* x, const float* grad, float* out, const float* noise,
+                                            const float* diffusion, int64_t diffusion_period, int64_t n_elem, float eta,
+                                            float sqrt_eta, uint64_t seed, uint64_t offset, void* stream);
+
+/*
  * The same step with the RNG coordinates read from DEVICE memory: rng_state = {seed, step} (two
  * uint64).  Kernel arguments are frozen when a launch is captured into a HIP graph; keeping
  * (seed, step) in a device buffer that the graph itself advances lets one captured

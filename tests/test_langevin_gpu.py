@@ -274,3 +274,36 @@ def test_full_size_properties_config2(cuda_device):
     assert torch.equal(c, a[:4096])
     # two chains never share noise
     assert (a[0] - a[1]).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("shape", ["scalar", "per_dim", "full", "per_chain"])
+def test_integrator_step_with_tensor_diffusion_runs_on_hip(cuda_device, shape):
+    """BaseSDERungeKuttaIntegrator.step(..., diffusion=D) with a TENSOR D (core/base_integrator.py:652-671, 724-729):
+    one launch of ebm_langevin_step_diffusion_f32, bit-identical to the reference's own ops evaluated by torch on the
+    device with the same noise ((2 D) ** 0.5 is a correctly rounded square root there and here).  torch's CPU
+    vectorised pow(x, 0.5) is one ulp off on ~5 % of the inputs, so the CPU run agrees to 2e-7 only."""
+    n, dim, h = 257, 6, 0.03
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, dim, generator=g)
+    noise = torch.randn(n, dim, generator=g)
+    d = {"scalar": torch.tensor(0.37), "per_dim": torch.rand(dim, generator=g) + 0.1,
+         "full": torch.rand(n, dim, generator=g) + 0.1, "per_chain": torch.rand(n, 1, generator=g) + 0.1}[shape]
+    drift = lambda x_, t_: -(x_**3)  # noqa: E731
+    want = ta.EulerMaruyamaIntegrator().step({"x": x}, h, drift=drift, diffusion=d, noise=noise)["x"]
+    assert torch.equal(want, (x + h * (1.0 * drift(x, None))) + (2.0 * d) ** 0.5 * (noise * (h**0.5)))  # the reference's own ops
+    em = ta.EulerMaruyamaIntegrator(device=cuda_device)
+    c0, e0 = hip_calls("ebm_langevin_step_diffusion_f32"), hip_calls("ebm_langevin_step_f32")
+    got = em.step({"x": x.to(cuda_device)}, h, drift=drift, diffusion=d.to(cuda_device), noise=noise.to(cuda_device))["x"]
+    assert hip_calls("ebm_langevin_step_diffusion_f32") == c0 + 1 and hip_calls("ebm_langevin_step_f32") == e0
+    xg, dg, ng = x.to(cuda_device), d.to(cuda_device), noise.to(cuda_device)
+    want_dev = (xg + h * (1.0 * drift(xg, None))) + (2.0 * dg) ** 0.5 * (ng * (h**0.5))  # base_integrator.py:724-729 in torch ops
+    assert torch.equal(got, want_dev)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-7, atol=2e-7)
+    # native draws: the (seed, step, element) field of every other kernel
+    gen = torch.Generator(device=cuda_device).manual_seed(9)
+    got2 = em.step({"x": x.to(cuda_device)}, h, drift=drift, diffusion=d.to(cuda_device), generator=gen)["x"]
+    assert gen.get_offset() == 4
+    field = torch.empty(n, dim, device=cuda_device)
+    _lib.call("ebm_noise_fill_f32", field.data_ptr(), n * dim, _lib.NOISE_NORMAL, _rng.kernel_seed(9), 0, _lib.stream_handle(cuda_device))
+    want2 = (xg + h * (1.0 * drift(xg, None))) + (2.0 * dg) ** 0.5 * (field * (h**0.5))
+    assert torch.equal(got2, want2)

@@ -31,6 +31,7 @@ EXPORTS = (
     "ebm_version",
     "ebm_last_error_string",
     "ebm_langevin_step_f32",
+    "ebm_langevin_step_diffusion_f32",
     "ebm_langevin_step_dev_f32",
     "ebm_langevin_chain_f32",
     "ebm_langevin_heun_chain_f32",
@@ -78,6 +79,7 @@ _PROTOTYPES = {
     "ebm_version": (C.c_int, []),
     "ebm_last_error_string": (C.c_char_p, []),
     "ebm_langevin_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _u64, _u64, _p]),
+    "ebm_langevin_step_diffusion_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f, _f, _u64, _u64, _p]),
     "ebm_langevin_step_dev_f32": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _i32, _f, _f, _p, _p]),
     "ebm_langevin_chain_f32": (
         C.c_int,

@@ -112,14 +112,12 @@ class BaseSDERungeKuttaIntegrator(BaseIntegrator):
             t = torch.zeros(x.size(0), device=x.device, dtype=x.dtype)
 
         scalar_noise = diffusion is None  # D is a Python float (or absent)
-        if (
-            on_hip_path(x)
-            and self._is_forward_euler()
-            and scalar_noise
-            and not torch.is_tensor(step_size)
-            and not torch.is_tensor(noise_scale)
-        ):
-            return {"x": self._hip_em_step(x, float(step_size), drift_fn(x, t), noise, noise_scale, generator)}
+        if on_hip_path(x) and self._is_forward_euler() and not torch.is_tensor(step_size):
+            if scalar_noise and not torch.is_tensor(noise_scale):
+                return {"x": self._hip_em_step(x, float(step_size), drift_fn(x, t), noise, noise_scale, generator)}
+            d = diffusion if diffusion is not None else noise_scale**2  # (a tensor noise_scale: D = noise_scale ** 2)
+            if torch.is_tensor(d) and d.is_cuda and d.device == x.device and d.dtype == torch.float32:
+                return {"x": self._hip_em_step_diffusion(x, float(step_size), drift_fn(x, t), noise, d, generator)}
 
         if x.is_cuda:
             warn_once(
@@ -136,6 +134,29 @@ class BaseSDERungeKuttaIntegrator(BaseIntegrator):
             dw = noise * (step_size**0.5)
             x_new = x_new + (2.0 * d_val) ** 0.5 * dw
         return {"x": x_new}
+
+    def _hip_em_step_diffusion(self, x, eta: float, drift_val, noise, d: torch.Tensor, generator) -> torch.Tensor:
+        """Tensor diffusion coefficient (base_integrator.py:652-671): ``x + h k0 + (2 D) ** 0.5 * (eps * h ** 0.5)`` in one
+        launch of ``ebm_langevin_step_diffusion_f32``; D is a 0-dim tensor, one value per trailing coordinate, or
+        anything else broadcastable to ``x`` (then materialised as a full field)."""
+        xin = _lib.dense_f32(x)
+        dv = _lib.dense_f32(drift_val)
+        out = torch.empty_like(xin)
+        if d.numel() == 1:
+            dd, period = d.reshape(1), 1
+        elif d.numel() == x.shape[-1] and d.shape[-1] == x.shape[-1]:
+            dd, period = d.reshape(-1), x.shape[-1]
+        else:
+            dd, period = torch.broadcast_to(d, x.shape), xin.numel()
+        dd = _lib.dense_f32(dd)
+        seed, step = (0, 0) if noise is not None else _rng.reserve(generator, x.device, 1)
+        nz = None if noise is None else _lib.dense_f32(noise.to(x.device))
+        _lib.call(
+            "ebm_langevin_step_diffusion_f32",
+            _lib.ptr(xin), _lib.ptr(dv), _lib.ptr(out), _lib.ptr(nz), _lib.ptr(dd), period, xin.numel(),
+            -eta, eta**0.5, seed, step, _lib.stream_handle(x.device),
+        )
+        return out.view_as(x)
 
     def _hip_em_step(self, x, eta: float, drift_val, noise, noise_scale, generator) -> torch.Tensor:
         xin = _lib.dense_f32(x)

@@ -13,6 +13,8 @@ namespace ebm {
 // launchers implemented in the kernel translation units
 int launch_langevin_step(const float*, const float*, float*, const float*, int64_t, float, float,
                          float, int, float, float, uint64_t, uint64_t, const uint64_t*, hipStream_t);
+int launch_langevin_step_diffusion(const float*, const float*, float*, const float*, const float*, int64_t, int64_t, float, float,
+                                   uint64_t, uint64_t, hipStream_t);
 int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
                                const float*, uint64_t, uint64_t, int heun, hipStream_t);
@@ -160,6 +162,21 @@ int ebm_langevin_step_f32(const float* x, const float* grad, float* out, const f
     return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
   return launch_langevin_step(x, grad, out, noise, n_elem, eta, sqrt_eta, noise_coef, clamp_on,
                               cmin, cmax, seed, offset, nullptr, (hipStream_t)stream);
+}
+
+int ebm_langevin_step_diffusion_f32(const float* x, const float* grad, float* out, const float* noise, const float* diffusion,
+                                    int64_t diffusion_period, int64_t n_elem, float eta, float sqrt_eta, uint64_t seed,
+                                    uint64_t offset, void* stream) {
+  const char* who = "ebm_langevin_step_diffusion_f32";
+  if (n_elem < 0) return fail(EBM_EINVAL, "%s: n_elem < 0", who);
+  if (n_elem == 0) return 0;
+  if (!x || !out || !diffusion) return fail(EBM_EINVAL, "%s: x/out/diffusion is NULL", who);
+  if (diffusion_period < 1 || (diffusion_period != 1 && n_elem % diffusion_period != 0))
+    return fail(EBM_EINVAL, "%s: diffusion_period %lld does not tile n_elem %lld", who, (long long)diffusion_period, (long long)n_elem);
+  if (!aligned16(x) || !aligned16(out) || (grad && !aligned16(grad)) || (noise && !aligned16(noise)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_langevin_step_diffusion(x, grad, out, noise, diffusion, diffusion_period, n_elem, eta, sqrt_eta, seed, offset,
+                                        (hipStream_t)stream);
 }
 
 int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* out, int64_t n_elem, float eta,

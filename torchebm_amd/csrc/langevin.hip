@@ -196,8 +196,58 @@ int grid_for(int64_t n_threads, int max_blocks) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------
+// per-step kernel with a TENSOR diffusion coefficient (core/base_integrator.py:652-671, 724-729):
+//   x' = (x - eta * grad) + sqrt(2 D_e) * (eps * sqrt_eta),   D_e = diffusion[e % period]
+// (2.0 * D) ** 0.5 is torch's pow-with-0.5 = a correctly rounded fp32 square root of the rounded product.
+// period = 1 (a 0-dim tensor), dim (one value per coordinate) or n_elem (a full field).
+// ---------------------------------------------------------------------------------
+template <bool NOISE_PTR>
+__global__ __launch_bounds__(kBlock) void langevin_step_diffusion_kernel(StepArgs a, const float* __restrict__ diffusion,
+                                                                         int64_t period) {
+  const int64_t n_groups = ceil_div64(a.n_elem, 4);
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * kBlock) {
+    const int64_t e0 = g * 4;
+    const int64_t left = a.n_elem - e0;
+    const int nv = left >= 4 ? 4 : (int)left;
+    const F4 x = load4(a.x, e0, nv, true);
+    F4 gr;
+    if (a.grad) gr = load4(a.grad, e0, nv, true);
+    else gr = F4{{0.f, 0.f, 0.f, 0.f}};
+    F4 eps;
+    if constexpr (NOISE_PTR) eps = load4(a.noise, e0, nv, true);
+    else eps = normal4_at(a.key, (uint64_t)g, a.step);
+    F4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float d = (i < nv) ? diffusion[period == 1 ? 0 : (e0 + i) % period] : 0.0f;
+      const float coef = sqrtf(2.0f * d);
+      const float x1 = x.v[i] - a.c.eta * gr.v[i];
+      const float dw = eps.v[i] * a.c.sqrt_eta;
+      o.v[i] = x1 + coef * dw;
+    }
+    store4(a.out, e0, nv, true, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // host entry points (called from api.hip)
 // ---------------------------------------------------------------------------------
+int launch_langevin_step_diffusion(const float* x, const float* grad, float* out, const float* noise, const float* diffusion,
+                                   int64_t period, int64_t n_elem, float eta, float sqrt_eta, uint64_t seed, uint64_t offset,
+                                   hipStream_t st) {
+  StepArgs a;
+  a.rng_dev = nullptr;
+  a.x = x; a.grad = grad; a.out = out; a.noise = noise; a.n_elem = n_elem;
+  a.c = StepCoef{eta, sqrt_eta, 0.0f};
+  a.clamp_on = 0; a.cmin = 0.0f; a.cmax = 0.0f;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step = offset;
+  const int grid = grid_for(ceil_div64(n_elem, 4), 256 * 8);
+  if (noise) hipLaunchKernelGGL(langevin_step_diffusion_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a, diffusion, period);
+  else hipLaunchKernelGGL(langevin_step_diffusion_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a, diffusion, period);
+  return check_launch("ebm_langevin_step_diffusion_f32");
+}
+
 int launch_langevin_step(const float* x, const float* grad, float* out, const float* noise,
                          int64_t n_elem, float eta, float sqrt_eta, float noise_coef, int clamp_on,
                          float cmin, float cmax, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
