@@ -6,15 +6,16 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries you want judged into profiles/.
 set -u
 TAG="${1:-r01}"
-ARGS="${2:---steps 5 --warmup 1 --no-cpu-baseline}"
+ARGS="${2:---steps 20 --warmup 3 --no-cpu-baseline}"          # the kernel trace: the driver's own command line minus the CPU baseline
+PMC_ARGS="${3:---steps 5 --warmup 1 --no-cpu-baseline --no-extra}"  # counter passes: the headline kernel only
 REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" $PMC_ARGS > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python "$REPO/bench.py" $PMC_ARGS > "$OUT/pmc_write.log" 2>&1
 echo "pmc write rc=$?"
 find "$OUT" -name '*.csv' | head -20

@@ -42,6 +42,24 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
             f"{float(r['MinNs'])/1e6:.4f},{float(r['MaxNs'])/1e6:.4f},{float(r['Percentage']):.3f}\n"
         )
 
+# The default bench.py run also measures the other BASELINE configs (`extra`), some of them with the SAME kernel at
+# another shape (config 4's shard uses the lean chain kernel at dim 128, k 500).  The plain per-name statistics above
+# mix them; this second table splits the package's kernels by launch grid, from the kernel trace.
+trace = os.path.join(src, "trace", "bench_kernel_trace.csv")
+if os.path.exists(trace):
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "ebm::" not in r["Kernel_Name"]:
+            continue
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["LDS_Block_Size"]),
+               int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["Scratch_Size"]))
+        groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open(os.path.join(dst, f"{tag}_kernel_stats_by_grid.csv"), "w") as f:
+        f.write("kernel,workgroups,lds_bytes,vgprs,agprs,scratch_bytes,calls,avg_ms,min_ms,max_ms\n")
+        for key, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            f.write(",".join(str(k) for k in key) + f",{len(v)},{sum(v)/len(v):.4f},{min(v):.4f},{max(v):.4f}\n")
+    print(open(os.path.join(dst, f"{tag}_kernel_stats_by_grid.csv")).read())
+
 pmc = {}
 for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     path = os.path.join(src, sub, "bench_counter_collection.csv")
