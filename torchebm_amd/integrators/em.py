@@ -30,9 +30,9 @@ class EulerMaruyamaIntegrator(BaseSDERungeKuttaIntegrator):
 class HeunIntegrator(BaseSDERungeKuttaIntegrator):
     r"""Heun (improved Euler) predictor-corrector drift update with the same Euler-order noise term
     (reference: torchebm/integrators/heun.py; ``LangevinDynamics(integrator="heun")`` in the reference's
-    tests/samplers/test_langevin_dynamics.py:259-268).  Two drift evaluations per step; runs the generic
-    explicit-tableau path (eager torch ops) -- SURVEY.md §8f n3 lists it as a follow-up, it is not one
-    of the fused kernels."""
+    tests/samplers/test_langevin_dynamics.py:259-268).  Two drift evaluations per step.  ``step()`` /
+    ``integrate()`` here run the generic explicit-tableau path (eager torch ops); the sampler's whole-chain
+    route for the analytic energies is fused (``ebm_langevin_heun_chain_f32``, samplers/langevin.py)."""
 
     @property
     def tableau_a(self):
