@@ -52,11 +52,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 // block's state into tile[0 .. E) in flat order (element offset inside the block).  L = number of valid flat
 // elements of this block (a multiple of dim when E % dim == 0).  e_part / acc_part: this thread's share of the
 // block's energy sum and accept count.  Ends with a barrier: the tile may be rewritten right after.
-__device__ __noinline__ void emit(const DiagArgs d, int keep, float* tile, int L, int dim, float e_part, float acc_part) {
+// `scratch`: scratch_floats(S) floats (directly behind the tile unless the caller keeps the tile elsewhere).
+__device__ __noinline__ void emit(const DiagArgs d, int keep, const float* tile, float* scratch, int L, int dim, float e_part,
+                                  float acc_part) {
   const int tid = threadIdx.x;
   const int S = d.S;
   const int smax = S > kBlock ? S : kBlock;
-  float* sum_s = tile + d.E;        // [P][S]
+  float* sum_s = scratch;           // [P][S]
   float* m2_s = sum_s + smax;       // [P][S]
   float* red = m2_s + smax;         // [8]
   e_part = wave_sum(e_part);
@@ -118,61 +120,76 @@ __device__ __noinline__ void emit(const DiagArgs d, int keep, float* tile, int L
 // again; the first dim/4 lanes store the wave's part of the record.  All four waves do the same ~70 instructions,
 // so none of them lags at the next barrier (a reduction left to ONE wave is time-sliced with the seven other
 // waves of its SIMD and holds its workgroup back eight times its own length).
-//   x4: the lane's elements; L: valid flat elements of this workgroup; rows_b = L / dim;
+//   x4: the lane's elements; L: valid flat elements of this workgroup; inv_rows = 1 / (L / dim);
 //   lds: 2 * fast_lds_floats() floats.
 __host__ __device__ inline bool fast_flat_ok(int dim) { return dim >= 4 && dim <= 256 && (dim & (dim - 1)) == 0; }
 __host__ __device__ inline int fast_lds_floats() { return 1024; }
 
-__device__ __forceinline__ float wave_sum_dpp(float v) {  // total in every lane of rows 0 / 2; used from lane 0
-  auto dpp = [](float x, auto ctrl) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+// total of the wave in lane 63 (DPP only: the row totals, then row_bcast:15 / row_bcast:31 carry them upwards)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, true));
   };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  using all = std::integral_constant<int, 0xF>;
+  v += dpp(v, std::integral_constant<int, 0xB1>{}, all{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{}, all{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{}, all{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{}, all{});  // row_mirror: every lane holds its row's total
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast:15 into rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast:31 into rows 2, 3
   return v;
 }
 
-__device__ __forceinline__ void emit_flat_fast(const DiagArgs d, int keep, float* lds, int dim, float4 x4, int L, int rows_b,
+// inv_rows = 1 / (valid rows of this workgroup) (0 when it has none): the rows of a full workgroup are a power of two,
+// where the product is the quotient; in the one ragged workgroup the centre is an ulp off the block mean, which the
+// merge's pairwise identity does not notice (it shifts M2 by rows * ulp^2).
+__device__ __forceinline__ void emit_flat_fast(const DiagArgs d, int keep, float* lds, int dim, float4 x4, int L, float inv_rows,
                                                float e_part) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // The lane geometry is recomputed here at every kept step (a dozen integer instructions): left to the compiler it
+  // is hoisted out of the step loop, does not fit the 64 registers of eight waves per SIMD, and comes back from
+  // scratch one dependent reload at a time right behind the barrier.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* tile = lds + (keep & 1) * fast_lds_floats();
   *reinterpret_cast<float4*>(tile + 4 * tid) = x4;
   // ONE barrier: the tiles alternate with the kept step, and no wave can reach the barrier of the step after next
   // (behind which this tile is written again) before it has finished reading here
   __syncthreads();
-  const int cw = dim >> 2;        // columns per wave (1 .. 64)
-  const int lpc = 64 / cw;        // lanes per column; each takes rows lane / cw + lpc * i, i < 4
+  const int cw = dim >> 2;                 // columns per wave (1 .. 64)
+  const int sh = __builtin_ctz(cw);        // 64 / cw lanes share a column; lane takes rows lane / cw + (64 / cw) i, i < 4
   const int col = wave * cw + (lane & (cw - 1));
-  const int r0 = lane / cw;
+  const int e0 = (lane >> sh) * dim + col;  // the four elements sit 256 apart: (64 / cw) rows = 256 floats
   float v[4];
   bool ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int e = (r0 + lpc * i) * dim + col;
-    ok[i] = e < L;
-    v[i] = ok[i] ? tile[e] : 0.0f;
+    const float t = tile[e0 + 256 * i];    // always inside the tile
+    ok[i] = e0 + 256 * i < L;
+    v[i] = ok[i] ? t : 0.0f;
   }
+  const int lane4 = lane << 2;
   float sum = (v[0] + v[1]) + (v[2] + v[3]);
-  for (int m = cw; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
-  const float mu = rows_b > 0 ? sum / (float)rows_b : 0.0f;
+  for (int m4 = cw << 2; m4 < 256; m4 <<= 1)
+    sum += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ m4, __float_as_int(sum)));
+  const float mu = sum * inv_rows;
   float m2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float dv = ok[i] ? v[i] - mu : 0.0f;
     m2 = __builtin_fmaf(dv, dv, m2);
   }
-  for (int m = cw; m < 64; m <<= 1) m2 += __shfl_xor(m2, m);
+  for (int m4 = cw << 2; m4 < 256; m4 <<= 1)
+    m2 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ m4, __float_as_int(m2)));
   float* rec = d.partials + ((int64_t)keep * d.n_blocks + blockIdx.x) * (int64_t)record_floats(d.S);
   if (lane < cw) {
     rec[col] = sum;
     rec[d.S + col] = m2;
   }
-  const float e = wave_sum_dpp(e_part);
-  if (lane == 0) {  // tail: four per-wave energy shares, four accept shares
+  const float e = wave_sum_to_lane63(e_part);
+  if (lane == 63) {  // tail: four per-wave energy shares, four accept shares
     rec[2 * d.S + wave] = e;
     rec[2 * d.S + 4 + wave] = 0.0f;
   }

@@ -89,16 +89,18 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   if (geo.NV >= 4) smem += (size_t)kBlock * geo.NV * 16 * (geo.NV <= 4 ? 3 : 2);
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
   a.diag_offset_floats = (int)(smem / sizeof(float));
-  if (diag_partials) {
+  const bool diag_kernel = diag_partials != nullptr;
+  if (diag_kernel) {
     if (!diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, a.diag))
       return fail(EBM_EDIM, "ebm_hmc_chain_f32: diagnostics records are not available for dim %d", dim);
     a.diag.partials = diag_partials;
-    smem += (size_t)diag::lds_floats(a.diag.E, a.diag.S) * sizeof(float);
+    // scratch rows, then (narrow rows only: the wide ones reuse the state's parking slot) the tile
+    smem += (size_t)(geo.NV >= 4 ? diag::scratch_floats(a.diag.S) : diag::lds_floats(a.diag.E, a.diag.S)) * sizeof(float);
   }
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks);
-  if (diag_partials) {
+  if (diag_kernel) {
     switch (e.kind) {
       case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well_diag(geo, grid, smem, st, a); break;
       case EBM_ENERGY_HARMONIC:    hmc::launch_harmonic_diag(geo, grid, smem, st, a); break;

@@ -405,10 +405,19 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
       if constexpr (DIAG) {
         // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain
         // holds now (its accepted proposal's E1, else E0 -- what the reference re-evaluates), acceptance rate
-        float* tile = hmc_smem + a.diag_offset_floats;
+        // The tile: with XC_LDS the slot the old state was parked in -- dead until the next transition parks
+        // again, and exactly one block of rows wide -- so the records cost no LDS beyond the scratch rows (a tile of
+        // its own took the one-lane-per-chain kernels from two workgroups per CU to one: +25 % on config 3).  The
+        // barrier: a slower wave may still have to bring its parked state back.
+        float* scratch = hmc_smem + a.diag_offset_floats;
+        float* tile = scratch + diag::scratch_floats(a.diag.S);
+        if constexpr (XC_LDS) {
+          tile = hmc_smem + a.park_offset_floats;
+          __syncthreads();
+        }
         tile_store(L, tile, xc);
         const float e_now = clamp_nanprop(e_cur, -1e10f, 1e10f);
-        diag::emit(a.diag, keep, tile, tile_valid<G>(a.n_chains, a.dim), a.dim, leader ? e_now : 0.0f,
+        diag::emit(a.diag, keep, tile, scratch, tile_valid<G>(a.n_chains, a.dim), a.dim, leader ? e_now : 0.0f,
                    (accept && leader) ? 1.0f : 0.0f);
         ++keep;
       }

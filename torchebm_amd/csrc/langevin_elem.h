@@ -163,6 +163,7 @@ __device__ __forceinline__ void lean_body(const ChainArgs& a) {
     const int L = rest >= kBlock * 4 ? kBlock * 4 : (int)rest;  // valid elements of this workgroup
     const bool fast = diag::fast_flat_ok(a.dim);
     const int rows_b = L / a.dim;
+    const float inv_rows = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rows_b > 0 ? 1.0f / (float)rows_b : 0.0f)));
     int i = 0;
     for (int keep = 0; keep < a.n_kept; ++keep) {
       const int stop = i + a.thin;
@@ -181,10 +182,10 @@ __device__ __forceinline__ void lean_body(const ChainArgs& a) {
         e_part += (q < nv) ? t : 0.0f;
       }
       if (fast) {
-        diag::emit_flat_fast(a.diag, keep, elem_smem, a.dim, make_float4(x.v[0], x.v[1], x.v[2], x.v[3]), L, rows_b, a.s0 * e_part);
+        diag::emit_flat_fast(a.diag, keep, elem_smem, a.dim, make_float4(x.v[0], x.v[1], x.v[2], x.v[3]), L, inv_rows, a.s0 * e_part);
       } else {
         *reinterpret_cast<float4*>(elem_smem + 4 * threadIdx.x) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
-        diag::emit(a.diag, keep, elem_smem, L, a.dim, a.s0 * e_part, 0.0f);
+        diag::emit(a.diag, keep, elem_smem, elem_smem + a.diag.E, L, a.dim, a.s0 * e_part, 0.0f);
       }
     }
 #pragma unroll 2

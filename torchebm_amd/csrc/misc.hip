@@ -423,7 +423,30 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
     if (p < P && s < S) {
       const int cnt0 = s < len_first ? (int)((len_first - s + dim - 1) / dim) : 0;
       shift = cnt0 > 0 ? (double)base[(int64_t)w * R + s] / (double)cnt0 : 0.0;
-      for (int64_t i = i0 + p; i < i1; i += P) {
+      // full blocks first, four records in flight per lane (one record per trip leaves the loop waiting on a single
+      // pair of loads); the ragged tail of the state goes through the general trip below
+      const int64_t n_full = n_elem / E;
+      const double cnt_full = (double)((E + dim - 1) / dim);
+      double Cf = 0.0;
+      int64_t i = i0 + p;
+      for (; i + 3 * P < i1 && w + (i + 3 * P) * W < n_full; i += 4 * P) {
+        float sx[4], m2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* rec = base + (w + (i + (int64_t)u * P) * W) * R;
+          sx[u] = __builtin_nontemporal_load(rec + s);
+          m2[u] = __builtin_nontemporal_load(rec + S + s);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double dm = (double)sx[u] * inv_full - shift;
+          A += (double)sx[u];
+          B += (double)m2[u];
+          Cf = __builtin_fma(dm, dm, Cf);
+        }
+      }
+      C = cnt_full * Cf;
+      for (; i < i1; i += P) {
         const int64_t b = w + i * W;
         const int64_t len = diag_block_len(b, E, n_elem);
         if (s >= len) continue;
@@ -457,16 +480,31 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {  // energy / accept sums of this workgroup's blocks
+  {  // energy / accept sums of this workgroup's blocks: a record per lane and trip (ONE lane walking them all was
+     // the whole run time of this kernel: 6.7 ms for 200 kept steps of config 2), then one total per workgroup
     double es = 0.0, as = 0.0;
-    for (int64_t i = i0; i < i1; ++i) {
-      const float* rec = base + (w + i * W) * R;
-      es += ((double)rec[2 * S] + (double)rec[2 * S + 1]) + ((double)rec[2 * S + 2] + (double)rec[2 * S + 3]);
-      as += ((double)rec[2 * S + 4] + (double)rec[2 * S + 5]) + ((double)rec[2 * S + 6] + (double)rec[2 * S + 7]);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kBlock) {
+      const float* tail = base + (w + i * W) * R + 2 * S;
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(tail + u);
+      es += ((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3]);
+      as += ((double)t[4] + (double)t[5]) + ((double)t[6] + (double)t[7]);
     }
-    const double r0 = atomicAdd(&wrow[3 * dim], es);
-    const double r1 = atomicAdd(&wrow[3 * dim + 1], as);
-    asm volatile("" ::"v"(r0), "v"(r1));
+    red[0][threadIdx.x] = es; red[1][threadIdx.x] = as;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+      if ((int)threadIdx.x < h) {
+        red[0][threadIdx.x] += red[0][threadIdx.x + h];
+        red[1][threadIdx.x] += red[1][threadIdx.x + h];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const double r0 = atomicAdd(&wrow[3 * dim], red[0][0]);
+      const double r1 = atomicAdd(&wrow[3 * dim + 1], red[1][0]);
+      asm volatile("" ::"v"(r0), "v"(r1));
+    }
   }
   __shared__ bool last;
   __syncthreads();

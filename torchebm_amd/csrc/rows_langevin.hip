@@ -94,7 +94,7 @@ __device__ __forceinline__ void langevin_chain_rows_body(const RowChainArgs& a) 
         tile_store(L, tile, x);
         Slice<NV> g_unused;
         const float e_now = en.template eval<true>(L, x, g_unused);
-        diag::emit(a.diag, keep, tile, tile_valid<G>(a.n_chains, a.dim), a.dim, (L.active && L.lg == 0) ? e_now : 0.0f, 0.0f);
+        diag::emit(a.diag, keep, tile, tile + a.diag.E, tile_valid<G>(a.n_chains, a.dim), a.dim, (L.active && L.lg == 0) ? e_now : 0.0f, 0.0f);
         ++keep;
       }
     }
