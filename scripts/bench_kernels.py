@@ -155,6 +155,7 @@ gauss64 = ta.GaussianModel(torch.zeros(64), (A @ A.t() / 64 + torch.eye(64)), de
 chain_case("chain_gauss_dim64", gauss64, 1 << 18, 64, 50)
 gauss2 = ta.GaussianModel(torch.zeros(2), torch.tensor([[1.0, 0.8], [0.8, 1.0]]), device=dev)
 chain_case("chain_gauss_dim2", gauss2, 1 << 22, 2, 100)
+chain_case("chain_gmm8_dim2", ta.core.ring_mixture(8, 2, device=dev), 1 << 22, 2, 100)
 chain_case("chain_gmm8_dim32", ta.core.ring_mixture(8, 32, device=dev), 1 << 18, 32, 50)
 step_case("step_native_rng_2^26", 1 << 26)
 step_case("step_noise_ptr_2^26", 1 << 26, noise_ptr=True)

@@ -156,12 +156,16 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     if (a.p_noise) {
       load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * dim + row, p);
     } else {
+      // (the per-quad Philox counters are formed here at every transition: hoisted out of the transition loop they
+      //  are 2 registers per quad held across the whole trajectory)
+      uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+      asm volatile("" : "+v"(e_row));
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int k0 = 32 * t + 8 * q + 4 * h;
-          const F4 n = normal4_at(a.key, ((uint64_t)chain * dim + (uint64_t)k0) >> 2, a.step0 + 2ull * (uint64_t)tr);
+          const F4 n = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + 2ull * (uint64_t)tr);
 #pragma unroll
           for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = k0 < dim ? n.v[i] : 0.0f;  // (straight-line: see gauss_mfma.hip)
         }

@@ -119,6 +119,135 @@ __global__ __launch_bounds__(kBlock) void langevin_heun_rows_kernel(RowChainArgs
 }
 
 // ---------------------------------------------------------------------------------
+// dim == 2 (the 2-D Gaussian of BASELINE config 1, 2-D mixtures): TWO chains per lane.
+// A Philox counter covers four consecutive flat elements = two whole rows, so with one chain per lane every lane
+// pays the ten rounds and both Box-Muller pairs for two normals it uses and two it discards -- and the RNG is
+// 85 % of a 2-D step.  Here the lane's float4 is the pair of rows (2p, 2p+1): one counter, four normals, all used;
+// the energy body is the one-lane-per-chain body of rows.h evaluated twice (same arithmetic, bit for bit, as the
+// one-chain-per-lane kernel this replaces), the update is the same expression on four slots.
+// ---------------------------------------------------------------------------------
+template <int KIND, bool HEUN>
+__device__ __forceinline__ void langevin_chain_pair_body(const RowChainArgs& a) {
+  using LaneT = Lane<1, 1, false>;
+  const int64_t pair = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneT lane[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    LaneT& L = lane[c];
+    L.chain = 2 * pair + c;
+    L.lg = 0;
+    L.chain_in_wave = threadIdx.x & 63;
+    L.active = L.chain < a.n_chains;
+    L.vec_ok = false;
+    L.dim = 2;
+    L.col[0] = 0;
+    L.valid = L.active ? 0x3u : 0u;
+  }
+  const Smem S = carve_smem<1>(rows_smem, a.param_floats);
+  stage_params(a.energy, a.dim, S.param);
+  Energy<KIND, LaneT> en;
+  en.init(a.energy, lane[0], S);
+
+  float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool vec = lane[1].active && (((uintptr_t)a.x & 15u) == 0);
+  if (vec) {
+    const float4 t = *reinterpret_cast<const float4*>(a.x + 4 * pair);
+    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane[i >> 1].active) x[i] = a.x[4 * pair + i];
+  }
+  auto grad = [&](const float (&xs)[4], float (&g)[4]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      Slice<1> xc, gc;
+      xc.a[0][0] = xs[2 * c]; xc.a[0][1] = xs[2 * c + 1]; xc.a[0][2] = 0.0f; xc.a[0][3] = 0.0f;
+      en.template eval<false>(lane[c], xc, gc);
+      g[2 * c] = gc.a[0][0]; g[2 * c + 1] = gc.a[0][1];
+    }
+  };
+  int until_keep = a.thin;
+  int keep = 0;
+  const bool keeping = a.traj != nullptr || a.diag.partials != nullptr;
+  float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
+  for (int s = 0; s < a.k_steps; ++s) {
+    if (a.table) {
+      const float4 t = a.table[s];
+      eta = t.x; sqrt_eta = t.y; noise_coef = t.z;
+    }
+    float g[4];
+    grad(x, g);
+    if constexpr (HEUN) {
+      float x1[4], g1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x1[i] = lane[i >> 1].active ? x[i] - eta * g[i] : 0.0f;
+      grad(x1, g1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = 0.5f * g[i] + 0.5f * g1[i];
+    }
+    F4 eps;
+    if (a.noise) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        eps.v[i] = lane[i >> 1].active ? a.noise[((int64_t)s * a.n_chains) * 2 + 4 * pair + i] : 0.0f;
+    } else {
+      eps = normal4_at(a.key, (uint64_t)pair, a.step0 + (uint64_t)s);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x1 = x[i] - eta * g[i];
+      const float dw = eps.v[i] * sqrt_eta;
+      float nv = x1 + noise_coef * dw;
+      if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+      x[i] = lane[i >> 1].active ? nv : 0.0f;
+    }
+    if (keeping && --until_keep == 0) {
+      until_keep = a.thin;
+      if (a.traj) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (lane[c].active) {
+            float* dst = a.traj + (lane[c].chain * (int64_t)a.n_kept + keep) * 2;
+            dst[0] = x[2 * c]; dst[1] = x[2 * c + 1];
+          }
+      }
+      if (a.diag.partials) {
+        float* tile = rows_smem + a.diag_offset_floats;
+        float e_part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          Slice<1> xc, g_unused;
+          xc.a[0][0] = x[2 * c]; xc.a[0][1] = x[2 * c + 1]; xc.a[0][2] = 0.0f; xc.a[0][3] = 0.0f;
+          const float e_now = en.template eval<true>(lane[c], xc, g_unused);
+          if (lane[c].active) {
+            e_part += e_now;
+            tile[4 * threadIdx.x + 2 * c] = x[2 * c];
+            tile[4 * threadIdx.x + 2 * c + 1] = x[2 * c + 1];
+          }
+        }
+        const int64_t left = a.n_chains - (int64_t)blockIdx.x * (2 * kBlock);
+        const int valid = left >= 2 * kBlock ? 4 * kBlock : (left > 0 ? (int)left * 2 : 0);
+        diag::emit(a.diag, keep, tile, tile + a.diag.E, valid, 2, e_part, 0.0f);
+      }
+      ++keep;
+    }
+  }
+  if (vec) {
+    *reinterpret_cast<float4*>(a.x + 4 * pair) = make_float4(x[0], x[1], x[2], x[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane[i >> 1].active) a.x[4 * pair + i] = x[i];
+  }
+}
+
+template <int KIND, bool HEUN>
+__global__ __launch_bounds__(kBlock) void langevin_chain_pair_kernel(RowChainArgs a) {
+  langevin_chain_pair_body<KIND, HEUN>(a);
+}
+
+// ---------------------------------------------------------------------------------
 // noise-free descent (gradient descent / Nesterov), k fused steps, any analytic energy
 // ---------------------------------------------------------------------------------
 struct DescentArgs {
@@ -248,6 +377,12 @@ __global__ __launch_bounds__(kBlock) void energy_grad_wide_row_kernel(const floa
 
 // Lane geometry of the row-coupled Langevin chain for this energy / row width (shared by the launcher and the
 // diagnostics layout query, which must agree).
+static bool rows_langevin_pair(const ebm_energy_t& e, int32_t dim) {
+  // A/B switch for tests and profiling: EBM_NO_PAIR=1 keeps one chain per lane at dim 2
+  static const bool off = [] { const char* v = getenv("EBM_NO_PAIR"); return v && v[0] == '1'; }();
+  return !off && dim == 2 && (e.kind == EBM_ENERGY_GAUSSIAN || e.kind == EBM_ENERGY_GMM);
+}
+
 static bool rows_langevin_geometry(const ebm_energy_t& e, int32_t dim, int heun, Geometry& geo, bool& lane_per_chain) {
   if (!pick_geometry(dim, geo)) return false;
   // small mixture, dim 16 / 32: one lane per chain, the means become wave-uniform scalar operands
@@ -262,6 +397,7 @@ bool rows_langevin_diag_plan(const ebm_energy_t& e, int heun, int64_t n_chains, 
   bool lpc;
   if (!rows_langevin_geometry(e, dim, heun, geo, lpc)) return false;
   if (heun && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC)) return false;  // Heun element-wise: flat kernel only
+  if (rows_langevin_pair(e, dim)) return diag::plan(n_chains, dim, 4 * (int64_t)kBlock, d);  // two chains per lane
   return diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, d);
 }
 
@@ -292,10 +428,17 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
     a.diag.partials = diag_partials;
     smem += (size_t)diag::lds_floats(a.diag.E, a.diag.S) * sizeof(float);
   }
-  const int64_t blocks = blocks_for(n_chains, geo);
+  const bool pair = rows_langevin_pair(e, dim);
+  const int64_t blocks = pair ? ceil_div64(n_chains, 2 * (int64_t)kBlock) : blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks), block(kBlock);
-  if (heun && e.kind == EBM_ENERGY_GAUSSIAN)
+  if (pair && e.kind == EBM_ENERGY_GAUSSIAN) {
+    if (heun) hipLaunchKernelGGL((langevin_chain_pair_kernel<EBM_ENERGY_GAUSSIAN, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((langevin_chain_pair_kernel<EBM_ENERGY_GAUSSIAN, false>), grid, block, smem, st, a);
+  } else if (pair) {
+    if (heun) hipLaunchKernelGGL((langevin_chain_pair_kernel<EBM_ENERGY_GMM, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((langevin_chain_pair_kernel<EBM_ENERGY_GMM, false>), grid, block, smem, st, a);
+  } else if (heun && e.kind == EBM_ENERGY_GAUSSIAN)
     EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GAUSSIAN, geo, grid, block, smem, st, a);
   else if (heun && e.kind == EBM_ENERGY_GMM)
     EBM_GEO_LAUNCH(langevin_heun_rows_kernel, EBM_ENERGY_GMM, geo, grid, block, smem, st, a);
