@@ -37,6 +37,7 @@ struct GaussHmcArgs {
   uint64_t step0;
   const float* mean;  // [dim]
   const float* prec;  // [dim, dim], symmetric
+  const float* mass_diag;  // [dim] diagonal mass (null: none / scalar)
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -84,7 +85,8 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   return 0.5f * acc;
 }
 
-template <int NT>
+// DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
+template <int NT, bool DIAGM>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr int DIM = 32 * NT;
   float* Ps = gauss_hmc_smem;
@@ -97,6 +99,14 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
   }
   for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
+  // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
+  // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
+  // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
+  float* mraw = mus + DIM;                                   // [DIM]
+  float* dsw = mraw + DIM + (threadIdx.x >> 6) * DIM;        // [DIM], this wave's
+  constexpr bool diag_mass = DIAGM;
+  if constexpr (diag_mass)
+    for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = i < dim ? a.mass_diag[i] : 1.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -104,6 +114,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
   const bool active = chain < a.n_chains;
   const int64_t row = active ? chain * (int64_t)dim : 0;
+  auto quad_of = [&](const float* arr, int t, int q) { return *reinterpret_cast<const float4*>(arr + 32 * t + 8 * q + 4 * h); };
 
   // quad q of tile t = coordinates 32t + 8q + 4h .. +3  (one float4, one Philox counter)
   auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst) {
@@ -129,10 +140,23 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   // K(p) = 0.5 p^T p [/ m], clamped to [0, 1e10]  (samplers/hmc.py:136-159, :251-254)
   auto kinetic = [&](const Tile<NT>& q) -> float {
     float acc = 0.0f;
+    if constexpr (diag_mass) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc += q.t[t][r] * q.t[t][r];
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 mq = quad_of(mraw, t, qd);
+          acc += q.t[t][4 * qd] * q.t[t][4 * qd] / mq.x;
+          acc += q.t[t][4 * qd + 1] * q.t[t][4 * qd + 1] / mq.y;
+          acc += q.t[t][4 * qd + 2] * q.t[t][4 * qd + 2] / mq.z;
+          acc += q.t[t][4 * qd + 3] * q.t[t][4 * qd + 3] / mq.w;
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += q.t[t][r] * q.t[t][r];
+    }
     acc += __shfl_xor(acc, 32);
     float k = 0.5f * acc;
     if (a.has_mass) k = k / a.mass_raw;
@@ -176,6 +200,24 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) p.t[t][r] *= a.mass_sqrt;
     }
+    if constexpr (diag_mass) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 mq = quad_of(mraw, t, qd);
+          p.t[t][4 * qd] *= sqrtf(mq.x); p.t[t][4 * qd + 1] *= sqrtf(mq.y);
+          p.t[t][4 * qd + 2] *= sqrtf(mq.z); p.t[t][4 * qd + 3] *= sqrtf(mq.w);
+          if (m == 0) {  // this transition's drift factors, once per K-half
+            const float4 ds = make_float4(eps / (mq.x < 1e-10f ? 1e-10f : mq.x), eps / (mq.y < 1e-10f ? 1e-10f : mq.y),
+                                          eps / (mq.z < 1e-10f ? 1e-10f : mq.z), eps / (mq.w < 1e-10f ? 1e-10f : mq.w));
+            *reinterpret_cast<float4*>(dsw + 32 * t + 8 * qd + 4 * h) = ds;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     // ---- H0 and the first (clamped) force
     Tile<NT> f;
@@ -189,39 +231,68 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
     float e1 = e0;
     for (int l = 0; l < a.n_leapfrog; ++l) {
+      if constexpr (diag_mass) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float ph = __builtin_fmaf(half_eps, f.t[t][r], p.t[t][r]);
-          p.t[t][r] = ph;
-          x.t[t][r] = __builtin_fmaf(drift_scale, ph, x.t[t][r]);
-        }
-      e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);  // f holds +g here
-      // E finite => x finite, g clean.  The decision is taken per WAVE: the literal path re-runs the
-      // MFMA evaluation, and an MFMA writes its result for every lane whatever EXEC says -- it must not
-      // run while other chains of the wave sit in the fast path.  (For a chain that is fine the literal
-      // path computes exactly what the fast path does.)
-      if (__all(__builtin_fabsf(e1) < __builtin_inff())) {
-        float pz = 0.0f;
+          for (int qd = 0; qd < 4; ++qd) {
+            const float4 ds4 = quad_of(dsw, t, qd);
+            const float ds[4] = {ds4.x, ds4.y, ds4.z, ds4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float ph = __builtin_fmaf(half_eps, f.t[t][4 * qd + i], p.t[t][4 * qd + i]);
+              p.t[t][4 * qd + i] = ph;
+              x.t[t][4 * qd + i] = __builtin_fmaf(ds[i], ph, x.t[t][4 * qd + i]);
+            }
+          }
+      } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float fn = __builtin_amdgcn_fmed3f(-f.t[t][r], -1e6f, 1e6f);
-            const float pn = __builtin_fmaf(half_eps, fn, p.t[t][r]);
-            f.t[t][r] = fn;
-            p.t[t][r] = pn;
-            pz = __builtin_fmaf(pn, 0.0f, pz);
+            const float ph = __builtin_fmaf(half_eps, f.t[t][r], p.t[t][r]);
+            p.t[t][r] = ph;
+            x.t[t][r] = __builtin_fmaf(drift_scale, ph, x.t[t][r]);
           }
-        pz += __shfl_xor(pz, 32);
-        if (pz != pz) {  // momentum overflow: x is finite, so f stands
+      }
+      // ONE call site for the evaluation inside the step (the literal path below re-enters it with `scrubbed` set:
+      // a second inlined copy of the 64 NT^2 MFMAs costs registers in the hot loop)
+      bool scrubbed = false;
+      for (;;) {
+        e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);  // f holds +g here
+        if (scrubbed) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p.t[t][r] = nan_to_num0(p.t[t][r]);
+            for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+          break;
         }
-      } else {  // rare: literal semantics (NaN-propagating clamp, scrub, re-evaluate on the scrubbed x)
+        // E finite => x finite, g clean.  The decision is taken per WAVE: the literal path re-runs the
+        // MFMA evaluation, and an MFMA writes its result for every lane whatever EXEC says -- it must not
+        // run while other chains of the wave sit in the fast path.  (For a chain that is fine the literal
+        // path computes exactly what the fast path does.)
+        if (__all(__builtin_fabsf(e1) < __builtin_inff())) {
+          float pz = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float fn = __builtin_amdgcn_fmed3f(-f.t[t][r], -1e6f, 1e6f);
+              const float pn = __builtin_fmaf(half_eps, fn, p.t[t][r]);
+              f.t[t][r] = fn;
+              p.t[t][r] = pn;
+              pz = __builtin_fmaf(pn, 0.0f, pz);
+            }
+          pz += __shfl_xor(pz, 32);
+          if (pz != pz) {  // momentum overflow: x is finite, so f stands
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) p.t[t][r] = nan_to_num0(p.t[t][r]);
+          }
+          break;
+        }
+        // rare: literal semantics (NaN-propagating clamp, scrub, re-evaluate on the scrubbed x)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -230,11 +301,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
             p.t[t][r] = nan_to_num0(__builtin_fmaf(half_eps, fn, p.t[t][r]));
             x.t[t][r] = nan_to_num0(x.t[t][r]);
           }
-        e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+        scrubbed = true;
       }
     }
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
@@ -267,42 +334,43 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
-template <int NT>
+template <int NT, bool DIAGM>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT>(a);
+  gauss_hmc_mfma_body<NT, DIAGM>(a);
 }
-template <int NT>
+template <int NT, bool DIAGM>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT>(a);
+  gauss_hmc_mfma_body<NT, DIAGM>(a);
 }
 
-template <int NT>
+template <int NT, bool DIAGM>
 int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
-  const size_t smem = (size_t)((32 * NT) * (32 * NT) + 32 * NT) * sizeof(float);
+  // precision matrix, mean, raw masses, one row of drift factors per wave
+  const size_t smem = (size_t)((32 * NT) * (32 * NT) + (2 + kBlock / 64) * 32 * NT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {  // dim 128: 64.5 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  if constexpr (NT <= 2) hipLaunchKernelGGL(gauss_hmc_mfma_kernel_w2<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else hipLaunchKernelGGL(gauss_hmc_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  if constexpr (NT <= 2) hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
 }
 
 }  // namespace
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
-  // four-tile kernels (dims 100..128) spill; measured against the lane-group kernel they win from ~112 up
-  // (dim 100: 4.4 vs 3.9 ms, dim 128: 4.5 vs 12.4 ms per 10 transitions; scripts/bench_gauss_hmc_dims.py)
-  return dim >= 20 && dim <= 128 && (dim <= 96 || dim >= 112) && (dim % 4) == 0 && mass_kind != EBM_MASS_DIAG;
+  // measured against the lane-group kernel (scripts/bench_gauss_hmc_dims.py, ms per 10 transitions, L = 10, 2^16 chains):
+  // dim 32: 0.26 vs 0.41, dim 64: 0.72 vs 1.32, dim 96: 1.48 vs 3.50, dim 100: 2.72 vs 3.89, dim 128: 2.74 vs 11.5
+  return dim >= 20 && dim <= 128 && (dim % 4) == 0;
 }
 
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
                                 int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
-                                double mass_scalar, int32_t thin, float* traj, uint8_t* accept_mask,
+                                double mass_scalar, const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
                                 uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
                                 uint64_t offset, hipStream_t st) {
   GaussHmcArgs a;
@@ -316,11 +384,20 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
   a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
+  a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
+  if (a.mass_diag) {
+    switch ((dim + 31) / 32) {
+      case 1: return launch_nt<1, true>(a, st);
+      case 2: return launch_nt<2, true>(a, st);
+      case 3: return launch_nt<3, true>(a, st);
+      default: return launch_nt<4, true>(a, st);
+    }
+  }
   switch ((dim + 31) / 32) {
-    case 1: return launch_nt<1>(a, st);
-    case 2: return launch_nt<2>(a, st);
-    case 3: return launch_nt<3>(a, st);
-    default: return launch_nt<4>(a, st);
+    case 1: return launch_nt<1, false>(a, st);
+    case 2: return launch_nt<2, false>(a, st);
+    case 3: return launch_nt<3, false>(a, st);
+    default: return launch_nt<4, false>(a, st);
   }
 }
 

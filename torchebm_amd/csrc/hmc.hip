@@ -25,7 +25,7 @@ using hmc::HmcArgs;
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
-                                int32_t, double, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
+                                int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
                                 uint64_t, uint64_t, hipStream_t);
 
 // Lane geometry of the transition kernel for this energy / row width (shared by the launcher and the
@@ -68,7 +68,7 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
     if (!force_rows)
       return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
+                                         mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
   }
   Geometry geo;
   if (!hmc_geometry(e, dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
