@@ -246,17 +246,33 @@ def extra_measurements(device, valu_rate):
         t = timed(fn, reps=5, warm=2, device=device)
         kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 3, device)
         _, d = s.sample(x=x0, n_steps=T, thin=T, return_diagnostics=True, generator=gen)
-        evals = n * T * (L + 1)
-        # flops of one mixture gradient: two K x dim passes of FMAs (2 * 2 * 8 * 32) + the leapfrog's 6 per coordinate
-        flops = evals * (2 * 2 * 8 * dim) + n * T * L * 6 * dim
+        # Work actually executed.  The ring's modes differ in columns 0..1 only; the kernel (rows.h: kGmmSlot1) runs the
+        # two K x 4 passes over the one float4 slot that holds them and treats the other 28 columns as the shared
+        # quadratic, and it carries energy / force across transitions: L evaluations per transition, not L + 1.
+        evals = n * T * L
+        flops = evals * (2 * 2 * 8 * 4 + 2 * (dim - 4)) + n * T * L * 6 * dim
+        # the same call on a mixture whose means differ in EVERY column (the general body: two K x dim passes)
+        gd = torch.Generator().manual_seed(7)
+        dense = ta.GaussianMixtureModel(torch.randn(8, dim, generator=gd) * 2.0, sigma=1.0, device=device)
+        sd = ta.HamiltonianMonteCarlo(dense, step_size=0.1, n_leapfrog_steps=L, device=device)
+        fd = lambda: sd.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
+        kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 3, device)
+        td = timed(fd, reps=3, warm=1, device=device)
+        dense_flops = evals * (2 * 2 * 8 * dim) + n * T * L * 6 * dim
         return {
             "name": "config3_hmc_gmm8", "workload": "HamiltonianMonteCarlo.sample, L=20, 8-mode GaussianMixture, n_chains=2^18, dim=32, "
             "eps=0.1, 50 MH steps per call (BASELINE configs[2])", "metric": "MH-steps/s", "value": n * T / t,
             "ms_per_call": t * 1e3, "kernel_ms_per_call": kms, "leapfrog_steps_per_s": n * T * L / t,
-            "grad_evals_per_s": evals / t, "fp32_TFLOPs": flops / (kms * 1e-3 if kms else t) / 1e12,
-            "frac_of_fp32_vector_peak": flops / (kms * 1e-3 if kms else t) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-            "bound": "valu", "step_equivalent_GBps": n * T * 8 * dim / t / 1e9,
+            "grad_evals_per_s": evals / t, "executed_fp32_TFLOPs": flops / (kms * 1e-3 if kms else t) / 1e12,
+            "bound": "valu", "body": "active-column (the ring's means differ in columns 0..1 only)",
+            "step_equivalent_GBps": n * T * 8 * dim / t / 1e9,
             "acceptance_rate": float(d["acceptance_rate"][-1]),
+            "dense_means": {
+                "workload": "same call, 8 random means that differ in every column (general mixture body)",
+                "value": n * T / td, "ms_per_call": td * 1e3, "kernel_ms_per_call": kd,
+                "executed_fp32_TFLOPs": dense_flops / (kd * 1e-3 if kd else td) / 1e12,
+                "frac_of_fp32_vector_peak": dense_flops / (kd * 1e-3 if kd else td) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            },
         }
 
     def c4():

@@ -119,6 +119,9 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
       ma = mb;
     }
     // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad
+    // (the counters are formed here at every step: hoisted out of the step loop they are two registers per quad)
+    uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+    asm volatile("" : "+v"(e_row));
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
           if (active) nv = *reinterpret_cast<const float4*>(a.noise + ((int64_t)step * a.n_chains) * dim + row + k0);
           eps.v[0] = nv.x; eps.v[1] = nv.y; eps.v[2] = nv.z; eps.v[3] = nv.w;
         } else {
-          eps = normal4_at(a.key, ((uint64_t)chain * dim + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
+          eps = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
         }
         // (padding quads run the same straight-line code -- a branch here costs 160 VGPRs -- and whatever
         //  they hold never reaches a real coordinate: their columns of Ps are zero and they are never stored)
