@@ -1,5 +1,6 @@
+"""Plain-VALU issue rate of the chip against resident waves per SIMD (ebm_probe_valu_f32: eight independent FMA chains per lane)."""
 import os, sys, json, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchebm_amd import _lib
 dev = torch.device("cuda"); st = _lib.stream_handle(dev)
 iters = 20000
