@@ -13,6 +13,7 @@ from .schedules import (
     WarmupScheduler,
 )
 from .energies import (
+    AckleyModel,
     BaseModel,
     DoubleWellModel,
     FusedSpec,
@@ -20,6 +21,8 @@ from .energies import (
     GaussianModel,
     HarmonicModel,
     MLPEnergy,
+    RastriginModel,
+    RosenbrockModel,
     ring_mixture,
 )
 from .integrator_base import BaseIntegrator, BaseSDERungeKuttaIntegrator, BaseSymplecticIntegrator
@@ -31,7 +34,7 @@ __all__ = [
     "BaseScheduler", "ConstantScheduler", "ExponentialDecayScheduler", "LinearScheduler",
     "CosineScheduler", "MultiStepScheduler", "WarmupScheduler", "TemperatureScheduler", "Schedulable",
     "BaseModel", "DoubleWellModel", "GaussianModel", "HarmonicModel", "GaussianMixtureModel",
-    "FusedSpec", "MLPEnergy", "ring_mixture",
+    "RosenbrockModel", "AckleyModel", "RastriginModel", "FusedSpec", "MLPEnergy", "ring_mixture",
     "BaseIntegrator", "BaseSDERungeKuttaIntegrator", "BaseSymplecticIntegrator",
     "BaseSampler", "BaseLoss", "BaseContrastiveDivergence",
 ]

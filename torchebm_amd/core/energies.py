@@ -139,6 +139,53 @@ class HarmonicModel(BaseModel):
         return FusedSpec(_lib.ENERGY_HARMONIC, (0.5 * self.k, 0.0, 0.0, 0.0), elementwise=True)
 
 
+class RosenbrockModel(BaseModel):
+    r"""``E(x) = \sum_{i<n} b (x_{i+1} - x_i^2)^2 + (a - x_i)^2`` (base_model.py:232-264).  A test landscape of the
+    reference's ``core``; no fused kernel -- the samplers drive it through the autograd step route."""
+
+    def __init__(self, a: float = 1.0, b: float = 100.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.a, self.b = a, b
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        if x.shape[-1] < 2:
+            raise ValueError(f"Rosenbrock energy function requires at least 2 dimensions, got {x.shape[-1]}")
+        head, tail = x[:, :-1], x[:, 1:]
+        return ((self.a - head).pow(2) + self.b * (tail - head.pow(2)).pow(2)).sum(dim=-1)
+
+
+class AckleyModel(BaseModel):
+    r"""``E(x) = -a e^{-b \sqrt{\overline{x^2}}} - e^{\overline{\cos(c x)}} + a + e`` (base_model.py:267-294); autograd
+    step route."""
+
+    def __init__(self, a: float = 20.0, b: float = 0.2, c: float = 2 * math.pi, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.a, self.b, self.c = a, b, c
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        n = x.shape[-1]
+        radial = -self.a * torch.exp(-self.b * torch.sqrt(torch.sum(x**2, dim=-1) / n))
+        ripple = -torch.exp(torch.sum(torch.cos(self.c * x), dim=-1) / n)
+        return radial + ripple + self.a + math.e
+
+
+class RastriginModel(BaseModel):
+    r"""``E(x) = a n + \sum_j x_j^2 - a \cos(2 \pi x_j)`` (base_model.py:297-316); autograd step route."""
+
+    def __init__(self, a: float = 10.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.a = a
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        return self.a * x.shape[-1] + torch.sum(x**2 - self.a * torch.cos(2 * math.pi * x), dim=-1)
+
+
 class GaussianModel(BaseModel):
     r"""``E(x) = \tfrac12 (x-\mu)^\top \Sigma^{-1} (x-\mu)`` (base_model.py:151-210)."""
 

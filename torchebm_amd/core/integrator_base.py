@@ -201,6 +201,8 @@ class BaseSDERungeKuttaIntegrator(BaseIntegrator):
                 )
         if adaptive:
             raise NotImplementedError("adaptive Runge-Kutta stepping is outside the Langevin/HMC hot path")
+        if n_steps <= 0:  # base_integrator.py:418-419 (checked before the grid, whether or not one is passed)
+            raise ValueError("n_steps must be positive")
         x = state["x"]
         drift_fn = self._resolve_drift(drift)
         if t is None:

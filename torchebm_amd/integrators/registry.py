@@ -7,7 +7,7 @@ reference (heun, rk4, dopri5, ...) is out of scope and asking for one is an expl
 
 from __future__ import annotations
 
-from typing import Optional, Type, Union
+from typing import Callable, Optional, Type, Union
 
 import torch
 
@@ -69,3 +69,15 @@ def resolve_integrator(
     if not isinstance(made, family):
         raise TypeError(f"{owner} requires a {family.__name__}; got {type(made).__name__}")
     return made
+
+
+def _integrate_time_grid(x: torch.Tensor, t: torch.Tensor, step_fn: Callable) -> torch.Tensor:
+    """Walk a 1-D time grid: ``x <- step_fn(x, t_i expanded over the batch, t_{i+1} - t_i)`` for every interval
+    (reference: integrators/integrator_utils.py:114-127, the loop shape of the fixed-step ``integrate()`` methods)."""
+    if t.ndim != 1:
+        raise ValueError("t must be a 1D tensor")
+    if t.numel() < 2:
+        raise ValueError("t must have length >= 2")
+    for i in range(t.numel() - 1):
+        x = step_fn(x, t[i].expand(x.size(0)), t[i + 1] - t[i])
+    return x
