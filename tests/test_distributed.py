@@ -175,3 +175,29 @@ def test_bench_refuses_more_gpus_than_visible():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "GPU(s) are visible" in out.stderr
+
+
+def test_unsharded_is_duck_typed():
+    """utils.unsharded (reference: utils/distributed.py:129-175): toggles reshard-after-forward on modules that have the
+    switch (FSDP2), restores it on exit even when the block raises, and passes every other module through."""
+    import torch.nn as nn
+
+    from torchebm_amd.utils import unsharded
+
+    calls = []
+
+    class Sharded(nn.Linear):
+        def set_reshard_after_forward(self, flag, recurse=True):
+            calls.append((flag, recurse))
+
+    m = Sharded(2, 2)
+    with unsharded(m, recurse=False) as inside:
+        assert inside is m and calls == [(False, False)]
+    assert calls == [(False, False), (True, False)]
+    with pytest.raises(RuntimeError):
+        with unsharded(m):
+            raise RuntimeError("boom")
+    assert calls[-1] == (True, True)
+    plain = nn.Linear(2, 2)
+    with unsharded(plain) as inside:
+        assert inside is plain

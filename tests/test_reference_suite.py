@@ -80,3 +80,26 @@ def test_reference_test_files_pass_against_this_package():
         got = sum(n for where, n in passed.items() if where.endswith(key))
         assert got >= minimum, (target, got, minimum, sorted(passed))
     assert sum(passed.values()) >= 340, sum(passed.values())
+
+
+def test_reference_distributed_tests_pass_against_this_package():
+    """The reference's 2-process gloo tests for the sharded path: the torch.distributed shim, per-rank
+    generator streams of the samplers, rank-local PCD buffers + cross-rank mixing + checkpoint round trip, and an
+    FSDP2-sharded energy model under the seeded samplers.  Their worker processes get the import alias through
+    tests/ref_compat/sitecustomize.py."""
+    files = ["test_distributed_shim.py", "test_generator_ranks.py", "test_pcd_buffer_ranks.py", "test_fsdp2_energy_model.py"]
+    with tempfile.TemporaryDirectory() as tmp:
+        xml = os.path.join(tmp, "report.xml")
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([os.path.join(HERE, "ref_compat"), "/root/reference", REPO])
+        env.pop("PYTEST_ADDOPTS", None)
+        cmd = [sys.executable, "-m", "pytest", "-p", "ref_alias", *[os.path.join(REF_TESTS, "distributed", f) for f in files],
+               "-q", "--no-header", "-p", "no:cacheprovider", "--rootdir", tmp, "-c", os.devnull, "-W", "ignore", "--tb=short",
+               f"--junit-xml={xml}", "-o", "junit_family=xunit1"]
+        run = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=1500)
+        assert os.path.exists(xml), run.stdout[-3000:] + run.stderr[-3000:]
+        cases = list(ET.parse(xml).getroot().iter("testcase"))
+    bad = [(c.get("file"), c.get("name")) for c in cases if {child.tag for child in c} & {"failure", "error"}]
+    ok = [c for c in cases if not len(c)]
+    assert not bad, (bad, run.stdout[-2000:])
+    assert len(ok) >= 15, (len(ok), run.stdout[-2000:])

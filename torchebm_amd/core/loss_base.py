@@ -183,6 +183,11 @@ class BaseContrastiveDivergence(BaseLoss):
             out[n_new:] = self.replay_buffer[rows]
         return out
 
+    @property
+    def _buffer_ptr_int(self) -> int:
+        """The reference's name for the host copy of ``buffer_ptr`` (core/base_loss.py:187; its tests read it)."""
+        return self._write_pos
+
     def update_buffer(self, samples: torch.Tensor) -> None:
         """FIFO write with wrap-around; the write position is tracked on the host
         (base_loss.py:390-426)."""

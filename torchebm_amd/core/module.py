@@ -31,6 +31,9 @@ def _canonical(device: torch.device) -> torch.device:
     return device
 
 
+_normalize = _canonical  # the reference's name for it (core/base_module.py:24-27)
+
+
 class TorchEBMModule(nn.Module):
     """``nn.Module`` whose ``device`` / ``dtype`` follow its parameters (or, for a
     parameter-less module, a zero-element probe buffer that ``.to()`` moves along)."""

@@ -1,12 +1,14 @@
 from .distributed import (
     all_gather_cat,
     all_reduce_diagnostics,
+    broadcast_object,
     broadcast_tensor,
     get_rank,
     get_world_size,
     is_distributed,
     sample_and_gather,
     shard_rows,
+    unsharded,
 )
 
-__all__ = ["all_gather_cat", "all_reduce_diagnostics", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "sample_and_gather", "shard_rows"]
+__all__ = ["all_gather_cat", "all_reduce_diagnostics", "broadcast_object", "broadcast_tensor", "get_rank", "get_world_size", "is_distributed", "sample_and_gather", "shard_rows", "unsharded"]

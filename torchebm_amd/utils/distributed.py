@@ -9,7 +9,8 @@ Every helper is the identity when ``torch.distributed`` is not initialised.
 
 from __future__ import annotations
 
-from typing import Optional
+import contextlib
+from typing import Iterator, Optional
 
 import torch
 import torch.distributed as dist
@@ -103,6 +104,17 @@ def all_reduce_diagnostics(diag: dict, n_local: int, group=None) -> dict:
     return out
 
 
+def broadcast_object(obj, src: int = 0, group=None):
+    """A picklable object (a seed, a config dict) from rank ``src`` to every rank; the object itself when not
+    distributed (reference: utils/distributed.py:73-96).  Control-plane only: the data path of a sharded sampling
+    run has no collective before the read-back."""
+    if get_world_size(group) == 1:
+        return obj
+    box = [obj if get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
 def broadcast_tensor(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     """Broadcast ``x`` from ``src``; a CPU tensor hops through the GPU when the backend is
     NCCL/RCCL (which cannot move host memory)."""
@@ -126,3 +138,20 @@ def shard_rows(n_total: int, group=None) -> tuple:
     count = base + (1 if rank < extra else 0)
     start = rank * base + min(rank, extra)
     return start, count
+
+
+@contextlib.contextmanager
+def unsharded(module: torch.nn.Module, recurse: bool = True) -> Iterator[torch.nn.Module]:
+    """Hold an FSDP2-wrapped energy model's parameters gathered for the duration of a sampling block
+    (reference: utils/distributed.py:129-175): a k-step chain calls the model k times, and with reshard-after-forward
+    each call would repeat the parameter all-gather.  Duck-typed on ``set_reshard_after_forward`` -- plain modules, DDP
+    and single-process runs pass through untouched; nothing is imported from FSDP and no process group is needed."""
+    toggle = getattr(module, "set_reshard_after_forward", None)
+    if toggle is None:
+        yield module
+        return
+    toggle(False, recurse=recurse)
+    try:
+        yield module
+    finally:
+        toggle(True, recurse=recurse)
