@@ -588,3 +588,52 @@ def test_three_d_state_of_an_analytic_energy_raises_like_the_reference():
     with pytest.raises(ValueError, match="expected shape"):
         s.sample(n_samples=3, dim=(2, 3), n_steps=2)
     assert s.sample(n_samples=3, dim=(2,), n_steps=2).shape == (3, 2)
+
+
+def test_datasets_module():
+    """torchebm_amd.datasets: the two generators on the path (two-moons = config 5's data, the ring mixture = config 3's
+    centres); equal to the reference's tensors for the same seed where the reference is present."""
+    from torchebm_amd.datasets import GaussianMixtureDataset, TwoMoonsDataset
+
+    moons = TwoMoonsDataset(n_samples=301, noise=0.05, seed=3)
+    assert len(moons) == 301 and moons.get_data().shape == (301, 2) and moons[5].shape == (2,)
+    assert torch.equal(moons.get_data(), TwoMoonsDataset(n_samples=301, noise=0.05, seed=3).get_data())
+    from torchebm_amd.utils.synthetic import two_moons
+
+    assert torch.equal(moons.get_data(), two_moons(301, 0.05, seed=3))
+    before = torch.get_rng_state()
+    TwoMoonsDataset(n_samples=10, seed=1)
+    assert torch.equal(torch.get_rng_state(), before)  # a seeded dataset leaves the global generator alone
+    moons.regenerate(seed=4)
+    assert not torch.equal(moons.get_data(), TwoMoonsDataset(n_samples=301, noise=0.05, seed=3).get_data())
+    with pytest.raises(IndexError):
+        moons[301]
+    with pytest.raises(ValueError):
+        TwoMoonsDataset(n_samples=0)
+    ring = GaussianMixtureDataset(n_samples=2001, n_components=8, std=0.05, radius=4.0, seed=0)
+    assert ring.get_data().shape == (2001, 2)
+    means = ta.core.ring_mixture(8, 2, radius=4.0).means
+    assert torch.allclose(ring.centers(), means.cpu().to(torch.float32), atol=1e-6)
+    nearest = torch.cdist(ring.get_data(), ring.centers()).argmin(1)
+    assert torch.bincount(nearest, minlength=8).tolist() == [251] + [250] * 7
+    with pytest.raises(ValueError):
+        GaussianMixtureDataset(n_components=0)
+    if os.path.isdir("/root/reference/torchebm"):  # authoring container: the reference's own generators, same seeds
+        import subprocess
+        import sys
+
+        code = r'''
+import sys, types
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r)
+v = types.ModuleType("torchebm._version"); v.__version__ = "0"; sys.modules["torchebm._version"] = v
+import torch
+from torchebm.datasets import TwoMoonsDataset as RefMoons, GaussianMixtureDataset as RefRing
+from torchebm_amd.datasets import TwoMoonsDataset, GaussianMixtureDataset
+for seed in (0, 4):
+    assert torch.equal(TwoMoonsDataset(301, 0.05, seed=seed).get_data(), RefMoons(301, 0.05, seed=seed).get_data())
+    assert torch.equal(GaussianMixtureDataset(2001, 8, 0.05, 4.0, seed=seed).get_data(), RefRing(2001, 8, 0.05, 4.0, seed=seed).get_data())
+print("datasets-ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert "datasets-ok" in out.stdout, out.stderr[-2000:]

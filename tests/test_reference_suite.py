@@ -103,3 +103,24 @@ def test_reference_distributed_tests_pass_against_this_package():
     ok = [c for c in cases if not len(c)]
     assert not bad, (bad, run.stdout[-2000:])
     assert len(ok) >= 15, (len(ok), run.stdout[-2000:])
+
+
+def test_reference_examples_on_the_path_run_unmodified():
+    """The reference's example scripts that live on the path -- energy landscapes, a custom energy, scheduler anatomy,
+    Langevin 101, HMC 101, parallel chains, CD-k and PERSISTENT CD (BASELINE config 5's recipe: MLP 2-128-128-1 on
+    two-moons) -- executed unmodified by the reference's own smoke test (TORCHEBM_SMOKE=1), importing this package."""
+    slugs = ["01-energy-landscapes", "02-custom-energy", "01-scheduler-anatomy", "01-langevin-101", "02-hmc-101",
+             "03-parallel-chains", "01-cd-k", "02-persistent-cd"]
+    with tempfile.TemporaryDirectory() as tmp:
+        xml = os.path.join(tmp, "report.xml")
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([os.path.join(HERE, "ref_compat"), "/root/reference", REPO])
+        env.pop("PYTEST_ADDOPTS", None)
+        cmd = [sys.executable, "-m", "pytest", "-p", "ref_alias", os.path.join(REF_TESTS, "examples", "test_examples_smoke.py"),
+               "-k", " or ".join(slugs), "-q", "--no-header", "-p", "no:cacheprovider", "--rootdir", tmp, "-c", os.devnull,
+               "-W", "ignore", "--tb=short", f"--junit-xml={xml}", "-o", "junit_family=xunit1"]
+        run = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=1500)
+        assert os.path.exists(xml), run.stdout[-3000:] + run.stderr[-3000:]
+        cases = list(ET.parse(xml).getroot().iter("testcase"))
+    bad = [c.get("name") for c in cases if len(c)]  # failed, errored or skipped
+    assert not bad and len(cases) == len(slugs), (bad, len(cases), run.stdout[-3000:])

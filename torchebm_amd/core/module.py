@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 _already_warned: set = set()
+_WARNED_ONCE = _already_warned  # the reference's name for the registry (core/base_module.py:30; its tests clear it)
 
 
 def warn_once(key: str, message: str, category: type = DeprecationWarning, stacklevel: int = 3) -> None:

@@ -1,8 +1,7 @@
 """Synthetic 2-D input for BASELINE config 5 (PCD on two-moons).
 
-The reference's dataset package is out of scope; this is the one generator the
-path's caller needs, restated from torchebm/datasets/generators.py:272-315 (`TwoMoonsDataset`):
-two half circles, the inner one shifted by (1, -0.5), plus isotropic Gaussian noise.
+Function form of ``torchebm_amd.datasets.TwoMoonsDataset`` (reference: torchebm/datasets/generators.py:272-315):
+two half circles, the inner one shifted by (1, -0.5), plus isotropic Gaussian noise; generated on the CPU and moved.
 """
 
 from __future__ import annotations
