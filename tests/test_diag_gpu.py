@@ -242,7 +242,7 @@ def test_config2_with_diagnostics_is_one_launch_at_full_size(cuda_device):
     pairs = _lib.timed_events.pop("ebm_langevin_chain_f32")
     assert hip_calls("ebm_langevin_chain_f32") == c0 + 2 and len(pairs) == 2
     t_plain, t_diag = pairs[0][0].elapsed_time(pairs[0][1]), pairs[1][0].elapsed_time(pairs[1][1])
-    assert t_diag < 1.15 * t_plain, (t_plain, t_diag)
+    assert t_diag < 1.3 * t_plain, (t_plain, t_diag)  # measured 1.04; the bound only catches a structural regression
     assert torch.equal(fin, out) and diag["mean"].shape == (4, dim)
     xs = out.double()
     torch.testing.assert_close(diag["mean"][3].double(), xs.mean(dim=0), rtol=1e-4, atol=2e-6)
