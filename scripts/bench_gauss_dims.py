@@ -1,5 +1,5 @@
 import sys, time, json, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torchebm_amd as ta
 from torchebm_amd import _lib
 from torchebm_amd.samplers.langevin import em_coefficients

@@ -11,7 +11,7 @@ def timeit(fn, reps=10, warm=2):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
-for dim in (16, 20, 24, 32, 48, 64, 96, 100, 104, 108, 112, 128):
+for dim in [int(d) for d in os.environ.get("DIMS", "16,20,24,32,48,64,96,100,104,108,112,128").split(",")]:
     g = torch.Generator().manual_seed(dim)
     a = torch.randn(dim, dim, generator=g)
     model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=dev)

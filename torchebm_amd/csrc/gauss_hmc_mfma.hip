@@ -11,6 +11,7 @@
 // of hmc_kernel.h; the accepted state is "parked" in the x array itself (written on accept, re-read on
 // reject), which costs 256 B per chain and transition and no registers.
 #include "ebm_common.h"
+#include "gauss_bf16x3.h"
 
 namespace ebm {
 namespace {
@@ -48,19 +49,24 @@ struct Tile {
 };
 
 // g^T = Ps (x - mu)^T and E = 0.5 (x - mu)^T Ps (x - mu) per chain (both halves of the wave hold E).
-template <int NT>
+// B3: the contraction on the bf16 matrix pipe with three-way split operands (gauss_bf16x3.h; `Ps` then points at the
+// operand-ready splits) -- 6/16 of the exact-f32 MFMA's matrix time; B3 = false: v_mfma_f32_32x32x2_f32 on fp32 Ps.
+template <int NT, bool B3>
 __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
   constexpr int DIM = 32 * NT;
+  auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
+  float acc = 0.0f;
+  if constexpr (B3) {
+    gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
+  } else {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) g.t[t][r] = 0.0f;
-  auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
   float pa[NT], pb[NT], ma, mb;
 #pragma unroll
   for (int it = 0; it < NT; ++it) pa[it] = Ps[k_of(0) * DIM + 32 * it + m];
   ma = mus[k_of(0)];
-  float acc = 0.0f;
 #pragma unroll
   for (int s = 0; s < 16 * NT; ++s) {  // operands of K-step s+1 are requested before the MFMAs of K-step s issue
     if (s + 1 < 16 * NT) {
@@ -77,6 +83,7 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
     for (int it = 0; it < NT; ++it) pa[it] = pb[it];
     ma = mb;
   }
+  }  // exact-f32 MFMA
   // E = 0.5 d.g with d = x - mu recomputed (a cheap LDS read of mu, two distinct addresses per wave) rather
   // than kept: 16*NT fewer live registers across the MFMA loop
 #pragma unroll
@@ -86,17 +93,21 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
 }
 
 // DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
-template <int NT, bool DIAGM>
+template <int NT, bool DIAGM, bool B3>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr int DIM = 32 * NT;
-  float* Ps = gauss_hmc_smem;
-  float* mus = gauss_hmc_smem + DIM * DIM;
+  float* Ps = gauss_hmc_smem;  // fp32 [DIM][DIM], or (B3) the three operand-ready bf16 splits: 1.5x the bytes
+  float* mus = gauss_hmc_smem + (B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM);
   // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
   // rows / columns of Ps are zero, their momentum draw is discarded) and are never loaded or stored
   const int dim = a.dim;
-  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
-    const int r = i / DIM, c = i - r * DIM;
-    Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+  if constexpr (B3) {
+    gauss3::stage_split_precision<NT>(a.prec, dim, reinterpret_cast<__bf16*>(Ps), kBlock);
+  } else {
+    for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+      const int r = i / DIM, c = i - r * DIM;
+      Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+    }
   }
   for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
   // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
@@ -221,7 +232,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 
     // ---- H0 and the first (clamped) force
     Tile<NT> f;
-    const float e0 = gauss_eval<NT>(Ps, mus, x, f, m, h);
+    const float e0 = gauss_eval<NT, B3>(Ps, mus, x, f, m, h);
     const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -259,7 +270,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       // a second inlined copy of the 64 NT^2 MFMAs costs registers in the hot loop)
       bool scrubbed = false;
       for (;;) {
-        e1 = gauss_eval<NT>(Ps, mus, x, f, m, h);  // f holds +g here
+        e1 = gauss_eval<NT, B3>(Ps, mus, x, f, m, h);  // f holds +g here
         if (scrubbed) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -334,30 +345,47 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
-template <int NT, bool DIAGM>
+template <int NT, bool DIAGM, bool B3>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, B3>(a);
 }
-template <int NT, bool DIAGM>
+template <int NT, bool DIAGM, bool B3>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, B3>(a);
 }
 
-template <int NT, bool DIAGM>
-int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
-  // precision matrix, mean, raw masses, one row of drift factors per wave
-  const size_t smem = (size_t)((32 * NT) * (32 * NT) + (2 + kBlock / 64) * 32 * NT) * sizeof(float);
+template <int NT, bool DIAGM, bool B3>
+int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
+  // precision matrix (fp32, or its three bf16 splits), mean, raw masses, one row of drift factors per wave
+  const size_t smem = (B3 ? gauss3::aop_bytes(NT) : (size_t)(32 * NT) * (32 * NT) * sizeof(float)) +
+                      (size_t)((2 + kBlock / 64) * 32 * NT) * sizeof(float);
   static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {  // dim 128: 64.5 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM>),
+  if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, B3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  if constexpr (NT <= 2) hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  // two waves per SIMD (256 VGPRs) where the body fits them: one tile, and two tiles on the exact-f32 contraction; the
+  // bf16x3 form of two tiles needs the transient split registers and runs better unconstrained (0.53 vs 0.97 ms, dim 64)
+  if constexpr (NT == 1 || (NT == 2 && !B3))
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, B3>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, B3>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
+}
+
+template <int NT, bool DIAGM>
+int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
+  // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
+  static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
+  // measured (scripts/bench_gauss_hmc_dims.py, ms per 10 transitions, bf16x3 vs exact f32): dim 32: 0.22 vs 0.26, dim 64:
+  // 0.53 vs 0.66, dim 96: 1.29 vs 1.43, dim 128: 4.4 vs 2.6 -- with x, p and the force resident the four-tile body has
+  // no room for the split's transients (1.9 KB of scratch), and neither has the three-tile body with a diagonal mass
+  constexpr bool b3_fits = DIAGM ? NT <= 2 : NT <= 3;
+  if constexpr (b3_fits) return f32_mfma ? launch_nt_b<NT, DIAGM, false>(a, st) : launch_nt_b<NT, DIAGM, true>(a, st);
+  else return launch_nt_b<NT, DIAGM, false>(a, st);
 }
 
 }  // namespace

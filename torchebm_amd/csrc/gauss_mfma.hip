@@ -13,6 +13,7 @@
 // Ps = (P + P^T)/2 is symmetric, so the A-operand Ps[i = 32 it + m][k] is read as Ps[k][32 it + m]:
 // consecutive lanes, consecutive LDS banks.
 #include "ebm_common.h"
+#include "gauss_bf16x3.h"
 
 namespace ebm {
 namespace {
@@ -40,19 +41,30 @@ struct GaussArgs {
 
 extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 
-template <int NT>
-// (no minimum-waves bound: at dim 128 the state alone is 128 VGPRs and the kernel needs 432 -- one wave per
-//  SIMD without spills is 4.6 ms on 2^18 x 128 x 50 where a 256-VGPR cap with spills was 6.9 ms)
-__global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a) {
+// B3: the contraction on the bf16 matrix pipe with three-way split operands (gauss_bf16x3.h) -- 6/16 of the exact-f32
+// MFMA's matrix time and, unlike it, concurrent with the step's Philox / Box-Muller VALU work.  B3 = false keeps the
+// exact-f32 MFMA (EBM_GAUSS_F32MFMA=1: the A/B switch).
+// FAST (B3 only): no injected noise, no clamp -- the step is ONE basic block: the normals of all quads are drawn
+// first, then the contraction, and the scheduler is told to place ~VPM VALU instructions behind every MFMA, so that the
+// wave's own Philox / Box-Muller work runs while the matrix pipe is busy (a bf16 32x32x16 MFMA occupies it for 32
+// cycles; left alone the compiler issues the MFMAs back to back and the VALU work after them).
+template <int NT, bool B3, bool FAST = false>
+__device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   constexpr int DIM = 32 * NT;
-  float* Ps = gauss_smem;            // [DIM][DIM]
-  float* mus = gauss_smem + DIM * DIM;  // [DIM]
+  // LDS: the precision matrix -- fp32 [DIM][DIM], or its three operand-ready bf16 splits (1.5x the bytes) -- then mu
+  float* Ps = gauss_smem;
+  __bf16* aop = reinterpret_cast<__bf16*>(gauss_smem);
+  float* mus = gauss_smem + (B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM);  // [DIM]
   // dim <= DIM, dim % 4 == 0: the tiles are zero-padded -- padded coordinates stay exactly 0 (d = 0, g = 0,
   // no noise) and whole register quads beyond dim are never loaded, drawn or stored
   const int dim = a.dim;
-  for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
-    const int r = i / DIM, c = i - r * DIM;
-    Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+  if constexpr (B3) {
+    gauss3::stage_split_precision<NT>(a.prec, dim, aop, kBlock);
+  } else {
+    for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+      const int r = i / DIM, c = i - r * DIM;
+      Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+    }
   }
   for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
   __syncthreads();
@@ -87,6 +99,60 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
     }
     // ---- g^T = Ps d^T on the matrix cores
     f32x16 g[NT];
+    if constexpr (FAST) {
+      // The step's normals, drawn in STAGES that the contraction places behind its MFMAs: per quad one stage sets the
+      // Philox counter, ten run one round each, two do a Box-Muller pair each (~8 .. 30 VALU instructions a stage).
+      uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+      asm volatile("" : "+v"(e_row));
+      f32x16 eps[NT];
+      constexpr int QUADS = 4 * NT, PER_QUAD = 13, STAGES = QUADS * PER_QUAD, N_MFMA = 6 * NT * (2 * NT);
+      constexpr int PER_MFMA = (STAGES + N_MFMA - 1) / N_MFMA;
+      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, k0 = 0, k1 = 0;
+      auto stage = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S < STAGES) {
+          constexpr int qd = S / PER_QUAD, sub = S % PER_QUAD;
+          if constexpr (sub == 0) {
+            const uint64_t grp = (e_row + (uint64_t)(32 * (qd >> 2) + 8 * (qd & 3) + 4 * h)) >> 2;
+            const uint64_t stp = a.step0 + (uint64_t)step;
+            c0 = (uint32_t)grp; c1 = (uint32_t)(grp >> 32); c2 = (uint32_t)stp; c3 = (uint32_t)(stp >> 32);
+            k0 = a.key.k0; k1 = a.key.k1;
+          } else if constexpr (sub <= 10) {  // one round of philox4x32_10 (ebm_common.h)
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+            const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+          } else if constexpr (sub == 11) {
+            float n0, n1;
+            box_muller(c0, c1, n0, n1);
+            eps[qd >> 2][4 * (qd & 3) + 0] = n0; eps[qd >> 2][4 * (qd & 3) + 1] = n1;
+          } else {
+            float n0, n1;
+            box_muller(c2, c3, n0, n1);
+            eps[qd >> 2][4 * (qd & 3) + 2] = n0; eps[qd >> 2][4 * (qd & 3) + 3] = n1;
+          }
+        }
+      };
+      gauss3::contract<NT>(aop, mus, x, g, lane, [&](auto ord) {
+        gauss3::static_for<PER_MFMA>([&](auto u) { stage(std::integral_constant<int, decltype(ord)::value * PER_MFMA + decltype(u)::value>{}); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
+      static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x1 = x[t][r] - eta * g[t][r];
+          const float dw = eps[t][r] * sqrt_eta;
+          x[t][r] = x1 + noise_coef * dw;
+        }
+    } else {
+    if constexpr (B3) {
+      gauss3::contract<NT>(aop, mus, x, g, lane);
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -118,6 +184,7 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
       for (int it = 0; it < NT; ++it) pa[it] = pb[it];
       ma = mb;
     }
+    }  // exact-f32 MFMA
     // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad
     // (the counters are formed here at every step: hoisted out of the step loop they are two registers per quad)
     uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
@@ -147,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
         }
         if constexpr (NT >= 3) __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
       }
+    }  // !FAST
     if (a.traj && --until_keep == 0) {
       until_keep = a.thin;
       if (active) {
@@ -172,18 +240,41 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a
   }
 }
 
+// (no minimum-waves bound on the exact-f32 form: at dim 128 the state alone is 128 VGPRs and that kernel needs 432 -- one
+//  wave per SIMD without spills was 4.6 ms on 2^18 x 128 x 50 where a 256-VGPR cap with spills was 6.9 ms)
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, false>(a);
+}
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true>(a);
+}
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true, true>(a);
+}
+
 template <int NT>
 int launch_nt(const GaussArgs& a, hipStream_t st) {
-  const size_t smem = (size_t)((32 * NT) * (32 * NT) + 32 * NT) * sizeof(float);
+  // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
+  static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
+  const size_t smem = (f32_mfma ? (size_t)(32 * NT) * (32 * NT) * sizeof(float) : gauss3::aop_bytes(NT)) + 32 * NT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_mfma_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL(gauss_langevin_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  if (f32_mfma) hipLaunchKernelGGL(gauss_langevin_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else if (!a.noise && !a.clamp_on) hipLaunchKernelGGL(gauss_langevin_bf16x3_fast_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else hipLaunchKernelGGL(gauss_langevin_bf16x3_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
