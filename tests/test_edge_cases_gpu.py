@@ -377,3 +377,30 @@ def test_concurrent_streams_and_threads(cuda_device):
         t.join()
     for i in range(4):
         assert torch.equal(got[i], want[i]), i
+
+
+@pytest.mark.parametrize("dim", [32, 64, 96, 128])
+def test_gaussian_bf16x3_contraction_is_fp32_accurate(cuda_device, dim):
+    """The matrix-core Gaussian kernels contract on the bf16 pipe with three-way split operands (csrc/gauss_bf16x3.h).
+    One noise-free Langevin step x' = x - eta * Ps (x - mu) against float64, on inputs with six decades of dynamic
+    range in both the state and the precision matrix: the error stays within a few fp32 roundings of the sum's
+    natural scale  sum_j |Ps_ij| |d_j|  -- what an fp32 accumulation can deliver, nothing bf16-sized."""
+    g = torch.Generator().manual_seed(dim)
+    a = torch.randn(dim, dim, generator=g, dtype=torch.float64)
+    scale = 10.0 ** (torch.rand(dim, generator=g, dtype=torch.float64) * 3.0 - 1.5)
+    cov = (a @ a.t() / dim + 0.5 * torch.eye(dim, dtype=torch.float64)) * scale[:, None] * scale[None, :]
+    mean = torch.randn(dim, generator=g, dtype=torch.float64)
+    model = ta.GaussianModel(mean.float(), cov.float(), device=cuda_device)
+    n = 96
+    x0 = (torch.randn(n, dim, generator=g, dtype=torch.float64) * 10.0 ** (torch.rand(n, dim, generator=g, dtype=torch.float64) * 6 - 3)).float()
+    spec = model.fused_spec()
+    x = x0.to(cuda_device).clone()
+    eta = 0.25
+    _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, 1, eta, eta ** 0.5, 0.0, None, 0, 0.0, 0.0, 1, None, None,
+              None, 3, 0, _lib.stream_handle(cuda_device))
+    ps = spec.dev1.double().cpu().view(dim, dim)      # the symmetrised fp32 precision the kernel was handed
+    d = x0.double() - spec.dev0.double().cpu()
+    want = x0.double() - eta * (d @ ps.t())
+    natural = eta * (d.abs() @ ps.abs().t()) + x0.double().abs()
+    err = (x.cpu().double() - want).abs() / natural
+    assert err.max().item() < 16 * 2.0 ** -24, err.max().item()
