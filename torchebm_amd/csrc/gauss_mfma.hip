@@ -48,7 +48,11 @@ extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 // first, then the contraction, and the scheduler is told to place ~VPM VALU instructions behind every MFMA, so that the
 // wave's own Philox / Box-Muller work runs while the matrix pipe is busy (a bf16 32x32x16 MFMA occupies it for 32
 // cycles; left alone the compiler issues the MFMAs back to back and the VALU work after them).
-template <int NT, bool B3, bool FAST = false>
+// BLOCK: threads per workgroup.  512 for the wide FAST kernels: eight waves share ONE LDS copy of the split matrix, i.e.
+// two waves per SIMD where a 256-thread workgroup (one per CU: the matrix is 55 / 98 KB) leaves each SIMD one wave, which
+// can issue at only 39 % of the VALU rate.  HIDE: tiles whose normals are drawn behind the MFMAs (the others are drawn
+// after the contraction: their 16 registers per tile are then not live across it, which is what fits 256 VGPRs).
+template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT>
 __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   constexpr int DIM = 32 * NT;
   // LDS: the precision matrix -- fp32 [DIM][DIM], or its three operand-ready bf16 splits (1.5x the bytes) -- then mu
@@ -59,19 +63,19 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   // no noise) and whole register quads beyond dim are never loaded, drawn or stored
   const int dim = a.dim;
   if constexpr (B3) {
-    gauss3::stage_split_precision<NT>(a.prec, dim, aop, kBlock);
+    gauss3::stage_split_precision<NT>(a.prec, dim, aop, BLOCK);
   } else {
-    for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+    for (int i = threadIdx.x; i < DIM * DIM; i += BLOCK) {
       const int r = i / DIM, c = i - r * DIM;
       Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
     }
   }
-  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
+  for (int i = threadIdx.x; i < DIM; i += BLOCK) mus[i] = i < dim ? a.mean[i] : 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const int64_t chain = ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 32 + m;
   const bool active = chain < a.n_chains;
   const int64_t row = active ? chain * (int64_t)dim : 0;
 
@@ -105,7 +109,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
       asm volatile("" : "+v"(e_row));
       f32x16 eps[NT];
-      constexpr int QUADS = 4 * NT, PER_QUAD = 13, STAGES = QUADS * PER_QUAD, N_MFMA = 6 * NT * (2 * NT);
+      constexpr int QUADS = 4 * HIDE, PER_QUAD = 13, STAGES = QUADS * PER_QUAD, N_MFMA = 6 * NT * (2 * NT);
       constexpr int PER_MFMA = (STAGES + N_MFMA - 1) / N_MFMA;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, k0 = 0, k1 = 0;
       auto stage = [&](auto sc) {
@@ -141,8 +145,26 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       });
       // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
       static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
+      if constexpr (HIDE < NT) {  // the remaining tiles: drawn now, one quad at a time
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = HIDE; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const F4 n4 = normal4_at(a.key, (e_row + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2, a.step0 + (uint64_t)step);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eps[t][4 * q + i] = n4.v[i];
+            // update this quad at once: its normals do not stay live
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * q + i;
+              const float x1 = x[t][r] - eta * g[t][r];
+              const float dw = eps[t][r] * sqrt_eta;
+              x[t][r] = x1 + noise_coef * dw;
+            }
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < HIDE; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float x1 = x[t][r] - eta * g[t][r];
@@ -254,6 +276,11 @@ template <int NT>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(GaussArgs a) {
   gauss_langevin_mfma_body<NT, true, true>(a);
 }
+constexpr int kWideBlock = 512;
+template <int NT, int HIDE>
+__global__ __launch_bounds__(kWideBlock) void gauss_langevin_bf16x3_fast_wide_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true, true, kWideBlock, HIDE>(a);
+}
 
 template <int NT>
 int launch_nt(const GaussArgs& a, hipStream_t st) {
@@ -272,6 +299,22 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  if constexpr (NT == 3) {  // (four tiles: the 256-register cap costs 80 B of scratch and the unhidden half of the RNG -- no gain)
+    // A/B switch: EBM_GAUSS_WIDE=0 keeps the 256-thread workgroups (dim 96: 1.81 ms against 1.68)
+    static const bool wide_off = [] { const char* v = getenv("EBM_GAUSS_WIDE"); return v && v[0] == '0'; }();
+    if (!f32_mfma && !a.noise && !a.clamp_on && !wide_off) {
+      constexpr int HIDE = 2;
+      static bool wide_attr = false;
+      if (!wide_attr && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        wide_attr = true;
+      }
+      const int64_t wblocks = ceil_div64(a.n_chains, 32 * (kWideBlock / 64));
+      hipLaunchKernelGGL((gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE>), dim3((unsigned)wblocks), dim3(kWideBlock), smem, st, a);
+      return check_launch("ebm_langevin_chain_f32");
+    }
+  }
   if (f32_mfma) hipLaunchKernelGGL(gauss_langevin_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else if (!a.noise && !a.clamp_on) hipLaunchKernelGGL(gauss_langevin_bf16x3_fast_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else hipLaunchKernelGGL(gauss_langevin_bf16x3_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
