@@ -180,8 +180,14 @@ def test_hmc_records(cuda_device, kind, dim, mass):
     # without diagnostics the same chains
     plain = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True,
                      generator=torch.Generator(device=cuda_device).manual_seed(5))
-    if kind != "gauss":
+    # (with records the lane-group kernel runs; without, dense Gaussians and mixtures at dims 20 .. 96 take the
+    #  matrix-layout kernels: the same chains to the tolerance tier, not bit for bit)
+    matrix_route = kind == "gauss" or (kind.startswith("gmm") and 20 <= dim <= 96 and dim % 4 == 0)
+    if not matrix_route:
         assert torch.equal(plain, traj)
+    else:
+        err = ((plain - traj).abs() / traj.abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+        assert (err <= 5e-4).float().mean().item() >= 0.97, err.max().item()
 
 
 def test_c_abi_layout_and_injected_noise_records(cuda_device):

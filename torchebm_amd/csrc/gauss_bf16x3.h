@@ -53,15 +53,14 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
   lo = (__bf16)(r1 - (float)mid);
 }
 
-// All threads of the workgroup: prec[dim][dim] (symmetric, fp32, global) -> the three operand-ready splits in LDS.
-template <int NT>
-__device__ __forceinline__ void stage_split_precision(const float* __restrict__ prec, int dim, __bf16* aop, int n_threads) {
-  constexpr int DIM = 32 * NT, KB = DIM / 16;
-  constexpr int PER_SPLIT = NT * KB * 64 * 8;  // = DIM * DIM
+// All threads of the workgroup: an [32 MT] x [16 KB] matrix given by `at(row, col)` -> its three operand-ready splits in
+// LDS, Aop[split][it][kb][lane][8]: lane (m, h) of (it, kb) holds row 32 it + m at the columns k_of(kb, h, 0..7).
+template <int MT, int KB, class At>
+__device__ __forceinline__ void stage_split_matrix(At&& at, __bf16* aop, int n_threads) {
+  constexpr int PER_SPLIT = MT * KB * 64 * 8;
   for (int i = threadIdx.x; i < PER_SPLIT; i += n_threads) {
     const int j = i & 7, lane = (i >> 3) & 63, kb = (i >> 9) % KB, it = (i >> 9) / KB;
-    const int row = 32 * it + (lane & 31), col = k_of(kb, lane >> 5, j);
-    const float v = (row < dim && col < dim) ? prec[row * dim + col] : 0.0f;
+    const float v = at(32 * it + (lane & 31), k_of(kb, lane >> 5, j));
     __bf16 hi, mid, lo;
     split3(v, hi, mid, lo);
     aop[i] = hi;
@@ -69,19 +68,29 @@ __device__ __forceinline__ void stage_split_precision(const float* __restrict__ 
     aop[2 * PER_SPLIT + i] = lo;
   }
 }
+__host__ __device__ constexpr size_t aop_bytes_general(int MT, int KB) { return (size_t)3 * MT * KB * 64 * 8 * 2; }
 
-// g (C/D layout, overwritten) = Ps (x - mu).  mus: [DIM] fp32 in LDS (zero padded).  Returns nothing; the caller
-// forms d . g for the energy where it needs it.
+// prec[dim][dim] (symmetric, fp32, global), zero-padded to (32 NT)^2
+template <int NT>
+__device__ __forceinline__ void stage_split_precision(const float* __restrict__ prec, int dim, __bf16* aop, int n_threads) {
+  stage_split_matrix<NT, 2 * NT>([&](int row, int col) { return (row < dim && col < dim) ? prec[row * dim + col] : 0.0f; }, aop,
+                                 n_threads);
+}
+
+// out (C/D layout, MT tiles, overwritten) = A (b - mus) for the [32 MT] x [16 KB] matrix A staged by stage_split_matrix;
+// b: the K operand in the C/D layout of its own 32-row tiles (K-block kb = registers 8 (kb & 1) .. + 7 of tile kb >> 1);
+// SUB: subtract mus[k] (fp32 [16 KB] in LDS) first.
 // `fill()` is called once behind every MFMA: the caller's independent VALU work (the Philox rounds of the step), fenced
 // so that it stays there -- it issues while the matrix pipe is busy with that MFMA (32 cycles each).
 struct NoFill {
   template <class Ord>
   __device__ __forceinline__ void operator()(Ord) const {}
 };
-template <int NT, class Fill = NoFill>
-__device__ __forceinline__ void contract(const __bf16* __restrict__ aop, const float* __restrict__ mus, const f32x16 (&x)[NT],
-                                         f32x16 (&g)[NT], int lane, Fill&& fill = NoFill{}) {
-  constexpr int DIM = 32 * NT, KB = DIM / 16, PER_SPLIT = DIM * DIM;
+template <int MT, int KB, bool SUB, class Fill = NoFill>
+__device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop, const float* __restrict__ mus,
+                                                 const f32x16 (&x)[(KB + 1) / 2], f32x16 (&g)[MT], int lane,
+                                                 Fill&& fill = NoFill{}) {
+  constexpr int NT = MT, PER_SPLIT = MT * KB * 64 * 8;
   const int h = lane >> 5;
   // one tile: two accumulator sets, so that consecutive MFMAs never wait on each other's result; with more tiles the
   // term-major order below already puts NT independent instructions between dependent ones
@@ -97,8 +106,11 @@ __device__ __forceinline__ void contract(const __bf16* __restrict__ aop, const f
   static_for<KB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value;
     constexpr int t = kb >> 1, b = kb & 1;
-    const float4 m0 = *reinterpret_cast<const float4*>(mus + 32 * t + 16 * b + 4 * h);
-    const float4 m1 = *reinterpret_cast<const float4*>(mus + 32 * t + 16 * b + 8 + 4 * h);
+    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+    if constexpr (SUB) {
+      m0 = *reinterpret_cast<const float4*>(mus + 32 * t + 16 * b + 4 * h);
+      m1 = *reinterpret_cast<const float4*>(mus + 32 * t + 16 * b + 8 + 4 * h);
+    }
     f32x8 d;
     d[0] = x[t][8 * b + 0] - m0.x; d[1] = x[t][8 * b + 1] - m0.y; d[2] = x[t][8 * b + 2] - m0.z; d[3] = x[t][8 * b + 3] - m0.w;
     d[4] = x[t][8 * b + 4] - m1.x; d[5] = x[t][8 * b + 5] - m1.y; d[6] = x[t][8 * b + 6] - m1.z; d[7] = x[t][8 * b + 7] - m1.w;
@@ -131,6 +143,13 @@ __device__ __forceinline__ void contract(const __bf16* __restrict__ aop, const f
     if constexpr (SETS == 2) g[it] = acc[0][it] + acc[1][it];
     else g[it] = acc[0][it];
   }
+}
+
+// the Gaussian form: g = Ps (x - mu) on (32 NT)^2
+template <int NT, class Fill = NoFill>
+__device__ __forceinline__ void contract(const __bf16* __restrict__ aop, const float* __restrict__ mus, const f32x16 (&x)[NT],
+                                         f32x16 (&g)[NT], int lane, Fill&& fill = NoFill{}) {
+  contract_general<NT, 2 * NT, true>(aop, mus, x, g, lane, static_cast<Fill&&>(fill));
 }
 
 }  // namespace gauss3

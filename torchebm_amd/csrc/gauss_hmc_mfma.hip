@@ -39,6 +39,12 @@ struct GaussHmcArgs {
   const float* mean;  // [dim]
   const float* prec;  // [dim, dim], symmetric
   const float* mass_diag;  // [dim] diagonal mass (null: none / scalar)
+  // Gaussian mixture (GmmE below): means [n_comp, dim], log-weights [n_comp], 1 / (2 sigma^2), 1 / sigma^2
+  const float* gm_means;
+  const float* gm_logw;
+  int32_t n_comp;
+  float inv2s2, invs2;
+  const int32_t* aux;      // the mixture's active-column mask (rows.h); null: none
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -92,28 +98,157 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   return 0.5f * acc;
 }
 
-// DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
-template <int NT, bool DIAGM, bool B3>
-__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
-  constexpr int DIM = 32 * NT;
-  float* Ps = gauss_hmc_smem;  // fp32 [DIM][DIM], or (B3) the three operand-ready bf16 splits: 1.5x the bytes
-  float* mus = gauss_hmc_smem + (B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM);
-  // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
-  // rows / columns of Ps are zero, their momentum draw is discarded) and are never loaded or stored
-  const int dim = a.dim;
-  if constexpr (B3) {
-    gauss3::stage_split_precision<NT>(a.prec, dim, reinterpret_cast<__bf16*>(Ps), kBlock);
-  } else {
-    for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
-      const int r = i / DIM, c = i - r * DIM;
-      Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+// ---------------------------------------------------------------------------------
+// Energies of the matrix-layout transition body: what sits in LDS and how E / dE/dx come out of the state tiles.
+// ---------------------------------------------------------------------------------
+// Dense Gaussian.  LDS: Ps (fp32 [DIM][DIM], or its three operand-ready bf16 splits), mu [DIM].
+template <int NT, bool B3>
+struct GaussE {
+  static constexpr int DIM = 32 * NT;
+  static constexpr int kMatFloats = B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM;
+  static constexpr int kLdsFloats = kMatFloats + DIM;
+  static constexpr bool kEvalGivesEnergy = true;
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
+    const int dim = a.dim;
+    if constexpr (B3) {
+      gauss3::stage_split_precision<NT>(a.prec, dim, reinterpret_cast<__bf16*>(lds), kBlock);
+    } else {
+      for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
+        const int r = i / DIM, c = i - r * DIM;
+        lds[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+      }
+    }
+    for (int i = threadIdx.x; i < DIM; i += kBlock) lds[kMatFloats + i] = i < dim ? a.mean[i] : 0.0f;
+  }
+  __device__ static __forceinline__ float eval(const GaussHmcArgs&, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
+    return gauss_eval<NT, B3>(lds, lds + kMatFloats, x, g, m, h);
+  }
+  __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
+};
+
+// Isotropic Gaussian mixture, up to 32 components (core/energies.py: GaussianMixtureModel):
+//   E = -logsumexp_k(log w_k - |x - mu_k|^2 / (2 sigma^2)),   dE/dx = (x - sum_k r_k mu_k) / sigma^2,  r = softmax.
+// The two K x dim passes of the gradient are small GEMMs and run on the bf16 matrix pipe with split operands
+// (gauss_bf16x3.h), both reading their K operand straight from registers in the C/D layout:
+//   1. logits^T [comp, chain] = Mu [comp, d] . x^T [d, chain]        (one 32-row tile of components, 2 NT K-blocks)
+//      l_k = c_k + (x . mu_k) / sigma^2 with c_k = log w_k - |mu_k|^2 / (2 sigma^2): softmax is shift-invariant, |x|^2 drops
+//      out (the gradient-only form of rows.h); lane (n, h) holds components (r & 3) + 8 (r >> 2) + 4 h in register r, so
+//      the softmax is per-lane arithmetic plus two xor-32 shuffles (max, sum);
+//   2. acc^T [d, chain] = Mu^T [d, comp] . w [comp, chain]            (NT tiles, one K-block per 16 components)
+//      whose result lands in the state's own layout: g = (x - acc / sum) / sigma^2 is register-to-register.
+// KR = live logit registers per lane: 4 (K <= 8), 8 (K <= 16), 16 (K <= 32).  The ENERGY (needed twice per transition)
+// keeps the reference's difference form, on the VALU.  LDS: A1 splits, A2 splits, c[32], log w[32], means fp32 [2 KR][DIM].
+template <int NT, int KR>
+struct GmmE {
+  static constexpr int DIM = 32 * NT, KP = 2 * KR, KBC = KR > 8 ? 2 : 1;
+  static constexpr int kA1Floats = (int)(gauss3::aop_bytes_general(1, 2 * NT) / sizeof(float));
+  static constexpr int kA2Floats = (int)(gauss3::aop_bytes_general(NT, KBC) / sizeof(float));
+  static constexpr int kLdsFloats = kA1Floats + kA2Floats + 64 + KP * DIM;
+  static constexpr bool kEvalGivesEnergy = false;
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
+    const int dim = a.dim, K = a.n_comp;
+    const float* mu = a.gm_means;
+    gauss3::stage_split_matrix<1, 2 * NT>([&](int comp, int d) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
+                                           reinterpret_cast<__bf16*>(lds), kBlock);
+    gauss3::stage_split_matrix<NT, KBC>([&](int d, int comp) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
+                                         reinterpret_cast<__bf16*>(lds + kA1Floats), kBlock);
+    float* cvec = lds + kA1Floats + kA2Floats;
+    float* lw = cvec + 32;
+    float* mf = lw + 32;
+    for (int k = threadIdx.x; k < 32; k += kBlock) {
+      float nrm = 0.0f;
+      if (k < K)
+        for (int d = 0; d < dim; ++d) nrm = __builtin_fmaf(mu[k * dim + d], mu[k * dim + d], nrm);
+      const float w = k < K ? a.gm_logw[k] : -__builtin_inff();
+      lw[k] = w;
+      cvec[k] = k < K ? __builtin_fmaf(-nrm, a.inv2s2, w) : -__builtin_inff();
+    }
+    for (int i = threadIdx.x; i < KP * DIM; i += kBlock) {
+      const int k = i / DIM, d = i - k * DIM;
+      mf[i] = (k < K && d < dim) ? mu[k * dim + d] : 0.0f;
     }
   }
-  for (int i = threadIdx.x; i < DIM; i += kBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
+  // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not)
+  __device__ static __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
+    const int lane = m + 32 * h;
+    f32x16 dot[1];
+    gauss3::contract_general<1, 2 * NT, false>(reinterpret_cast<const __bf16*>(lds), nullptr, x.t, dot, lane);
+    const float* cvec = lds + kA1Floats + kA2Floats;
+    float top = -__builtin_inff();
+    f32x16 w[1];
+#pragma unroll
+    for (int q = 0; q < KR / 4; ++q) {
+      const float4 c4 = *reinterpret_cast<const float4*>(cvec + 8 * q + 4 * h);
+      const float cq[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[0][4 * q + i] = __builtin_fmaf(dot[0][4 * q + i], a.invs2, cq[i]);
+        top = __builtin_fmaxf(top, w[0][4 * q + i]);  // a NaN logit resurfaces in the sum
+      }
+    }
+    top = __builtin_fmaxf(top, __shfl_xor(top, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < KR) {
+        w[0][r] = __expf(w[0][r] - top);  // 0 for the padding components (c = -inf)
+        sum += w[0][r];
+      } else {
+        w[0][r] = 0.0f;
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    f32x16 acc[NT];
+    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, acc, lane);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g.t[t][r] = a.invs2 * (x.t[t][r] - acc[t][r] * inv);
+    return sum;
+  }
+  // the exact energy, difference form, online logsumexp over the components
+  __device__ static __forceinline__ float energy(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, int, int h) {
+    const float* lw = lds + kA1Floats + kA2Floats + 32;
+    const float* mf = lw + 32;
+    float run_max = -__builtin_inff(), run_sum = 0.0f;
+    for (int k = 0; k < a.n_comp; ++k) {
+      float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 mq = *reinterpret_cast<const float4*>(mf + k * DIM + 32 * t + 8 * q + 4 * h);
+          const float e0 = x.t[t][4 * q] - mq.x, e1 = x.t[t][4 * q + 1] - mq.y;
+          const float e2 = x.t[t][4 * q + 2] - mq.z, e3 = x.t[t][4 * q + 3] - mq.w;
+          d0 = __builtin_fmaf(e0, e0, d0); d1 = __builtin_fmaf(e1, e1, d1);
+          d0 = __builtin_fmaf(e2, e2, d0); d1 = __builtin_fmaf(e3, e3, d1);
+        }
+      float dist = d0 + d1;
+      dist += __shfl_xor(dist, 32);
+      const float logit = __builtin_fmaf(-dist, a.inv2s2, lw[k]);
+      const float new_max = logit > run_max ? logit : run_max;
+      run_sum = __builtin_fmaf(run_sum, __expf(run_max - new_max), __expf(logit - new_max));
+      run_max = new_max;
+    }
+    return -(run_max + logf(run_sum));
+  }
+};
+
+// DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
+// E: the energy (GaussE / GmmE above).
+template <int NT, bool DIAGM, class E>
+__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
+  constexpr int DIM = 32 * NT;
+  float* elds = gauss_hmc_smem;  // the energy's own area
+  // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
+  // rows / columns of the parameters are zero, their momentum draw is discarded) and are never loaded or stored
+  const int dim = a.dim;
+  E::stage(a, elds);
   // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
   // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
   // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
-  float* mraw = mus + DIM;                                   // [DIM]
+  float* mraw = elds + E::kLdsFloats;                        // [DIM]
   float* dsw = mraw + DIM + (threadIdx.x >> 6) * DIM;        // [DIM], this wave's
   constexpr bool diag_mass = DIAGM;
   if constexpr (diag_mass)
@@ -232,7 +367,8 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 
     // ---- H0 and the first (clamped) force
     Tile<NT> f;
-    const float e0 = gauss_eval<NT, B3>(Ps, mus, x, f, m, h);
+    float e0 = E::eval(a, elds, x, f, m, h);
+    if constexpr (!E::kEvalGivesEnergy) e0 = E::energy(a, elds, x, m, h);
     const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -270,7 +406,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       // a second inlined copy of the 64 NT^2 MFMAs costs registers in the hot loop)
       bool scrubbed = false;
       for (;;) {
-        e1 = gauss_eval<NT, B3>(Ps, mus, x, f, m, h);  // f holds +g here
+        e1 = E::eval(a, elds, x, f, m, h);  // f holds +g here (e1: the energy, or a finiteness witness)
         if (scrubbed) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -315,6 +451,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
         scrubbed = true;
       }
     }
+    if constexpr (!E::kEvalGivesEnergy) e1 = E::energy(a, elds, x, m, h);
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
 
     // ---- Metropolis accept (samplers/hmc.py:277-292)
@@ -345,35 +482,51 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
-template <int NT, bool DIAGM, bool B3>
+// SKIP1 (mixture kernels at the shapes where the lane-group kernel has its active-column body): leave at once when the
+// means differ in the first four columns only -- the caller launches that kernel beside this one, and whichever does
+// not apply retires at its first instruction (the mask lives on the device; no host read).
+template <int NT, bool DIAGM, class E, bool SKIP1 = false>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, B3>(a);
+  if constexpr (SKIP1) {
+    if (a.aux != nullptr && __builtin_amdgcn_readfirstlane(a.aux[0]) == 1) return;
+  }
+  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
 }
-template <int NT, bool DIAGM, bool B3>
+template <int NT, bool DIAGM, class E, bool SKIP1 = false>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, B3>(a);
+  if constexpr (SKIP1) {
+    if (a.aux != nullptr && __builtin_amdgcn_readfirstlane(a.aux[0]) == 1) return;
+  }
+  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
 }
 
-template <int NT, bool DIAGM, bool B3>
-int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
-  // precision matrix (fp32, or its three bf16 splits), mean, raw masses, one row of drift factors per wave
-  const size_t smem = (B3 ? gauss3::aop_bytes(NT) : (size_t)(32 * NT) * (32 * NT) * sizeof(float)) +
-                      (size_t)((2 + kBlock / 64) * 32 * NT) * sizeof(float);
+// W2: hold the kernel to 256 VGPRs (two waves per SIMD)
+template <int NT, bool DIAGM, class E, bool W2, bool SKIP1 = false>
+int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
+  // the energy's area, raw masses, one row of drift factors per wave
+  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, B3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, SKIP1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  // two waves per SIMD (256 VGPRs) where the body fits them: one tile, and two tiles on the exact-f32 contraction; the
-  // bf16x3 form of two tiles needs the transient split registers and runs better unconstrained (0.53 vs 0.97 ms, dim 64)
-  if constexpr (NT == 1 || (NT == 2 && !B3))
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, B3>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  if constexpr (W2)
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E, SKIP1>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, B3>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E, SKIP1>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
+}
+
+// dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64) on the exact-f32 contraction,
+// dims 96 / 128 need more than that for the state alone; the bf16x3 form of two tiles needs the transient split
+// registers and runs better unconstrained (0.53 vs 0.97 ms, dim 64).  (Two entry points because hipcc 7.2 silently
+// ignores a template-dependent __launch_bounds__ argument.)
+template <int NT, bool DIAGM, bool B3>
+int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
+  return launch_policy<NT, DIAGM, GaussE<NT, B3>, (NT == 1 || (NT == 2 && !B3))>(a, st);
 }
 
 template <int NT, bool DIAGM>
@@ -413,6 +566,7 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
   a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
+  a.gm_means = nullptr; a.gm_logw = nullptr; a.n_comp = 0; a.inv2s2 = 0.0f; a.invs2 = 0.0f; a.aux = nullptr;
   if (a.mass_diag) {
     switch ((dim + 31) / 32) {
       case 1: return launch_nt<1, true>(a, st);
@@ -427,6 +581,58 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
     case 3: return launch_nt<3, false>(a, st);
     default: return launch_nt<4, false>(a, st);
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Gaussian mixture on the matrix-layout body (GmmE)
+// ---------------------------------------------------------------------------------
+bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
+  // three tiles at most: with x, p and the force resident the four-tile body has no registers for the split's
+  // transients (as for the Gaussian); a diagonal mass: two tiles
+  const int max_dim = mass_kind == EBM_MASS_DIAG ? 64 : 96;
+  return dim >= 20 && dim <= max_dim && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32;
+}
+
+namespace {
+template <int NT, bool DIAGM, bool SKIP1>
+int launch_gmm_nt(const GaussHmcArgs& a, hipStream_t st) {
+  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, NT == 1, SKIP1>(a, st);
+  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, NT == 1, SKIP1>(a, st);
+  return launch_policy<NT, DIAGM, GmmE<NT, 16>, NT == 1, SKIP1>(a, st);
+}
+template <bool DIAGM, bool SKIP1>
+int launch_gmm_dim(const GaussHmcArgs& a, hipStream_t st) {
+  switch ((a.dim + 31) / 32) {
+    case 1: return launch_gmm_nt<1, DIAGM, SKIP1>(a, st);
+    case 2: return launch_gmm_nt<2, DIAGM, SKIP1>(a, st);
+    default:
+      if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 64");
+      else return launch_gmm_nt<3, false, SKIP1>(a, st);
+  }
+}
+}  // namespace
+
+// skip_slot1: the caller launches the lane-group kernel (active-column body) beside this one; see SKIP1 above
+int launch_hmc_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
+                              int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
+                              double mass_scalar, const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
+                              uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
+                              uint64_t offset, int skip_slot1, hipStream_t st) {
+  GaussHmcArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.eps = eps; a.eps_table = eps_table;
+  a.has_mass = mass_kind == EBM_MASS_SCALAR;
+  a.mass_raw = (float)mass_scalar;
+  a.mass_sqrt = (float)sqrt(mass_scalar);
+  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
+  a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
+  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
+  a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
+  a.gm_means = e.dev0; a.gm_logw = e.dev1; a.n_comp = e.n_comp; a.inv2s2 = e.s[0]; a.invs2 = e.s[1]; a.aux = e.aux;
+  if (a.mass_diag) return skip_slot1 ? launch_gmm_dim<true, true>(a, st) : launch_gmm_dim<true, false>(a, st);
+  return skip_slot1 ? launch_gmm_dim<false, true>(a, st) : launch_gmm_dim<false, false>(a, st);
 }
 
 }  // namespace ebm
