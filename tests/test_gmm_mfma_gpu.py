@@ -58,26 +58,23 @@ def test_mixture_hmc_matrix_kernel_matches_oracle(cuda_device, K, dim, mass):
         assert (err <= 5e-4).float().mean().item() >= 0.9
 
 
-def test_ring_at_dim_32_keeps_the_active_column_body_and_other_masks_take_the_matrix_kernel(cuda_device):
-    """dim 32, K <= 8 is launched on BOTH kernels; the mask on the device decides which one runs.  The ring (means differ in
-    columns 0..1) must give what it gave before the matrix kernel existed -- the accept mask of the oracle, bit for bit --
-    and a dense mixture of the same shape must agree with the oracle too."""
+def test_dim_32_small_mixtures_stay_on_the_lane_group_kernel(cuda_device):
+    """dim 32 with K <= 8 keeps one lane per chain (means as scalar operands, the active-column body for the ring): the ring
+    and a dense mixture of that shape against the oracle, and a K = 9 mixture of the same width on the matrix kernel."""
     n, dim, T, L, eps = 512, 32, 5, 20, 0.1
-    for name, model, en in (
-        ("ring", ta.core.ring_mixture(8, dim, device=cuda_device), None),
-        ("dense", None, None),
-    ):
+    for name in ("ring", "dense8", "dense9"):
         g = torch.Generator().manual_seed(3)
-        if name == "dense":
-            means = torch.randn(8, dim, generator=g) * 1.5
-            model, en = ta.GaussianMixtureModel(means, sigma=1.0, device=cuda_device), oracle.GaussianMixture(means, 1.0)
-        else:
+        if name == "ring":
+            model = ta.core.ring_mixture(8, dim, device=cuda_device)
             en = oracle.GaussianMixture(model.means.detach().cpu().float(), 1.0)
+        else:
+            means = torch.randn(int(name[5:]), dim, generator=g) * 1.5
+            model, en = ta.GaussianMixtureModel(means, sigma=1.0, device=cuda_device), oracle.GaussianMixture(means, 1.0)
         s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, device=cuda_device)
         x0 = torch.randn(n, dim, generator=g)
         c0 = hip_calls("ebm_hmc_chain_f32")
         out = s.sample(x=x0.to(cuda_device), n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(11))
-        assert hip_calls("ebm_hmc_chain_f32") == c0 + 1   # one entry-point call (two kernel launches inside it)
+        assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
         p = _field((n, dim), _rng.kernel_seed(11), range(0, 2 * T, 2), cuda_device).cpu()
         u = _field((n,), _rng.kernel_seed(11), range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
         want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, want_traj=False)

@@ -44,7 +44,6 @@ struct GaussHmcArgs {
   const float* gm_logw;
   int32_t n_comp;
   float inv2s2, invs2;
-  const int32_t* aux;      // the mixture's active-column mask (rows.h); null: none
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -482,41 +481,32 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
-// SKIP1 (mixture kernels at the shapes where the lane-group kernel has its active-column body): leave at once when the
-// means differ in the first four columns only -- the caller launches that kernel beside this one, and whichever does
-// not apply retires at its first instruction (the mask lives on the device; no host read).
-template <int NT, bool DIAGM, class E, bool SKIP1 = false>
+template <int NT, bool DIAGM, class E>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  if constexpr (SKIP1) {
-    if (a.aux != nullptr && __builtin_amdgcn_readfirstlane(a.aux[0]) == 1) return;
-  }
   gauss_hmc_mfma_body<NT, DIAGM, E>(a);
 }
-template <int NT, bool DIAGM, class E, bool SKIP1 = false>
+template <int NT, bool DIAGM, class E>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  if constexpr (SKIP1) {
-    if (a.aux != nullptr && __builtin_amdgcn_readfirstlane(a.aux[0]) == 1) return;
-  }
   gauss_hmc_mfma_body<NT, DIAGM, E>(a);
 }
 
 // W2: hold the kernel to 256 VGPRs (two waves per SIMD)
-template <int NT, bool DIAGM, class E, bool W2, bool SKIP1 = false>
+template <int NT, bool DIAGM, class E, bool W2>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   // the energy's area, raw masses, one row of drift factors per wave
   const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, SKIP1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   if constexpr (W2)
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E, SKIP1>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E, SKIP1>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
 }
 
@@ -566,7 +556,7 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
   a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
-  a.gm_means = nullptr; a.gm_logw = nullptr; a.n_comp = 0; a.inv2s2 = 0.0f; a.invs2 = 0.0f; a.aux = nullptr;
+  a.gm_means = nullptr; a.gm_logw = nullptr; a.n_comp = 0; a.inv2s2 = 0.0f; a.invs2 = 0.0f;
   if (a.mass_diag) {
     switch ((dim + 31) / 32) {
       case 1: return launch_nt<1, true>(a, st);
@@ -594,30 +584,29 @@ bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
 }
 
 namespace {
-template <int NT, bool DIAGM, bool SKIP1>
+template <int NT, bool DIAGM>
 int launch_gmm_nt(const GaussHmcArgs& a, hipStream_t st) {
-  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, NT == 1, SKIP1>(a, st);
-  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, NT == 1, SKIP1>(a, st);
-  return launch_policy<NT, DIAGM, GmmE<NT, 16>, NT == 1, SKIP1>(a, st);
+  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, NT == 1>(a, st);
+  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, NT == 1>(a, st);
+  return launch_policy<NT, DIAGM, GmmE<NT, 16>, NT == 1>(a, st);
 }
-template <bool DIAGM, bool SKIP1>
+template <bool DIAGM>
 int launch_gmm_dim(const GaussHmcArgs& a, hipStream_t st) {
   switch ((a.dim + 31) / 32) {
-    case 1: return launch_gmm_nt<1, DIAGM, SKIP1>(a, st);
-    case 2: return launch_gmm_nt<2, DIAGM, SKIP1>(a, st);
+    case 1: return launch_gmm_nt<1, DIAGM>(a, st);
+    case 2: return launch_gmm_nt<2, DIAGM>(a, st);
     default:
       if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 64");
-      else return launch_gmm_nt<3, false, SKIP1>(a, st);
+      else return launch_gmm_nt<3, false>(a, st);
   }
 }
 }  // namespace
 
-// skip_slot1: the caller launches the lane-group kernel (active-column body) beside this one; see SKIP1 above
 int launch_hmc_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
                               int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
                               double mass_scalar, const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
                               uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
-                              uint64_t offset, int skip_slot1, hipStream_t st) {
+                              uint64_t offset, hipStream_t st) {
   GaussHmcArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table;
@@ -630,9 +619,8 @@ int launch_hmc_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_chains,
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
   a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
-  a.gm_means = e.dev0; a.gm_logw = e.dev1; a.n_comp = e.n_comp; a.inv2s2 = e.s[0]; a.invs2 = e.s[1]; a.aux = e.aux;
-  if (a.mass_diag) return skip_slot1 ? launch_gmm_dim<true, true>(a, st) : launch_gmm_dim<true, false>(a, st);
-  return skip_slot1 ? launch_gmm_dim<false, true>(a, st) : launch_gmm_dim<false, false>(a, st);
+  a.gm_means = e.dev0; a.gm_logw = e.dev1; a.n_comp = e.n_comp; a.inv2s2 = e.s[0]; a.invs2 = e.s[1];
+  return a.mass_diag ? launch_gmm_dim<true>(a, st) : launch_gmm_dim<false>(a, st);
 }
 
 }  // namespace ebm

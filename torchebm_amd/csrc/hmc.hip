@@ -27,7 +27,7 @@ bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
 bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);
 int launch_hmc_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
                               int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
-                              uint64_t, uint64_t, int, hipStream_t);
+                              uint64_t, uint64_t, hipStream_t);
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
                                 int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
                                 uint64_t, uint64_t, hipStream_t);
@@ -75,26 +75,21 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
                                          mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
   }
   // Mixtures of up to 32 components, dims 20 .. 96: the two K x dim passes of the gradient on the bf16 matrix pipe
-  // (gauss_hmc_mfma.hip: GmmE).  One shape keeps the lane-group kernel as well: dim 32, K <= 8, where that kernel has the
-  // active-column body for means that differ in the first four columns only -- which of the two applies is written on
-  // the DEVICE (ebm_energy_t.aux), so both are launched and the one that does not apply retires at its first instruction.
-  bool only_slot1 = false;
-  if (!diag_partials && e.kind == EBM_ENERGY_GMM && gmm_hmc_mfma_supported(dim, e.n_comp, mass_kind)) {
+  // (gauss_hmc_mfma.hip: GmmE).  One shape stays on the lane-group kernel: dim 32 with K <= 8, where one lane per chain
+  // with the means as scalar operands (and the active-column body) is faster -- dense means, ms per 10 transitions at
+  // L = 20, 2^18 chains (scripts/bench_gmm_dense.py): dim 32: K = 8 0.96 there vs 1.43 here, K = 16 / 32 4.30 / 7.86 vs
+  // 1.63 / 2.38; dim 64: K = 8 / 16 / 32 4.20 / 8.71 / 16.0 vs 3.07 / 3.52 / 5.41.
+  if (!diag_partials && e.kind == EBM_ENERGY_GMM && gmm_hmc_mfma_supported(dim, e.n_comp, mass_kind) &&
+      !(dim == 32 && e.n_comp <= 8)) {
     // A/B switch for tests and profiling: EBM_GMM_ROWS=1 keeps the lane-group kernels
     static const bool force_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
-    if (!force_rows) {
-      const bool rows_has_slot1 = dim == 32 && e.n_comp <= 8 && e.aux != nullptr;
-      const int rc = launch_hmc_chain_gmm_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                               mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset,
-                                               rows_has_slot1 ? 1 : 0, st);
-      if (rc != 0 || !rows_has_slot1) return rc;
-      only_slot1 = true;  // ... and fall through to the lane-group kernel, which runs only if the mask says so
-    }
+    if (!force_rows)
+      return launch_hmc_chain_gmm_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                       mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
   }
   Geometry geo;
   if (!hmc_geometry(e, dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
   HmcArgs a;
-  a.only_slot1 = only_slot1 ? 1 : 0;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
   a.mass_raw = (float)mass_scalar;

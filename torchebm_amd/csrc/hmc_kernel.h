@@ -32,8 +32,6 @@ struct HmcArgs {
   int park_offset_floats;  // start of the lane-private parking slots in dynamic LDS
   diag::DiagArgs diag;     // per-block diagnostics records at the kept transitions (null: off)
   int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
-  int only_slot1;          // mixture, one lane per chain: run only if the active-column body applies (the matrix-layout
-                           // kernel launched beside this one takes every other mask: hmc.hip)
 };
 
 extern __shared__ __attribute__((aligned(16))) float hmc_smem[];
@@ -449,7 +447,6 @@ __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
       hmc_chain_body<kGmmSlot1, G, NV, FULL, MASS, DIAG, true>(a);
       return;
     }
-    if (a.only_slot1) return;
   }
   hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG, true>(a);
 }
