@@ -14,7 +14,7 @@ def timeit(fn, reps=10, warm=2):
     return sorted(ts)[len(ts) // 2]
 n, dim = 1 << 18, 32
 x = torch.randn(n, dim, device=dev)
-for K in (4, 8, 9, 16, 32):
+for K in (4, 8, 9, 16, 25, 32):
     model = ta.core.ring_mixture(K, dim, device=dev)
     ld = ta.LangevinDynamics(model, step_size=0.01, device=dev)
     hm = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=20, device=dev)

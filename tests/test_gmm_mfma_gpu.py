@@ -80,3 +80,39 @@ def test_dim_32_small_mixtures_stay_on_the_lane_group_kernel(cuda_device):
         want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, want_traj=False)
         err = ((out.cpu() - want["x"]).abs() / want["x"].abs().clamp(min=1.0)).amax(dim=1)
         assert (err <= 5e-4).float().mean().item() >= 0.97, (name, err.max().item())
+
+
+@pytest.mark.parametrize("K", [1, 5, 9, 16, 25, 32])
+@pytest.mark.parametrize("dim", [20, 32, 64, 96, 128])
+def test_mixture_langevin_matrix_kernel(cuda_device, K, dim):
+    """Langevin on mixtures in the matrix layout (csrc/gauss_mfma.hip with gmm3::Mixture): native draws == the same field
+    injected (bit for bit, clamp + schedule + thinned trajectory included), and the injected run against the oracle."""
+    from torchebm_amd.samplers.langevin import em_coefficients
+
+    g = torch.Generator().manual_seed(10 * K + dim)
+    means = torch.randn(K, dim, generator=g) * 1.3
+    model = ta.GaussianMixtureModel(means, sigma=0.9, device=cuda_device)
+    en = oracle.GaussianMixture(means, 0.9)
+    spec = model.fused_spec()
+    n, k, thin = 130, 9, 3
+    etas = [0.03 * 0.93 ** i for i in range(k)]
+    sigs = [1.0 - 0.02 * i for i in range(k)]
+    rows = [em_coefficients(e, s) for e, s in zip(etas, sigs)]
+    table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2, 2)
+    seed = _rng.kernel_seed(900 + K + dim)
+
+    def run(noise, sd):
+        x = x0.to(cuda_device).clone()
+        traj = torch.full((n, k // thin, dim), float("nan"), device=cuda_device)
+        _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
+                  1, -2.2, 2.4, thin, traj.data_ptr(), None, _lib.ptr(noise), sd, 0, _lib.stream_handle(cuda_device))
+        return x, traj
+
+    xa, ta_ = run(None, seed)
+    noise = _field((n, dim), seed, range(k), cuda_device)
+    xb, tb = run(noise, 0)
+    assert torch.equal(xa, xb) and torch.equal(ta_, tb)
+    want_x, want_t, _ = oracle.langevin_chain(en, x0, noise.cpu(), etas, sigs, clamp=(-2.2, 2.4), thin=thin, want_traj=True)
+    err = ((tb.cpu() - want_t).abs() / want_t.abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    assert (err <= 5e-5).float().mean().item() >= 0.95 and (err <= 5e-3).all(), err.max().item()

@@ -58,6 +58,10 @@ int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
+bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
+int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                   const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
+                                   hipStream_t);
 int launch_langevin_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                      const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                      hipStream_t);
@@ -234,6 +238,15 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (!force_rows)
       return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                               clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  }
+  // mixtures of up to 32 components on the matrix layout (gauss_mfma.hip / gmm_bf16x3.h); dims 16 / 32 with K <= 8 keep
+  // one lane per chain with the means as scalar operands
+  if (!heun && energy->kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, energy->n_comp) &&
+      !(dim == 32 && energy->n_comp <= 8)) {
+    static const bool force_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+    if (!force_rows)
+      return launch_langevin_chain_gmm_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                            clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
   }
   return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef,
                                     coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,

@@ -12,6 +12,7 @@
 // reject), which costs 256 B per chain and transition and no registers.
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"
+#include "gmm_bf16x3.h"
 
 namespace ebm {
 namespace {
@@ -125,112 +126,23 @@ struct GaussE {
   __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
 };
 
-// Isotropic Gaussian mixture, up to 32 components (core/energies.py: GaussianMixtureModel):
-//   E = -logsumexp_k(log w_k - |x - mu_k|^2 / (2 sigma^2)),   dE/dx = (x - sum_k r_k mu_k) / sigma^2,  r = softmax.
-// The two K x dim passes of the gradient are small GEMMs and run on the bf16 matrix pipe with split operands
-// (gauss_bf16x3.h), both reading their K operand straight from registers in the C/D layout:
-//   1. logits^T [comp, chain] = Mu [comp, d] . x^T [d, chain]        (one 32-row tile of components, 2 NT K-blocks)
-//      l_k = c_k + (x . mu_k) / sigma^2 with c_k = log w_k - |mu_k|^2 / (2 sigma^2): softmax is shift-invariant, |x|^2 drops
-//      out (the gradient-only form of rows.h); lane (n, h) holds components (r & 3) + 8 (r >> 2) + 4 h in register r, so
-//      the softmax is per-lane arithmetic plus two xor-32 shuffles (max, sum);
-//   2. acc^T [d, chain] = Mu^T [d, comp] . w [comp, chain]            (NT tiles, one K-block per 16 components)
-//      whose result lands in the state's own layout: g = (x - acc / sum) / sigma^2 is register-to-register.
-// KR = live logit registers per lane: 4 (K <= 8), 8 (K <= 16), 16 (K <= 32).  The ENERGY (needed twice per transition)
-// keeps the reference's difference form, on the VALU.  LDS: A1 splits, A2 splits, c[32], log w[32], means fp32 [2 KR][DIM].
+// Isotropic Gaussian mixture, up to 32 components: gmm_bf16x3.h (both K x dim passes of the gradient on the bf16 matrix
+// pipe; the energy -- needed twice per transition -- in the reference's difference form on the VALU).
 template <int NT, int KR>
 struct GmmE {
-  static constexpr int DIM = 32 * NT, KP = 2 * KR, KBC = KR > 8 ? 2 : 1;
-  static constexpr int kA1Floats = (int)(gauss3::aop_bytes_general(1, 2 * NT) / sizeof(float));
-  static constexpr int kA2Floats = (int)(gauss3::aop_bytes_general(NT, KBC) / sizeof(float));
-  static constexpr int kLdsFloats = kA1Floats + kA2Floats + 64 + KP * DIM;
+  using M = gmm3::Mixture<NT, KR>;
+  static constexpr int kLdsFloats = M::kLdsFloats;
   static constexpr bool kEvalGivesEnergy = false;
-  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
-    const int dim = a.dim, K = a.n_comp;
-    const float* mu = a.gm_means;
-    gauss3::stage_split_matrix<1, 2 * NT>([&](int comp, int d) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
-                                           reinterpret_cast<__bf16*>(lds), kBlock);
-    gauss3::stage_split_matrix<NT, KBC>([&](int d, int comp) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
-                                         reinterpret_cast<__bf16*>(lds + kA1Floats), kBlock);
-    float* cvec = lds + kA1Floats + kA2Floats;
-    float* lw = cvec + 32;
-    float* mf = lw + 32;
-    for (int k = threadIdx.x; k < 32; k += kBlock) {
-      float nrm = 0.0f;
-      if (k < K)
-        for (int d = 0; d < dim; ++d) nrm = __builtin_fmaf(mu[k * dim + d], mu[k * dim + d], nrm);
-      const float w = k < K ? a.gm_logw[k] : -__builtin_inff();
-      lw[k] = w;
-      cvec[k] = k < K ? __builtin_fmaf(-nrm, a.inv2s2, w) : -__builtin_inff();
-    }
-    for (int i = threadIdx.x; i < KP * DIM; i += kBlock) {
-      const int k = i / DIM, d = i - k * DIM;
-      mf[i] = (k < K && d < dim) ? mu[k * dim + d] : 0.0f;
-    }
+  __device__ static __forceinline__ gmm3::Params params(const GaussHmcArgs& a) {
+    return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2};
   }
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) { M::stage(params(a), lds, kBlock); }
   // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not)
   __device__ static __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-    const int lane = m + 32 * h;
-    f32x16 dot[1];
-    gauss3::contract_general<1, 2 * NT, false>(reinterpret_cast<const __bf16*>(lds), nullptr, x.t, dot, lane);
-    const float* cvec = lds + kA1Floats + kA2Floats;
-    float top = -__builtin_inff();
-    f32x16 w[1];
-#pragma unroll
-    for (int q = 0; q < KR / 4; ++q) {
-      const float4 c4 = *reinterpret_cast<const float4*>(cvec + 8 * q + 4 * h);
-      const float cq[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        w[0][4 * q + i] = __builtin_fmaf(dot[0][4 * q + i], a.invs2, cq[i]);
-        top = __builtin_fmaxf(top, w[0][4 * q + i]);  // a NaN logit resurfaces in the sum
-      }
-    }
-    top = __builtin_fmaxf(top, __shfl_xor(top, 32));
-    float sum = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r < KR) {
-        w[0][r] = __expf(w[0][r] - top);  // 0 for the padding components (c = -inf)
-        sum += w[0][r];
-      } else {
-        w[0][r] = 0.0f;
-      }
-    }
-    sum += __shfl_xor(sum, 32);
-    f32x16 acc[NT];
-    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, acc, lane);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) g.t[t][r] = a.invs2 * (x.t[t][r] - acc[t][r] * inv);
-    return sum;
+    return M::grad(params(a), lds, x.t, g.t, m + 32 * h);
   }
-  // the exact energy, difference form, online logsumexp over the components
-  __device__ static __forceinline__ float energy(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, int, int h) {
-    const float* lw = lds + kA1Floats + kA2Floats + 32;
-    const float* mf = lw + 32;
-    float run_max = -__builtin_inff(), run_sum = 0.0f;
-    for (int k = 0; k < a.n_comp; ++k) {
-      float d0 = 0.0f, d1 = 0.0f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 mq = *reinterpret_cast<const float4*>(mf + k * DIM + 32 * t + 8 * q + 4 * h);
-          const float e0 = x.t[t][4 * q] - mq.x, e1 = x.t[t][4 * q + 1] - mq.y;
-          const float e2 = x.t[t][4 * q + 2] - mq.z, e3 = x.t[t][4 * q + 3] - mq.w;
-          d0 = __builtin_fmaf(e0, e0, d0); d1 = __builtin_fmaf(e1, e1, d1);
-          d0 = __builtin_fmaf(e2, e2, d0); d1 = __builtin_fmaf(e3, e3, d1);
-        }
-      float dist = d0 + d1;
-      dist += __shfl_xor(dist, 32);
-      const float logit = __builtin_fmaf(-dist, a.inv2s2, lw[k]);
-      const float new_max = logit > run_max ? logit : run_max;
-      run_sum = __builtin_fmaf(run_sum, __expf(run_max - new_max), __expf(logit - new_max));
-      run_max = new_max;
-    }
-    return -(run_max + logf(run_sum));
+  __device__ static __forceinline__ float energy(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, int m, int h) {
+    return M::energy(params(a), lds, x.t, m + 32 * h);
   }
 };
 

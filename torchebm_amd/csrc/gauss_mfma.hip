@@ -14,6 +14,7 @@
 // consecutive lanes, consecutive LDS banks.
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"
+#include "gmm_bf16x3.h"
 
 namespace ebm {
 namespace {
@@ -37,6 +38,7 @@ struct GaussArgs {
   uint64_t step0;
   const float* mean;  // [dim]
   const float* prec;  // [dim, dim], symmetric
+  gmm3::Params gm;    // the mixture kernels (GKR > 0 below)
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
@@ -52,9 +54,13 @@ extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 // two waves per SIMD where a 256-thread workgroup (one per CU: the matrix is 55 / 98 KB) leaves each SIMD one wave, which
 // can issue at only 39 % of the VALU rate.  HIDE: tiles whose normals are drawn behind the MFMAs (the others are drawn
 // after the contraction: their 16 registers per tile are then not live across it, which is what fits 256 VGPRs).
-template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT>
+// GKR > 0: the energy is an isotropic Gaussian MIXTURE (gmm_bf16x3.h; GKR = its logit-register class 4 / 8 / 16 for up
+// to 8 / 16 / 32 components) instead of the dense Gaussian: same state layout, same update, the gradient from
+// gmm3::Mixture.
+template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, int GKR = 0>
 __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   constexpr int DIM = 32 * NT;
+  using Mix = gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>;
   // LDS: the precision matrix -- fp32 [DIM][DIM], or its three operand-ready bf16 splits (1.5x the bytes) -- then mu
   float* Ps = gauss_smem;
   __bf16* aop = reinterpret_cast<__bf16*>(gauss_smem);
@@ -62,7 +68,9 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   // dim <= DIM, dim % 4 == 0: the tiles are zero-padded -- padded coordinates stay exactly 0 (d = 0, g = 0,
   // no noise) and whole register quads beyond dim are never loaded, drawn or stored
   const int dim = a.dim;
-  if constexpr (B3) {
+  if constexpr (GKR > 0) {
+    Mix::stage(a.gm, gauss_smem, BLOCK);
+  } else if constexpr (B3) {
     gauss3::stage_split_precision<NT>(a.prec, dim, aop, BLOCK);
   } else {
     for (int i = threadIdx.x; i < DIM * DIM; i += BLOCK) {
@@ -70,7 +78,8 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
     }
   }
-  for (int i = threadIdx.x; i < DIM; i += BLOCK) mus[i] = i < dim ? a.mean[i] : 0.0f;
+  if constexpr (GKR == 0)
+    for (int i = threadIdx.x; i < DIM; i += BLOCK) mus[i] = i < dim ? a.mean[i] : 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -172,7 +181,9 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           x[t][r] = x1 + noise_coef * dw;
         }
     } else {
-    if constexpr (B3) {
+    if constexpr (GKR > 0) {
+      Mix::grad(a.gm, gauss_smem, x, g, lane);
+    } else if constexpr (B3) {
       gauss3::contract<NT>(aop, mus, x, g, lane);
     } else {
 #pragma unroll
@@ -276,6 +287,10 @@ template <int NT>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(GaussArgs a) {
   gauss_langevin_mfma_body<NT, true, true>(a);
 }
+template <int NT, int GKR>
+__global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true, false, kBlock, NT, GKR>(a);
+}
 constexpr int kWideBlock = 512;
 template <int NT, int HIDE>
 __global__ __launch_bounds__(kWideBlock) void gauss_langevin_bf16x3_fast_wide_kernel(GaussArgs a) {
@@ -339,11 +354,61 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
+  a.gm = gmm3::Params{nullptr, nullptr, 0, dim, 0.0f, 0.0f};
   switch ((dim + 31) / 32) {
     case 1: return launch_nt<1>(a, st);
     case 2: return launch_nt<2>(a, st);
     case 3: return launch_nt<3>(a, st);
     default: return launch_nt<4>(a, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Gaussian mixture Langevin chain on the matrix layout
+// ---------------------------------------------------------------------------------
+bool gmm_mfma_supported(int32_t dim, int32_t n_comp) { return dim >= 20 && dim <= 128 && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32; }
+
+namespace {
+template <int NT, int GKR>
+int launch_gmm_langevin(const GaussArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)gmm3::Mixture<NT, GKR>::kLdsFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_langevin_bf16x3_kernel<NT, GKR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL((gmm_langevin_bf16x3_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+template <int NT>
+int launch_gmm_langevin_nt(const GaussArgs& a, hipStream_t st) {
+  if (a.gm.n_comp <= 8) return launch_gmm_langevin<NT, 4>(a, st);
+  if (a.gm.n_comp <= 16) return launch_gmm_langevin<NT, 8>(a, st);
+  return launch_gmm_langevin<NT, 16>(a, st);
+}
+}  // namespace
+
+int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                                   float eta, float sqrt_eta, float noise_coef, const float* coef_table,
+                                   int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
+                                   const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
+  GaussArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
+  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
+  a.gm = gmm3::Params{e.dev0, e.dev1, e.n_comp, dim, e.s[0], e.s[1]};
+  switch ((dim + 31) / 32) {
+    case 1: return launch_gmm_langevin_nt<1>(a, st);
+    case 2: return launch_gmm_langevin_nt<2>(a, st);
+    case 3: return launch_gmm_langevin_nt<3>(a, st);
+    default: return launch_gmm_langevin_nt<4>(a, st);
   }
 }
 
