@@ -90,3 +90,51 @@ def test_hmc_marginals_and_acceptance_match_the_oracle(cuda_device):
         assert stats.kstest((gx[:, c] - mean[c].item()) / np.sqrt(cov[c, c].item()), "norm").pvalue > P_MIN
     acc_gpu, acc_cpu = diag["acceptance_rate"].mean().item(), want["diagnostics"]["acceptance_rate"].mean().item()
     assert abs(acc_gpu - acc_cpu) < 0.01, (acc_gpu, acc_cpu)
+
+
+def test_matrix_pipe_kernels_sample_the_target_law(cuda_device):
+    """The kernels that contract on the bf16 pipe with split operands (dense Gaussian, dim 64; a 16-component mixture,
+    dim 32): HMC is exact, so after burn-in every marginal must follow the TARGET's own marginal -- N(mu_c, Sigma_cc) for
+    the Gaussian, the 1-D mixture sum_k w_k N(mu_kc, sigma^2) for the mixture -- and Langevin with a small step must agree
+    with the oracle's CPU chain of the same length."""
+    n = 8192
+    # dense Gaussian, dim 64
+    g = torch.Generator().manual_seed(64)
+    dim = 64
+    a = torch.randn(dim, dim, generator=g)
+    cov = a @ a.t() / dim + 0.5 * torch.eye(dim)
+    mean = torch.randn(dim, generator=g)
+    s = ta.HamiltonianMonteCarlo(ta.GaussianModel(mean, cov, device=cuda_device), step_size=0.15, n_leapfrog_steps=10, device=cuda_device)
+    x = s.sample(x=torch.randn(n, dim, generator=g).to(cuda_device), n_steps=60,
+                 generator=torch.Generator(device=cuda_device).manual_seed(1)).cpu().double().numpy()
+    for c in (0, 17, 40, 63):
+        assert stats.kstest((x[:, c] - mean[c].item()) / np.sqrt(cov[c, c].item()), "norm").pvalue > P_MIN, c
+    emp = np.cov(x, rowvar=False)
+    assert np.abs(emp - cov.double().numpy()).max() < 0.12
+    # 16-component mixture, dim 32, well-mixed modes (sigma comparable to the spread of the means)
+    g = torch.Generator().manual_seed(16)
+    K, dim, sigma = 16, 32, 1.0
+    means = torch.randn(K, dim, generator=g) * 0.8
+    w = torch.rand(K, generator=g) + 0.5
+    model = ta.GaussianMixtureModel(means, sigma=sigma, weights=w, device=cuda_device)
+    s = ta.HamiltonianMonteCarlo(model, step_size=0.2, n_leapfrog_steps=12, device=cuda_device)
+    x = s.sample(x=torch.randn(n, dim, generator=g).to(cuda_device), n_steps=150,
+                 generator=torch.Generator(device=cuda_device).manual_seed(2)).cpu().double().numpy()
+    wn = (w / w.sum()).double().numpy()
+    for c in (0, 9, 31):
+        mu_c = means[:, c].double().numpy()
+        cdf = lambda t, mu_c=mu_c: sum(wk * stats.norm.cdf(t, loc=m, scale=sigma) for wk, m in zip(wn, mu_c))  # noqa: E731
+        assert stats.kstest(x[:, c], cdf).pvalue > P_MIN, c
+    # Langevin on the same mixture against the oracle's chain (independent noise, same law)
+    k, eta = 400, 0.02
+    ld = ta.LangevinDynamics(model, step_size=eta, device=cuda_device)
+    x0 = torch.randn(2048, dim, generator=g)
+    got = ld.sample(x=x0.to(cuda_device), n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(3)).cpu().double().numpy()
+    en = oracle.GaussianMixture(means, sigma, log_weights=model.log_weights.detach().cpu())
+    xc = x0.clone()
+    gn = torch.Generator().manual_seed(5)
+    for _ in range(k):
+        xc = oracle.em_step(xc, en.grad_autograd(xc), torch.randn(2048, dim, generator=gn), eta, 1.0)
+    ref = xc.double().numpy()
+    for c in (0, 9, 31):
+        assert stats.ks_2samp(got[:, c], ref[:, c]).pvalue > P_MIN, c
