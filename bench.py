@@ -360,6 +360,30 @@ def extra_measurements(device, valu_rate):
         res["chain_steps_per_s"] = n * k * res["value"]
         return res
 
+    def matrix_pipe():
+        # the row-coupled energies on the bf16 matrix pipe with split operands (csrc/gauss_bf16x3.h, gmm_bf16x3.h)
+        n, k = 1 << 18, 50
+        gd = torch.Generator().manual_seed(64)
+        a64 = torch.randn(64, 64, generator=gd)
+        gauss = ta.GaussianModel(torch.zeros(64), a64 @ a64.t() / 64 + 0.5 * torch.eye(64), device=device)
+        mix = ta.GaussianMixtureModel(torch.randn(16, 32, generator=gd) * 2.0, sigma=1.0, device=device)
+        out = {"name": "matrix_pipe_energies", "workload": "dense Gaussian (dim 64) and a 16-component mixture (dim 32), 2^18 chains: "
+               "Langevin k=50 and HMC L=20 x 10 transitions through the public samplers", "bound": "valu + bf16 mfma"}
+        for tag, model, dim in (("gaussian_dim64", gauss, 64), ("mixture16_dim32", mix, 32)):
+            x0 = torch.randn(n, dim, device=device)
+            ld = ta.LangevinDynamics(model, step_size=0.01, device=device)
+            f1 = lambda: ld.sample(x=x0, n_steps=k)  # noqa: E731
+            kms = kernel_ms_of("ebm_langevin_chain_f32", f1, 3, device)
+            hm = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=20, device=device)
+            f2 = lambda: hm.sample(x=x0, n_steps=10)  # noqa: E731
+            hms = kernel_ms_of("ebm_hmc_chain_f32", f2, 3, device)
+            out[tag] = {
+                "langevin_kernel_ms": kms, "langevin_chain_steps_per_s": n * k / (kms * 1e-3),
+                "langevin_step_equivalent_frac_of_8TBps": n * k * 8 * dim / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hmc_kernel_ms": hms, "hmc_mh_steps_per_s": n * 10 / (hms * 1e-3),
+            }
+        return out
+
     def step_kernel():
         # the genuinely HBM-bound kernel of the path: one Euler-Maruyama step with an external gradient, 2^26 elements
         n = 1 << 26
@@ -405,6 +429,7 @@ def extra_measurements(device, valu_rate):
     guarded("config5_pcd_mlp", c5)
     guarded("mlp_benchmark_network_dim32", mlp_bench_net)
     guarded("langevin_step_kernel", step_kernel)
+    guarded("matrix_pipe_energies", matrix_pipe)
     return out
 
 
