@@ -401,9 +401,13 @@ template <int NT, bool DIAGM, class E>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
   gauss_hmc_mfma_body<NT, DIAGM, E>(a);
 }
+template <int NT, bool DIAGM, class E>
+__global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcArgs a) {
+  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
+}
 
-// W2: hold the kernel to 256 VGPRs (two waves per SIMD)
-template <int NT, bool DIAGM, class E, bool W2>
+// WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
+template <int NT, bool DIAGM, class E, int WAVES>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   // the energy's area, raw masses, one row of drift factors per wave
   const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT) * sizeof(float);
@@ -415,7 +419,9 @@ int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  if constexpr (W2)
+  if constexpr (WAVES == 3)
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w3<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else if constexpr (WAVES == 2)
     hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else
     hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
@@ -428,7 +434,7 @@ int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
 // ignores a template-dependent __launch_bounds__ argument.)
 template <int NT, bool DIAGM, bool B3>
 int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
-  return launch_policy<NT, DIAGM, GaussE<NT, B3>, (NT == 1 || (NT == 2 && !B3))>(a, st);
+  return launch_policy<NT, DIAGM, GaussE<NT, B3>, (NT == 1 || (NT == 2 && !B3)) ? 2 : 0>(a, st);
 }
 
 template <int NT, bool DIAGM>
@@ -498,9 +504,12 @@ bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
 namespace {
 template <int NT, bool DIAGM>
 int launch_gmm_nt(const GaussHmcArgs& a, hipStream_t st) {
-  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, NT == 1>(a, st);
-  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, NT == 1>(a, st);
-  return launch_policy<NT, DIAGM, GmmE<NT, 16>, NT == 1>(a, st);
+  // one tile: three waves per SIMD (168 VGPRs, ~100 B of scratch) -- the evaluation is one dependent chain (contraction,
+  // softmax, contraction), and a third wave hides more of it than the spills cost: 1.53 -> 1.42 ms at K = 9, dim 32
+  constexpr int W = NT == 1 ? 3 : 0;
+  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, W>(a, st);
+  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, W>(a, st);
+  return launch_policy<NT, DIAGM, GmmE<NT, 16>, W>(a, st);
 }
 template <bool DIAGM>
 int launch_gmm_dim(const GaussHmcArgs& a, hipStream_t st) {
