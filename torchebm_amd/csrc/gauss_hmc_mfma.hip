@@ -160,7 +160,8 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
   // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
   float* mraw = elds + E::kLdsFloats;                        // [DIM]
-  float* dsw = mraw + DIM + (threadIdx.x >> 6) * DIM;        // [DIM], this wave's
+  float* dsw_base = mraw + DIM;
+  float* dsw = dsw_base + (threadIdx.x >> 6) * DIM;          // [DIM], this wave's
   constexpr bool diag_mass = DIAGM;
   if constexpr (diag_mass)
     for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = i < dim ? a.mass_diag[i] : 1.0f;
@@ -227,6 +228,20 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   int64_t keep_off = 0;
   float eps = a.eps;
 
+  // Energy and clamped force of the state the chain holds are CARRIED from transition to transition (as in
+  // hmc_kernel.h): an accepted proposal brings its own E1 and end-of-trajectory force -- what the reference recomputes at
+  // the top of the next transition on the same x, bit for bit -- a rejected one keeps the saved pair.  L evaluations per
+  // transition instead of L + 1 (and, for the mixture, one exact energy instead of two).  The force is parked in LDS,
+  // one slot per lane and register: [16 NT][kBlock].
+  float* fpark = dsw_base + (kBlock / 64) * DIM + threadIdx.x;
+  Tile<NT> f;
+  float e_cur = E::eval(a, elds, x, f, m, h);
+  if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+
   for (int tr = 0; tr < a.n_mh; ++tr) {
     if (a.eps_table) eps = a.eps_table[tr];
     const float half_eps = 0.5f * eps;
@@ -276,15 +291,13 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    // ---- H0 and the first (clamped) force
-    Tile<NT> f;
-    float e0 = E::eval(a, elds, x, f, m, h);
-    if constexpr (!E::kEvalGivesEnergy) e0 = E::energy(a, elds, x, m, h);
+    // ---- H0 and the first (clamped) force: the carried pair
+    const float e0 = e_cur;
     const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+      for (int r = 0; r < 16; ++r) f.t[t][r] = fpark[(16 * t + r) * kBlock];
 
     // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
     float e1 = e0;
@@ -373,8 +386,16 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + chain] : 2.0f;
     else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)chain >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(chain & 3)));
     const bool accept = active && (uu < acc_p);
-    if (accept) store_rows(a.x, row, x);   // the x array always holds the accepted state ...
-    else load_rows(a.x, row, x);           // ... which a rejected proposal falls back to
+    if (accept) {
+      store_rows(a.x, row, x);             // the x array always holds the accepted state ...
+      e_cur = e1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = f.t[t][r];
+    } else {
+      load_rows(a.x, row, x);              // ... which a rejected proposal falls back to (its energy / force stay parked)
+    }
 
     const bool leader = active && h == 0;
     if (a.accept_mask && leader) a.accept_mask[(int64_t)tr * a.n_chains + chain] = accept ? 1 : 0;
@@ -409,8 +430,8 @@ __global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcAr
 // WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
 template <int NT, bool DIAGM, class E, int WAVES>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
-  // the energy's area, raw masses, one row of drift factors per wave
-  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT) * sizeof(float);
+  // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register)
+  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + 16 * NT * kBlock) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E>),
