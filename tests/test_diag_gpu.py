@@ -191,6 +191,35 @@ def test_hmc_records(cuda_device, kind, dim, mass):
         assert (err <= 5e-4).float().mean().item() >= 0.97, err.max().item()
 
 
+@pytest.mark.parametrize("kind,dim", [("gauss", 20), ("gauss", 32), ("gauss", 64), ("gauss", 96), ("gmm16", 32), ("gmm16", 64),
+                                      ("gmm5", 48), ("gmm32", 96)])
+def test_matrix_layout_kernels_emit_records(cuda_device, kind, dim):
+    """Dense Gaussians and mixtures where the matrix-layout Langevin kernels run (dims 20 .. 96): the records come from
+    those kernels -- the layout query says 128 chains per workgroup, the chains are bit for bit those of the call without
+    diagnostics, statistics and energy agree with the kept states."""
+    g = torch.Generator().manual_seed(dim)
+    if kind == "gauss":
+        a = torch.randn(dim, dim, generator=g)
+        model = ta.GaussianModel(torch.randn(dim, generator=g), a @ a.t() / dim + 0.5 * torch.eye(dim), device=cuda_device)
+    else:
+        model = ta.GaussianMixtureModel(torch.randn(int(kind[3:]), dim, generator=g) * 2, sigma=0.9, device=cuda_device)
+    n = 1001
+    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim) == ((n + 127) // 128, dim, 128 * dim)
+    s = ta.LangevinDynamics(model, step_size=0.02, noise_scale=0.8, clamp=(-3.0, 3.5), device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).to(cuda_device)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    traj, diag = s.sample(x=x0, n_steps=9, thin=2, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    _check_against_trajectory(model, traj, diag, e_rtol=1e-4)
+    plain = s.sample(x=x0, n_steps=9, thin=2, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert torch.equal(plain, traj)
+    # and without a trajectory, a single chain per workgroup tail
+    out, diag2 = s.sample(x=x0[:130], n_steps=4, thin=4, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    torch.testing.assert_close(diag2["mean"][0].double(), out.double().mean(0), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(diag2["energy"][0].double(), model(out).double().mean(), rtol=1e-4, atol=1e-4)
+
+
 def test_c_abi_layout_and_injected_noise_records(cuda_device):
     """The layout query mirrors the dispatch; records with injected noise run on the lane-group kernel."""
     spec = ta.DoubleWellModel(device=cuda_device).fused_spec()

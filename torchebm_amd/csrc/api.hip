@@ -59,6 +59,10 @@ int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, 
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
+bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
+int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                      const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
+                                      float*, hipStream_t);
 int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                    hipStream_t);
@@ -124,7 +128,7 @@ int reject_mlp(const ebm_energy_t* en, const char* who) {
 
 // Which kernel family serves a chain call that asks for diagnostics records, and with what record geometry.
 // One function for the layout query and for the dispatch, so the two cannot disagree.
-enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows };
+enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows, kDiagMatrix };
 
 DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32_t dim, bool has_noise, bool has_traj,
                      diag::DiagArgs& d) {
@@ -133,6 +137,11 @@ DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32
   if (sampler == EBM_DIAG_HMC) return hmc_diag_plan(e, n_chains, dim, d) ? kDiagHmcRows : kDiagNone;
   const int heun = sampler == EBM_DIAG_LANGEVIN_HEUN;
   if (elementwise && elem_diag_supported(dim, has_noise, has_traj) && elem_diag_plan(n_chains, dim, d)) return kDiagElemFlat;
+  // dense Gaussians and mixtures where the matrix-layout kernels run (dims up to 96): records from those kernels
+  static const bool gauss_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+  static const bool gmm_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+  const bool forced_rows = (e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows);
+  if (!heun && !forced_rows && matrix_langevin_diag_plan(e, n_chains, dim, d)) return kDiagMatrix;
   return rows_langevin_diag_plan(e, heun, n_chains, dim, d) ? kDiagRows : kDiagNone;
 }
 
@@ -222,6 +231,9 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (fam == kDiagRows)
       return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
                                         cmax, thin, traj, noise, seed, offset, heun, diag_partials, (hipStream_t)stream);
+    if (fam == kDiagMatrix)
+      return launch_langevin_chain_matrix_diag(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on,
+                                               cmin, cmax, thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
     return fail(energy->kind == EBM_ENERGY_MLP ? EBM_EKIND : EBM_EDIM,
                 "%s: no in-kernel diagnostics for this energy / dim %d (see ebm_diag_layout)", who, dim);
   }

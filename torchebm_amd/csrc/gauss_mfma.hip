@@ -13,6 +13,7 @@
 // Ps = (P + P^T)/2 is symmetric, so the A-operand Ps[i = 32 it + m][k] is read as Ps[k][32 it + m]:
 // consecutive lanes, consecutive LDS banks.
 #include "ebm_common.h"
+#include "diag.h"
 #include "gauss_bf16x3.h"
 #include "gmm_bf16x3.h"
 
@@ -39,6 +40,8 @@ struct GaussArgs {
   const float* mean;  // [dim]
   const float* prec;  // [dim, dim], symmetric
   gmm3::Params gm;    // the mixture kernels (GKR > 0 below)
+  diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept steps (DIAG kernels)
+  int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
@@ -57,7 +60,10 @@ extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 // GKR > 0: the energy is an isotropic Gaussian MIXTURE (gmm_bf16x3.h; GKR = its logit-register class 4 / 8 / 16 for up
 // to 8 / 16 / 32 components) instead of the dense Gaussian: same state layout, same update, the gradient from
 // gmm3::Mixture.
-template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, int GKR = 0>
+// DIAG: the in-kernel diagnostics records (diag.h) at the kept steps -- the workgroup's 128 chains go to an LDS tile
+// in flat order, the energy of a kept state is one more evaluation (Gaussian: contraction + dot; mixture: the
+// difference-form logsumexp).
+template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, int GKR = 0, bool DIAG = false>
 __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   constexpr int DIM = 32 * NT;
   using Mix = gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>;
@@ -103,6 +109,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
   int until_keep = a.thin;
   int64_t keep_off = 0;
+  int keep = 0;
   const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim : 0;
 
   for (int step = 0; step < a.k_steps; ++step) {
@@ -243,14 +250,17 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           const float dw = eps.v[i] * sqrt_eta;
           float nv = x1 + noise_coef * dw;
           if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+          // (mixture: padding coordinates are held at 0 -- their "gradient" is x / sigma^2, and a select is free where the
+          //  Gaussian's zero rows of Ps make it unnecessary)
+          if constexpr (GKR > 0) nv = k0 < dim ? nv : 0.0f;
           x[t][4 * q + i] = nv;
         }
         if constexpr (NT >= 3) __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
       }
     }  // !FAST
-    if (a.traj && --until_keep == 0) {
+    if ((a.traj || DIAG) && --until_keep == 0) {
       until_keep = a.thin;
-      if (active) {
+      if (a.traj && active) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -260,6 +270,44 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
                   make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
       }
       keep_off += dim;
+      if constexpr (DIAG) {
+        // langevin_dynamics.py:170-185: population mean / var per coordinate, mean energy of the kept state
+        float* tile = gauss_smem + a.diag_offset_floats;
+        const int cib = (threadIdx.x >> 6) * 32 + m;  // chain inside the workgroup
+        if (active) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (32 * t + 8 * q + 4 * h < dim)
+                *reinterpret_cast<float4*>(tile + cib * dim + 32 * t + 8 * q + 4 * h) =
+                    make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+        }
+        float e_now;
+        if constexpr (GKR > 0) {
+          e_now = Mix::energy(a.gm, gauss_smem, x, lane);
+        } else {
+          f32x16 g2[NT];
+          gauss3::contract<NT>(aop, mus, x, g2, lane);
+          float acc = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 mq = *reinterpret_cast<const float4*>(mus + 32 * t + 8 * q + 4 * h);
+              acc = __builtin_fmaf(x[t][4 * q] - mq.x, g2[t][4 * q], acc);
+              acc = __builtin_fmaf(x[t][4 * q + 1] - mq.y, g2[t][4 * q + 1], acc);
+              acc = __builtin_fmaf(x[t][4 * q + 2] - mq.z, g2[t][4 * q + 2], acc);
+              acc = __builtin_fmaf(x[t][4 * q + 3] - mq.w, g2[t][4 * q + 3], acc);
+            }
+          acc += __shfl_xor(acc, 32);
+          e_now = 0.5f * acc;
+        }
+        const int64_t left = a.n_chains - (int64_t)blockIdx.x * (BLOCK / 2);
+        const int valid = (left >= BLOCK / 2 ? BLOCK / 2 : (left > 0 ? (int)left : 0)) * dim;
+        diag::emit(a.diag, keep, tile, tile + a.diag.E, valid, dim, (active && h == 0) ? e_now : 0.0f, 0.0f);
+        ++keep;
+      }
     }
   }
   if (active) {
@@ -290,6 +338,11 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(Gaus
 template <int NT, int GKR>
 __global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_kernel(GaussArgs a) {
   gauss_langevin_mfma_body<NT, true, false, kBlock, NT, GKR>(a);
+}
+// with diagnostics records (GKR = 0: the dense Gaussian)
+template <int NT, int GKR>
+__global__ __launch_bounds__(kBlock) void matrix_langevin_diag_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true, false, kBlock, NT, GKR, true>(a);
 }
 constexpr int kWideBlock = 512;
 template <int NT, int HIDE>
@@ -355,6 +408,7 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
   a.gm = gmm3::Params{nullptr, nullptr, 0, dim, 0.0f, 0.0f};
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0}; a.diag_offset_floats = 0;
   switch ((dim + 31) / 32) {
     case 1: return launch_nt<1>(a, st);
     case 2: return launch_nt<2>(a, st);
@@ -404,11 +458,75 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
   a.gm = gmm3::Params{e.dev0, e.dev1, e.n_comp, dim, e.s[0], e.s[1]};
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0}; a.diag_offset_floats = 0;
   switch ((dim + 31) / 32) {
     case 1: return launch_gmm_langevin_nt<1>(a, st);
     case 2: return launch_gmm_langevin_nt<2>(a, st);
     case 3: return launch_gmm_langevin_nt<3>(a, st);
     default: return launch_gmm_langevin_nt<4>(a, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Diagnostics records on the matrix-layout Langevin kernels (dense Gaussian, mixtures): dims up to 96 -- the tile of a
+// workgroup's 128 chains next to the split matrix does not fit LDS beyond that; the lane-group kernels take the rest.
+// ---------------------------------------------------------------------------------
+bool matrix_langevin_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim);
+  const bool mix = e.kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, e.n_comp) && !(dim == 32 && e.n_comp <= 8);
+  if (!(gauss || mix) || dim > 96) return false;
+  return diag::plan(n_chains, dim, (int64_t)(kBlock / 2) * dim, d);
+}
+
+namespace {
+template <int NT, int GKR>
+int launch_matrix_diag(GaussArgs& a, hipStream_t st) {
+  const size_t energy_floats = GKR > 0 ? (size_t)gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>::kLdsFloats
+                                       : gauss3::aop_bytes(NT) / sizeof(float) + 32 * NT;
+  a.diag_offset_floats = (int)energy_floats;
+  const size_t smem = (energy_floats + (size_t)diag::lds_floats(a.diag.E, a.diag.S)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_langevin_diag_kernel<NT, GKR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL((matrix_langevin_diag_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+template <int NT>
+int launch_matrix_diag_nt(GaussArgs& a, bool mixture, hipStream_t st) {
+  if (!mixture) return launch_matrix_diag<NT, 0>(a, st);
+  if (a.gm.n_comp <= 8) return launch_matrix_diag<NT, 4>(a, st);
+  if (a.gm.n_comp <= 16) return launch_matrix_diag<NT, 8>(a, st);
+  return launch_matrix_diag<NT, 16>(a, st);
+}
+}  // namespace
+
+int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                                      float eta, float sqrt_eta, float noise_coef, const float* coef_table,
+                                      int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
+                                      const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
+  GaussArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
+  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
+  const bool mixture = e.kind == EBM_ENERGY_GMM;
+  a.mean = mixture ? nullptr : e.dev0; a.prec = mixture ? nullptr : e.dev1;
+  a.gm = mixture ? gmm3::Params{e.dev0, e.dev1, e.n_comp, dim, e.s[0], e.s[1]} : gmm3::Params{nullptr, nullptr, 0, dim, 0.0f, 0.0f};
+  if (!matrix_langevin_diag_plan(e, n_chains, dim, a.diag))
+    return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout diagnostics records for this energy / dim %d", dim);
+  a.diag.partials = diag_partials;
+  switch ((dim + 31) / 32) {
+    case 1: return launch_matrix_diag_nt<1>(a, mixture, st);
+    case 2: return launch_matrix_diag_nt<2>(a, mixture, st);
+    default: return launch_matrix_diag_nt<3>(a, mixture, st);
   }
 }
 

@@ -106,9 +106,11 @@ struct Mixture {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          // (padding quads beyond dim hold no state: the Langevin body lets them drift with the noise)
+          const bool real = 32 * t + 8 * q + 4 * h < a.dim;
           const float4 mq = *reinterpret_cast<const float4*>(mf + k * DIM + 32 * t + 8 * q + 4 * h);
-          const float e0 = x[t][4 * q] - mq.x, e1 = x[t][4 * q + 1] - mq.y;
-          const float e2 = x[t][4 * q + 2] - mq.z, e3 = x[t][4 * q + 3] - mq.w;
+          const float e0 = real ? x[t][4 * q] - mq.x : 0.0f, e1 = real ? x[t][4 * q + 1] - mq.y : 0.0f;
+          const float e2 = real ? x[t][4 * q + 2] - mq.z : 0.0f, e3 = real ? x[t][4 * q + 3] - mq.w : 0.0f;
           d0 = __builtin_fmaf(e0, e0, d0); d1 = __builtin_fmaf(e1, e1, d1);
           d0 = __builtin_fmaf(e2, e2, d0); d1 = __builtin_fmaf(e3, e3, d1);
         }
