@@ -220,6 +220,39 @@ def test_matrix_layout_kernels_emit_records(cuda_device, kind, dim):
     torch.testing.assert_close(diag2["energy"][0].double(), model(out).double().mean(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kind,dim,mass", [("gauss", 32, None), ("gauss", 64, 1.5), ("gauss", 96, "diag"), ("gauss", 96, None),
+                                           ("gmm16", 32, None), ("gmm9", 64, "diag"), ("gmm32", 48, 0.7)])
+def test_matrix_layout_hmc_kernels_emit_records(cuda_device, kind, dim, mass):
+    """HMC with diagnostics where the matrix-layout kernels run and their layout does not depend on the mass form (dense
+    Gaussians at dims 20 .. 96, mixtures at dims 20 .. 64): records from those kernels -- 128 chains per workgroup, the
+    chains bit for bit those of the call without diagnostics, statistics / energy / acceptance rate of the kept states."""
+    g = torch.Generator().manual_seed(dim)
+    if kind == "gauss":
+        a = torch.randn(dim, dim, generator=g)
+        model = ta.GaussianModel(torch.randn(dim, generator=g), a @ a.t() / dim + 0.5 * torch.eye(dim), device=cuda_device)
+    else:
+        model = ta.GaussianMixtureModel(torch.randn(int(kind[3:]), dim, generator=g) * 1.5, sigma=1.1, device=cuda_device)
+    if mass == "diag":
+        mass = torch.rand(dim, generator=g) + 0.5
+    n, T, L, thin = 700, 6, 4, 2
+    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_HMC, n, dim) == ((n + 127) // 128, dim, 128 * dim)
+    s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass,
+                                 device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-1.5, 1.5).to(cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    traj, diag = s.sample(x=x0, n_steps=T, thin=thin, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(5))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    _check_against_trajectory(model, traj, diag, e_rtol=1e-4, accept=True)
+    plain = s.sample(x=x0, n_steps=T, thin=thin, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(5))
+    assert torch.equal(plain, traj)
+    # acceptance rate of a kept transition = the fraction of chains that moved in it (an accepted proposal differs from x)
+    _, counts = s.sample(x=x0, n_steps=1, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(5))
+    one = s.sample(x=x0, n_steps=1, generator=torch.Generator(device=cuda_device).manual_seed(5))
+    moved = (one != x0).any(dim=1).float().mean()
+    torch.testing.assert_close(counts["acceptance_rate"][0], moved, rtol=0, atol=1e-6)
+
+
 def test_c_abi_layout_and_injected_noise_records(cuda_device):
     """The layout query mirrors the dispatch; records with injected noise run on the lane-group kernel."""
     spec = ta.DoubleWellModel(device=cuda_device).fused_spec()

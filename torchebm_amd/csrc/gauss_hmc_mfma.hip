@@ -1,457 +1,12 @@
-// HMC transitions for the dense Gaussian energy on the matrix cores (dim 32 or 64, no mass or a scalar
-// mass): same mapping as gauss_mfma.hip -- a wavefront owns 32 chains, lane l = (m, h), the chain
-// state x, momentum p and force f all live in the C/D layout of v_mfma_f32_32x32x2_f32 tiles, so that
-// g^T = Ps (x - mu)^T takes its B-operand straight from the state registers and lands in the layout the
-// leapfrog arithmetic runs in.  The LDS mat-vec of the lane-group kernel (rows.h) is bound by LDS reads
-// (one 16-byte read per four FMAs); here the precision matrix is read once per K-step for 32 chains.
-//
-// Reference: samplers/hmc.py:201-315 (transition), integrators/leapfrog.py:116-187 (safe leapfrog),
-// core/base_model.py:181-210 (energy).  Semantics, RNG coordinates (momentum at step 2t, uniforms at
-// 2t+1, one Philox counter per four coordinates) and the fast/literal split of the safe mode are those
-// of hmc_kernel.h; the accepted state is "parked" in the x array itself (written on accept, re-read on
-// reject), which costs 256 B per chain and transition and no registers.
-#include "ebm_common.h"
-#include "gauss_bf16x3.h"
-#include "gmm_bf16x3.h"
+// HMC transitions for the dense Gaussian energy on the matrix cores: launchers (the body: mfma_hmc_body.h).
+#include "mfma_hmc_body.h"
 
 namespace ebm {
 namespace {
 
-constexpr int kBlock = 256;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GaussHmcArgs {
-  float* x;
-  int64_t n_chains;
-  int32_t dim;
-  int32_t n_mh, n_leapfrog;
-  float eps;
-  const float* eps_table;
-  int32_t has_mass;
-  float mass_raw, mass_sqrt, mass_safe;
-  int32_t thin, n_kept;
-  float* traj;
-  uint8_t* accept_mask;
-  uint32_t* accept_count;
-  const float* p_noise;
-  const float* u;
-  RngKey key;
-  uint64_t step0;
-  const float* mean;  // [dim]
-  const float* prec;  // [dim, dim], symmetric
-  const float* mass_diag;  // [dim] diagonal mass (null: none / scalar)
-  // Gaussian mixture (GmmE below): means [n_comp, dim], log-weights [n_comp], 1 / (2 sigma^2), 1 / sigma^2
-  const float* gm_means;
-  const float* gm_logw;
-  int32_t n_comp;
-  float inv2s2, invs2;
-};
-
-extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
-
-template <int NT>
-struct Tile {
-  f32x16 t[NT];
-};
-
-// g^T = Ps (x - mu)^T and E = 0.5 (x - mu)^T Ps (x - mu) per chain (both halves of the wave hold E).
-// B3: the contraction on the bf16 matrix pipe with three-way split operands (gauss_bf16x3.h; `Ps` then points at the
-// operand-ready splits) -- 6/16 of the exact-f32 MFMA's matrix time; B3 = false: v_mfma_f32_32x32x2_f32 on fp32 Ps.
-template <int NT, bool B3>
-__device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-  constexpr int DIM = 32 * NT;
-  auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
-  float acc = 0.0f;
-  if constexpr (B3) {
-    gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
-  } else {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g.t[t][r] = 0.0f;
-  float pa[NT], pb[NT], ma, mb;
-#pragma unroll
-  for (int it = 0; it < NT; ++it) pa[it] = Ps[k_of(0) * DIM + 32 * it + m];
-  ma = mus[k_of(0)];
-#pragma unroll
-  for (int s = 0; s < 16 * NT; ++s) {  // operands of K-step s+1 are requested before the MFMAs of K-step s issue
-    if (s + 1 < 16 * NT) {
-      const int kn = k_of(s + 1);
-#pragma unroll
-      for (int it = 0; it < NT; ++it) pb[it] = Ps[kn * DIM + 32 * it + m];
-      mb = mus[kn];
-    }
-    const float dv = x.t[s >> 4][s & 15] - ma;
-#pragma unroll
-    for (int it = 0; it < NT; ++it) g.t[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it], dv, g.t[it], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < NT; ++it) pa[it] = pb[it];
-    ma = mb;
-  }
-  }  // exact-f32 MFMA
-  // E = 0.5 d.g with d = x - mu recomputed (a cheap LDS read of mu, two distinct addresses per wave) rather
-  // than kept: 16*NT fewer live registers across the MFMA loop
-#pragma unroll
-  for (int s = 0; s < 16 * NT; ++s) acc = __builtin_fmaf(x.t[s >> 4][s & 15] - mus[k_of(s)], g.t[s >> 4][s & 15], acc);
-  acc += __shfl_xor(acc, 32);
-  return 0.5f * acc;
-}
-
-// ---------------------------------------------------------------------------------
-// Energies of the matrix-layout transition body: what sits in LDS and how E / dE/dx come out of the state tiles.
-// ---------------------------------------------------------------------------------
-// Dense Gaussian.  LDS: Ps (fp32 [DIM][DIM], or its three operand-ready bf16 splits), mu [DIM].
-template <int NT, bool B3>
-struct GaussE {
-  static constexpr int DIM = 32 * NT;
-  static constexpr int kMatFloats = B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM;
-  static constexpr int kLdsFloats = kMatFloats + DIM;
-  static constexpr bool kEvalGivesEnergy = true;
-  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
-    const int dim = a.dim;
-    if constexpr (B3) {
-      gauss3::stage_split_precision<NT>(a.prec, dim, reinterpret_cast<__bf16*>(lds), kBlock);
-    } else {
-      for (int i = threadIdx.x; i < DIM * DIM; i += kBlock) {
-        const int r = i / DIM, c = i - r * DIM;
-        lds[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
-      }
-    }
-    for (int i = threadIdx.x; i < DIM; i += kBlock) lds[kMatFloats + i] = i < dim ? a.mean[i] : 0.0f;
-  }
-  __device__ static __forceinline__ float eval(const GaussHmcArgs&, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-    return gauss_eval<NT, B3>(lds, lds + kMatFloats, x, g, m, h);
-  }
-  __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
-};
-
-// Isotropic Gaussian mixture, up to 32 components: gmm_bf16x3.h (both K x dim passes of the gradient on the bf16 matrix
-// pipe; the energy -- needed twice per transition -- in the reference's difference form on the VALU).
-template <int NT, int KR>
-struct GmmE {
-  using M = gmm3::Mixture<NT, KR>;
-  static constexpr int kLdsFloats = M::kLdsFloats;
-  static constexpr bool kEvalGivesEnergy = false;
-  __device__ static __forceinline__ gmm3::Params params(const GaussHmcArgs& a) {
-    return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2};
-  }
-  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) { M::stage(params(a), lds, kBlock); }
-  // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not)
-  __device__ static __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-    return M::grad(params(a), lds, x.t, g.t, m + 32 * h);
-  }
-  __device__ static __forceinline__ float energy(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, int m, int h) {
-    return M::energy(params(a), lds, x.t, m + 32 * h);
-  }
-};
-
-// DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
-// E: the energy (GaussE / GmmE above).
-template <int NT, bool DIAGM, class E>
-__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
-  constexpr int DIM = 32 * NT;
-  float* elds = gauss_hmc_smem;  // the energy's own area
-  // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
-  // rows / columns of the parameters are zero, their momentum draw is discarded) and are never loaded or stored
-  const int dim = a.dim;
-  E::stage(a, elds);
-  // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
-  // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
-  // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
-  float* mraw = elds + E::kLdsFloats;                        // [DIM]
-  float* dsw_base = mraw + DIM;
-  float* dsw = dsw_base + (threadIdx.x >> 6) * DIM;          // [DIM], this wave's
-  constexpr bool diag_mass = DIAGM;
-  if constexpr (diag_mass)
-    for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = i < dim ? a.mass_diag[i] : 1.0f;
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
-  const bool active = chain < a.n_chains;
-  const int64_t row = active ? chain * (int64_t)dim : 0;
-  auto quad_of = [&](const float* arr, int t, int q) { return *reinterpret_cast<const float4*>(arr + 32 * t + 8 * q + 4 * h); };
-
-  // quad q of tile t = coordinates 32t + 8q + 4h .. +3  (one float4, one Philox counter)
-  auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && 32 * t + 8 * q + 4 * h < dim) v = *reinterpret_cast<const float4*>(base + off + 32 * t + 8 * q + 4 * h);
-        dst.t[t][4 * q] = v.x; dst.t[t][4 * q + 1] = v.y; dst.t[t][4 * q + 2] = v.z; dst.t[t][4 * q + 3] = v.w;
-      }
-  };
-  auto store_rows = [&](float* base, int64_t off, const Tile<NT>& src) {
-    if (!active) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (32 * t + 8 * q + 4 * h < dim)
-          *reinterpret_cast<float4*>(base + off + 32 * t + 8 * q + 4 * h) =
-              make_float4(src.t[t][4 * q], src.t[t][4 * q + 1], src.t[t][4 * q + 2], src.t[t][4 * q + 3]);
-  };
-  // K(p) = 0.5 p^T p [/ m], clamped to [0, 1e10]  (samplers/hmc.py:136-159, :251-254)
-  auto kinetic = [&](const Tile<NT>& q) -> float {
-    float acc = 0.0f;
-    if constexpr (diag_mass) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const float4 mq = quad_of(mraw, t, qd);
-          acc += q.t[t][4 * qd] * q.t[t][4 * qd] / mq.x;
-          acc += q.t[t][4 * qd + 1] * q.t[t][4 * qd + 1] / mq.y;
-          acc += q.t[t][4 * qd + 2] * q.t[t][4 * qd + 2] / mq.z;
-          acc += q.t[t][4 * qd + 3] * q.t[t][4 * qd + 3] / mq.w;
-        }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc += q.t[t][r] * q.t[t][r];
-    }
-    acc += __shfl_xor(acc, 32);
-    float k = 0.5f * acc;
-    if (a.has_mass) k = k / a.mass_raw;
-    return clamp_nanprop(k, 0.0f, 1e10f);
-  };
-
-  Tile<NT> x;
-  load_rows(a.x, row, x);
-  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim : 0;
-  int until_keep = a.thin;
-  int64_t keep_off = 0;
-  float eps = a.eps;
-
-  // Energy and clamped force of the state the chain holds are CARRIED from transition to transition (as in
-  // hmc_kernel.h): an accepted proposal brings its own E1 and end-of-trajectory force -- what the reference recomputes at
-  // the top of the next transition on the same x, bit for bit -- a rejected one keeps the saved pair.  L evaluations per
-  // transition instead of L + 1 (and, for the mixture, one exact energy instead of two).  The force is parked in LDS,
-  // one slot per lane and register: [16 NT][kBlock].
-  float* fpark = dsw_base + (kBlock / 64) * DIM + threadIdx.x;
-  Tile<NT> f;
-  float e_cur = E::eval(a, elds, x, f, m, h);
-  if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
-
-  for (int tr = 0; tr < a.n_mh; ++tr) {
-    if (a.eps_table) eps = a.eps_table[tr];
-    const float half_eps = 0.5f * eps;
-    const float drift_scale = a.has_mass ? eps / a.mass_safe : eps;  // x += eps * p / max(m, 1e-10), one FMA per step
-
-    // ---- momentum draw p ~ N(0, M)
-    Tile<NT> p;
-    if (a.p_noise) {
-      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * dim + row, p);
-    } else {
-      // (the per-quad Philox counters are formed here at every transition: hoisted out of the transition loop they
-      //  are 2 registers per quad held across the whole trajectory)
-      uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
-      asm volatile("" : "+v"(e_row));
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k0 = 32 * t + 8 * q + 4 * h;
-          const F4 n = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + 2ull * (uint64_t)tr);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = k0 < dim ? n.v[i] : 0.0f;  // (straight-line: see gauss_mfma.hip)
-        }
-    }
-    if (a.has_mass) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p.t[t][r] *= a.mass_sqrt;
-    }
-    if constexpr (diag_mass) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const float4 mq = quad_of(mraw, t, qd);
-          p.t[t][4 * qd] *= sqrtf(mq.x); p.t[t][4 * qd + 1] *= sqrtf(mq.y);
-          p.t[t][4 * qd + 2] *= sqrtf(mq.z); p.t[t][4 * qd + 3] *= sqrtf(mq.w);
-          if (m == 0) {  // this transition's drift factors, once per K-half
-            const float4 ds = make_float4(eps / (mq.x < 1e-10f ? 1e-10f : mq.x), eps / (mq.y < 1e-10f ? 1e-10f : mq.y),
-                                          eps / (mq.z < 1e-10f ? 1e-10f : mq.z), eps / (mq.w < 1e-10f ? 1e-10f : mq.w));
-            *reinterpret_cast<float4*>(dsw + 32 * t + 8 * qd + 4 * h) = ds;
-          }
-        }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // ---- H0 and the first (clamped) force: the carried pair
-    const float e0 = e_cur;
-    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) f.t[t][r] = fpark[(16 * t + r) * kBlock];
-
-    // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
-    float e1 = e0;
-    for (int l = 0; l < a.n_leapfrog; ++l) {
-      if constexpr (diag_mass) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const float4 ds4 = quad_of(dsw, t, qd);
-            const float ds[4] = {ds4.x, ds4.y, ds4.z, ds4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float ph = __builtin_fmaf(half_eps, f.t[t][4 * qd + i], p.t[t][4 * qd + i]);
-              p.t[t][4 * qd + i] = ph;
-              x.t[t][4 * qd + i] = __builtin_fmaf(ds[i], ph, x.t[t][4 * qd + i]);
-            }
-          }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float ph = __builtin_fmaf(half_eps, f.t[t][r], p.t[t][r]);
-            p.t[t][r] = ph;
-            x.t[t][r] = __builtin_fmaf(drift_scale, ph, x.t[t][r]);
-          }
-      }
-      // ONE call site for the evaluation inside the step (the literal path below re-enters it with `scrubbed` set:
-      // a second inlined copy of the 64 NT^2 MFMAs costs registers in the hot loop)
-      bool scrubbed = false;
-      for (;;) {
-        e1 = E::eval(a, elds, x, f, m, h);  // f holds +g here (e1: the energy, or a finiteness witness)
-        if (scrubbed) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
-          break;
-        }
-        // E finite => x finite, g clean.  The decision is taken per WAVE: the literal path re-runs the
-        // MFMA evaluation, and an MFMA writes its result for every lane whatever EXEC says -- it must not
-        // run while other chains of the wave sit in the fast path.  (For a chain that is fine the literal
-        // path computes exactly what the fast path does.)
-        if (__all(__builtin_fabsf(e1) < __builtin_inff())) {
-          float pz = 0.0f;
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float fn = __builtin_amdgcn_fmed3f(-f.t[t][r], -1e6f, 1e6f);
-              const float pn = __builtin_fmaf(half_eps, fn, p.t[t][r]);
-              f.t[t][r] = fn;
-              p.t[t][r] = pn;
-              pz = __builtin_fmaf(pn, 0.0f, pz);
-            }
-          pz += __shfl_xor(pz, 32);
-          if (pz != pz) {  // momentum overflow: x is finite, so f stands
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) p.t[t][r] = nan_to_num0(p.t[t][r]);
-          }
-          break;
-        }
-        // rare: literal semantics (NaN-propagating clamp, scrub, re-evaluate on the scrubbed x)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float fn = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
-            p.t[t][r] = nan_to_num0(__builtin_fmaf(half_eps, fn, p.t[t][r]));
-            x.t[t][r] = nan_to_num0(x.t[t][r]);
-          }
-        scrubbed = true;
-      }
-    }
-    if constexpr (!E::kEvalGivesEnergy) e1 = E::energy(a, elds, x, m, h);
-    const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
-
-    // ---- Metropolis accept (samplers/hmc.py:277-292)
-    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
-    float acc_p = expf(dlt);
-    acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
-    float uu;
-    if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + chain] : 2.0f;
-    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)chain >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(chain & 3)));
-    const bool accept = active && (uu < acc_p);
-    if (accept) {
-      store_rows(a.x, row, x);             // the x array always holds the accepted state ...
-      e_cur = e1;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = f.t[t][r];
-    } else {
-      load_rows(a.x, row, x);              // ... which a rejected proposal falls back to (its energy / force stay parked)
-    }
-
-    const bool leader = active && h == 0;
-    if (a.accept_mask && leader) a.accept_mask[(int64_t)tr * a.n_chains + chain] = accept ? 1 : 0;
-    if (a.accept_count) {
-      const unsigned long long b = __ballot(accept && leader);
-      if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
-    }
-    if (a.traj && --until_keep == 0) {
-      until_keep = a.thin;
-      store_rows(a.traj, traj_row + keep_off, x);
-      keep_off += dim;
-    }
-  }
-}
-
-// dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
-// need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
-// template-dependent __launch_bounds__ argument.)
-template <int NT, bool DIAGM, class E>
-__global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
-}
-template <int NT, bool DIAGM, class E>
-__global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
-}
-template <int NT, bool DIAGM, class E>
-__global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E>(a);
-}
-
-// WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
-template <int NT, bool DIAGM, class E, int WAVES>
-int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
-  // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register)
-  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + 16 * NT * kBlock) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
-  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
-  if constexpr (WAVES == 3)
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w3<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else if constexpr (WAVES == 2)
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  return check_launch("ebm_hmc_chain_f32");
-}
-
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64) on the exact-f32 contraction,
 // dims 96 / 128 need more than that for the state alone; the bf16x3 form of two tiles needs the transient split
-// registers and runs better unconstrained (0.53 vs 0.97 ms, dim 64).  (Two entry points because hipcc 7.2 silently
+// registers and runs better unconstrained (0.53 vs 0.97 ms, dim 64).  (Several entry points because hipcc 7.2 silently
 // ignores a template-dependent __launch_bounds__ argument.)
 template <int NT, bool DIAGM, bool B3>
 int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
@@ -473,8 +28,9 @@ int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
-  // measured against the lane-group kernel (scripts/bench_gauss_hmc_dims.py, ms per 10 transitions, L = 10, 2^16 chains):
-  // dim 32: 0.26 vs 0.41, dim 64: 0.72 vs 1.32, dim 96: 1.48 vs 3.50, dim 100: 2.72 vs 3.89, dim 128: 2.74 vs 11.5
+  // measured against the lane-group kernel (profiles/r02_bench_gauss_hmc_{mfma,rows}.jsonl, ms per 10 transitions, L = 10,
+  // 2^16 chains): dim 32: 0.20 vs 0.41, dim 64: 0.45 vs 1.32, dim 96: 1.19 vs 3.50, dim 100: 2.27 vs 3.89, dim 128: 2.26 vs 11.5
+  (void)mass_kind;
   return dim >= 20 && dim <= 128 && (dim % 4) == 0;
 }
 
@@ -483,19 +39,8 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
                                 double mass_scalar, const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
                                 uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
                                 uint64_t offset, hipStream_t st) {
-  GaussHmcArgs a;
-  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
-  a.eps = eps; a.eps_table = eps_table;
-  a.has_mass = mass_kind == EBM_MASS_SCALAR;
-  a.mass_raw = (float)mass_scalar;
-  a.mass_sqrt = (float)sqrt(mass_scalar);
-  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
-  a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
-  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
-  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
-  a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
-  a.gm_means = nullptr; a.gm_logw = nullptr; a.n_comp = 0; a.inv2s2 = 0.0f; a.invs2 = 0.0f;
+  const GaussHmcArgs a = matrix_hmc_args(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
+                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset);
   if (a.mass_diag) {
     switch ((dim + 31) / 32) {
       case 1: return launch_nt<1, true>(a, st);
@@ -510,59 +55,6 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
     case 3: return launch_nt<3, false>(a, st);
     default: return launch_nt<4, false>(a, st);
   }
-}
-
-// ---------------------------------------------------------------------------------
-// Gaussian mixture on the matrix-layout body (GmmE)
-// ---------------------------------------------------------------------------------
-bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
-  // three tiles at most: with x, p and the force resident the four-tile body has no registers for the split's
-  // transients (as for the Gaussian); a diagonal mass: two tiles
-  const int max_dim = mass_kind == EBM_MASS_DIAG ? 64 : 96;
-  return dim >= 20 && dim <= max_dim && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32;
-}
-
-namespace {
-template <int NT, bool DIAGM>
-int launch_gmm_nt(const GaussHmcArgs& a, hipStream_t st) {
-  // one tile: three waves per SIMD (168 VGPRs, ~100 B of scratch) -- the evaluation is one dependent chain (contraction,
-  // softmax, contraction), and a third wave hides more of it than the spills cost: 1.53 -> 1.42 ms at K = 9, dim 32
-  constexpr int W = NT == 1 ? 3 : 0;
-  if (a.n_comp <= 8) return launch_policy<NT, DIAGM, GmmE<NT, 4>, W>(a, st);
-  if (a.n_comp <= 16) return launch_policy<NT, DIAGM, GmmE<NT, 8>, W>(a, st);
-  return launch_policy<NT, DIAGM, GmmE<NT, 16>, W>(a, st);
-}
-template <bool DIAGM>
-int launch_gmm_dim(const GaussHmcArgs& a, hipStream_t st) {
-  switch ((a.dim + 31) / 32) {
-    case 1: return launch_gmm_nt<1, DIAGM>(a, st);
-    case 2: return launch_gmm_nt<2, DIAGM>(a, st);
-    default:
-      if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 64");
-      else return launch_gmm_nt<3, false>(a, st);
-  }
-}
-}  // namespace
-
-int launch_hmc_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
-                              int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind,
-                              double mass_scalar, const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
-                              uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed,
-                              uint64_t offset, hipStream_t st) {
-  GaussHmcArgs a;
-  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
-  a.eps = eps; a.eps_table = eps_table;
-  a.has_mass = mass_kind == EBM_MASS_SCALAR;
-  a.mass_raw = (float)mass_scalar;
-  a.mass_sqrt = (float)sqrt(mass_scalar);
-  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
-  a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
-  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
-  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
-  a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
-  a.gm_means = e.dev0; a.gm_logw = e.dev1; a.n_comp = e.n_comp; a.inv2s2 = e.s[0]; a.invs2 = e.s[1];
-  return a.mass_diag ? launch_gmm_dim<true>(a, st) : launch_gmm_dim<false>(a, st);
 }
 
 }  // namespace ebm

@@ -25,6 +25,10 @@ using hmc::HmcArgs;
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
 bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);
+bool matrix_hmc_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
+int launch_hmc_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
+                                 int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
+                                 uint64_t, uint64_t, float*, hipStream_t);
 int launch_hmc_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
                               int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
                               uint64_t, uint64_t, hipStream_t);
@@ -55,7 +59,17 @@ static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
   return true;
 }
 
+// Records from the matrix-layout kernels where they run and their layout does not depend on the mass form (the layout
+// query is not told it): dense Gaussians at dims 20 .. 96, mixtures at dims 20 .. 64.
+static bool hmc_matrix_records(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  static const bool gauss_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+  static const bool gmm_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+  if ((e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows)) return false;
+  return matrix_hmc_diag_plan(e, n_chains, dim, d);
+}
+
 bool hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  if (hmc_matrix_records(e, n_chains, dim, d)) return true;
   Geometry geo;
   if (!hmc_geometry(e, dim, geo)) return false;
   return diag::plan(n_chains, dim, (int64_t)(kBlock / geo.G) * dim, d);
@@ -66,7 +80,13 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
                      double mass_scalar, const float* mass_diag, int32_t thin, float* traj,
                      uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
                      const float* u, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
-  // (with diagnostics records the lane-group kernel runs: the MFMA kernel keeps the state in the matrix layout)
+  if (diag_partials) {
+    diag::DiagArgs dm;
+    if (hmc_matrix_records(e, n_chains, dim, dm))
+      return launch_hmc_chain_matrix_diag(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
+                                          thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st);
+  }
+  // (records beyond those shapes: the lane-group kernels)
   if (!diag_partials && e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
