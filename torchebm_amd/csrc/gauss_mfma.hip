@@ -125,7 +125,8 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
       asm volatile("" : "+v"(e_row));
       f32x16 eps[NT];
-      constexpr int QUADS = 4 * HIDE, PER_QUAD = 13, STAGES = QUADS * PER_QUAD, N_MFMA = 6 * NT * (2 * NT);
+      constexpr int QUADS = 4 * HIDE, PER_QUAD = 13, STAGES = QUADS * PER_QUAD;
+      constexpr int N_MFMA = GKR > 0 ? Mix::kMfmas : 6 * NT * (2 * NT);
       constexpr int PER_MFMA = (STAGES + N_MFMA - 1) / N_MFMA;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, k0 = 0, k1 = 0;
       auto stage = [&](auto sc) {
@@ -155,10 +156,12 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           }
         }
       };
-      gauss3::contract<NT>(aop, mus, x, g, lane, [&](auto ord) {
+      auto behind_mfma = [&](auto ord) {
         gauss3::static_for<PER_MFMA>([&](auto u) { stage(std::integral_constant<int, decltype(ord)::value * PER_MFMA + decltype(u)::value>{}); });
         __builtin_amdgcn_sched_barrier(0);
-      });
+      };
+      if constexpr (GKR > 0) Mix::grad(a.gm, gauss_smem, x, g, lane, behind_mfma);
+      else gauss3::contract<NT>(aop, mus, x, g, lane, behind_mfma);
       // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
       static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
       if constexpr (HIDE < NT) {  // the remaining tiles: drawn now, one quad at a time
@@ -185,7 +188,9 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
         for (int r = 0; r < 16; ++r) {
           const float x1 = x[t][r] - eta * g[t][r];
           const float dw = eps[t][r] * sqrt_eta;
-          x[t][r] = x1 + noise_coef * dw;
+          float nv = x1 + noise_coef * dw;
+          if constexpr (GKR > 0) nv = 32 * t + 8 * (r >> 2) + 4 * h < dim ? nv : 0.0f;  // mixture: padding held at 0
+          x[t][r] = nv;
         }
     } else {
     if constexpr (GKR > 0) {
@@ -339,6 +344,10 @@ template <int NT, int GKR>
 __global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_kernel(GaussArgs a) {
   gauss_langevin_mfma_body<NT, true, false, kBlock, NT, GKR>(a);
 }
+template <int NT, int GKR>
+__global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_fast_kernel(GaussArgs a) {
+  gauss_langevin_mfma_body<NT, true, true, kBlock, NT, GKR>(a);
+}
 // with diagnostics records (GKR = 0: the dense Gaussian)
 template <int NT, int GKR>
 __global__ __launch_bounds__(kBlock) void matrix_langevin_diag_kernel(GaussArgs a) {
@@ -430,11 +439,19 @@ int launch_gmm_langevin(const GaussArgs& a, hipStream_t st) {
   if (!attr_set && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_langevin_bf16x3_kernel<NT, GKR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_langevin_bf16x3_fast_kernel<NT, GKR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL((gmm_langevin_bf16x3_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  // no clamp, no injected noise: the step's normals are drawn in stages behind the MFMAs (as for the Gaussian)
+  static const bool no_fast = [] { const char* v = getenv("EBM_GMM_NOFAST"); return v && v[0] == '1'; }();
+  // (three tiles: the staged form drops to one wave per SIMD -- 1.54 ms against 1.39 at dim 96 -- and stays off)
+  if (NT != 3 && !a.noise && !a.clamp_on && !no_fast)
+    hipLaunchKernelGGL((gmm_langevin_bf16x3_fast_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else
+    hipLaunchKernelGGL((gmm_langevin_bf16x3_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 template <int NT>

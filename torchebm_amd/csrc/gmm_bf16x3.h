@@ -55,11 +55,16 @@ struct Mixture {
       mf[i] = (k < K && d < dim) ? mu[k * dim + d] : 0.0f;
     }
   }
-  // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not)
-  __device__ static __forceinline__ float grad(const Params& a, const float* lds, const f32x16 (&x)[NT], f32x16 (&g)[NT], int lane) {
+  // MFMAs of one gradient: 12 NT for the logits, 6 NT KBC for the weighted mean
+  static constexpr int kMfmas = 12 * NT + 6 * NT * KBC;
+  // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not).
+  // `fill(ordinal)` is called behind every MFMA (ordinals 0 .. kMfmas - 1): the caller's independent VALU work.
+  template <class Fill = gauss3::NoFill>
+  __device__ static __forceinline__ float grad(const Params& a, const float* lds, const f32x16 (&x)[NT], f32x16 (&g)[NT], int lane,
+                                               Fill&& fill = gauss3::NoFill{}) {
     const int h = lane >> 5;
     f32x16 dot[1];
-    gauss3::contract_general<1, 2 * NT, false>(reinterpret_cast<const __bf16*>(lds), nullptr, x, dot, lane);
+    gauss3::contract_general<1, 2 * NT, false>(reinterpret_cast<const __bf16*>(lds), nullptr, x, dot, lane, fill);
     const float* cvec = lds + kA1Floats + kA2Floats;
     float top = -__builtin_inff();
     f32x16 w[1];
@@ -86,7 +91,8 @@ struct Mixture {
     }
     sum += __shfl_xor(sum, 32);
     f32x16 acc[NT];
-    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, acc, lane);
+    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, acc, lane,
+                                             [&](auto ord) { fill(std::integral_constant<int, 12 * NT + decltype(ord)::value>{}); });
     const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
