@@ -13,7 +13,7 @@ def timeit(fn, reps=7, warm=2):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
 n = 1 << 18
-for dim in (32, 64):
+for dim in (32, 64, 128):
     x = torch.randn(n, dim, device=dev)
     for K in (4, 8, 16, 32):
         g = torch.Generator().manual_seed(K)
