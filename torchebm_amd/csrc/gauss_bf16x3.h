@@ -86,11 +86,13 @@ struct NoFill {
   template <class Ord>
   __device__ __forceinline__ void operator()(Ord) const {}
 };
-template <int MT, int KB, bool SUB, class Fill = NoFill>
+// MTL / IT0: the staged matrix has MTL row tiles and this call produces tiles IT0 .. IT0 + MT - 1 of them (MT < MTL:
+// the output in pieces, for bodies that have no registers for all accumulators and operands at once).
+template <int MT, int KB, bool SUB, class Fill = NoFill, int MTL = MT, int IT0 = 0>
 __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop, const float* __restrict__ mus,
                                                  const f32x16 (&x)[(KB + 1) / 2], f32x16 (&g)[MT], int lane,
                                                  Fill&& fill = NoFill{}) {
-  constexpr int NT = MT, PER_SPLIT = MT * KB * 64 * 8;
+  constexpr int NT = MT, PER_SPLIT = MTL * KB * 64 * 8;
   const int h = lane >> 5;
   // one tile: two accumulator sets, so that consecutive MFMAs never wait on each other's result; with more tiles the
   // term-major order below already puts NT independent instructions between dependent ones
@@ -127,7 +129,7 @@ __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop,
       constexpr int n_terms = grp + 1, first = grp * (grp + 1) / 2;
       bf16x8 pa[NT];
 #pragma unroll
-      for (int it = 0; it < NT; ++it) pa[it] = ap[(2 - grp) * (PER_SPLIT / 8) + (it * KB + kb) * 64];
+      for (int it = 0; it < NT; ++it) pa[it] = ap[(2 - grp) * (PER_SPLIT / 8) + ((IT0 + it) * KB + kb) * 64];
       static_for<n_terms * NT>([&](auto oc) {
         constexpr int o = decltype(oc)::value, tg = o / NT, it = o % NT;
         constexpr int term = first + tg;                  // 0: Pl dh | 1: Pm dm, 2: Pm dh | 3: Ph dl, 4: Ph dm, 5: Ph dh

@@ -17,12 +17,7 @@ template <int NT, bool DIAGM>
 int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
   // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
   static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
-  // measured (scripts/bench_gauss_hmc_dims.py, ms per 10 transitions, bf16x3 vs exact f32): dim 32: 0.22 vs 0.26, dim 64:
-  // 0.53 vs 0.66, dim 96: 1.29 vs 1.43, dim 128: 4.4 vs 2.6 -- with x, p and the force resident the four-tile body has
-  // no room for the split's transients (1.9 KB of scratch), and neither has the three-tile body with a diagonal mass
-  constexpr bool b3_fits = DIAGM ? NT <= 2 : NT <= 3;
-  if constexpr (b3_fits) return f32_mfma ? launch_nt_b<NT, DIAGM, false>(a, st) : launch_nt_b<NT, DIAGM, true>(a, st);
-  else return launch_nt_b<NT, DIAGM, false>(a, st);
+  return f32_mfma ? launch_nt_b<NT, DIAGM, false>(a, st) : launch_nt_b<NT, DIAGM, true>(a, st);
 }
 
 }  // namespace

@@ -16,11 +16,9 @@ bool matrix_hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, 
 }
 
 namespace {
-// the Gaussian with a diagonal mass at three tiles keeps the exact-f32 contraction (as without records)
 template <int NT, bool DIAGM>
 int launch_gauss_diag(const GaussHmcArgs& a, hipStream_t st) {
-  constexpr bool B3 = DIAGM ? NT <= 2 : NT <= 3;
-  return launch_policy<NT, DIAGM, GaussE<NT, B3>, 0, true>(a, st);
+  return launch_policy<NT, DIAGM, GaussE<NT, true>, 0, true>(a, st);
 }
 template <int NT, bool DIAGM>
 int launch_gmm_diag(const GaussHmcArgs& a, hipStream_t st) {

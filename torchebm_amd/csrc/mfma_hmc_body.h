@@ -66,7 +66,26 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   constexpr int DIM = 32 * NT;
   auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
   float acc = 0.0f;
-  if constexpr (B3) {
+  if constexpr (B3 && NT >= 3) {
+    // three / four tiles: the output in two pieces of at most two tiles -- all accumulators, the A operands of every tile
+    // and the split's transients do not fit beside x, p and the force at once (1 - 2 KB of scratch); the split of x is
+    // formed twice instead, the second time from an OPAQUE copy of x: left visible, the compiler merges the two
+    // identical splits and keeps the 12 split registers of every K-block live across both pieces.
+    constexpr int KB = 2 * NT;
+    f32x16 lo[2];
+    gauss3::contract_general<2, KB, true, gauss3::NoFill, NT, 0>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, lo, m + 32 * h);
+    g.t[0] = lo[0]; g.t[1] = lo[1];
+    f32x16 xb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      xb[t] = x.t[t];
+      asm volatile("" : "+v"(xb[t]));
+    }
+    f32x16 hi[NT - 2];
+    gauss3::contract_general<NT - 2, KB, true, gauss3::NoFill, NT, 2>(reinterpret_cast<const __bf16*>(Ps), mus, xb, hi, m + 32 * h);
+#pragma unroll
+    for (int t = 2; t < NT; ++t) g.t[t] = hi[t - 2];
+  } else if constexpr (B3) {
     gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else {
 #pragma unroll
@@ -112,6 +131,7 @@ struct GaussE {
   static constexpr int kMatFloats = B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM;
   static constexpr int kLdsFloats = kMatFloats + DIM;
   static constexpr bool kEvalGivesEnergy = true;
+  static constexpr bool kCarry = !(B3 && NT == 4);
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
     const int dim = a.dim;
     if constexpr (B3) {
@@ -137,6 +157,7 @@ struct GmmE {
   using M = gmm3::Mixture<NT, KR>;
   static constexpr int kLdsFloats = M::kLdsFloats;
   static constexpr bool kEvalGivesEnergy = false;
+  static constexpr bool kCarry = true;
   __device__ static __forceinline__ gmm3::Params params(const GaussHmcArgs& a) {
     return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2};
   }
@@ -154,8 +175,11 @@ struct GmmE {
 // E: the energy (GaussE / GmmE above).
 // DIAG: emit the in-kernel diagnostics records (diag.h) at the kept transitions: the workgroup's 128 chains go to an LDS
 // tile in flat order; the energy is the carried one, the accept share the decision just taken.
+// CARRY off (E::kCarry: the four-tile Gaussian on the split contraction, whose 96 KB of operands leave no LDS for the parked
+// force): energy and force are evaluated at the top of every transition, as the reference does.
 template <int NT, bool DIAGM, class E, bool DIAG = false>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
+  constexpr bool CARRY = E::kCarry;
   constexpr int DIM = 32 * NT;
   float* elds = gauss_hmc_smem;  // the energy's own area
   // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
@@ -243,12 +267,15 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   float* fpark = fpark_base + threadIdx.x;
   int keep = 0;
   Tile<NT> f;
-  float e_cur = E::eval(a, elds, x, f, m, h);
-  if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
+  float e_cur = 0.0f;
+  if constexpr (CARRY) {
+    e_cur = E::eval(a, elds, x, f, m, h);
+    if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+      for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+  }
 
   for (int tr = 0; tr < a.n_mh; ++tr) {
     if (a.eps_table) eps = a.eps_table[tr];
@@ -300,12 +327,19 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     }
 
     // ---- H0 and the first (clamped) force: the carried pair
+    if constexpr (!CARRY) {
+      e_cur = E::eval(a, elds, x, f, m, h);
+      if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
+    }
     const float e0 = e_cur;
     const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) f.t[t][r] = fpark[(16 * t + r) * kBlock];
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (CARRY) f.t[t][r] = fpark[(16 * t + r) * kBlock];
+        else f.t[t][r] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
+      }
 
     // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
     float e1 = e0;
@@ -396,11 +430,13 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     const bool accept = active && (uu < acc_p);
     if (accept) {
       store_rows(a.x, row, x);             // the x array always holds the accepted state ...
-      e_cur = e1;
+      e_cur = e1;  // (kept for the records even when nothing is carried)
+      if constexpr (CARRY) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = f.t[t][r];
+          for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = f.t[t][r];
+      }
     } else {
       load_rows(a.x, row, x);              // ... which a rejected proposal falls back to (its energy / force stay parked)
     }
@@ -418,7 +454,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       if constexpr (DIAG) {
         // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain holds now,
         // acceptance rate of this transition
-        float* tile = fpark_base + 16 * NT * kBlock;
+        float* tile = fpark_base + (CARRY ? 16 * NT * kBlock : 0);
         store_rows(tile, (int64_t)((threadIdx.x >> 6) * 32 + m) * dim, x);
         const int64_t left = a.n_chains - (int64_t)blockIdx.x * (kBlock / 2);
         const int valid = (left >= kBlock / 2 ? kBlock / 2 : (left > 0 ? (int)left : 0)) * dim;
@@ -451,7 +487,7 @@ template <int NT, bool DIAGM, class E, int WAVES, bool DIAG = false>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register),
   // and with records the tile + scratch rows of diag::emit
-  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + 16 * NT * kBlock +
+  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + (E::kCarry ? 16 * NT * kBlock : 0) +
                                (DIAG ? diag::lds_floats(a.diag.E, a.diag.S) : 0)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
