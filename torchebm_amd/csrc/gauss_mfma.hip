@@ -196,7 +196,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
     if constexpr (GKR > 0) {
       Mix::grad(a.gm, gauss_smem, x, g, lane);
     } else if constexpr (B3) {
-      gauss3::contract<NT>(aop, mus, x, g, lane);
+      gauss3::contract<NT>(aop, mus, x, g, lane);  // (contract_pieces costs this body registers: it has no spill to cure)
     } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t)

@@ -67,24 +67,7 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
   float acc = 0.0f;
   if constexpr (B3 && NT >= 3) {
-    // three / four tiles: the output in two pieces of at most two tiles -- all accumulators, the A operands of every tile
-    // and the split's transients do not fit beside x, p and the force at once (1 - 2 KB of scratch); the split of x is
-    // formed twice instead, the second time from an OPAQUE copy of x: left visible, the compiler merges the two
-    // identical splits and keeps the 12 split registers of every K-block live across both pieces.
-    constexpr int KB = 2 * NT;
-    f32x16 lo[2];
-    gauss3::contract_general<2, KB, true, gauss3::NoFill, NT, 0>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, lo, m + 32 * h);
-    g.t[0] = lo[0]; g.t[1] = lo[1];
-    f32x16 xb[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      xb[t] = x.t[t];
-      asm volatile("" : "+v"(xb[t]));
-    }
-    f32x16 hi[NT - 2];
-    gauss3::contract_general<NT - 2, KB, true, gauss3::NoFill, NT, 2>(reinterpret_cast<const __bf16*>(Ps), mus, xb, hi, m + 32 * h);
-#pragma unroll
-    for (int t = 2; t < NT; ++t) g.t[t] = hi[t - 2];
+    gauss3::contract_pieces<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);  // (gauss_bf16x3.h: why)
   } else if constexpr (B3) {
     gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else {
