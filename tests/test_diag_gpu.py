@@ -221,10 +221,10 @@ def test_matrix_layout_kernels_emit_records(cuda_device, kind, dim):
 
 
 @pytest.mark.parametrize("kind,dim,mass", [("gauss", 32, None), ("gauss", 64, 1.5), ("gauss", 96, "diag"), ("gauss", 96, None),
-                                           ("gmm16", 32, None), ("gmm9", 64, "diag"), ("gmm32", 48, 0.7)])
+                                           ("gmm16", 32, None), ("gmm9", 64, "diag"), ("gmm32", 48, 0.7), ("gmm12", 96, "diag")])
 def test_matrix_layout_hmc_kernels_emit_records(cuda_device, kind, dim, mass):
     """HMC with diagnostics where the matrix-layout kernels run and their layout does not depend on the mass form (dense
-    Gaussians at dims 20 .. 96, mixtures at dims 20 .. 64): records from those kernels -- 128 chains per workgroup, the
+    Gaussians and mixtures at dims 20 .. 96): records from those kernels -- 128 chains per workgroup, the
     chains bit for bit those of the call without diagnostics, statistics / energy / acceptance rate of the kept states."""
     g = torch.Generator().manual_seed(dim)
     if kind == "gauss":

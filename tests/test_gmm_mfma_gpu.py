@@ -1,5 +1,5 @@
 """Gaussian-mixture HMC on the matrix-layout kernel (csrc/gauss_hmc_mfma.hip: GmmE): mixtures of up to 32 components
-at dims 20 .. 128 (64 with a diagonal mass) run the two K x dim passes of the gradient on the bf16 matrix pipe with
+at dims 20 .. 128 (96 with a diagonal mass) run the two K x dim passes of the gradient on the bf16 matrix pipe with
 three-way split operands.  Its own Philox draws against the oracle fed with the same field, over component counts on
 both sides of the 8 / 16 / 32 register classes, every tile count and every mass form; the energy it reports in the
 diagnostics-free path is checked through the accept decisions (bit-identical to the oracle's wherever the oracle's own
@@ -28,7 +28,7 @@ def _field(shape, seed, steps, device, kind=None):
 
 @pytest.mark.parametrize("K", [1, 3, 8, 9, 16, 17, 32])
 @pytest.mark.parametrize("dim,mass", [(20, None), (32, None), (32, 1.7), (36, "diag"), (64, None), (64, "diag"), (96, None), (96, 0.6),
-                                      (100, None), (128, 1.3)])
+                                      (96, "diag"), (100, None), (128, 1.3)])
 def test_mixture_hmc_matrix_kernel_matches_oracle(cuda_device, K, dim, mass):
     g = torch.Generator().manual_seed(100 * K + dim)
     means = torch.randn(K, dim, generator=g) * 1.2

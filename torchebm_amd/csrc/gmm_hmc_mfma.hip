@@ -5,8 +5,8 @@ namespace ebm {
 
 bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
   // up to four tiles (the mixture's contractions are narrow -- one tile of components -- so, unlike the Gaussian's, the
-  // split's transients fit beside x, p and the force); a diagonal mass: two tiles
-  const int max_dim = mass_kind == EBM_MASS_DIAG ? 64 : 128;
+  // split's transients fit beside x, p and the force); a diagonal mass: three tiles (four spill 0.6 - 0.9 KB)
+  const int max_dim = mass_kind == EBM_MASS_DIAG ? 96 : 128;
   return dim >= 20 && dim <= max_dim && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32;
 }
 
@@ -25,11 +25,9 @@ int launch_gmm_dim(const GaussHmcArgs& a, hipStream_t st) {
   switch ((a.dim + 31) / 32) {
     case 1: return launch_gmm_nt<1, DIAGM>(a, st);
     case 2: return launch_gmm_nt<2, DIAGM>(a, st);
-    case 3:
-      if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 64");
-      else return launch_gmm_nt<3, false>(a, st);
+    case 3: return launch_gmm_nt<3, DIAGM>(a, st);
     default:
-      if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 64");
+      if constexpr (DIAGM) return fail(EBM_EDIM, "ebm_hmc_chain_f32: mixture matrix kernel, diagonal mass: dim <= 96");
       else return launch_gmm_nt<4, false>(a, st);
   }
 }

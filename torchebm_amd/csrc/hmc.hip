@@ -60,7 +60,7 @@ static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
 }
 
 // Records from the matrix-layout kernels where they run and their layout does not depend on the mass form (the layout
-// query is not told it): dense Gaussians at dims 20 .. 96, mixtures at dims 20 .. 64.
+// query is not told it): dense Gaussians and mixtures at dims 20 .. 96.
 static bool hmc_matrix_records(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
   static const bool gauss_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
   static const bool gmm_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
