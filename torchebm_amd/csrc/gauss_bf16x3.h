@@ -147,30 +147,30 @@ __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop,
   }
 }
 
-// The Gaussian form for three / four tiles in two pieces of at most two output tiles: all accumulators, the A operands of
-// every tile and the split's transients do not fit beside a body's resident state at once; the split of x is formed twice
-// instead, the second time from an OPAQUE copy of x -- left visible, the compiler merges the two identical splits and keeps
-// the 12 split registers of every K-block live across both pieces (1 - 2 KB of scratch in the HMC body).
-// `fill` ordinals run over both pieces: 0 .. 6 NT (2 NT) - 1, as in the one-piece form.
-template <int NT, class Fill = NoFill>
+// The Gaussian form with the OUTPUT in pieces of P tiles: all accumulators, the A operands of every tile and the split's
+// transients do not fit beside an HMC body's resident state (x, p, force) at once; the split of x is formed once per piece
+// instead, every time after the first from an OPAQUE copy of x -- left visible, the compiler merges the identical splits and
+// keeps the 12 split registers of every K-block live across the pieces (1 - 2 KB of scratch at three / four tiles).
+// `fill` ordinals run over all pieces: 0 .. 6 NT (2 NT) - 1, as in the one-piece form.
+template <int NT, int P, class Fill = NoFill>
 __device__ __forceinline__ void contract_pieces(const __bf16* __restrict__ aop, const float* __restrict__ mus, const f32x16 (&x)[NT],
                                                 f32x16 (&g)[NT], int lane, Fill&& fill = NoFill{}) {
-  static_assert(NT >= 3, "two pieces of at most two tiles");
-  constexpr int KB = 2 * NT, FIRST = 6 * 2 * KB;
-  f32x16 lo[2];
-  contract_general<2, KB, true, Fill&, NT, 0>(aop, mus, x, lo, lane, fill);
-  g[0] = lo[0]; g[1] = lo[1];
-  f32x16 xb[NT];
+  static_assert(P >= 1 && P < NT, "more than one piece");
+  constexpr int KB = 2 * NT, PIECES = (NT + P - 1) / P;
+  static_for<PIECES>([&](auto pc) {
+    constexpr int pi = decltype(pc)::value, it0 = pi * P, mt = (NT - it0) < P ? (NT - it0) : P;
+    f32x16 xb[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    xb[t] = x[t];
-    asm volatile("" : "+v"(xb[t]));
-  }
-  f32x16 hi[NT - 2];
-  auto shifted = [&](auto ord) { fill(std::integral_constant<int, FIRST + decltype(ord)::value>{}); };
-  contract_general<NT - 2, KB, true, decltype(shifted)&, NT, 2>(aop, mus, xb, hi, lane, shifted);
+    for (int t = 0; t < NT; ++t) {
+      xb[t] = x[t];
+      if constexpr (pi > 0) asm volatile("" : "+v"(xb[t]));
+    }
+    f32x16 out[mt];
+    auto shifted = [&](auto ord) { fill(std::integral_constant<int, 6 * it0 * KB + decltype(ord)::value>{}); };
+    contract_general<mt, KB, true, decltype(shifted)&, NT, it0>(aop, mus, xb, out, lane, shifted);
 #pragma unroll
-  for (int t = 2; t < NT; ++t) g[t] = hi[t - 2];
+    for (int t = 0; t < mt; ++t) g[it0 + t] = out[t];
+  });
 }
 
 // the Gaussian form: g = Ps (x - mu) on (32 NT)^2

@@ -67,7 +67,10 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
   auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
   float acc = 0.0f;
   if constexpr (B3 && NT >= 3) {
-    gauss3::contract_pieces<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);  // (gauss_bf16x3.h: why)
+    // the output in two pieces of at most two tiles: gauss_bf16x3.h says why.  (Two tiles in single-tile pieces fit 256
+    // VGPRs / two waves per SIMD without spills, but run 0.54 - 0.58 ms per 10 transitions at dims 48 / 64 where the one-piece
+    // form, unconstrained, runs 0.46 - 0.50.)
+    gauss3::contract_pieces<NT, 2>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else if constexpr (B3) {
     gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else {
