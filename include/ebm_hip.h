@@ -63,7 +63,7 @@ enum {
                                  A wrong mask gives wrong samples; NULL is always safe.                                    */
   EBM_ENERGY_MLP         = 4  /* E = w3 . silu(W2 silu(W1 x + b1) + b2) + b3   (the energy of the reference's
                                  examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31)
-                                 n_comp = hidden width H (64 or 128), dim <= 128 (the reference's benchmark network
+                                 n_comp = hidden width H (64, 128 or 256), dim <= 128 (the reference's benchmark network
                                  benchmarks/registry.py:372-387 at dim 8 / 32 / 128),
                                  dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
                                  Supported by ebm_langevin_chain_f32 and ebm_energy_grad_f32; by ebm_hmc_chain_f32 for

@@ -17,7 +17,10 @@ from torchebm_amd import _lib  # noqa: E402
 dev = torch.device("cuda")
 PEAK = 157.3
 n, k = 65536, 20
-for dim, hidden in ((2, 128), (8, 128), (32, 128), (128, 128), (32, 64)):
+CASES = ((2, 128), (8, 128), (32, 128), (128, 128), (32, 64), (8, 256), (32, 256), (128, 256))
+if os.environ.get("MLP_CASES"):  # e.g. MLP_CASES=32x256,128x256
+    CASES = tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["MLP_CASES"].split(","))
+for dim, hidden in CASES:
     torch.manual_seed(0)
     model = ta.MLPEnergy(dim, hidden, device=dev)
     s = ta.LangevinDynamics(model, step_size=0.05, device=dev)

@@ -1,4 +1,4 @@
-"""The fused MLP energy beyond the two-moons shape (csrc/mlp_wide.hip): hidden width 64 / 128, input dim up to 128 --
+"""The fused MLP energy beyond the two-moons shape (csrc/mlp_wide.hip): hidden width 64 / 128 / 256 (256: weights streamed from L2), input dim up to 128 --
 the reference's benchmark network (benchmarks/registry.py:372-387: Linear(dim,128)-SiLU-Linear(128,128)-SiLU-
 Linear(128,1) at dim 8 / 32 / 128).  One evaluation against autograd (and against the fp64 network), the k-fused
 chain against the CPU autograd chain on injected noise, the sampler's routes, and the native-RNG field."""
@@ -27,7 +27,7 @@ def _models(cuda_device, in_dim, hidden, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (5, 128), (33, 128), (100, 128), (64, 64), (7, 64),
-                                           (128, 64), (2, 64)])
+                                           (128, 64), (2, 64), (32, 256), (8, 256), (33, 256), (64, 256), (100, 256), (128, 256)])
 def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
     cpu, gpu = _models(cuda_device, in_dim, hidden, seed=in_dim + hidden, scale=1.5)
     spec = gpu.fused_spec()
@@ -51,7 +51,7 @@ def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
     torch.testing.assert_close(g.cpu(), want_g, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (30, 64)])
+@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (30, 64), (32, 256), (30, 256), (128, 256)])
 def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden):
     cpu, gpu = _models(cuda_device, in_dim, hidden, seed=5)
     n, k, eta, sigma = 200, 12, 0.05, 0.7

@@ -318,7 +318,7 @@ class MLPEnergy(BaseModel):
     -- the trainable energy of the reference's PCD example
     (examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).
 
-    With ``hidden`` 64 or 128 and ``in_dim <= 128`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
+    With ``hidden`` 64, 128 or 256 and ``in_dim <= 128`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
     forward, input-gradient on the matrix cores, update, noise -- in one ``ebm_langevin_chain_f32``
     launch instead of one autograd round trip per step: the reference's benchmark network
     ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
@@ -328,7 +328,7 @@ class MLPEnergy(BaseModel):
     ``sample()`` call.
     """
 
-    FUSED_HIDDEN = (64, 128)
+    FUSED_HIDDEN = (64, 128, 256)
     FUSED_MAX_DIM = 128
     HMC_HIDDEN, HMC_MAX_DIM = 128, 4
 
@@ -346,7 +346,7 @@ class MLPEnergy(BaseModel):
         """Adopt an existing ``Linear(d, H) - SiLU - Linear(H, H) - SiLU - Linear(H, 1)`` stack (the network
         the reference's example writes by hand) WITHOUT copying it: the returned energy shares ``net``'s
         parameters, so an optimiser built on either sees the same tensors, and sampling from it takes the
-        fused route when the shape qualifies (H = 64 or 128, d <= 128, CUDA fp32)."""
+        fused route when the shape qualifies (H = 64, 128 or 256, d <= 128, CUDA fp32)."""
         from torch import nn
 
         layers = list(net)

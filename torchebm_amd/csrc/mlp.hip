@@ -372,7 +372,7 @@ int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool small_on
     return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width %d and 1 <= dim <= %d (got %d, %d)", who, H, kMaxDim,
                 e.n_comp, dim);
   if (!mlp_wide_supported(e.n_comp, dim))
-    return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64 or 128 and 1 <= dim <= 128 (got %d, %d)", who, e.n_comp, dim);
+    return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64, 128 or 256 and 1 <= dim <= 128 (got %d, %d)", who, e.n_comp, dim);
   return 0;
 }
 

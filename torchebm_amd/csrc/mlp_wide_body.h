@@ -1,0 +1,437 @@
+// Kernel body of mlp_wide.hip / mlp_stream.hip (the two translation units compile in parallel): see mlp_wide.hip.
+#pragma once
+#include "ebm_common.h"
+#include "gauss_bf16x3.h"  // static_for
+
+namespace ebm {
+namespace widemlp {
+
+constexpr int kBlock = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1))) * gptr4;  // 16-byte global loads of the STREAM variant
+
+struct WideArgs {
+  float* x;              // [n, dim] in/out (k_steps > 0) or input (k_steps == 0)
+  int64_t n_chains;
+  int32_t dim;
+  int32_t k_steps;
+  float eta, sqrt_eta, noise_coef;
+  const float4* table;
+  int clamp_on;
+  float cmin, cmax;
+  int32_t thin, n_kept;
+  float* traj;
+  const float* noise;    // [k, n, dim] or null
+  RngKey key;
+  uint64_t step0;
+  const float* params;   // packed W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1]
+  float* energy_out;     // k_steps == 0: E(x)[n]
+  float* grad_out;       // k_steps == 0: dE/dx[n, dim]
+};
+
+extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+
+__device__ __forceinline__ float sigmoid_fast(float a) { return __builtin_amdgcn_rcpf(1.0f + __expf(-a)); }
+__device__ __forceinline__ constexpr int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// out[t] += A_t * B over NK x 16 K-steps; the LDS operands of step s + 1 are requested before the MFMAs of step s
+// issue, so their latency hides under NT x 64 matrix-pipe cycles.  addr(t, tk, r): LDS word of A for output tile t at
+// K-step (tk, r) (this lane's row / K-half folded in by the caller); bval(tk, r): this lane's B value.
+template <int NT, int NK, class Addr, class Bval>
+__device__ __forceinline__ void contract(f32x16 (&out)[NT], const float* lds, Addr addr, Bval bval) {
+  float cur[NT], nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cur[t] = lds[addr(t, 0, 0)];
+#pragma unroll
+  for (int tk = 0; tk < NK; ++tk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = tk * 16 + r;
+      if (s + 1 < NK * 16) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nxt[t] = lds[addr(t, (s + 1) >> 4, (s + 1) & 15)];
+      }
+      const float b = bval(tk, r);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t], b, out[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: next loads, this step's MFMAs
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+    }
+}
+
+using gauss3::static_for;
+
+// STREAM, forward walk: ld4(t, tk, q) -> the four A words of output tile t at K-steps (tk, 4 q .. 4 q + 3) (one 16-byte
+// global load: lane (m, h) takes bytes 32 q + 16 h .. + 15 of the 128-byte segment of weight row 32 t + m).  A stage
+// is one (t, tk): its four loads go out back to back, so every 128-byte line they touch is fetched from L2 once (a
+// stage built across tiles instead re-fetched each line four times -- the L1 does not hold 4 waves x 16 KB), and feed
+// 16 accumulations into ONE tile (the matrix pipe forwards a back-to-back accumulator); requested PF stages ahead.
+template <int NT, int NK, int PF, class Ld4, class Bval>
+__device__ __forceinline__ void contract_rows(f32x16 (&out)[NT], Ld4 ld4, Bval bval) {
+  constexpr int NS = NT * NK;
+  f32x4 buf[PF + 1][4];
+  static_for<(PF < NS ? PF : NS)>([&](auto s_) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_)::value;
+    static_for<4>([&](auto q_) __attribute__((always_inline)) {
+      buf[s % (PF + 1)][decltype(q_)::value] = ld4(std::integral_constant<int, s / NK>{}, std::integral_constant<int, s % NK>{}, q_);
+    });
+  });
+  static_for<NS>([&](auto s_) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_)::value;
+    if constexpr (s + PF < NS) {
+      constexpr int n = s + PF;
+      static_for<4>([&](auto q_) __attribute__((always_inline)) {
+        buf[n % (PF + 1)][decltype(q_)::value] = ld4(std::integral_constant<int, n / NK>{}, std::integral_constant<int, n % NK>{}, q_);
+      });
+    }
+    constexpr int t = s / NK, tk = s % NK;
+    static_for<16>([&](auto r_) __attribute__((always_inline)) {
+      constexpr int r = decltype(r_)::value;
+      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[s % (PF + 1)][r >> 2][r & 3], bval(tk, r), out[t], 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// STREAM, transposed walk: ld1(t, tk, r) -> the A word of output tile t at K-step (tk, r) (one coalesced dword load);
+// a stage = one K-step = NT loads feeding NT MFMAs, requested PF stages ahead.
+template <int NT, int NK, int PF, class Ld1, class Bval>
+__device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval bval) {
+  constexpr int NS = NK * 16;
+  float buf[PF + 1][NT];
+  static_for<(PF < NS ? PF : NS)>([&](auto s_) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_)::value;
+    static_for<NT>([&](auto t_) __attribute__((always_inline)) {
+      constexpr int t = decltype(t_)::value;
+      buf[s % (PF + 1)][t] = ld1(std::integral_constant<int, t>{}, std::integral_constant<int, s / 16>{}, std::integral_constant<int, s & 15>{});
+    });
+  });
+  static_for<NS>([&](auto s_) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_)::value;
+    if constexpr (s + PF < NS) {
+      constexpr int n = s + PF;
+      static_for<NT>([&](auto t_) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_)::value;
+        buf[n % (PF + 1)][t] = ld1(std::integral_constant<int, t>{}, std::integral_constant<int, n / 16>{}, std::integral_constant<int, n & 15>{});
+      });
+    }
+    const float b = bval(s / 16, s & 15);
+    static_for<NT>([&](auto t_) __attribute__((always_inline)) {
+      constexpr int t = decltype(t_)::value;
+      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[s % (PF + 1)][t], b, out[t], 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <int HT, int DT, bool STREAM>
+__global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
+  constexpr int H = 32 * HT, DP = 32 * DT;  // hidden width, padded input width
+  constexpr int S1 = DP + 1, S2 = H + 1;    // LDS row strides
+  // LDS: the padded weights, or (STREAM) the parked s1 = silu'(a1): [16 HT][kBlock], one word per lane per slot
+  float* W2s = wide_smem;                                        // [H][S2]
+  float* W1s = W2s + H * S2;                                     // [H][S1], columns >= dim zero
+  float* b1s = STREAM ? wide_smem : W1s + H * S1;                // [H]  (STREAM: first, inside the 64 KiB an LDS offset field reaches)
+  float* park = wide_smem + 3 * H;                               // STREAM
+  float* b2s = b1s + H;
+  float* w3s = b2s + H;
+  const int dim = a.dim;
+  const float* W1g = a.params;
+  const float* b1g = W1g + H * dim;
+  const float* W2g = b1g + H;
+  {  // stage the weights (once per launch)
+    const float* b2g = W2g + H * H;
+    const float* w3g = b2g + H;
+    if constexpr (!STREAM) {
+      for (int i = threadIdx.x; i < H * H; i += kBlock) W2s[(i / H) * S2 + (i % H)] = W2g[i];
+      for (int i = threadIdx.x; i < H * DP; i += kBlock) {
+        const int row = i / DP, c = i - row * DP;
+        W1s[row * S1 + c] = c < dim ? W1g[row * dim + c] : 0.0f;
+      }
+    }
+    for (int i = threadIdx.x; i < H; i += kBlock) {
+      b1s[i] = b1g[i];
+      b2s[i] = b2g[i];
+      w3s[i] = w3g[i];
+    }
+    __syncthreads();
+  }
+  const float b3 = a.params[H * dim + H + H * H + H + H];
+
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t sample = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const bool active = sample < a.n_chains;
+  const bool quads = (dim & 3) == 0;  // a register quad r = 4q .. 4q+3 is four consecutive, 16-byte aligned columns
+
+  // the state in the C/D layout: xr[td][r] = x[sample][32 td + row_of(r, h)], zero beyond dim
+  float xr[DT][16];
+#pragma unroll
+  for (int td = 0; td < DT; ++td)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = 32 * td + 8 * q + 4 * h;
+      if (quads && active && c0 + 3 < dim) {
+        const float4 v = *reinterpret_cast<const float4*>(a.x + sample * dim + c0);
+        xr[td][4 * q] = v.x; xr[td][4 * q + 1] = v.y; xr[td][4 * q + 2] = v.z; xr[td][4 * q + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[td][4 * q + i] = (active && c0 + i < dim) ? a.x[sample * dim + c0 + i] : 0.0f;
+      }
+    }
+
+  float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
+  int until_keep = a.thin;
+  int64_t keep_off = 0;
+  const int n_evals = a.k_steps > 0 ? a.k_steps : 1;
+
+  for (int step = 0; step < n_evals; ++step) {
+    // STREAM: the weight loads do not depend on the step -- opaque bases keep them from being hoisted out of the loop
+    // (thousands of values) instead of being re-read from L2 just ahead of their MFMAs
+    typedef const float __attribute__((address_space(1))) * gptr;  // a laundered pointer is generic: say "global" again
+    const float* W1o = W1g;
+    const float* W2o = W2g;
+    if constexpr (STREAM) asm volatile("" : "+s"(W1o), "+s"(W2o));
+    const gptr W1p = (gptr)W1o, W2p = (gptr)W2o;
+    int ms = m, hs = h;  // ... and so do the lane parts of the addresses (hundreds of hoisted offsets would spill)
+    if constexpr (STREAM) asm volatile("" : "+v"(ms), "+v"(hs));
+    // ------------------------------------------------------------ layer 1: a1^T tiles, K = input columns
+    f32x16 u[HT];  // a1, then h1 = silu(a1)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[t][r] = 0.0f;
+    if constexpr (STREAM) {
+      // branch-free: a column past dim reads column 0 of its row and is zeroed afterwards (a load behind a branch ends the
+      // prefetch -- the wait-count pass drains at every block boundary)
+      const auto xb = [&](int tk, int r) { return xr[tk][r]; };
+      if (quads) {
+        contract_rows<HT, DT, 2>(
+            u,
+            [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
+              const int c0 = 32 * decltype(tk_)::value + 8 * decltype(q_)::value + 4 * hs;
+              const bool in = c0 < dim;
+              const f32x4 w = *(gptr4)(W1p + (uint32_t)((32 * decltype(t_)::value + ms) * dim + (in ? c0 : 0)));
+              const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+              return in ? w : z;
+            },
+            xb);
+      } else {
+        contract_rows<HT, DT, 2>(
+            u,
+            [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
+              const int c0 = 32 * decltype(tk_)::value + 8 * decltype(q_)::value + 4 * hs;
+              const gptr row = W1p + (uint32_t)((32 * decltype(t_)::value + ms) * dim);
+              f32x4 w;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float v = row[c0 + i < dim ? c0 + i : 0];
+                w[i] = c0 + i < dim ? v : 0.0f;
+              }
+              return w;
+            },
+            xb);
+      }
+    } else {
+      contract<HT, DT>(u, W1s, [&](int t, int tk, int r) { return (32 * t + m) * S1 + 32 * tk + row_of(r, h); },
+                       [&](int tk, int r) { return xr[tk][r]; });
+    }
+    f32x16 s1[STREAM ? 1 : HT];  // silu'(a1) (STREAM: parked in LDS)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a1 = u[t][r] + b1s[32 * t + row_of(r, h)];
+        const float sg = sigmoid_fast(a1);
+        u[t][r] = a1 * sg;
+        const float ds = sg * (1.0f + a1 * (1.0f - sg));
+        if constexpr (STREAM) park[(16 * t + r) * kBlock + threadIdx.x] = ds;
+        else s1[t][r] = ds;
+      }
+    // ------------------------------------------------------------ layer 2: a2^T tiles, K = hidden units of layer 1
+    f32x16 v[HT];  // a2, then d2 = w3 * silu'(a2)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[t][r] = 0.0f;
+    if constexpr (STREAM) {
+      contract_rows<HT, HT, 2>(
+          v,
+          [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
+            return *(gptr4)(W2p + (uint32_t)((32 * decltype(t_)::value + ms) * H + 32 * decltype(tk_)::value +
+                                                                                      8 * decltype(q_)::value + 4 * hs));
+          },
+          [&](int tk, int r) { return u[tk][r]; });
+    } else {
+      contract<HT, HT>(v, W2s, [&](int t, int tk, int r) { return (32 * t + m) * S2 + 32 * tk + row_of(r, h); },
+                       [&](int tk, int r) { return u[tk][r]; });
+    }
+    float e_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * t + row_of(r, h);
+        const float a2 = v[t][r] + b2s[j];
+        const float sg = sigmoid_fast(a2);
+        const float w3 = w3s[j];
+        e_part = __builtin_fmaf(w3, a2 * sg, e_part);
+        v[t][r] = w3 * (sg * (1.0f + a2 * (1.0f - sg)));
+      }
+    // ------------------------------------------------------------ backward through W2: T^T tiles, K = units of layer 2
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[t][r] = 0.0f;
+    if constexpr (STREAM) {
+      contract_cols<HT, HT, 4>(
+          u,
+          [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
+            return W2p[(uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, hs)) * H + 32 * decltype(t_)::value + ms)];
+          },
+          [&](int tk, int r) { return v[tk][r]; });
+    } else {
+      contract<HT, HT>(u, W2s, [&](int t, int tk, int r) { return (32 * tk + row_of(r, h)) * S2 + 32 * t + m; },
+                       [&](int tk, int r) { return v[tk][r]; });
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // d1
+        if constexpr (STREAM) u[t][r] *= park[(16 * t + r) * kBlock + threadIdx.x];
+        else u[t][r] *= s1[t][r];
+      }
+    // ------------------------------------------------------------ backward through W1: g^T tiles, K = units of layer 1
+    f32x16 g[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = 0.0f;
+    if constexpr (STREAM) {
+      contract_cols<DT, HT, (DT >= 4 ? 6 : (DT >= 2 ? 10 : 16))>(
+          g,
+          [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
+            const int c = 32 * decltype(t_)::value + ms;
+            const float w = W1p[(uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, hs)) * dim + (c < dim ? c : 0))];
+            return c < dim ? w : 0.0f;
+          },
+          [&](int tk, int r) { return u[tk][r]; });
+    } else {
+      contract<DT, HT>(g, W1s, [&](int t, int tk, int r) { return (32 * tk + row_of(r, h)) * S1 + 32 * t + m; },
+                       [&](int tk, int r) { return u[tk][r]; });
+    }
+    const float energy = e_part + __shfl_xor(e_part, 32) + b3;  // the two K-halves hold the two halves of the rows
+
+    if (a.k_steps == 0) {  // evaluation only
+      if (active) {
+        if (a.energy_out && h == 0) a.energy_out[sample] = energy;
+        if (a.grad_out) {
+#pragma unroll
+          for (int td = 0; td < DT; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = 32 * td + row_of(r, h);
+              if (c < dim) a.grad_out[sample * dim + c] = g[td][r];
+            }
+        }
+      }
+      return;
+    }
+
+    // ------------------------------------------------------------ Euler-Maruyama update (reference op order)
+    int64_t smp = sample;  // STREAM: nothing derived from the chain index (counters, addresses) is hoisted out of the loop and spilled
+    if constexpr (STREAM) asm volatile("" : "+v"(smp));
+    if (a.table) {
+      const float4 tb = a.table[step];
+      eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
+    }
+#pragma unroll
+    for (int td = 0; td < DT; ++td)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * td + 8 * q + 4 * h;
+        float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (c0 < dim) {
+          if (a.noise) {
+            if (active)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (c0 + i < dim) eps[i] = a.noise[((int64_t)step * a.n_chains + smp) * dim + c0 + i];
+          } else if (quads) {  // the quad is exactly one Philox counter
+            const F4 nrm = normal4_at(a.key, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, a.step0 + (uint64_t)step);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eps[i] = nrm.v[i];
+          } else {
+            uint64_t have = ~0ull;
+            F4 nrm;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint64_t e = (uint64_t)smp * (uint64_t)dim + (uint64_t)(c0 + i);
+              if ((e >> 2) != have) {
+                have = e >> 2;
+                nrm = normal4_at(a.key, have, a.step0 + (uint64_t)step);
+              }
+              const int w = (int)(e & 3);
+              eps[i] = w == 0 ? nrm.v[0] : (w == 1 ? nrm.v[1] : (w == 2 ? nrm.v[2] : nrm.v[3]));
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          const float x1 = xr[td][r] - eta * g[td][r];
+          const float dw = eps[i] * sqrt_eta;
+          float nv = x1 + noise_coef * dw;
+          if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+          xr[td][r] = (c0 + i < dim) ? nv : 0.0f;
+        }
+      }
+    if (a.traj && --until_keep == 0) {
+      until_keep = a.thin;
+      if (active) {
+        float* dst = a.traj + smp * (int64_t)a.n_kept * dim + keep_off;
+#pragma unroll
+        for (int td = 0; td < DT; ++td)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = 32 * td + row_of(r, h);
+            if (c < dim) dst[c] = xr[td][r];
+          }
+      }
+      keep_off += dim;
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int td = 0; td < DT; ++td)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * td + row_of(r, h);
+        if (c < dim) a.x[sample * dim + c] = xr[td][r];
+      }
+  }
+}
+
+template <int HT, int DT>
+int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
+  constexpr int H = 32 * HT, DP = 32 * DT;
+  constexpr bool STREAM = HT > 4;
+  const size_t smem = (size_t)(STREAM ? 16 * HT * kBlock + 3 * H : H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
+  if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
+    return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_chain_kernel<HT, DT, STREAM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
+  hipLaunchKernelGGL((mlp_wide_chain_kernel<HT, DT, STREAM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  return check_launch(who);
+}
+
+}  // namespace widemlp
+}  // namespace ebm
