@@ -197,6 +197,11 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
     const gptr W1p = (gptr)W1o, W2p = (gptr)W2o;
     int ms = m, hs = h;  // ... and so do the lane parts of the addresses (hundreds of hoisted offsets would spill)
     if constexpr (STREAM) asm volatile("" : "+v"(ms), "+v"(hs));
+    // Every address = uniform pointer (scalar unit: weight base + the compile-time part) + one 32-bit lane byte offset --
+    // the SGPR-base form of global_load, no vector arithmetic per load (the exact-f32 MFMA shares the VALU's lanes).
+    typedef const char __attribute__((address_space(1))) * gbytes;
+    const uint32_t lane_f2 = (uint32_t)(ms * H + 4 * hs) * 4u, lane_b2 = (uint32_t)(4 * hs * H + ms) * 4u;
+    const uint32_t lane_f1 = (uint32_t)(ms * dim + 4 * hs) * 4u, lane_b1 = (uint32_t)(4 * hs * dim + ms) * 4u;
     // ------------------------------------------------------------ layer 1: a1^T tiles, K = input columns
     f32x16 u[HT];  // a1, then h1 = silu(a1)
 #pragma unroll
@@ -204,31 +209,30 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[t][r] = 0.0f;
     if constexpr (STREAM) {
-      // branch-free: a column past dim reads column 0 of its row and is zeroed afterwards (a load behind a branch ends the
-      // prefetch -- the wait-count pass drains at every block boundary)
+      // branch-free: a column past dim is read where it falls (the next row -- still inside the parameter block: W2
+      // follows) and zeroed afterwards (a load behind a branch ends the prefetch: the wait counts drain at block ends)
       const auto xb = [&](int tk, int r) { return xr[tk][r]; };
       if (quads) {
         contract_rows<HT, DT, 2>(
             u,
             [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-              const int c0 = 32 * decltype(tk_)::value + 8 * decltype(q_)::value + 4 * hs;
-              const bool in = c0 < dim;
-              const f32x4 w = *(gptr4)(W1p + (uint32_t)((32 * decltype(t_)::value + ms) * dim + (in ? c0 : 0)));
+              constexpr int cu = 32 * decltype(tk_)::value + 8 * decltype(q_)::value;
+              const f32x4 w = *(gptr4)((gbytes)(W1p + (uint32_t)(32 * decltype(t_)::value * dim + cu)) + lane_f1);
               const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-              return in ? w : z;
+              return cu + 4 * hs < dim ? w : z;
             },
             xb);
       } else {
         contract_rows<HT, DT, 2>(
             u,
             [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-              const int c0 = 32 * decltype(tk_)::value + 8 * decltype(q_)::value + 4 * hs;
-              const gptr row = W1p + (uint32_t)((32 * decltype(t_)::value + ms) * dim);
+              constexpr int cu = 32 * decltype(tk_)::value + 8 * decltype(q_)::value;
+              const gptr src = (gptr)((gbytes)(W1p + (uint32_t)(32 * decltype(t_)::value * dim + cu)) + lane_f1);
               f32x4 w;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const float v = row[c0 + i < dim ? c0 + i : 0];
-                w[i] = c0 + i < dim ? v : 0.0f;
+                const float v = src[i];
+                w[i] = cu + 4 * hs + i < dim ? v : 0.0f;
               }
               return w;
             },
@@ -260,8 +264,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       contract_rows<HT, HT, 2>(
           v,
           [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-            return *(gptr4)(W2p + (uint32_t)((32 * decltype(t_)::value + ms) * H + 32 * decltype(tk_)::value +
-                                                                                      8 * decltype(q_)::value + 4 * hs));
+            return *(gptr4)((gbytes)(W2p + (32 * decltype(t_)::value * H + 32 * decltype(tk_)::value + 8 * decltype(q_)::value)) + lane_f2);
           },
           [&](int tk, int r) { return u[tk][r]; });
     } else {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       contract_cols<HT, HT, 4>(
           u,
           [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
-            return W2p[(uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, hs)) * H + 32 * decltype(t_)::value + ms)];
+            return *(gptr)((gbytes)(W2p + ((32 * decltype(tk_)::value + row_of(decltype(r_)::value, 0)) * H + 32 * decltype(t_)::value)) + lane_b2);
           },
           [&](int tk, int r) { return v[tk][r]; });
     } else {
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       contract_cols<DT, HT, (DT >= 4 ? 6 : (DT >= 2 ? 10 : 16))>(
           g,
           [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
-            const int c = 32 * decltype(t_)::value + ms;
-            const float w = W1p[(uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, hs)) * dim + (c < dim ? c : 0))];
-            return c < dim ? w : 0.0f;
+            const float w = *(gptr)((gbytes)(W1p + (uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, 0)) * dim +
+                                                                32 * decltype(t_)::value)) + lane_b1);
+            return 32 * decltype(t_)::value + ms < dim ? w : 0.0f;
           },
           [&](int tk, int r) { return u[tk][r]; });
     } else {
