@@ -110,3 +110,30 @@ def test_sampler_routes_and_native_rng_field(cuda_device):
         xx = torch.zeros(4, 8, device=cuda_device)
         _lib.call("ebm_hmc_chain_f32", spec.to_c(), xx.data_ptr(), 4, 8, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
                   None, None, 0, 0, _lib.stream_handle(cuda_device))
+
+
+@pytest.mark.parametrize("in_dim", [32, 30, 128])
+def test_hidden_256_sampler_is_one_launch_on_the_shared_field(cuda_device, in_dim):
+    """Hidden width 256 (the streamed-weight variant): ``LangevinDynamics`` is one ``ebm_langevin_chain_f32`` launch, its
+    noise is the (seed, step, element) field of the step route, thinning / clamp / a scheduled step size included."""
+
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    torch.manual_seed(in_dim)
+    fused_model = ta.MLPEnergy(in_dim, 256, device=cuda_device)
+    step_model = Sub(in_dim, 256, device=cuda_device)
+    step_model.load_state_dict(fused_model.state_dict())
+    assert fused_model.fused_spec() is not None and step_model.fused_spec() is None
+    x0 = torch.randn(777, in_dim, device=cuda_device)
+    from torchebm_amd.core import LinearScheduler
+
+    sf = ta.LangevinDynamics(fused_model, step_size=LinearScheduler(0.05, 0.02, 8), clamp=(-3.0, 3.0), device=cuda_device)
+    ss = ta.LangevinDynamics(step_model, step_size=LinearScheduler(0.05, 0.02, 8), clamp=(-3.0, 3.0), device=cuda_device)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    a = sf.sample(x=x0, n_steps=8, thin=2, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    b = ss.sample(x=x0, n_steps=8, thin=2, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    assert a.shape == (777, 4, in_dim)
+    torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
