@@ -137,3 +137,59 @@ def test_hidden_256_sampler_is_one_launch_on_the_shared_field(cuda_device, in_di
     b = ss.sample(x=x0, n_steps=8, thin=2, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(9))
     assert a.shape == (777, 4, in_dim)
     torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 256), (100, 64)])
+def test_gradient_is_one_hip_launch(cuda_device, in_dim, hidden):
+    """``MLPEnergy.gradient`` on a CUDA fp32 state is one ``ebm_energy_grad_f32`` launch (forward + input gradient on the
+    matrix cores), equal to autograd within fp32 summation order; conditioning kwargs, a subclass with its own
+    ``forward``, a 3-D state or a CPU model stay on autograd."""
+    cpu, gpu = _models(cuda_device, in_dim, hidden, seed=11, scale=1.5)
+    x = torch.randn(501, in_dim, generator=torch.Generator().manual_seed(2))
+    c0 = hip_calls("ebm_energy_grad_f32")
+    got = gpu.gradient(x.to(cuda_device))
+    assert hip_calls("ebm_energy_grad_f32") == c0 + 1
+    want = cpu.gradient(x)
+    assert got.shape == want.shape and not got.requires_grad
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-5 * max(want.abs().max().item(), 1.0))
+
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    sub = Sub(in_dim, hidden, device=cuda_device)
+    sub.load_state_dict(gpu.state_dict())
+    c0 = hip_calls("ebm_energy_grad_f32")
+    torch.testing.assert_close(sub.gradient(x.to(cuda_device)), got, rtol=2e-4, atol=2e-4)
+    cpu.gradient(x)
+    assert hip_calls("ebm_energy_grad_f32") == c0
+    # parameter gradients are untouched: forward() is autograd
+    e = gpu(x.to(cuda_device)).sum()
+    e.backward()
+    assert all(p.grad is not None for p in gpu.parameters())
+
+
+def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
+    """HMC on a wide MLP has no transition kernel: the per-transition route (HIP kicks around ``model.gradient``) now
+    evaluates each of its L + 1 forces in one launch.  Same momenta, same uniforms as the autograd route."""
+
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    torch.manual_seed(3)
+    fast = ta.MLPEnergy(16, 128, device=cuda_device)
+    slow = Sub(16, 128, device=cuda_device)
+    slow.load_state_dict(fast.state_dict())
+    x0 = torch.randn(2000, 16, device=cuda_device)
+    outs = []
+    for model in (fast, slow):
+        h = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=4, device=cuda_device)
+        h.capture_graph = False
+        c0 = hip_calls("ebm_energy_grad_f32")
+        out, diag = h.sample(x=x0, n_steps=3, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(5))
+        outs.append((out, diag, hip_calls("ebm_energy_grad_f32") - c0))
+    assert outs[0][2] >= 3 * 4 and outs[1][2] == 0
+    close = ((outs[0][0] - outs[1][0]).abs().amax(dim=1) <= 2e-3).float().mean().item()
+    assert close >= 0.995, close  # a Metropolis tie may flip on a summation-order difference
+    torch.testing.assert_close(outs[0][1]["acceptance_rate"], outs[1][1]["acceptance_rate"], rtol=0, atol=5e-3)

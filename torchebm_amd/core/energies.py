@@ -72,6 +72,9 @@ class BaseModel(TorchEBMModule, ABC):
         in_dtype = x.dtype
         if self.device and x.device != self.device:
             x = x.to(self.device)
+        fast = self._hip_gradient(x, model_kwargs)
+        if fast is not None:
+            return fast
         work_dtype = torch.float32 if self.force_fp32_gradient else in_dtype
         with torch.enable_grad():
             leaf = x.detach().to(dtype=work_dtype).requires_grad_(True)
@@ -89,6 +92,30 @@ class BaseModel(TorchEBMModule, ABC):
         if grad is None:
             raise RuntimeError("Gradient computation failed unexpectedly. Check the forward pass implementation.")
         return grad.to(in_dtype).detach()
+
+    #: ``True`` on energies whose input gradient has a one-launch HIP evaluation that beats autograd (``MLPEnergy``:
+    #: forward + backward through both hidden layers on the matrix cores, ``ebm_energy_grad_f32``)
+    HIP_GRADIENT = False
+
+    def _hip_gradient(self, x: torch.Tensor, model_kwargs: Optional[dict]) -> Optional[torch.Tensor]:
+        """``gradient()`` in one ``ebm_energy_grad_f32`` launch when the energy opts in and the call is the plain
+        case (fp32 ``[n, dim]`` CUDA state, no conditioning, no autocast); ``None`` sends the caller to autograd.
+        Every per-step route -- HMC on the wide MLP, the integrators' drift, ``Integrator.step`` -- goes through
+        ``gradient()``, so they all take it; ``forward()`` (and with it every parameter gradient) stays autograd."""
+        if not self.HIP_GRADIENT or model_kwargs or not x.is_cuda or x.dtype != torch.float32 or x.ndim != 2:
+            return None
+        if torch.is_autocast_enabled() or getattr(self, "use_mixed_precision", False):
+            return None
+        spec = fused_spec_for(self, x, None)
+        if spec is None:
+            return None
+        state = x.detach().contiguous()
+        if state.data_ptr() % 16 != 0 or state.shape[0] == 0:
+            return None
+        grad = torch.empty_like(state)
+        _lib.call("ebm_energy_grad_f32", spec.to_c(), state.data_ptr(), state.shape[0], state.shape[1], None, grad.data_ptr(),
+                  _lib.stream_handle(state.device))
+        return grad
 
     # ---- hook for the fused kernels ------------------------------------------------
     def fused_spec(self) -> Optional[FusedSpec]:
@@ -329,6 +356,7 @@ class MLPEnergy(BaseModel):
     """
 
     FUSED_HIDDEN = (64, 128, 256)
+    HIP_GRADIENT = True
     FUSED_MAX_DIM = 128
     HMC_HIDDEN, HMC_MAX_DIM = 128, 4
 
