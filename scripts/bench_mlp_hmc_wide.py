@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""HMC on the reference's benchmark MLP energy (benchmarks/registry.py:372-387) beyond the 2-D kernel: the
-per-transition route with the one-launch HIP gradient (MLPEnergy.gradient -> ebm_energy_grad_f32) against the same
-route on autograd (a subclass with its own forward), eager and as a replayed HIP graph."""
+"""HMC on the reference's benchmark MLP energy (benchmarks/registry.py:372-387) beyond the 2-D kernel: MLPEnergy (the
+transition kernel of csrc/mlp_wide_hmc.hip where it exists -- H 64 / 128 at dim <= 128, H 256 at dim <= 64 -- else the
+per-transition route with the one-launch HIP gradient) against the per-transition route on autograd (a subclass with
+its own forward), eager and as a replayed HIP graph."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,18 +28,19 @@ def wall(fn, reps=5, warm=3):
 
 
 n, T, L = 65536, 10, 10
-for dim, hidden in ((8, 128), (32, 128), (128, 128), (32, 256)):
+for dim, hidden in ((8, 128), (32, 128), (64, 128), (128, 128), (32, 64), (32, 256), (64, 256), (128, 256)):
     torch.manual_seed(0)
     fast = ta.MLPEnergy(dim, hidden, device=dev)
     slow = Sub(dim, hidden, device=dev)
     slow.load_state_dict(fast.state_dict())
     x = torch.randn(n, dim, device=dev)
     row = {"config": f"HMC on MLP {dim}-{hidden}-{hidden}-1, n={n}, L={L}, {T} transitions per call"}
-    for name, model in (("hip_gradient", fast), ("autograd", slow)):
+    for name, model in (("mlp_energy", fast), ("autograd", slow)):
         for graph in (False, True):
             s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=dev)
             s.capture_graph = graph
             row[f"{name}_{'graph' if graph else 'eager'}_ms_per_call"] = wall(lambda: s.sample(x=x, n_steps=T)) * 1e3
-    row["speedup_graph_routes"] = row["autograd_graph_ms_per_call"] / row["hip_gradient_graph_ms_per_call"]
-    row["mh_steps_per_s"] = n * T / (min(row["hip_gradient_graph_ms_per_call"], row["hip_gradient_eager_ms_per_call"]) * 1e-3)
+    row["speedup_graph_routes"] = row["autograd_graph_ms_per_call"] / row["mlp_energy_graph_ms_per_call"]
+    row["useful_TFLOPs"] = n * T * (L + 1) * 2 * (2 * hidden * hidden + 2 * dim * hidden) / (min(row["mlp_energy_graph_ms_per_call"], row["mlp_energy_eager_ms_per_call"]) * 1e-3) / 1e12
+    row["mh_steps_per_s"] = n * T / (min(row["mlp_energy_graph_ms_per_call"], row["mlp_energy_eager_ms_per_call"]) * 1e-3)
     print(json.dumps(row), flush=True)

@@ -31,7 +31,7 @@ def _models(cuda_device, in_dim, hidden, seed=0, scale=1.0):
 def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
     cpu, gpu = _models(cuda_device, in_dim, hidden, seed=in_dim + hidden, scale=1.5)
     spec = gpu.fused_spec()
-    assert spec is not None and spec.dim == in_dim and spec.hmc is False
+    assert spec is not None and spec.dim == in_dim and spec.hmc is (in_dim <= ta.MLPEnergy.HMC_MAX_DIM[hidden])
     n = 333  # not a multiple of the 32-chain tile
     x = torch.randn(n, in_dim, generator=torch.Generator().manual_seed(1)) * 1.5
     x_d = x.to(cuda_device)
@@ -100,16 +100,107 @@ def test_sampler_routes_and_native_rng_field(cuda_device):
         traj, diag = sf.sample(x=x0, n_steps=6, thin=2, return_trajectory=True, return_diagnostics=True)
         assert traj.shape == (1000, 3, in_dim) and torch.isfinite(traj).all()
         torch.testing.assert_close(diag["energy"][-1], fused_model(traj[:, -1]).mean(), rtol=1e-4, atol=1e-4)
-    # HMC on a wide MLP: the per-transition route (HIP kicks around autograd), never the 2-D kernel
-    h = ta.HamiltonianMonteCarlo(ta.MLPEnergy(8, 128, device=cuda_device), step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
+    # HMC on a wide MLP past the transition kernel's shapes: the per-transition route (HIP kicks around gradient())
+    h = ta.HamiltonianMonteCarlo(ta.MLPEnergy(100, 256, device=cuda_device), step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
     c0 = hip_calls("ebm_hmc_chain_f32")
-    out = h.sample(x=torch.randn(64, 8, device=cuda_device), n_steps=2)
+    out = h.sample(x=torch.randn(64, 100, device=cuda_device), n_steps=2)
     assert hip_calls("ebm_hmc_chain_f32") == c0 and torch.isfinite(out).all()
     with pytest.raises(RuntimeError, match="HMC on the fused MLP"):
-        spec = ta.MLPEnergy(8, 128, device=cuda_device).fused_spec()
-        xx = torch.zeros(4, 8, device=cuda_device)
-        _lib.call("ebm_hmc_chain_f32", spec.to_c(), xx.data_ptr(), 4, 8, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
+        spec = ta.MLPEnergy(100, 256, device=cuda_device).fused_spec()
+        xx = torch.zeros(4, 100, device=cuda_device)
+        _lib.call("ebm_hmc_chain_f32", spec.to_c(), xx.data_ptr(), 4, 100, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
                   None, None, 0, 0, _lib.stream_handle(cuda_device))
+
+
+class _CpuMlpEnergy:
+    def __init__(self, model):
+        self.model = model
+
+    def energy(self, x):
+        return self.model(x).detach()
+
+    def grad(self, x):
+        return self.model.gradient(x)
+
+
+@pytest.mark.parametrize("in_dim,hidden,mass", [(8, 128, None), (32, 128, 1.7), (30, 128, "diag"), (64, 128, None), (33, 64, "diag"),
+                                                (64, 64, 0.6), (5, 64, None), (32, 256, None), (17, 256, "diag"), (8, 256, 2.0),
+                                                (96, 128, None), (100, 128, "diag"), (128, 128, 1.3), (128, 64, "diag"), (90, 64, None),
+                                                (64, 256, None), (50, 256, "diag")])
+def test_wide_hmc_kernel_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden, mass):
+    """csrc/mlp_wide_hmc.hip through the C ABI against the oracle's HMC on the CPU autograd network: same momenta, same
+    uniforms, every mass form, thinning; accept decisions identical except within fp32 round-off of u."""
+    cpu, gpu = _models(cuda_device, in_dim, hidden, seed=10 + in_dim, scale=1.2)
+    n, T, L, eps = 515, 4, 5, 0.05
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(n, in_dim, generator=g)
+    p = torch.randn(T, n, in_dim, generator=g)
+    u = torch.rand(T, n, generator=g)
+    if mass == "diag":
+        mass = torch.rand(in_dim, generator=g) + 0.5
+    want = oracle.hmc_chain(_CpuMlpEnergy(cpu), x0, p, u, [eps] * T, L, mass=mass, thin=2, want_traj=True)
+    from torchebm_amd.integrators.symplectic import _mass_args
+
+    spec = gpu.fused_spec()
+    assert spec.hmc
+    x = x0.to(cuda_device).clone()
+    kind, m_scalar, m_diag = _mass_args(mass.to(cuda_device) if torch.is_tensor(mass) else mass, x)
+    traj = torch.empty(n, T // 2, in_dim, device=cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    counts = torch.zeros(T, dtype=torch.int32, device=cuda_device)
+    p_d, u_d = p.to(cuda_device).contiguous(), u.to(cuda_device).contiguous()
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, in_dim, T, L, eps, None, kind, m_scalar, _lib.ptr(m_diag), 2,
+              traj.data_ptr(), None, mask.data_ptr(), counts.data_ptr(), p_d.data_ptr(), u_d.data_ptr(), 0, 0,
+              _lib.stream_handle(cuda_device))
+    got_mask = mask.cpu().bool()
+    agree = (got_mask == want["accepted"]).all(dim=0)
+    assert agree.float().mean().item() >= 0.99
+    assert torch.equal(counts.cpu().long(), got_mask.sum(dim=1))
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    assert (err[agree] <= 2e-3).all()
+    assert torch.equal(traj[:, -1], x)
+
+
+@pytest.mark.parametrize("in_dim,hidden", [(16, 128), (48, 64), (32, 256), (128, 128), (100, 64), (64, 256)])
+def test_sampler_hmc_on_the_wide_mlp_is_one_launch_on_the_shared_field(cuda_device, in_dim, hidden):
+    class Sub(ta.MLPEnergy):
+        def forward(self, x):
+            return super().forward(x)
+
+    torch.manual_seed(4)
+    fused_model = ta.MLPEnergy(in_dim, hidden, device=cuda_device)
+    step_model = Sub(in_dim, hidden, device=cuda_device)
+    step_model.load_state_dict(fused_model.state_dict())
+    x0 = torch.randn(3000, in_dim, device=cuda_device)
+    kw = dict(step_size=0.05, n_leapfrog_steps=5, device=cuda_device)
+    hf, hs = ta.HamiltonianMonteCarlo(fused_model, **kw), ta.HamiltonianMonteCarlo(step_model, **kw)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    a = hf.sample(x=x0, n_steps=6, generator=torch.Generator(device=cuda_device).manual_seed(8))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    b = hs.sample(x=x0, n_steps=6, generator=torch.Generator(device=cuda_device).manual_seed(8))
+    same = ((a - b).abs().amax(dim=1) <= 5e-3).float().mean().item()
+    assert same >= 0.99, same
+    _, da = hf.sample(x=x0, n_steps=4, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    _, db = hs.sample(x=x0, n_steps=4, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(9))
+    torch.testing.assert_close(da["acceptance_rate"], db["acceptance_rate"], rtol=0, atol=3e-3)
+    torch.testing.assert_close(da["energy"], db["energy"], rtol=1e-3, atol=1e-3)
+
+
+def test_wide_hmc_safe_mode_on_extreme_states(cuda_device):
+    torch.manual_seed(1)
+    model = ta.MLPEnergy(24, 128, device=cuda_device)
+    x0 = torch.randn(200, 24, device=cuda_device)
+    x0[5] = 1e30
+    x0[70, 3] = float("inf")
+    x0[131, 20] = float("nan")
+    h = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=4, device=cuda_device)
+    out = h.sample(x=x0, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    ok = torch.ones(200, dtype=torch.bool, device=cuda_device)
+    ok[[5, 70, 131]] = False
+    assert torch.isfinite(out[ok]).all()
+    # the poisoned chains do not leak into their wave: the clean chains land where they land without them
+    clean = h.sample(x=x0[ok], n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    assert clean.shape == (197, 24)
 
 
 @pytest.mark.parametrize("in_dim", [32, 30, 128])
@@ -170,7 +261,7 @@ def test_gradient_is_one_hip_launch(cuda_device, in_dim, hidden):
 
 
 def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
-    """HMC on a wide MLP has no transition kernel: the per-transition route (HIP kicks around ``model.gradient``) now
+    """HMC on the H = 256 MLP past dim 64 has no transition kernel: the per-transition route (HIP kicks around ``model.gradient``) now
     evaluates each of its L + 1 forces in one launch.  Same momenta, same uniforms as the autograd route."""
 
     class Sub(ta.MLPEnergy):
@@ -178,10 +269,10 @@ def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
             return super().forward(x)
 
     torch.manual_seed(3)
-    fast = ta.MLPEnergy(16, 128, device=cuda_device)
-    slow = Sub(16, 128, device=cuda_device)
+    fast = ta.MLPEnergy(80, 256, device=cuda_device)
+    slow = Sub(80, 256, device=cuda_device)
     slow.load_state_dict(fast.state_dict())
-    x0 = torch.randn(2000, 16, device=cuda_device)
+    x0 = torch.randn(2000, 80, device=cuda_device)
     outs = []
     for model in (fast, slow):
         h = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=4, device=cuda_device)

@@ -350,7 +350,9 @@ class MLPEnergy(BaseModel):
     launch instead of one autograd round trip per step: the reference's benchmark network
     ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
     (benchmarks/registry.py:372-387) as well as the 2-D two-moons energy of its PCD example, which has a kernel
-    of its own (``hidden == 128``, ``in_dim <= 4``; that shape is also fused for ``HamiltonianMonteCarlo``).
+    of its own (``hidden == 128``, ``in_dim <= 4``).  ``HamiltonianMonteCarlo`` is fused -- all transitions of a call in
+    one ``ebm_hmc_chain_f32`` launch -- for hidden 64 / 128 at ``in_dim <= 128`` and hidden 256 at ``in_dim <= 64``; wider
+    inputs take the per-transition route with ``gradient()`` as one HIP launch.
     Training is unaffected: the parameters are ordinary ``nn.Linear`` weights and are re-read at every
     ``sample()`` call.
     """
@@ -358,7 +360,10 @@ class MLPEnergy(BaseModel):
     FUSED_HIDDEN = (64, 128, 256)
     HIP_GRADIENT = True
     FUSED_MAX_DIM = 128
-    HMC_HIDDEN, HMC_MAX_DIM = 128, 4
+    #: HamiltonianMonteCarlo's transition kernels: hidden width -> widest input (csrc/mlp.hip for 128 x dim <= 4,
+    #: csrc/mlp_wide_hmc.hip beyond: state, momentum and force ride in registers next to the evaluation's own; H = 256
+    #: keeps two hidden-width tile sets live and stops at two 32-column state tiles)
+    HMC_MAX_DIM = {64: 128, 128: 128, 256: 64}
 
     def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -407,7 +412,7 @@ class MLPEnergy(BaseModel):
                 self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
                 self.net[4].weight, self.net[4].bias)])
         return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True, dim=int(self.in_dim),
-                         hmc=(self.hidden == self.HMC_HIDDEN and self.in_dim <= self.HMC_MAX_DIM))
+                         hmc=self.in_dim <= self.HMC_MAX_DIM.get(self.hidden, 0))
 
 
 #: widest chain row the lane-group kernels (csrc/rows.h: pick_geometry) take

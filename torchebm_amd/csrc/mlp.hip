@@ -24,6 +24,11 @@
 namespace ebm {
 
 bool mlp_wide_supported(int32_t hidden, int32_t dim);
+bool mlp_wide_hmc_supported(int32_t hidden, int32_t dim);  // mlp_wide_hmc.hip
+int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
+                              int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
+                              const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                              const float* p_noise, const float* u, uint64_t seed, uint64_t offset, hipStream_t st, const char* who);
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
@@ -369,8 +374,8 @@ int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool small_on
   if (!e.dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
   if (mlp_small(e, dim)) return 0;
   if (small_only)
-    return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width %d and 1 <= dim <= %d (got %d, %d)", who, H, kMaxDim,
-                e.n_comp, dim);
+    return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width 64 / 128 at dim <= 128 and 256 at dim <= 64 (got %d, %d)",
+                who, e.n_comp, dim);
   if (!mlp_wide_supported(e.n_comp, dim))
     return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64, 128 or 256 and 1 <= dim <= 128 (got %d, %d)", who, e.n_comp, dim);
   return 0;
@@ -417,6 +422,10 @@ int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int3
                          int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
                          const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
   const char* who = "ebm_hmc_chain_f32";
+  if (!e.dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
+  if (!mlp_small(e, dim) && mlp_wide_hmc_supported(e.n_comp, dim))  // the wide evaluation inside the same state machine
+    return launch_hmc_chain_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                     mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st, who);
   if (int r = mlp_check(e, dim, who, true)) return r;
   MlpHmcArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;

@@ -128,43 +128,7 @@ __device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval b
 
 template <int HT, int DT, bool STREAM>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
-  constexpr int H = 32 * HT, DP = 32 * DT;  // hidden width, padded input width
-  constexpr int S1 = DP + 1, S2 = H + 1;    // LDS row strides
-  // LDS: the padded weights, or (STREAM) the parked s1 = silu'(a1): [16 HT][kBlock], one word per lane per slot
-  float* W2s = wide_smem;                                        // [H][S2]
-  float* W1s = W2s + H * S2;                                     // [H][S1], columns >= dim zero
-  float* b1s = STREAM ? wide_smem : W1s + H * S1;                // [H]  (STREAM: first, inside the 64 KiB an LDS offset field reaches)
-  float* park = wide_smem + 3 * H;                               // STREAM
-  float* b2s = b1s + H;
-  float* w3s = b2s + H;
-  const int dim = a.dim;
-  const float* W1g = a.params;
-  const float* b1g = W1g + H * dim;
-  const float* W2g = b1g + H;
-  {  // stage the weights (once per launch)
-    const float* b2g = W2g + H * H;
-    const float* w3g = b2g + H;
-    if constexpr (!STREAM) {
-      for (int i = threadIdx.x; i < H * H; i += kBlock) W2s[(i / H) * S2 + (i % H)] = W2g[i];
-      for (int i = threadIdx.x; i < H * DP; i += kBlock) {
-        const int row = i / DP, c = i - row * DP;
-        W1s[row * S1 + c] = c < dim ? W1g[row * dim + c] : 0.0f;
-      }
-    }
-    for (int i = threadIdx.x; i < H; i += kBlock) {
-      b1s[i] = b1g[i];
-      b2s[i] = b2g[i];
-      w3s[i] = w3g[i];
-    }
-    __syncthreads();
-  }
-  const float b3 = a.params[H * dim + H + H * H + H + H];
-
-  const int lane = threadIdx.x & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int64_t sample = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
-  const bool active = sample < a.n_chains;
-  const bool quads = (dim & 3) == 0;  // a register quad r = 4q .. 4q+3 is four consecutive, 16-byte aligned columns
+#include "mlp_wide_setup.inc"
 
   // the state in the C/D layout: xr[td][r] = x[sample][32 td + row_of(r, h)], zero beyond dim
   float xr[DT][16];
@@ -188,144 +152,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   const int n_evals = a.k_steps > 0 ? a.k_steps : 1;
 
   for (int step = 0; step < n_evals; ++step) {
-    // STREAM: the weight loads do not depend on the step -- opaque bases keep them from being hoisted out of the loop
-    // (thousands of values) instead of being re-read from L2 just ahead of their MFMAs
-    typedef const float __attribute__((address_space(1))) * gptr;  // a laundered pointer is generic: say "global" again
-    const float* W1o = W1g;
-    const float* W2o = W2g;
-    if constexpr (STREAM) asm volatile("" : "+s"(W1o), "+s"(W2o));
-    const gptr W1p = (gptr)W1o, W2p = (gptr)W2o;
-    int ms = m, hs = h;  // ... and so do the lane parts of the addresses (hundreds of hoisted offsets would spill)
-    if constexpr (STREAM) asm volatile("" : "+v"(ms), "+v"(hs));
-    // Every address = uniform pointer (scalar unit: weight base + the compile-time part) + one 32-bit lane byte offset --
-    // the SGPR-base form of global_load, no vector arithmetic per load (the exact-f32 MFMA shares the VALU's lanes).
-    typedef const char __attribute__((address_space(1))) * gbytes;
-    const uint32_t lane_f2 = (uint32_t)(ms * H + 4 * hs) * 4u, lane_b2 = (uint32_t)(4 * hs * H + ms) * 4u;
-    const uint32_t lane_f1 = (uint32_t)(ms * dim + 4 * hs) * 4u, lane_b1 = (uint32_t)(4 * hs * dim + ms) * 4u;
-    // ------------------------------------------------------------ layer 1: a1^T tiles, K = input columns
-    f32x16 u[HT];  // a1, then h1 = silu(a1)
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) u[t][r] = 0.0f;
-    if constexpr (STREAM) {
-      // branch-free: a column past dim is read where it falls (the next row -- still inside the parameter block: W2
-      // follows) and zeroed afterwards (a load behind a branch ends the prefetch: the wait counts drain at block ends)
-      const auto xb = [&](int tk, int r) { return xr[tk][r]; };
-      if (quads) {
-        contract_rows<HT, DT, 2>(
-            u,
-            [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-              constexpr int cu = 32 * decltype(tk_)::value + 8 * decltype(q_)::value;
-              const f32x4 w = *(gptr4)((gbytes)(W1p + (uint32_t)(32 * decltype(t_)::value * dim + cu)) + lane_f1);
-              const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-              return cu + 4 * hs < dim ? w : z;
-            },
-            xb);
-      } else {
-        contract_rows<HT, DT, 2>(
-            u,
-            [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-              constexpr int cu = 32 * decltype(tk_)::value + 8 * decltype(q_)::value;
-              const gptr src = (gptr)((gbytes)(W1p + (uint32_t)(32 * decltype(t_)::value * dim + cu)) + lane_f1);
-              f32x4 w;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float v = src[i];
-                w[i] = cu + 4 * hs + i < dim ? v : 0.0f;
-              }
-              return w;
-            },
-            xb);
-      }
-    } else {
-      contract<HT, DT>(u, W1s, [&](int t, int tk, int r) { return (32 * t + m) * S1 + 32 * tk + row_of(r, h); },
-                       [&](int tk, int r) { return xr[tk][r]; });
-    }
-    f32x16 s1[STREAM ? 1 : HT];  // silu'(a1) (STREAM: parked in LDS)
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a1 = u[t][r] + b1s[32 * t + row_of(r, h)];
-        const float sg = sigmoid_fast(a1);
-        u[t][r] = a1 * sg;
-        const float ds = sg * (1.0f + a1 * (1.0f - sg));
-        if constexpr (STREAM) park[(16 * t + r) * kBlock + threadIdx.x] = ds;
-        else s1[t][r] = ds;
-      }
-    // ------------------------------------------------------------ layer 2: a2^T tiles, K = hidden units of layer 1
-    f32x16 v[HT];  // a2, then d2 = w3 * silu'(a2)
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[t][r] = 0.0f;
-    if constexpr (STREAM) {
-      contract_rows<HT, HT, 2>(
-          v,
-          [&](auto t_, auto tk_, auto q_) __attribute__((always_inline)) {
-            return *(gptr4)((gbytes)(W2p + (32 * decltype(t_)::value * H + 32 * decltype(tk_)::value + 8 * decltype(q_)::value)) + lane_f2);
-          },
-          [&](int tk, int r) { return u[tk][r]; });
-    } else {
-      contract<HT, HT>(v, W2s, [&](int t, int tk, int r) { return (32 * t + m) * S2 + 32 * tk + row_of(r, h); },
-                       [&](int tk, int r) { return u[tk][r]; });
-    }
-    float e_part = 0.0f;
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = 32 * t + row_of(r, h);
-        const float a2 = v[t][r] + b2s[j];
-        const float sg = sigmoid_fast(a2);
-        const float w3 = w3s[j];
-        e_part = __builtin_fmaf(w3, a2 * sg, e_part);
-        v[t][r] = w3 * (sg * (1.0f + a2 * (1.0f - sg)));
-      }
-    // ------------------------------------------------------------ backward through W2: T^T tiles, K = units of layer 2
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) u[t][r] = 0.0f;
-    if constexpr (STREAM) {
-      contract_cols<HT, HT, 4>(
-          u,
-          [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
-            return *(gptr)((gbytes)(W2p + ((32 * decltype(tk_)::value + row_of(decltype(r_)::value, 0)) * H + 32 * decltype(t_)::value)) + lane_b2);
-          },
-          [&](int tk, int r) { return v[tk][r]; });
-    } else {
-      contract<HT, HT>(u, W2s, [&](int t, int tk, int r) { return (32 * tk + row_of(r, h)) * S2 + 32 * t + m; },
-                       [&](int tk, int r) { return v[tk][r]; });
-    }
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {  // d1
-        if constexpr (STREAM) u[t][r] *= park[(16 * t + r) * kBlock + threadIdx.x];
-        else u[t][r] *= s1[t][r];
-      }
-    // ------------------------------------------------------------ backward through W1: g^T tiles, K = units of layer 1
-    f32x16 g[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) g[t][r] = 0.0f;
-    if constexpr (STREAM) {
-      contract_cols<DT, HT, (DT >= 4 ? 6 : (DT >= 2 ? 10 : 16))>(
-          g,
-          [&](auto t_, auto tk_, auto r_) __attribute__((always_inline)) {
-            const float w = *(gptr)((gbytes)(W1p + (uint32_t)((32 * decltype(tk_)::value + row_of(decltype(r_)::value, 0)) * dim +
-                                                                32 * decltype(t_)::value)) + lane_b1);
-            return 32 * decltype(t_)::value + ms < dim ? w : 0.0f;
-          },
-          [&](int tk, int r) { return u[tk][r]; });
-    } else {
-      contract<DT, HT>(g, W1s, [&](int t, int tk, int r) { return (32 * tk + row_of(r, h)) * S1 + 32 * t + m; },
-                       [&](int tk, int r) { return u[tk][r]; });
-    }
-    const float energy = e_part + __shfl_xor(e_part, 32) + b3;  // the two K-halves hold the two halves of the rows
+#include "mlp_wide_eval.inc"
 
     if (a.k_steps == 0) {  // evaluation only
       if (active) {
