@@ -407,6 +407,22 @@ def extra_measurements(device, valu_rate):
                 "algorithmic_bytes_per_launch": 12 * n, "kernel_ms": kms, "value": gbs, "peak": HBM_PEAK_GBS,
                 "frac": gbs / HBM_PEAK_GBS}
 
+    def wide(hidden, kind, n=65536, dim=32):
+        # the same network at another hidden width (256: weights streamed from L2), Langevin k = 20 or HMC L = 10, 10 transitions
+        torch.manual_seed(0)
+        m = ta.MLPEnergy(dim, hidden, device=device)
+        x0 = torch.randn(n, dim, device=device)
+        if kind == "langevin":
+            s, sym, evals = ta.LangevinDynamics(m, step_size=0.05, device=device), "ebm_langevin_chain_f32", 20
+            fn = lambda: s.sample(x=x0, n_steps=20)  # noqa: E731
+        else:
+            s, sym, evals = ta.HamiltonianMonteCarlo(m, step_size=0.05, n_leapfrog_steps=10, device=device), "ebm_hmc_chain_f32", 110
+            fn = lambda: s.sample(x=x0, n_steps=10)  # noqa: E731
+        timed(fn, reps=2, warm=2, device=device)
+        kms = kernel_ms_of(sym, fn, 3, device)
+        tf = n * evals * 2 * (2 * hidden * hidden + 2 * dim * hidden) / (kms * 1e-3) / 1e12
+        return {"kernel_ms": kms, "evaluations_per_launch": evals, "TFLOPs": tf, "frac": tf / FP32_MATRIX_PEAK_TFLOPS}
+
     def mlp_bench_net():
         # the reference's benchmark network (benchmarks/registry.py:372-387) at dim 32: Langevin chain fused on fp32 MFMA
         n, k, dim, hidden = 65536, 20, 32, 128
@@ -422,7 +438,8 @@ def extra_measurements(device, valu_rate):
                 "SiLU-Linear(128,1) (the reference's benchmarks/registry.py network), n_chains=65536, k=20: forward + input gradient + "
                 "update fused, four contractions on v_mfma_f32_32x32x2_f32", "metric": "TFLOP/s (exact fp32 matrix)", "bound": "mfma",
                 "kernel_ms": kms, "value": flops / (kms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                "frac": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3)}
+                "frac": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3),
+                "hidden_256": wide(256, "langevin"), "hmc_hidden_128": wide(128, "hmc"), "hmc_hidden_256": wide(256, "hmc")}
 
     guarded("config3_hmc_gmm8", c3)
     guarded("config4_shard", c4)
