@@ -284,3 +284,23 @@ def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
     close = ((outs[0][0] - outs[1][0]).abs().amax(dim=1) <= 2e-3).float().mean().item()
     assert close >= 0.995, close  # a Metropolis tie may flip on a summation-order difference
     torch.testing.assert_close(outs[0][1]["acceptance_rate"], outs[1][1]["acceptance_rate"], rtol=0, atol=5e-3)
+
+
+def test_streamed_weights_must_be_16_byte_aligned(cuda_device):
+    """H = 256 reads its weights with 16-byte loads straight from the parameter block: a misaligned block is refused by
+    the C ABI (EBM_EINVAL -> ValueError), never read."""
+    from torchebm_amd.core.energies import FusedSpec
+
+    model = ta.MLPEnergy(32, 256, device=cuda_device)
+    good = model.fused_spec()
+    shifted = torch.empty(good.dev0.numel() + 1, device=cuda_device)
+    shifted[1:] = good.dev0
+    bad = FusedSpec(_lib.ENERGY_MLP, n_comp=256, dev0=shifted[1:], langevin_only=True, dim=32, hmc=True)
+    x = torch.zeros(64, 32, device=cuda_device)
+    with pytest.raises((ValueError, RuntimeError), match="16-byte aligned"):
+        _lib.call("ebm_langevin_chain_f32", bad.to_c(), x.data_ptr(), 64, 32, 2, 0.01, 0.1, 1.0, None, 0, 0.0, 0.0, 1, None, None, None, 0, 0,
+                  _lib.stream_handle(cuda_device))
+    with pytest.raises((ValueError, RuntimeError), match="16-byte aligned"):
+        _lib.call("ebm_hmc_chain_f32", bad.to_c(), x.data_ptr(), 64, 32, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
+                  None, None, 0, 0, _lib.stream_handle(cuda_device))
+    assert torch.equal(x, torch.zeros_like(x))
