@@ -304,3 +304,35 @@ def test_streamed_weights_must_be_16_byte_aligned(cuda_device):
         _lib.call("ebm_hmc_chain_f32", bad.to_c(), x.data_ptr(), 64, 32, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
                   None, None, 0, 0, _lib.stream_handle(cuda_device))
     assert torch.equal(x, torch.zeros_like(x))
+
+
+@pytest.mark.parametrize("in_dim,hidden", [(20, 128), (70, 64), (40, 256)])
+def test_wide_hmc_edge_shapes_schedule_and_prefix_identity(cuda_device, in_dim, hidden):
+    """One chain, a batch that is not a multiple of the 32-chain tile, a scheduled step size with thinning that does not
+    divide the transitions, and prefix identity: a chain's native-RNG trajectory depends on its index and the seed only,
+    not on how many other chains share the launch."""
+    from torchebm_amd.core import LinearScheduler
+
+    torch.manual_seed(7)
+    model = ta.MLPEnergy(in_dim, hidden, device=cuda_device)
+    x0 = torch.randn(161, in_dim, device=cuda_device)
+
+    def run(x, **kw):
+        h = ta.HamiltonianMonteCarlo(model, step_size=LinearScheduler(0.08, 0.03, 5), n_leapfrog_steps=3, device=cuda_device)
+        c0 = hip_calls("ebm_hmc_chain_f32")
+        out = h.sample(x=x, n_steps=5, generator=torch.Generator(device=cuda_device).manual_seed(21), **kw)
+        assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+        return out
+
+    full = run(x0, thin=2, return_trajectory=True)
+    assert full.shape == (161, 2, in_dim) and torch.isfinite(full).all()
+    again = run(x0, thin=2, return_trajectory=True)
+    assert torch.equal(full, again)                                   # deterministic
+    for n in (1, 33, 128):
+        part = run(x0[:n].clone(), thin=2, return_trajectory=True)
+        assert torch.equal(part, full[:n])                            # prefix identity
+    last = run(x0)
+    assert last.shape == (161, in_dim) and not torch.equal(last, x0)
+    # the kept states are transitions 2 and 4; the final state (after 5) differs from the last kept one for most chains
+    assert (last != full[:, -1]).any(dim=1).float().mean().item() > 0.5
+    assert torch.equal(x0, x0.clone())                                # the caller's tensor is not the in/out buffer
