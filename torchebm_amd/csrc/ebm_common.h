@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/ebm_hip.h"
 
 namespace ebm {
@@ -19,6 +21,18 @@ namespace ebm {
 void set_error(const char* fmt, ...);  // api.hip
 int  fail(int code, const char* fmt, ...);
 int  check_launch(const char* what);
+
+// first() is true once per device: function attributes (the > 64 KiB dynamic-LDS opt-in) are per device, and one process
+// may drive several (a `static bool` would leave every device after the first without the opt-in).  Lock-free.
+struct DeviceOnce {
+  std::atomic<uint64_t> seen{0};
+  bool first() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return (seen.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+  }
+};
 
 // ---------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Known-answer vectors are checked in

@@ -364,15 +364,14 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
   // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
   static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
   const size_t smem = (f32_mfma ? (size_t)(32 * NT) * (32 * NT) * sizeof(float) : gauss3::aop_bytes(NT)) + 32 * NT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
+  if (attr_once.first() && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_mfma_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
@@ -435,13 +434,12 @@ namespace {
 template <int NT, int GKR>
 int launch_gmm_langevin(const GaussArgs& a, hipStream_t st) {
   const size_t smem = (size_t)gmm3::Mixture<NT, GKR>::kLdsFloats * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
+  if (attr_once.first() && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_langevin_bf16x3_kernel<NT, GKR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_langevin_bf16x3_fast_kernel<NT, GKR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
@@ -502,11 +500,10 @@ int launch_matrix_diag(GaussArgs& a, hipStream_t st) {
                                        : gauss3::aop_bytes(NT) / sizeof(float) + 32 * NT;
   a.diag_offset_floats = (int)energy_floats;
   const size_t smem = (energy_floats + (size_t)diag::lds_floats(a.diag.E, a.diag.S)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
+  if (attr_once.first() && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_langevin_diag_kernel<NT, GKR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");

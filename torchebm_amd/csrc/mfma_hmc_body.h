@@ -475,11 +475,10 @@ int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   // and with records the tile + scratch rows of diag::emit
   const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + (E::kCarry ? 16 * NT * kBlock : 0) +
                                (DIAG ? diag::lds_floats(a.diag.E, a.diag.S) : 0)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
+  if (attr_once.first() && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");

@@ -382,12 +382,11 @@ int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool small_on
 }
 
 int mlp_launch(const MlpArgs& a, hipStream_t st, const char* who) {
-  static bool attr_set = false;
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   const size_t smem = mlp_smem_bytes();
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+  if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_langevin_chain_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
@@ -437,12 +436,11 @@ int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int3
   a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.params = e.dev0;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   const size_t smem = mlp_smem_bytes();
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+  if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_hmc_chain_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);

@@ -251,11 +251,10 @@ int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
   const size_t smem = (size_t)(STREAM ? 16 * HT * kBlock + 3 * H : H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
+  if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_chain_kernel<HT, DT, STREAM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
