@@ -40,6 +40,9 @@ for dim, hidden in ((8, 128), (32, 128), (64, 128), (128, 128), (32, 64), (32, 2
             s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=dev)
             s.capture_graph = graph
             row[f"{name}_{'graph' if graph else 'eager'}_ms_per_call"] = wall(lambda: s.sample(x=x, n_steps=T)) * 1e3
+    s = ta.HamiltonianMonteCarlo(slow, step_size=0.05, n_leapfrog_steps=L, device=dev)
+    s.capture_graph, s.carry_force = True, True   # opt-in: L + 1 gradient evaluations per transition instead of 2 L
+    row["autograd_graph_carry_force_ms_per_call"] = wall(lambda: s.sample(x=x, n_steps=T)) * 1e3
     row["speedup_graph_routes"] = row["autograd_graph_ms_per_call"] / row["mlp_energy_graph_ms_per_call"]
     row["useful_TFLOPs"] = n * T * (L + 1) * 2 * (2 * hidden * hidden + 2 * dim * hidden) / (min(row["mlp_energy_graph_ms_per_call"], row["mlp_energy_eager_ms_per_call"]) * 1e-3) / 1e12
     row["mh_steps_per_s"] = n * T / (min(row["mlp_energy_graph_ms_per_call"], row["mlp_energy_eager_ms_per_call"]) * 1e-3)

@@ -181,3 +181,36 @@ def test_hmc_full_size_config3(cuda_device):
     b = s.sample(x=x0, n_steps=4, generator=torch.Generator(device=cuda_device).manual_seed(5))
     assert torch.equal(a, b) and torch.isfinite(a).all()
     assert (d["acceptance_rate"] > 0.97).all(), d["acceptance_rate"]
+
+
+def test_step_route_carry_force_halves_the_gradient_calls(cuda_device):
+    """``HamiltonianMonteCarlo.carry_force`` (opt-in, step route): the force a leapfrog step ends on starts the next one --
+    L + 1 gradient evaluations per transition instead of 2 L, the same chains for a deterministic energy (eager and
+    graph-replayed)."""
+
+    class Counting(ta.DoubleWellModel):
+        calls = 0
+
+        def forward(self, x):
+            return super().forward(x)
+
+        def gradient(self, x, model_kwargs=None):
+            type(self).calls += 1
+            return super().gradient(x, model_kwargs)
+
+    x0 = torch.randn(3000, 24, device=cuda_device)
+    L, T = 6, 5
+    outs = {}
+    for carry in (False, True):
+        for graph in (False, True):
+            model = Counting(device=cuda_device)
+            assert model.fused_spec() is None
+            h = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=cuda_device)
+            h.carry_force, h.capture_graph = carry, graph
+            Counting.calls = 0
+            outs[carry, graph] = h.sample(x=x0, n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(3))
+            if not graph:
+                assert Counting.calls == T * ((L + 1) if carry else 2 * L)
+    assert torch.equal(outs[False, False], outs[True, False])
+    assert torch.equal(outs[False, False], outs[False, True])
+    assert torch.equal(outs[False, False], outs[True, True])

@@ -43,13 +43,14 @@ class LeapfrogIntegrator(BaseSymplecticIntegrator):
         super().__init__(device=device, dtype=dtype)
 
     # ---- one step on the HIP path -----------------------------------------------------
-    def _hip_step(self, x, p, eps: float, mass: Mass, drift_fn: Drift, t, safe: bool):
+    def _hip_step(self, x, p, eps: float, mass: Mass, drift_fn: Drift, t, safe: bool, force=None):
         xin, pin = _lib.dense_f32(x), _lib.dense_f32(p)
         kind, m_scalar, m_diag = _mass_args(mass, xin)
         n_chains = xin.shape[0]
         dim = xin.numel() // max(n_chains, 1)
         stream = _lib.stream_handle(x.device)
-        force = _lib.dense_f32(drift_fn(x, t))
+        if force is None:  # else: the force the previous step ended on (same position), carried by the caller's opt-in
+            force = _lib.dense_f32(drift_fn(x, t))
         x_new, p_half = torch.empty_like(xin), torch.empty_like(pin)
         _lib.call(
             "ebm_leapfrog_kick_drift_f32",
@@ -63,7 +64,7 @@ class LeapfrogIntegrator(BaseSymplecticIntegrator):
             _lib.ptr(x_new), _lib.ptr(p_half), _lib.ptr(force_new), _lib.ptr(p_new),
             xin.numel(), eps, int(safe), stream,
         )
-        return x_new.view_as(x), p_new.view_as(p)
+        return x_new.view_as(x), p_new.view_as(p), force_new
 
     # ---- one step with eager torch ops (CPU states) -------------------------------------
     def _eager_step(self, x, p, eps_t, mass: Mass, drift_fn: Drift, t, safe: bool):
@@ -97,9 +98,15 @@ class LeapfrogIntegrator(BaseSymplecticIntegrator):
                 "by the HIP kernels; running eager torch ops on the GPU.",
                 UserWarning,
             )
+        # ``carry_force`` (an attribute the owning sampler may set, default off): the force at the end of a step is the
+        # force at the start of the next -- L + 1 drift evaluations per trajectory instead of the reference's 2 L.  Identical
+        # for a deterministic drift on finite states; with ``safe=True`` a position the kick kernel had to scrub keeps
+        # the force of the unscrubbed position for one step where the reference re-evaluates.
+        carried = None
         for _ in range(n_steps):
             if hip:
-                x, p = self._hip_step(x, p, float(step_size), mass, drift_fn, t, safe)
+                x, p, last = self._hip_step(x, p, float(step_size), mass, drift_fn, t, safe, carried)
+                carried = last if getattr(self, "carry_force", False) else None
             else:
                 x, p = self._eager_step(x, p, eps_t, mass, drift_fn, t, safe)
         return {"x": x, "p": p}
