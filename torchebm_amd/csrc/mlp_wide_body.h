@@ -1,4 +1,7 @@
-// Kernel body of mlp_wide.hip / mlp_stream.hip (the two translation units compile in parallel): see mlp_wide.hip.
+// Kernel body of the wide-MLP kernels -- see mlp_wide.hip for the design.  Three translation units instantiate it so that
+// they compile in parallel: mlp_wide.hip (H = 64 / 128, weights in LDS), mlp_stream.hip (H = 256, weights streamed from
+// L2), mlp_wide_hmc.hip (the HMC transition kernel).  The workgroup set-up and the evaluation itself are text shared by
+// the chain kernel here and the HMC state machine: mlp_wide_setup.inc, mlp_wide_eval.inc.
 #pragma once
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"  // static_for
