@@ -71,8 +71,13 @@ using gauss3::static_for;
 // is one (t, tk): its four loads go out back to back, so every 128-byte line they touch is fetched from L2 once (a
 // stage built across tiles instead re-fetched each line four times -- the L1 does not hold 4 waves x 16 KB), and feed
 // 16 accumulations into ONE tile (the matrix pipe forwards a back-to-back accumulator); requested PF stages ahead.
-template <int NT, int NK, int PF, class Ld4, class Bval>
-__device__ __forceinline__ void contract_rows(f32x16 (&out)[NT], Ld4 ld4, Bval bval) {
+struct NoFix {
+  template <class... A>
+  __device__ __forceinline__ float operator()(float v, A...) const { return v; }
+};
+
+template <int NT, int NK, int PF, class Ld4, class Bval, class Fix = NoFix>
+__device__ __forceinline__ void contract_rows(f32x16 (&out)[NT], Ld4 ld4, Bval bval, Fix fix = Fix{}) {
   constexpr int NS = NT * NK;
   f32x4 buf[PF + 1][4];
   static_for<(PF < NS ? PF : NS)>([&](auto s_) __attribute__((always_inline)) {
@@ -92,7 +97,10 @@ __device__ __forceinline__ void contract_rows(f32x16 (&out)[NT], Ld4 ld4, Bval b
     constexpr int t = s / NK, tk = s % NK;
     static_for<16>([&](auto r_) __attribute__((always_inline)) {
       constexpr int r = decltype(r_)::value;
-      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[s % (PF + 1)][r >> 2][r & 3], bval(tk, r), out[t], 0, 0, 0);
+      // fix(): what has to happen to a loaded word (zeroing a padding column) happens HERE, at its use -- applied where the
+      // load is issued it would make every stage wait for the request it has just made
+      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fix(buf[s % (PF + 1)][r >> 2][r & 3], std::integral_constant<int, tk>{}, r_), bval(tk, r),
+                                                    out[t], 0, 0, 0);
     });
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -100,8 +108,8 @@ __device__ __forceinline__ void contract_rows(f32x16 (&out)[NT], Ld4 ld4, Bval b
 
 // STREAM, transposed walk: ld1(t, tk, r) -> the A word of output tile t at K-step (tk, r) (one coalesced dword load);
 // a stage = one K-step = NT loads feeding NT MFMAs, requested PF stages ahead.
-template <int NT, int NK, int PF, class Ld1, class Bval>
-__device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval bval) {
+template <int NT, int NK, int PF, class Ld1, class Bval, class Fix = NoFix>
+__device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval bval, Fix fix = Fix{}) {
   constexpr int NS = NK * 16;
   float buf[PF + 1][NT];
   static_for<(PF < NS ? PF : NS)>([&](auto s_) __attribute__((always_inline)) {
@@ -123,7 +131,7 @@ __device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval b
     const float b = bval(s / 16, s & 15);
     static_for<NT>([&](auto t_) __attribute__((always_inline)) {
       constexpr int t = decltype(t_)::value;
-      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[s % (PF + 1)][t], b, out[t], 0, 0, 0);
+      out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fix(buf[s % (PF + 1)][t], t_), b, out[t], 0, 0, 0);
     });
     __builtin_amdgcn_sched_barrier(0);
   });
