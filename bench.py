@@ -256,8 +256,8 @@ def extra_measurements(device, valu_rate):
         dense = ta.GaussianMixtureModel(torch.randn(8, dim, generator=gd) * 2.0, sigma=1.0, device=device)
         sd = ta.HamiltonianMonteCarlo(dense, step_size=0.1, n_leapfrog_steps=L, device=device)
         fd = lambda: sd.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
-        kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 3, device)
         td = timed(fd, reps=3, warm=1, device=device)
+        kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 3, device)
         dense_flops = evals * (2 * 2 * 8 * dim) + n * T * L * 6 * dim
         return {
             "name": "config3_hmc_gmm8", "workload": "HamiltonianMonteCarlo.sample, L=20, 8-mode GaussianMixture, n_chains=2^18, dim=32, "
