@@ -160,6 +160,7 @@ chain_case("chain_gmm8_dim32", ta.core.ring_mixture(8, 32, device=dev), 1 << 18,
 step_case("step_native_rng_2^26", 1 << 26)
 step_case("step_noise_ptr_2^26", 1 << 26, noise_ptr=True)
 torch.manual_seed(0)
+chain_case("chain_mlp_2_128", ta.MLPEnergy(2, 128, device=dev), 1 << 16, 2, 20)
 chain_case("chain_mlp_32_128", ta.MLPEnergy(32, 128, device=dev), 1 << 16, 32, 20)
 chain_case("chain_mlp_32_256", ta.MLPEnergy(32, 256, device=dev), 1 << 16, 32, 20)
 hmc_case("hmc_mlp_32_128", ta.MLPEnergy(32, 128, device=dev), 1 << 16, 32, 10, 10, 0.05)
