@@ -66,8 +66,8 @@ enum {
                                  n_comp = hidden width H (64, 128 or 256), dim <= 128 (the reference's benchmark network
                                  benchmarks/registry.py:372-387 at dim 8 / 32 / 128),
                                  dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
-                                 Supported by ebm_langevin_chain_f32 and ebm_energy_grad_f32; by ebm_hmc_chain_f32 for
-                                 H = 64 / 128 at dim <= 128 and H = 256 at dim <= 64 (EBM_EDIM otherwise).  H = 256 reads
+                                 Supported by ebm_langevin_chain_f32, ebm_energy_grad_f32 and ebm_hmc_chain_f32 (EBM_EDIM for
+                                 other widths).  H = 256 reads
                                  the weights from dev0 throughout the launch: dev0 must then be 16-byte aligned.           */
 };
 

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """HMC on the reference's benchmark MLP energy (benchmarks/registry.py:372-387) beyond the 2-D kernel: MLPEnergy (the
-transition kernel of csrc/mlp_wide_hmc.hip where it exists -- H 64 / 128 at dim <= 128, H 256 at dim <= 64 -- else the
-per-transition route with the one-launch HIP gradient) against the per-transition route on autograd (a subclass with
+transition kernel of csrc/mlp_wide_hmc.hip / mlp_stream_hmc.hip: H 64 / 128 / 256 at dim <= 128) against the per-transition route on autograd (a subclass with
 its own forward), eager and as a replayed HIP graph."""
 import json, os, sys, time
 import torch

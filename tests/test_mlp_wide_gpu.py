@@ -100,16 +100,19 @@ def test_sampler_routes_and_native_rng_field(cuda_device):
         traj, diag = sf.sample(x=x0, n_steps=6, thin=2, return_trajectory=True, return_diagnostics=True)
         assert traj.shape == (1000, 3, in_dim) and torch.isfinite(traj).all()
         torch.testing.assert_close(diag["energy"][-1], fused_model(traj[:, -1]).mean(), rtol=1e-4, atol=1e-4)
-    # HMC on a wide MLP past the transition kernel's shapes: the per-transition route (HIP kicks around gradient())
-    h = ta.HamiltonianMonteCarlo(ta.MLPEnergy(100, 256, device=cuda_device), step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
-    c0 = hip_calls("ebm_hmc_chain_f32")
-    out = h.sample(x=torch.randn(64, 100, device=cuda_device), n_steps=2)
-    assert hip_calls("ebm_hmc_chain_f32") == c0 and torch.isfinite(out).all()
-    with pytest.raises(RuntimeError, match="HMC on the fused MLP"):
-        spec = ta.MLPEnergy(100, 256, device=cuda_device).fused_spec()
-        xx = torch.zeros(4, 100, device=cuda_device)
-        _lib.call("ebm_hmc_chain_f32", spec.to_c(), xx.data_ptr(), 4, 100, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
+    # every shape the Langevin kernels take has an HMC transition kernel too; other hidden widths are refused by the C ABI
+    from torchebm_amd.core.energies import FusedSpec
+
+    odd = FusedSpec(_lib.ENERGY_MLP, n_comp=96, dev0=torch.zeros(96 * 8 + 96 + 96 * 96 + 96 + 96 + 1, device=cuda_device), langevin_only=True, dim=8)
+    xx = torch.zeros(4, 8, device=cuda_device)
+    with pytest.raises((RuntimeError, ValueError), match="hidden width"):
+        _lib.call("ebm_hmc_chain_f32", odd.to_c(), xx.data_ptr(), 4, 8, 1, 1, 0.01, None, 0, 0.0, None, 1, None, None, None, None,
                   None, None, 0, 0, _lib.stream_handle(cuda_device))
+    # a hidden width outside 64 / 128 / 256 through the sampler: the per-transition route on autograd
+    h = ta.HamiltonianMonteCarlo(ta.MLPEnergy(8, 96, device=cuda_device), step_size=0.05, n_leapfrog_steps=3, device=cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    out = h.sample(x=torch.randn(64, 8, device=cuda_device), n_steps=2)
+    assert hip_calls("ebm_hmc_chain_f32") == c0 and torch.isfinite(out).all()
 
 
 class _CpuMlpEnergy:
@@ -126,7 +129,7 @@ class _CpuMlpEnergy:
 @pytest.mark.parametrize("in_dim,hidden,mass", [(8, 128, None), (32, 128, 1.7), (30, 128, "diag"), (64, 128, None), (33, 64, "diag"),
                                                 (64, 64, 0.6), (5, 64, None), (32, 256, None), (17, 256, "diag"), (8, 256, 2.0),
                                                 (96, 128, None), (100, 128, "diag"), (128, 128, 1.3), (128, 64, "diag"), (90, 64, None),
-                                                (64, 256, None), (50, 256, "diag")])
+                                                (64, 256, None), (50, 256, "diag"), (96, 256, None), (100, 256, "diag"), (128, 256, 0.8)])
 def test_wide_hmc_kernel_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden, mass):
     """csrc/mlp_wide_hmc.hip through the C ABI against the oracle's HMC on the CPU autograd network: same momenta, same
     uniforms, every mass form, thinning; accept decisions identical except within fp32 round-off of u."""
@@ -161,7 +164,7 @@ def test_wide_hmc_kernel_matches_cpu_autograd_chain_with_injected_noise(cuda_dev
     assert torch.equal(traj[:, -1], x)
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(16, 128), (48, 64), (32, 256), (128, 128), (100, 64), (64, 256)])
+@pytest.mark.parametrize("in_dim,hidden", [(16, 128), (48, 64), (32, 256), (128, 128), (100, 64), (64, 256), (128, 256)])
 def test_sampler_hmc_on_the_wide_mlp_is_one_launch_on_the_shared_field(cuda_device, in_dim, hidden):
     class Sub(ta.MLPEnergy):
         def forward(self, x):
@@ -261,7 +264,7 @@ def test_gradient_is_one_hip_launch(cuda_device, in_dim, hidden):
 
 
 def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
-    """HMC on the H = 256 MLP past dim 64 has no transition kernel: the per-transition route (HIP kicks around ``model.gradient``) now
+    """Forced onto the per-transition route (as a non-fusable mass or integrator would), HMC on an MLP energy (HIP kicks around ``model.gradient``) now
     evaluates each of its L + 1 forces in one launch.  Same momenta, same uniforms as the autograd route."""
 
     class Sub(ta.MLPEnergy):
@@ -277,6 +280,7 @@ def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
     for model in (fast, slow):
         h = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=4, device=cuda_device)
         h.capture_graph = False
+        h._route = lambda x_, kw_: ("step", None)  # the route a non-fusable configuration takes
         c0 = hip_calls("ebm_energy_grad_f32")
         out, diag = h.sample(x=x0, n_steps=3, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(5))
         outs.append((out, diag, hip_calls("ebm_energy_grad_f32") - c0))

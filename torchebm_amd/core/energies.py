@@ -351,8 +351,8 @@ class MLPEnergy(BaseModel):
     ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
     (benchmarks/registry.py:372-387) as well as the 2-D two-moons energy of its PCD example, which has a kernel
     of its own (``hidden == 128``, ``in_dim <= 4``).  ``HamiltonianMonteCarlo`` is fused -- all transitions of a call in
-    one ``ebm_hmc_chain_f32`` launch -- for hidden 64 / 128 at ``in_dim <= 128`` and hidden 256 at ``in_dim <= 64``; wider
-    inputs take the per-transition route with ``gradient()`` as one HIP launch.
+    one ``ebm_hmc_chain_f32`` launch -- for the same shapes; configurations the kernels do not take (a non-default
+    integrator, conditioning) run the per-transition route with ``gradient()`` as one HIP launch.
     Training is unaffected: the parameters are ordinary ``nn.Linear`` weights and are re-read at every
     ``sample()`` call.
     """
@@ -361,9 +361,8 @@ class MLPEnergy(BaseModel):
     HIP_GRADIENT = True
     FUSED_MAX_DIM = 128
     #: HamiltonianMonteCarlo's transition kernels: hidden width -> widest input (csrc/mlp.hip for 128 x dim <= 4,
-    #: csrc/mlp_wide_hmc.hip beyond: state, momentum and force ride in registers next to the evaluation's own; H = 256
-    #: keeps two hidden-width tile sets live and stops at two 32-column state tiles)
-    HMC_MAX_DIM = {64: 128, 128: 128, 256: 64}
+    #: csrc/mlp_wide_hmc.hip beyond: state, momentum and force ride in registers next to the evaluation's own)
+    HMC_MAX_DIM = {64: 128, 128: 128, 256: 128}
 
     def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):
         super().__init__(*args, **kwargs)

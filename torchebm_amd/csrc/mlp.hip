@@ -374,7 +374,7 @@ int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool small_on
   if (!e.dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
   if (mlp_small(e, dim)) return 0;
   if (small_only)
-    return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width 64 / 128 at dim <= 128 and 256 at dim <= 64 (got %d, %d)",
+    return fail(EBM_EDIM, "%s: HMC on the fused MLP energy supports hidden width 64 / 128 / 256 and 1 <= dim <= 128 (got %d, %d)",
                 who, e.n_comp, dim);
   if (!mlp_wide_supported(e.n_comp, dim))
     return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64, 128 or 256 and 1 <= dim <= 128 (got %d, %d)", who, e.n_comp, dim);

@@ -1,4 +1,4 @@
-// HMC transitions on the wide MLP energy (hidden width 64 / 128 at dim <= 128, 256 at dim <= 64): the evaluation of
+// HMC transitions on the wide MLP energy (hidden width 64 / 128 / 256, dim <= 128): the evaluation of
 // mlp_wide_body.h -- all four contractions on the exact-f32 matrix cores, weights in LDS (or streamed from L2 at H = 256)
 // -- sits ONCE inside the transition state machine of mlp.hip's 2-D kernel: mode 0: E and force at the current state,
 // mode 1: after a kick + drift, mode 2: re-evaluation on a scrubbed position (safe mode's literal path), so that every
@@ -9,289 +9,17 @@
 // xor-32 shuffle each).  RNG coordinates as in hmc_kernel.h: momentum at step 2t, uniforms at 2t + 1 -- the same
 // (seed, step, element) field as every other route.
 // Reference: torchebm/samplers/hmc.py:201-315 (transition, accept), integrators/leapfrog.py:116-187 (safe-mode leapfrog).
-#include "mlp_wide_body.h"
+#include "mlp_wide_hmc_body.h"
 
 namespace ebm {
-namespace widemlp {
 
-struct WideHmcArgs {
-  float* x;
-  int64_t n_chains;
-  int32_t dim, n_mh, n_leapfrog;
-  float eps;
-  const float* eps_table;
-  int32_t mass_kind;
-  float mass_raw, mass_sqrt, mass_safe;
-  const float* mass_diag;
-  int32_t thin, n_kept;
-  float* traj;
-  uint8_t* accept_mask;
-  uint32_t* accept_count;
-  const float* p_noise;
-  const float* u;
-  RngKey key;
-  uint64_t step0;
-  const float* params;
-};
+int launch_hmc_mlp_stream(const widemlp::WideHmcArgs& a, int dt, hipStream_t st, const char* who);  // mlp_stream_hmc.hip
 
-template <int HT, int DT, bool STREAM, bool DIAGM>
-__global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) {
-#include "mlp_wide_setup.inc"
-
-  // The accepted position stays in a.x (in/out): read at the top of a transition, written back by the chains that
-  // accept -- 16 DT registers fewer than carrying it, for one pass over the state per L + 1 evaluations.
-  auto load_state = [&](float (&dst)[DT][16], int64_t row) {
-#pragma unroll
-    for (int td = 0; td < DT; ++td)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * td + 8 * q + 4 * h;
-        if (quads && active && c0 + 3 < dim) {
-          const float4 v = *reinterpret_cast<const float4*>(a.x + row * dim + c0);
-          dst[td][4 * q] = v.x; dst[td][4 * q + 1] = v.y; dst[td][4 * q + 2] = v.z; dst[td][4 * q + 3] = v.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dst[td][4 * q + i] = (active && c0 + i < dim) ? a.x[row * dim + c0 + i] : 0.0f;
-        }
-      }
-  };
-  const bool has_mass = a.mass_kind != EBM_MASS_NONE;
-  // diagonal mass: per coordinate from the (L2-resident) vector where it is used; 1 beyond dim
-  auto mass_at = [&](int td, int r) -> float {
-    const int c = 32 * td + row_of(r, h);
-    return c < dim ? a.mass_diag[c] : 1.0f;
-  };
-  // 0.5 p^T M^-1 p over the whole chain (both K-halves), clamped to [0, 1e10]
-  auto kinetic = [&](const float (&q)[DT][16]) -> float {
-    float acc = 0.0f;
-#pragma unroll
-    for (int td = 0; td < DT; ++td)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sq = q[td][r] * q[td][r];
-        if constexpr (DIAGM) sq = sq / mass_at(td, r);
-        acc += sq;
-      }
-    acc += __shfl_xor(acc, 32);
-    float k = 0.5f * acc;
-    if (!DIAGM && has_mass) k = k / a.mass_raw;
-    return clamp_nanprop(k, 0.0f, 1e10f);
-  };
-
-  int until_keep = a.thin;
-  int64_t keep_off = 0;
-  float eps = a.eps;
-
-  for (int tr = 0; tr < a.n_mh; ++tr) {
-    if (a.eps_table) eps = a.eps_table[tr];
-    const float half_eps = 0.5f * eps;
-    int64_t smp = sample;  // nothing derived from the chain index is hoisted out of the transition loop and spilled
-    asm volatile("" : "+v"(smp));
-
-    // ---- momentum draw p ~ N(0, M)
-    float p[DT][16];
-#pragma unroll
-    for (int td = 0; td < DT; ++td)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * td + 8 * q + 4 * h;
-        float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (c0 < dim) {
-          if (a.p_noise) {
-            if (active)
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (c0 + i < dim) z[i] = a.p_noise[((int64_t)tr * a.n_chains + smp) * dim + c0 + i];
-          } else if (quads) {  // the quad is exactly one Philox counter
-            const F4 nrm = normal4_at(a.key, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, a.step0 + 2ull * (uint64_t)tr);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) z[i] = nrm.v[i];
-          } else {
-            uint64_t have = ~0ull;
-            F4 nrm;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const uint64_t e = (uint64_t)smp * (uint64_t)dim + (uint64_t)(c0 + i);
-              if ((e >> 2) != have) {
-                have = e >> 2;
-                nrm = normal4_at(a.key, have, a.step0 + 2ull * (uint64_t)tr);
-              }
-              const int w = (int)(e & 3);
-              z[i] = w == 0 ? nrm.v[0] : (w == 1 ? nrm.v[1] : (w == 2 ? nrm.v[2] : nrm.v[3]));
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = (c0 + i < dim) ? z[i] : 0.0f;
-          if constexpr (DIAGM) v *= sqrtf(mass_at(td, 4 * q + i));
-          else if (has_mass) v *= a.mass_sqrt;
-          p[td][4 * q + i] = v;
-        }
-      }
-    // drift coefficient eps / max(m, 1e-10) (diagonal mass: formed once per transition)
-    float em[DIAGM ? DT : 1][16];
-    if constexpr (DIAGM) {
-#pragma unroll
-      for (int td = 0; td < DT; ++td)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float mr = mass_at(td, r);
-          em[td][r] = eps / (mr < 1e-10f ? 1e-10f : mr);
-        }
-    }
-    const float em_s = has_mass ? eps / a.mass_safe : eps;
-
-    float xr[DT][16], f[DT][16];
-    load_state(xr, smp);
-#pragma unroll
-    for (int td = 0; td < DT; ++td)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) f[td][r] = 0.0f;
-    float h0 = 0.0f, e_last = 0.0f;
-    int done = 0, mode = 0;  // wave-uniform
-    while (done <= a.n_leapfrog) {
-      if (mode == 1) {  // first half kick + drift
-#pragma unroll
-        for (int td = 0; td < DT; ++td)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float ph = __builtin_fmaf(half_eps, f[td][r], p[td][r]);
-            p[td][r] = ph;
-            float coef = em_s;
-            if constexpr (DIAGM) coef = em[td][r];
-            const float xn = __builtin_fmaf(coef, ph, xr[td][r]);
-            xr[td][r] = (32 * td + row_of(r, h) < dim) ? xn : 0.0f;
-          }
-      }
-#include "mlp_wide_eval.inc"
-      if (mode == 0) {  // H0 and the first (clamped) force
-        h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
-#pragma unroll
-        for (int td = 0; td < DT; ++td)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) f[td][r] = clamp_nanprop(-g[td][r], -1e6f, 1e6f);
-        e_last = energy;
-        mode = 1;
-        ++done;
-      } else if (mode == 1) {
-        // E finite => x finite and the gradient free of NaN (hmc_kernel.h); decided per WAVE because the literal path
-        // re-runs the MFMA evaluation
-        if (__all(__builtin_fabsf(energy) < __builtin_inff())) {
-          float pz = 0.0f;
-#pragma unroll
-          for (int td = 0; td < DT; ++td)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float fn = __builtin_amdgcn_fmed3f(-g[td][r], -1e6f, 1e6f);
-              const float pn = __builtin_fmaf(half_eps, fn, p[td][r]);
-              f[td][r] = fn;
-              p[td][r] = pn;
-              pz = __builtin_fmaf(pn, 0.0f, pz);
-            }
-          if (pz != pz) {  // momentum overflow: x is finite, so f stands
-#pragma unroll
-            for (int td = 0; td < DT; ++td)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) p[td][r] = nan_to_num0(p[td][r]);
-          }
-          e_last = energy;
-          ++done;
-        } else {  // literal semantics: NaN-propagating clamp, scrub, then re-evaluate on the scrubbed x
-#pragma unroll
-          for (int td = 0; td < DT; ++td)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float fn = clamp_nanprop(-g[td][r], -1e6f, 1e6f);
-              p[td][r] = nan_to_num0(__builtin_fmaf(half_eps, fn, p[td][r]));
-              xr[td][r] = nan_to_num0(xr[td][r]);
-            }
-          mode = 2;
-        }
-      } else {  // mode 2: force and energy on the scrubbed position
-#pragma unroll
-        for (int td = 0; td < DT; ++td)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) f[td][r] = clamp_nanprop(-g[td][r], -1e6f, 1e6f);
-        e_last = energy;
-        mode = 1;
-        ++done;
-      }
-    }
-    const float h1 = clamp_nanprop(e_last, -1e10f, 1e10f) + kinetic(p);
-
-    // ---- Metropolis accept (samplers/hmc.py:277-292)
-    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
-    float acc_p = expf(dlt);
-    acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
-    float uu;
-    if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + smp] : 2.0f;
-    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)smp >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(smp & 3)));
-    const bool accept = active && (uu < acc_p);
-    if (accept) {
-#pragma unroll
-      for (int td = 0; td < DT; ++td)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = 32 * td + row_of(r, h);
-          if (c < dim) a.x[smp * dim + c] = xr[td][r];
-        }
-    }
-    const bool leader = active && h == 0;
-    if (a.accept_mask && leader) a.accept_mask[(int64_t)tr * a.n_chains + smp] = accept ? 1 : 0;
-    if (a.accept_count) {
-      const unsigned long long b = __ballot(accept && leader);
-      if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
-    }
-    if (a.traj && --until_keep == 0) {
-      until_keep = a.thin;
-      if (active) {
-        if (!accept) load_state(xr, smp);  // a rejected chain records the position it stays at
-        float* dst = a.traj + smp * (int64_t)a.n_kept * dim + keep_off;
-#pragma unroll
-        for (int td = 0; td < DT; ++td)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = 32 * td + row_of(r, h);
-            if (c < dim) dst[c] = xr[td][r];
-          }
-      }
-      keep_off += dim;
-    }
-  }
-}
-
-template <int HT, int DT, bool DIAGM>
-int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
-  constexpr int H = 32 * HT, DP = 32 * DT;
-  constexpr bool STREAM = HT > 4;
-  const size_t smem = (size_t)(STREAM ? 16 * HT * kBlock + 3 * H : H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
-  if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
-    return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
-  static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
-  if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_hmc_kernel<HT, DT, STREAM, DIAGM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  }
-  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
-  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
-  hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, STREAM, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  return check_launch(who);
-}
-
-template <int HT, int DT>
-int launch_hmc_mass(const WideHmcArgs& a, hipStream_t st, const char* who) {
-  return a.mass_kind == EBM_MASS_DIAG ? launch_hmc_one<HT, DT, true>(a, st, who) : launch_hmc_one<HT, DT, false>(a, st, who);
-}
-
-}  // namespace widemlp
-
-// the shapes the transition kernel is built for (momentum and force are 32 DT registers on top of the evaluation's own;
-// H = 256 keeps two hidden-width tile sets live and stops at two state tiles)
+// the shapes the transition kernel is built for: those of the chain kernel (momentum and force are 32 DT registers on top
+// of the evaluation's own; H = 256 at three or four state tiles runs with 1.4-1.8 KB of scratch per lane)
 bool mlp_wide_hmc_supported(int32_t hidden, int32_t dim) {
   if (dim < 1) return false;
-  if (hidden == 64 || hidden == 128) return dim <= 128;
-  return hidden == 256 && dim <= 64;
+  return (hidden == 64 || hidden == 128 || hidden == 256) && dim <= 128;
 }
 
 int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
@@ -319,7 +47,7 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
   if (hidden == 64) { EBM_WIDE_HMC(2) }
   if (hidden == 128) { EBM_WIDE_HMC(4) }
 #undef EBM_WIDE_HMC
-  return dt == 1 ? widemlp::launch_hmc_mass<8, 1>(a, st, who) : widemlp::launch_hmc_mass<8, 2>(a, st, who);
+  return launch_hmc_mlp_stream(a, dt, st, who);
 }
 
 }  // namespace ebm
