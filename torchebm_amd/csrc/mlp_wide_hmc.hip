@@ -13,7 +13,8 @@
 
 namespace ebm {
 
-int launch_hmc_mlp_stream(const widemlp::WideHmcArgs& a, int dt, hipStream_t st, const char* who);  // mlp_stream_hmc.hip
+int launch_hmc_mlp_stream(const widemlp::WideHmcArgs& a, int dt, hipStream_t st, const char* who);        // mlp_stream_hmc.hip
+int launch_hmc_mlp_wide_diag(const widemlp::WideHmcArgs& a, int hidden, int dt, hipStream_t st, const char* who);  // mlp_wide_hmc_diag.hip
 
 // the shapes the transition kernel is built for: those of the chain kernel (momentum and force are 32 DT registers on top
 // of the evaluation's own; H = 256 at three or four state tiles runs with 1.4-1.8 KB of scratch per lane)
@@ -39,11 +40,12 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
   const int dt = (dim + 31) / 32;
 #define EBM_WIDE_HMC(HTV)                                               \
   switch (dt) {                                                         \
-    case 1: return widemlp::launch_hmc_mass<HTV, 1>(a, st, who);        \
-    case 2: return widemlp::launch_hmc_mass<HTV, 2>(a, st, who);        \
-    case 3: return widemlp::launch_hmc_mass<HTV, 3>(a, st, who);        \
-    default: return widemlp::launch_hmc_mass<HTV, 4>(a, st, who);       \
+    case 1: return widemlp::launch_hmc_one<HTV, 1, false>(a, st, who);        \
+    case 2: return widemlp::launch_hmc_one<HTV, 2, false>(a, st, who);        \
+    case 3: return widemlp::launch_hmc_one<HTV, 3, false>(a, st, who);        \
+    default: return widemlp::launch_hmc_one<HTV, 4, false>(a, st, who);       \
   }
+  if (hidden != 256 && mass_kind == EBM_MASS_DIAG) return launch_hmc_mlp_wide_diag(a, hidden, dt, st, who);
   if (hidden == 64) { EBM_WIDE_HMC(2) }
   if (hidden == 128) { EBM_WIDE_HMC(4) }
 #undef EBM_WIDE_HMC
