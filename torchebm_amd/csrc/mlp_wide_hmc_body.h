@@ -1,4 +1,6 @@
-// Kernel body of mlp_wide_hmc.hip / mlp_stream_hmc.hip (two translation units, compiled in parallel): see mlp_wide_hmc.hip.
+// Kernel body of the wide-MLP HMC transition kernel: see mlp_wide_hmc.hip.  Four translation units instantiate it (compiled in
+// parallel): mlp_wide_hmc.hip / mlp_wide_hmc_diag.hip (H = 64, 128; scalar or identity / diagonal mass) and
+// mlp_stream_hmc.hip / mlp_stream_hmc_diag.hip (H = 256).
 #pragma once
 #include "mlp_wide_body.h"
 
@@ -268,11 +270,6 @@ int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
   hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, STREAM, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch(who);
-}
-
-template <int HT, int DT>
-int launch_hmc_mass(const WideHmcArgs& a, hipStream_t st, const char* who) {
-  return a.mass_kind == EBM_MASS_DIAG ? launch_hmc_one<HT, DT, true>(a, st, who) : launch_hmc_one<HT, DT, false>(a, st, who);
 }
 
 }  // namespace widemlp
