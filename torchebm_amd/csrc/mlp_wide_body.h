@@ -5,11 +5,30 @@
 #pragma once
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"  // static_for
+#include "mlp_b16.h"
 
 namespace ebm {
 namespace widemlp {
 
 constexpr int kBlock = 256;
+
+// How a shape keeps its weights (MODE of the kernels): 0 = fp32 in LDS, exact-f32 MFMA; 1 = STREAM (H = 256: fp32 read from
+// L2, exact-f32 MFMA); 2 = B16 (three bf16 split images in LDS, bf16 MFMA at fp32 accuracy: mlp_b16.h) wherever the images fit
+// the 160 KiB: H = 64 at every input width, H = 128 up to dim 64.  -DEBM_MLP_F32LDS (scripts only): the round-2 kernels.
+__host__ __device__ constexpr int b16_cols(int dt) { return dt == 1 ? 32 : (dt == 2 ? 64 : 128); }  // width of the W1 image
+__host__ __device__ constexpr int wide_mode(int ht, int dt) {
+#ifdef EBM_MLP_F32LDS
+  return ht > 4 ? 1 : 0;
+#else
+  return ht > 4 ? 1 : ((ht == 2 || dt <= 2) ? 2 : 0);
+#endif
+}
+__host__ __device__ constexpr size_t wide_smem_bytes(int ht, int dt) {
+  const int H = 32 * ht, DP = 32 * dt, mode = wide_mode(ht, dt);
+  return mode == 1 ? (size_t)(16 * ht * kBlock + 3 * H) * sizeof(float)
+         : mode == 2 ? (size_t)3 * H * sizeof(float) + mlpb16::image_bytes(H, H) + mlpb16::image_bytes(H, b16_cols(dt))
+                     : (size_t)(H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1))) * gptr4;  // 16-byte global loads of the STREAM variant
@@ -137,7 +156,7 @@ __device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval b
   });
 }
 
-template <int HT, int DT, bool STREAM>
+template <int HT, int DT, int MODE>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 #include "mlp_wide_setup.inc"
 
@@ -257,19 +276,19 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 
 template <int HT, int DT>
 int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
-  constexpr int H = 32 * HT, DP = 32 * DT;
-  constexpr bool STREAM = HT > 4;
-  const size_t smem = (size_t)(STREAM ? 16 * HT * kBlock + 3 * H : H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
+  constexpr int MODE = wide_mode(HT, DT);
+  constexpr bool STREAM = MODE == 1;
+  const size_t smem = wide_smem_bytes(HT, DT);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_chain_kernel<HT, DT, STREAM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_chain_kernel<HT, DT, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
-  hipLaunchKernelGGL((mlp_wide_chain_kernel<HT, DT, STREAM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  hipLaunchKernelGGL((mlp_wide_chain_kernel<HT, DT, MODE>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch(who);
 }
 

@@ -27,7 +27,7 @@ struct WideHmcArgs {
   const float* params;
 };
 
-template <int HT, int DT, bool STREAM, bool DIAGM>
+template <int HT, int DT, int MODE, bool DIAGM>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) {
 #include "mlp_wide_setup.inc"
 
@@ -256,19 +256,19 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
 
 template <int HT, int DT, bool DIAGM>
 int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
-  constexpr int H = 32 * HT, DP = 32 * DT;
-  constexpr bool STREAM = HT > 4;
-  const size_t smem = (size_t)(STREAM ? 16 * HT * kBlock + 3 * H : H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
+  constexpr int MODE = wide_mode(HT, DT);
+  constexpr bool STREAM = MODE == 1;
+  const size_t smem = wide_smem_bytes(HT, DT);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_hmc_kernel<HT, DT, STREAM, DIAGM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
-  hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, STREAM, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch(who);
 }
 
