@@ -93,13 +93,31 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ w, int row
 struct Split8 {
   bf16x8 h, m, l;
 };
+// Written on the packed conversions: one v_cvt_pk_bf16_f32 per pair and piece, the pair widened back to fp32 with a shift
+// and a mask (left to __builtin_convertvector the compiler re-converts every element on its own to widen it: 60 instead
+// of 44 instructions per K-block).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ Split8 split8(const f32x8& d) {
+  uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = d[2 * i], b = d[2 * i + 1];
+    ph[i] = cvt_pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, ph[i] << 16), rb = b - __builtin_bit_cast(float, ph[i] & 0xffff0000u);
+    pm[i] = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, pm[i] << 16), sb = rb - __builtin_bit_cast(float, pm[i] & 0xffff0000u);
+    pl[i] = cvt_pk_bf16(sa, sb);
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   Split8 s;
-  s.h = __builtin_convertvector(d, bf16x8);
-  const f32x8 r1 = d - __builtin_convertvector(s.h, f32x8);
-  s.m = __builtin_convertvector(r1, bf16x8);
-  const f32x8 r2 = r1 - __builtin_convertvector(s.m, f32x8);
-  s.l = __builtin_convertvector(r2, bf16x8);
+  s.h = __builtin_bit_cast(bf16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]});
+  s.m = __builtin_bit_cast(bf16x8, (u32x4){pm[0], pm[1], pm[2], pm[3]});
+  s.l = __builtin_bit_cast(bf16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
   return s;
 }
 
@@ -135,6 +153,143 @@ __device__ __forceinline__ void contract(f32x16 (&out)[NT], Lda lda, Breg breg) 
     });
   });
   if constexpr (SETS == 2) out[0] += extra[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The pipelined form.  One wave per SIMD issues about one instruction per four cycles whatever its kind, and a split-operand
+// evaluation is ~480 MFMAs of 32 cycles next to ~3500 VALU instructions: run one after the other (contract() above, then
+// the SiLU epilogue, then the next contract()) the matrix pipe idles through every epilogue and the VALU through every
+// contraction.  Here the epilogue of the PREVIOUS contraction's tile j + 1 (which yields K-blocks 2 j + 2, 2 j + 3 of this one)
+// is issued in slices behind the MFMAs of this contraction's K-blocks 2 j, 2 j + 1: `fill(ordinal)` is called once behind
+// every MFMA and fenced there (sched_barrier), the A operands of the next group are requested one group ahead.
+//
+// Split8 pieces are addressed as four packed pairs each (pair p = elements 2 p, 2 p + 1), so that an epilogue can complete
+// a K-block pair by pair.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct Split8p {
+  u32x4 h, m, l;
+};
+// stage A of a pair split: hi piece + residuals; stage B: mid piece + residuals; stage C: lo piece.  Pairs are f32x2 so that
+// the arithmetic is the packed form (v_pk_*): a lone wave per SIMD issues about one instruction per six cycles whatever the
+// instruction is, so the instruction COUNT is what an epilogue costs.
+struct PairSplit {
+  f32x2 r;
+};
+__device__ __forceinline__ f32x2 widen_pair(uint32_t packed) {
+  f32x2 w;
+  w.x = __builtin_bit_cast(float, packed << 16);
+  w.y = __builtin_bit_cast(float, packed & 0xffff0000u);
+  return w;
+}
+template <int P>
+__device__ __forceinline__ void pair_split_a(Split8p& s, PairSplit& t, f32x2 v) {
+  const uint32_t ph = cvt_pk_bf16(v.x, v.y);
+  s.h[P] = ph;
+  t.r = v - widen_pair(ph);
+}
+template <int P>
+__device__ __forceinline__ void pair_split_b(Split8p& s, PairSplit& t) {
+  const uint32_t pm = cvt_pk_bf16(t.r.x, t.r.y);
+  s.m[P] = pm;
+  t.r = t.r - widen_pair(pm);
+}
+template <int P>
+__device__ __forceinline__ void pair_split_c(Split8p& s, const PairSplit& t) {
+  s.l[P] = cvt_pk_bf16(t.r.x, t.r.y);
+}
+
+struct NoFill {
+  template <class O>
+  __device__ __forceinline__ void operator()(O) const {}
+};
+
+// out[it] (initialised by the caller: bias tiles or zero) += A_it B over K-blocks 0 .. KB - 1.
+//   lda(split, it, kb) -> this lane's A operand;  bs(kb) -> const Split8p& of K-block kb (complete before ordinal 6 NT kb);
+//   fill(ordinal): ordinals 0 .. 6 NT KB - 1 in issue order.
+// K-block outermost: groups (kb, A split) in the order lo | mid | hi with 1 | 2 | 3 terms each, term-major inside a group (NT
+// independent MFMAs between dependent ones); NT == 1 alternates two accumulators.
+// TAIL: the last two K-blocks are issued TILE-major instead (the 12 MFMAs of tile 0, then tile 1's ...): tile 0 is final
+// 12 (NT - 1) MFMAs before the contraction ends, and the caller's fill runs tile 0's epilogue behind those -- otherwise every
+// tile is final at the same moment and the first epilogue of the next stage has no MFMA to hide behind.
+template <int NT, int KB, bool TAIL, class Lda, class Bs, class Fill>
+__device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], Lda lda, Bs bs, Fill fill) {
+  static_assert(!TAIL || NT > 1, "a tail needs a second tile to hide behind");
+  constexpr int KBH = TAIL ? KB - 2 : KB;  // K-blocks of the K-block-major head
+  constexpr int G = 3 * KBH;
+  constexpr int SETS = NT == 1 ? 2 : 1;
+  f32x16 extra;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) extra[r] = 0.0f;
+  bf16x8 pa[2][NT];
+  bf16x8 pt[2][6];  // TAIL: the six operands (two K-blocks x lo, mid, hi) of one tile, requested one tile ahead
+  const auto load_tail = [&](auto itc) __attribute__((always_inline)) {
+    constexpr int it = decltype(itc)::value;
+    static_for<6>([&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;  // K-block q / 3 of the tail, group q % 3 (0: lo)
+      pt[it & 1][q] = lda(std::integral_constant<int, 2 - q % 3>{}, itc, std::integral_constant<int, KBH + q / 3>{});
+    });
+  };
+  if constexpr (G > 0) {
+    static_for<NT>([&](auto itc) __attribute__((always_inline)) {
+      pa[0][decltype(itc)::value] = lda(std::integral_constant<int, 2>{}, itc, std::integral_constant<int, 0>{});
+    });
+  } else {
+    load_tail(std::integral_constant<int, 0>{});
+  }
+  static_for<G>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value, kb = g / 3, grp = g % 3;
+    constexpr int n_terms = grp + 1, first = grp * (grp + 1) / 2;
+    if constexpr (g + 1 < G) {
+      constexpr int kn = (g + 1) / 3, gn = (g + 1) % 3;
+      static_for<NT>([&](auto itc) __attribute__((always_inline)) {
+        pa[(g + 1) & 1][decltype(itc)::value] = lda(std::integral_constant<int, 2 - gn>{}, itc, std::integral_constant<int, kn>{});
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (TAIL) {
+      load_tail(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const Split8p& b = bs(std::integral_constant<int, kb>{});
+    static_for<n_terms * NT>([&](auto oc) __attribute__((always_inline)) {
+      constexpr int o = decltype(oc)::value, tg = o / NT, it = o % NT;
+      constexpr int term = first + tg;  // 0: Al dh | 1: Am dm, 2: Am dh | 3: Ah dl, 4: Ah dm, 5: Ah dh
+      const bf16x8 db = __builtin_bit_cast(bf16x8, (term == 0 || term == 2 || term == 5) ? b.h : ((term == 1 || term == 4) ? b.m : b.l));
+      if constexpr (SETS == 2 && (term & 1)) extra = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[g & 1][it], db, extra, 0, 0, 0);
+      else out[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[g & 1][it], db, out[it], 0, 0, 0);
+      fill(std::integral_constant<int, (kb * 6 + term) * NT + it>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  if constexpr (TAIL) {
+    static_for<NT>([&](auto itc) __attribute__((always_inline)) {
+      constexpr int it = decltype(itc)::value;
+      if constexpr (it + 1 < NT) {
+        load_tail(std::integral_constant<int, it + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_for<12>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, kbl = q / 6, term = q % 6, grp = term == 0 ? 0 : (term < 3 ? 1 : 2);
+        const Split8p& b = bs(std::integral_constant<int, KBH + kbl>{});
+        const bf16x8 db = __builtin_bit_cast(bf16x8, (term == 0 || term == 2 || term == 5) ? b.h : ((term == 1 || term == 4) ? b.m : b.l));
+        out[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pt[it & 1][3 * kbl + grp], db, out[it], 0, 0, 0);
+        fill(std::integral_constant<int, KBH * 6 * NT + it * 12 + q>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  }
+  if constexpr (SETS == 2) out[0] += extra;
+}
+
+// the ordinals of contract_pipe<NT, KB, TAIL> at which tile `it` of the tail is being accumulated: [tail_begin + 12 it, + 12)
+template <int NT, int KB>
+constexpr int tail_begin() { return (KB - 2) * 6 * NT; }
+
+// Slots of a tile epilogue behind the MFMAs of one block (two K-blocks = NMB MFMAs): MFMA ob of the block runs slots
+// [48 ob / NMB, 48 (ob + 1) / NMB) of the 48 the epilogue of a 16-register tile is cut into.
+template <int NMB, int OB, class Slot>
+__device__ __forceinline__ void run_slots(Slot slot) {
+  constexpr int s0 = 48 * OB / NMB, s1 = 48 * (OB + 1) / NMB;
+  static_for<s1 - s0>([&](auto k) __attribute__((always_inline)) { slot(std::integral_constant<int, s0 + decltype(k)::value>{}); });
 }
 
 // The A operands of the two walks over an image of width C with R rows (split stride R 2 C).

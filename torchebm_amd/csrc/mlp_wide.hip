@@ -65,3 +65,10 @@ int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_cha
 }
 
 }  // namespace ebm
+
+#ifdef EBM_PHASE_TIMES
+// scripts/mlp_phase_times.py: the shader-clock log of wave 0 (mlp_wide_body.h, EBM_STAMP)
+extern "C" __attribute__((visibility("default"))) int ebm_debug_phase_log(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ebm::widemlp::ebm_phase_log), (size_t)n * sizeof(unsigned long long));
+}
+#endif

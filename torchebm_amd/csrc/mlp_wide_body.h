@@ -54,6 +54,24 @@ struct WideArgs {
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
 
+// -DEBM_PHASE_TIMES (scripts/mlp_phase_times.py only): wave 0 of workgroup 0 logs the shader clock at the phase boundaries of
+// every evaluation (stamps cost a drained LDS queue each: read the phases relative to each other, not against a plain run).
+#ifdef EBM_PHASE_TIMES
+__device__ unsigned long long ebm_phase_log[8192];
+#define EBM_STAMP()                                                                                     \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (__builtin_amdgcn_readfirstlane(blockIdx.x) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) { \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                      \
+      if (stamp_n_ < 8192 && (threadIdx.x & 63) == 0) ebm_phase_log[stamp_n_] = now_;                     \
+      ++stamp_n_;                                                                                        \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  } while (0)
+#else
+#define EBM_STAMP() do {} while (0)
+#endif
+
 __device__ __forceinline__ float sigmoid_fast(float a) { return __builtin_amdgcn_rcpf(1.0f + __expf(-a)); }
 __device__ __forceinline__ constexpr int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -181,7 +199,11 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   int64_t keep_off = 0;
   const int n_evals = a.k_steps > 0 ? a.k_steps : 1;
 
+#ifdef EBM_PHASE_TIMES
+  int stamp_n_ = 0;
+#endif
   for (int step = 0; step < n_evals; ++step) {
+    EBM_STAMP();
 #include "mlp_wide_eval.inc"
 
     if (a.k_steps == 0) {  // evaluation only
