@@ -33,9 +33,12 @@ for dim, hidden in CASES:
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in _lib.timed_events.pop("ebm_langevin_chain_f32"))
     ms = ts[len(ts) // 2]
-    dpad = dim if dim <= 4 and hidden == 128 else 32 * ((dim + 31) // 32)
+    dpad = 32 * ((dim + 31) // 32)
     useful = n * k * 2 * (2 * hidden * hidden + 2 * dim * hidden)          # the four contractions, real widths
     issued = n * k * 2 * (2 * hidden * hidden + 2 * dpad * hidden) if dpad > 4 else useful
+    if os.environ.get("MLP_NO_STEP_ROUTE"):  # A/B runs (scripts/ab_mlp.sh): the fused kernel only
+        print(json.dumps({"case": f"mlp_langevin dim={dim} H={hidden} n={n} k={k}", "kernel_ms": ms}), flush=True)
+        continue
     # the autograd step route on the same network (HIP-graph replay, the default)
     class Sub(ta.MLPEnergy):
         def forward(self, x):

@@ -349,8 +349,7 @@ class MLPEnergy(BaseModel):
     forward, input-gradient on the matrix cores, update, noise -- in one ``ebm_langevin_chain_f32``
     launch instead of one autograd round trip per step: the reference's benchmark network
     ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
-    (benchmarks/registry.py:372-387) as well as the 2-D two-moons energy of its PCD example, which has a kernel
-    of its own (``hidden == 128``, ``in_dim <= 4``).  ``HamiltonianMonteCarlo`` is fused -- all transitions of a call in
+    (benchmarks/registry.py:372-387) as well as the 2-D two-moons energy of its PCD example.  ``HamiltonianMonteCarlo`` is fused -- all transitions of a call in
     one ``ebm_hmc_chain_f32`` launch -- for the same shapes; configurations the kernels do not take (a non-default
     integrator, conditioning) run the per-transition route with ``gradient()`` as one HIP launch.
     Training is unaffected: the parameters are ordinary ``nn.Linear`` weights and are re-read at every
@@ -360,8 +359,8 @@ class MLPEnergy(BaseModel):
     FUSED_HIDDEN = (64, 128, 256)
     HIP_GRADIENT = True
     FUSED_MAX_DIM = 128
-    #: HamiltonianMonteCarlo's transition kernels: hidden width -> widest input (csrc/mlp.hip for 128 x dim <= 4,
-    #: csrc/mlp_wide_hmc.hip beyond: state, momentum and force ride in registers next to the evaluation's own)
+    #: HamiltonianMonteCarlo's transition kernels: hidden width -> widest input (csrc/mlp_wide_hmc.hip: state, momentum
+    #: and force ride in registers next to the evaluation's own)
     HMC_MAX_DIM = {64: 128, 128: 128, 256: 128}
 
     def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):

@@ -89,113 +89,52 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ w, int row
   }
 }
 
-// three bf16 pieces of the eight K values a lane supplies to one K-block
-struct Split8 {
-  bf16x8 h, m, l;
-};
-// Written on the packed conversions: one v_cvt_pk_bf16_f32 per pair and piece, the pair widened back to fp32 with a shift
-// and a mask (left to __builtin_convertvector the compiler re-converts every element on its own to widen it: 60 instead
-// of 44 instructions per K-block).
+// ---------------------------------------------------------------------------------------------------------------------------
+// The pipelined contraction.  ONE wave per SIMD (the images leave room for one workgroup per CU, the live tiles for one wave
+// per SIMD) issues about one instruction per six cycles WHATEVER the instruction is (scripts/mlp_phase_times.py; the same
+// figure as the 39 % single-wave VALU rate of profiles/r02_valu_occupancy.txt and the "five fillers per MFMA gap" of the
+// programming guide): an evaluation is ~480 MFMAs of 32 cycles next to ~2500 other instructions, so what it costs is its
+// instruction COUNT, and the matrix time hides behind the issue time if -- and only if -- MFMAs and the rest alternate.
+// Hence: the epilogue of the PREVIOUS contraction's tile j + 1 (which yields K-blocks 2 j + 2, 2 j + 3 of this one) is issued
+// in slices behind the MFMAs of this contraction's K-blocks 2 j, 2 j + 1 (`fill(ordinal)`, called once behind every MFMA
+// and fenced there); pairs stay <2 x float> from the accumulator to the packed conversion so that the arithmetic selects
+// v_pk_*; an operand address is one lane register + an immediate; a group's operands are awaited once.
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ Split8 split8(const f32x8& d) {
-  uint32_t ph[4], pm[4], pl[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = d[2 * i], b = d[2 * i + 1];
-    ph[i] = cvt_pk_bf16(a, b);
-    const float ra = a - __builtin_bit_cast(float, ph[i] << 16), rb = b - __builtin_bit_cast(float, ph[i] & 0xffff0000u);
-    pm[i] = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __builtin_bit_cast(float, pm[i] << 16), sb = rb - __builtin_bit_cast(float, pm[i] & 0xffff0000u);
-    pl[i] = cvt_pk_bf16(sa, sb);
-  }
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  Split8 s;
-  s.h = __builtin_bit_cast(bf16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]});
-  s.m = __builtin_bit_cast(bf16x8, (u32x4){pm[0], pm[1], pm[2], pm[3]});
-  s.l = __builtin_bit_cast(bf16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
-  return s;
-}
-
-// out[it] += A_it B over KB K-blocks of 16, K-block outermost: the eight B values of a K-block (breg(kb, j): element j of
-// this lane for K-block kb, in the C/D layout of the 32-row tile kb >> 1: register 8 (kb & 1) + j) are split once and meet
-// all NT output tiles; per K-block the six terms run smallest first, grouped by the split of A they read (lo: dh | mid: dm,
-// dh | hi: dl, dm, dh), term-major inside a group so that NT independent MFMAs sit between dependent ones.
-// lda(split, it, kb) -> this lane's A operand.
-template <int NT, int KB, class Lda, class Breg>
-__device__ __forceinline__ void contract(f32x16 (&out)[NT], Lda lda, Breg breg) {
-  constexpr int SETS = NT == 1 ? 2 : 1;  // one tile: two accumulators, so that consecutive MFMAs never wait on each other
-  f32x16 extra[SETS == 2 ? 1 : 1];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) extra[0][r] = 0.0f;
-  static_for<KB>([&](auto kbc) __attribute__((always_inline)) {
-    f32x8 d;
-    static_for<8>([&](auto jc) __attribute__((always_inline)) { d[decltype(jc)::value] = breg(kbc, jc); });
-    const Split8 b = split8(d);
-    static_for<3>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int grp = decltype(gc)::value;  // 0: A lo, 1: A mid, 2: A hi
-      constexpr int n_terms = grp + 1, first = grp * (grp + 1) / 2;
-      bf16x8 pa[NT];
-      static_for<NT>([&](auto itc) __attribute__((always_inline)) {
-        pa[decltype(itc)::value] = lda(std::integral_constant<int, 2 - grp>{}, itc, kbc);
-      });
-      static_for<n_terms * NT>([&](auto oc) __attribute__((always_inline)) {
-        constexpr int o = decltype(oc)::value, tg = o / NT, it = o % NT;
-        constexpr int term = first + tg;  // 0: Al dh | 1: Am dm, 2: Am dh | 3: Ah dl, 4: Ah dm, 5: Ah dh
-        const bf16x8& db = (term == 0 || term == 2 || term == 5) ? b.h : ((term == 1 || term == 4) ? b.m : b.l);
-        if constexpr (SETS == 2 && (term & 1)) extra[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[it], db, extra[0], 0, 0, 0);
-        else out[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[it], db, out[it], 0, 0, 0);
-      });
-    });
-  });
-  if constexpr (SETS == 2) out[0] += extra[0];
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// The pipelined form.  One wave per SIMD issues about one instruction per four cycles whatever its kind, and a split-operand
-// evaluation is ~480 MFMAs of 32 cycles next to ~3500 VALU instructions: run one after the other (contract() above, then
-// the SiLU epilogue, then the next contract()) the matrix pipe idles through every epilogue and the VALU through every
-// contraction.  Here the epilogue of the PREVIOUS contraction's tile j + 1 (which yields K-blocks 2 j + 2, 2 j + 3 of this one)
-// is issued in slices behind the MFMAs of this contraction's K-blocks 2 j, 2 j + 1: `fill(ordinal)` is called once behind
-// every MFMA and fenced there (sched_barrier), the A operands of the next group are requested one group ahead.
-//
-// Split8 pieces are addressed as four packed pairs each (pair p = elements 2 p, 2 p + 1), so that an epilogue can complete
-// a K-block pair by pair.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// A K-block's three pieces as four packed pairs each (pair p = elements 2 p, 2 p + 1): an epilogue completes it pair by pair.
 struct Split8p {
   u32x4 h, m, l;
 };
-// stage A of a pair split: hi piece + residuals; stage B: mid piece + residuals; stage C: lo piece.  Pairs are f32x2 so that
-// the arithmetic is the packed form (v_pk_*): a lone wave per SIMD issues about one instruction per six cycles whatever the
-// instruction is, so the instruction COUNT is what an epilogue costs.
-struct PairSplit {
-  f32x2 r;
-};
+__device__ __forceinline__ uint32_t cvt_pair(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
 __device__ __forceinline__ f32x2 widen_pair(uint32_t packed) {
-  f32x2 w;
-  w.x = __builtin_bit_cast(float, packed << 16);
-  w.y = __builtin_bit_cast(float, packed & 0xffff0000u);
-  return w;
+  u32x2 w = {packed, packed};
+  w = (w << (u32x2){16u, 0u}) & (u32x2){0xffffffffu, 0xffff0000u};
+  return __builtin_bit_cast(f32x2, w);
 }
+// stage A of a pair split: hi piece + residual; stage B: mid piece + residual; stage C: lo piece (the residual of B has at
+// most eight significant bits: the conversion is exact)
 template <int P>
-__device__ __forceinline__ void pair_split_a(Split8p& s, PairSplit& t, f32x2 v) {
-  const uint32_t ph = cvt_pk_bf16(v.x, v.y);
+__device__ __forceinline__ void pair_split_a(Split8p& s, f32x2& r, f32x2 v) {
+  const uint32_t ph = cvt_pair(v);
   s.h[P] = ph;
-  t.r = v - widen_pair(ph);
+  r = v - widen_pair(ph);
 }
 template <int P>
-__device__ __forceinline__ void pair_split_b(Split8p& s, PairSplit& t) {
-  const uint32_t pm = cvt_pk_bf16(t.r.x, t.r.y);
+__device__ __forceinline__ void pair_split_b(Split8p& s, f32x2& r) {
+  const uint32_t pm = cvt_pair(r);
   s.m[P] = pm;
-  t.r = t.r - widen_pair(pm);
+  r = r - widen_pair(pm);
 }
 template <int P>
-__device__ __forceinline__ void pair_split_c(Split8p& s, const PairSplit& t) {
-  s.l[P] = cvt_pk_bf16(t.r.x, t.r.y);
+__device__ __forceinline__ void pair_split_c(Split8p& s, f32x2 r) {
+  s.l[P] = cvt_pair(r);
+}
+template <int R0>
+__device__ __forceinline__ f32x2 pair_of(const f32x16& tile) {
+  return __builtin_shufflevector(tile, tile, R0, R0 + 1);
 }
 
 struct NoFill {
@@ -203,53 +142,145 @@ struct NoFill {
   __device__ __forceinline__ void operator()(O) const {}
 };
 
+#define EBM_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f) /* lgkmcnt(0), vmcnt / expcnt untouched */
+
+// The A operands of the two walks over an image of width C with R rows (split stride R 2 C).  Every address is ONE lane
+// register (per K-block of the forward walk; per (output tile, half) of the transposed walk) plus an immediate; the one
+// image whose far split lies beyond the 64 KiB an LDS offset reaches (W2 at H = 128) gets a second register for it.
+template <int R, int C>
+struct Walk {
+  static constexpr uint32_t RB = Img<C>::RB, SPLIT = (uint32_t)R * RB;
+  uint32_t base;       // LDS byte address of split 0
+  uint32_t fwd_lane;   // forward: row m
+  uint32_t fwd_x;      // ... its unit h, swizzled
+  uint32_t bwd_lane;   // transposed: row 4 h + (i >> 2) of a 16-row K-block
+  uint32_t bwd_x;      // ... columns 16 g + 4 (i & 3) .. + 3, swizzled by that row
+  __device__ __forceinline__ Walk(lds_bytes img, int lane) {
+    base = (uint32_t)(uintptr_t)img;
+    const uint32_t m = lane & 31, h = lane >> 5, i = lane & 15, g = (lane >> 4) & 1;
+    fwd_lane = m * RB;
+    fwd_x = (16u * h) ^ Img<C>::swz(m);
+    const uint32_t row = 4u * h + (i >> 2);
+    bwd_lane = row * RB;
+    bwd_x = (32u * g + 16u * (i & 1u) + 8u * ((i >> 1) & 1u)) ^ Img<C>::swz(row);
+  }
+  // The images never change after staging, so every operand load is invariant over the step loop: left visible, the
+  // compiler hoists them all (a whole image per wave) and spills.  An opaque copy per evaluation keeps them at their MFMAs.
+  __device__ __forceinline__ Walk opaque() const {
+    Walk w = *this;
+    asm volatile("" : "+v"(w.fwd_lane), "+v"(w.bwd_lane));
+    return w;
+  }
+  struct Addr {
+    uint32_t a, far;  // far = a + 64 KiB (only formed where an offset can exceed the field)
+  };
+  template <uint32_t OFF>
+  static __device__ __forceinline__ lds_bytes at(const Addr& b) {
+    if constexpr (OFF < 65536u) return (lds_bytes)(uintptr_t)(b.a + OFF);
+    else return (lds_bytes)(uintptr_t)(b.far + (OFF - 65536u));
+  }
+  static constexpr bool FAR_F = 2u * SPLIT + (R / 32 - 1) * 32u * RB >= 65536u;
+  static constexpr bool FAR_B = 2u * SPLIT + (R - 8) * RB >= 65536u;
+  // forward, K-block kb: one register for every (split, output tile)
+  template <int KBI>
+  __device__ __forceinline__ Addr fwd_kb() const {
+    Addr b;
+    b.a = base + fwd_lane + (fwd_x ^ (32u * KBI));
+    b.far = b.a;
+    if constexpr (FAR_F) b.far = b.a + 65536u;
+    asm volatile("" : "+v"(b.a), "+v"(b.far));  // one value each, not re-derived per load
+    return b;
+  }
+  template <int SP, int IT>
+  static __device__ __forceinline__ bf16x8 fwd_load(const Addr& b) {
+    return *(lds_bf16x8)at<(uint32_t)SP * SPLIT + (uint32_t)IT * 32u * RB>(b);
+  }
+  // transposed, output tile it, half s (rows + 8 s of a K-block): one register for every (split, K-block)
+  template <int IT, int S>
+  __device__ __forceinline__ Addr bwd_tile() const {
+    constexpr uint32_t c = (64u * IT) ^ (S ? Img<C>::swz(8u) : 0u);  // the swizzle is XOR-linear in the row bits
+    Addr b;
+    b.a = base + bwd_lane + (bwd_x ^ c) + (S ? 8u * RB : 0u);
+    b.far = b.a;
+    if constexpr (FAR_B) b.far = b.a + 65536u;
+    asm volatile("" : "+v"(b.a), "+v"(b.far));
+    return b;
+  }
+  template <int SP, int KBI>
+  static __device__ __forceinline__ bf16x8 bwd_load(const Addr& b0, const Addr& b1) {
+    constexpr uint32_t off = (uint32_t)SP * SPLIT + 16u * KBI * RB;
+    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)at<off>(b0));
+    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)at<off>(b1));
+    return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+
 // out[it] (initialised by the caller: bias tiles or zero) += A_it B over K-blocks 0 .. KB - 1.
-//   lda(split, it, kb) -> this lane's A operand;  bs(kb) -> const Split8p& of K-block kb (complete before ordinal 6 NT kb);
+//   TR: the transposed walk (A = image^T);  bs(kb) -> const Split8p& of K-block kb (complete before ordinal 6 NT kb);
 //   fill(ordinal): ordinals 0 .. 6 NT KB - 1 in issue order.
-// K-block outermost: groups (kb, A split) in the order lo | mid | hi with 1 | 2 | 3 terms each, term-major inside a group (NT
-// independent MFMAs between dependent ones); NT == 1 alternates two accumulators.
+// K-block outermost: groups (kb, A split) in the order lo | mid | hi with 1 | 2 | 3 terms each (smallest products first),
+// term-major inside a group (NT independent MFMAs between dependent ones); NT == 1 alternates two accumulators.  A group's
+// operands are requested in front of the group before (a whole group of MFMAs to land in) and awaited once.
 // TAIL: the last two K-blocks are issued TILE-major instead (the 12 MFMAs of tile 0, then tile 1's ...): tile 0 is final
-// 12 (NT - 1) MFMAs before the contraction ends, and the caller's fill runs tile 0's epilogue behind those -- otherwise every
+// 12 (NT - 1) MFMAs before the contraction ends and the caller's fill runs tile 0's epilogue behind those -- otherwise every
 // tile is final at the same moment and the first epilogue of the next stage has no MFMA to hide behind.
-template <int NT, int KB, bool TAIL, class Lda, class Bs, class Fill>
-__device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], Lda lda, Bs bs, Fill fill) {
+template <int NT, int KB, bool TAIL, bool TR, class W, class Bs, class Fill>
+__device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs bs, Fill fill) {
   static_assert(!TAIL || NT > 1, "a tail needs a second tile to hide behind");
   constexpr int KBH = TAIL ? KB - 2 : KB;  // K-blocks of the K-block-major head
   constexpr int G = 3 * KBH;
   constexpr int SETS = NT == 1 ? 2 : 1;
+  typedef typename W::Addr Addr;
   f32x16 extra;
 #pragma unroll
   for (int r = 0; r < 16; ++r) extra[r] = 0.0f;
   bf16x8 pa[2][NT];
   bf16x8 pt[2][6];  // TAIL: the six operands (two K-blocks x lo, mid, hi) of one tile, requested one tile ahead
+  Addr bt[TR ? NT : 1][2];  // transposed walk: the (tile, half) registers
+  if constexpr (TR)
+    static_for<NT>([&](auto itc) __attribute__((always_inline)) {
+      constexpr int it = decltype(itc)::value;
+      bt[it][0] = w.template bwd_tile<it, 0>();
+      bt[it][1] = w.template bwd_tile<it, 1>();
+    });
+  Addr fk;  // forward walk: the register of the K-block being requested
+  // operands of group (kb, grp) for every tile
+  const auto load_group = [&](auto kbc, auto grpc, auto bufc) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kbc)::value, grp = decltype(grpc)::value, buf = decltype(bufc)::value;
+    if constexpr (!TR && grp == 0) fk = w.template fwd_kb<kb>();
+    static_for<NT>([&](auto itc) __attribute__((always_inline)) {
+      constexpr int it = decltype(itc)::value;
+      if constexpr (TR) pa[buf][it] = W::template bwd_load<2 - grp, kb>(bt[it][0], bt[it][1]);
+      else pa[buf][it] = W::template fwd_load<2 - grp, it>(fk);
+    });
+  };
+  Addr ft[2];  // TAIL, forward walk: the registers of the two K-blocks
   const auto load_tail = [&](auto itc) __attribute__((always_inline)) {
     constexpr int it = decltype(itc)::value;
     static_for<6>([&](auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;  // K-block q / 3 of the tail, group q % 3 (0: lo)
-      pt[it & 1][q] = lda(std::integral_constant<int, 2 - q % 3>{}, itc, std::integral_constant<int, KBH + q / 3>{});
+      if constexpr (TR) pt[it & 1][q] = W::template bwd_load<2 - q % 3, KBH + q / 3>(bt[it][0], bt[it][1]);
+      else pt[it & 1][q] = W::template fwd_load<2 - q % 3, it>(ft[q / 3]);
     });
   };
-  if constexpr (G > 0) {
-    static_for<NT>([&](auto itc) __attribute__((always_inline)) {
-      pa[0][decltype(itc)::value] = lda(std::integral_constant<int, 2>{}, itc, std::integral_constant<int, 0>{});
-    });
-  } else {
-    load_tail(std::integral_constant<int, 0>{});
+  if constexpr (TAIL && !TR) {
+    ft[0] = w.template fwd_kb<KBH>();
+    ft[1] = w.template fwd_kb<KBH + 1>();
   }
+  if constexpr (G > 0) load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  else load_tail(std::integral_constant<int, 0>{});
   static_for<G>([&](auto gc) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value, kb = g / 3, grp = g % 3;
     constexpr int n_terms = grp + 1, first = grp * (grp + 1) / 2;
-    if constexpr (g + 1 < G) {
-      constexpr int kn = (g + 1) / 3, gn = (g + 1) % 3;
-      static_for<NT>([&](auto itc) __attribute__((always_inline)) {
-        pa[(g + 1) & 1][decltype(itc)::value] = lda(std::integral_constant<int, 2 - gn>{}, itc, std::integral_constant<int, kn>{});
-      });
-      __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (TAIL) {
-      load_tail(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
     const Split8p& b = bs(std::integral_constant<int, kb>{});
+    EBM_WAIT_LDS();
+    __builtin_amdgcn_sched_barrier(0);
+    // the next group's operands: a whole group of MFMAs (4 / 8 / 12 NT / 4) to land in
+    if constexpr (g + 1 < G)
+      load_group(std::integral_constant<int, (g + 1) / 3>{}, std::integral_constant<int, (g + 1) % 3>{}, std::integral_constant<int, (g + 1) & 1>{});
+    else if constexpr (TAIL)
+      load_tail(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
     static_for<n_terms * NT>([&](auto oc) __attribute__((always_inline)) {
       constexpr int o = decltype(oc)::value, tg = o / NT, it = o % NT;
       constexpr int term = first + tg;  // 0: Al dh | 1: Am dm, 2: Am dh | 3: Ah dl, 4: Ah dm, 5: Ah dh
@@ -263,6 +294,8 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], Lda lda, Bs bs,
   if constexpr (TAIL) {
     static_for<NT>([&](auto itc) __attribute__((always_inline)) {
       constexpr int it = decltype(itc)::value;
+      EBM_WAIT_LDS();
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (it + 1 < NT) {
         load_tail(std::integral_constant<int, it + 1>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -280,10 +313,6 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], Lda lda, Bs bs,
   if constexpr (SETS == 2) out[0] += extra;
 }
 
-// the ordinals of contract_pipe<NT, KB, TAIL> at which tile `it` of the tail is being accumulated: [tail_begin + 12 it, + 12)
-template <int NT, int KB>
-constexpr int tail_begin() { return (KB - 2) * 6 * NT; }
-
 // Slots of a tile epilogue behind the MFMAs of one block (two K-blocks = NMB MFMAs): MFMA ob of the block runs slots
 // [48 ob / NMB, 48 (ob + 1) / NMB) of the 48 the epilogue of a 16-register tile is cut into.
 template <int NMB, int OB, class Slot>
@@ -291,55 +320,6 @@ __device__ __forceinline__ void run_slots(Slot slot) {
   constexpr int s0 = 48 * OB / NMB, s1 = 48 * (OB + 1) / NMB;
   static_for<s1 - s0>([&](auto k) __attribute__((always_inline)) { slot(std::integral_constant<int, s0 + decltype(k)::value>{}); });
 }
-
-// The A operands of the two walks over an image of width C with R rows (split stride R 2 C).
-template <int R, int C>
-struct Walk {
-  static constexpr uint32_t SPLIT = (uint32_t)R * 2u * C;
-  lds_bytes img;
-  uint32_t fwd_lane;   // forward: row m, unit h
-  uint32_t bwd_lane;   // transposed: row 4 h + (i >> 2), columns 16 g + 4 (i & 3) .. + 3 of output tile 0, K-block 0, s = 0
-  uint32_t bwd_swz;    // the row's swizzle (independent of kb and it)
-  __device__ __forceinline__ Walk(lds_bytes base, int lane) : img(base) {
-    const uint32_t m = lane & 31, h = lane >> 5, i = lane & 15, g = (lane >> 4) & 1;
-    fwd_lane = m * (uint32_t)Img<C>::RB;
-    fwd_swz_ = (16u * h) ^ Img<C>::swz(m);
-    const uint32_t row = 4u * h + (i >> 2);
-    bwd_lane = row * (uint32_t)Img<C>::RB;
-    bwd_swz = Img<C>::swz(row);  // rows 16 kb + 8 s + this: the swizzle of s is folded in below
-    bwd_col_ = 32u * g + 16u * (i & 1u) + 8u * ((i >> 1) & 1u);
-  }
-  uint32_t fwd_swz_, bwd_col_;
-  // The images never change after staging, so every operand load is invariant over the step loop: left visible, the
-  // compiler hoists them all (a whole image per wave) and spills.  An opaque copy of the lane offsets per evaluation keeps
-  // the loads where their MFMAs are.
-  __device__ __forceinline__ Walk opaque() const {
-    Walk w = *this;
-    asm volatile("" : "+v"(w.fwd_lane), "+v"(w.bwd_lane));
-    return w;
-  }
-  // forward: row 32 it + m at the columns of (kb, h)
-  template <int SP, int IT, int KBI>
-  __device__ __forceinline__ bf16x8 fwd(std::integral_constant<int, SP>, std::integral_constant<int, IT>, std::integral_constant<int, KBI>) const {
-    const uint32_t off = fwd_lane + (fwd_swz_ ^ (32u * KBI));
-    return *(lds_bf16x8)(img + (uint32_t)SP * SPLIT + (uint32_t)IT * 32u * Img<C>::RB + off);
-  }
-  // transposed: column 32 it + m at the rows of (kb, h)
-  template <int SP, int IT, int KBI>
-  __device__ __forceinline__ bf16x8 bwd(std::integral_constant<int, SP>, std::integral_constant<int, IT>, std::integral_constant<int, KBI>) const {
-    constexpr uint32_t rows0 = 16u * KBI;
-    // swizzle of row 16 kb + 8 s + (4 h + A): the row bits above bit 3 never enter it; bit 3 (s) does for C = 128 / 64 / 32
-    // through v = (row >> LB): fold the compile-time part
-    constexpr uint32_t s1 = Img<C>::swz(8u);  // the swizzle contribution of s = 1 (XOR-linear in the row bits)
-    const uint32_t c0 = (64u * IT) ^ 0u, c1 = (64u * IT) ^ s1;
-    const uint32_t lane_x = bwd_col_ ^ bwd_swz;
-    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (lds_bf16x4)(img + (uint32_t)SP * SPLIT + rows0 * Img<C>::RB + bwd_lane + (lane_x ^ c0)));
-    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (lds_bf16x4)(img + (uint32_t)SP * SPLIT + (rows0 + 8u) * Img<C>::RB + bwd_lane + (lane_x ^ c1)));
-    return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-  }
-};
 
 }  // namespace mlpb16
 }  // namespace ebm
