@@ -15,7 +15,10 @@
  *     and return, they never synchronise the device or the host;
  *   - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = EBM_E* argument
  *     error; the text is available from ebm_last_error_string() (thread local);
- *   - no C++ exception crosses the boundary; no mutable global state.
+ *   - no C++ exception crosses the boundary; no mutable global state; the library reads no
+ *     environment variable (the kernel-selection switches of scripts/ -- EBM_GAUSS_ROWS and
+ *     friends -- exist only in builds made with -DEBM_AB_SWITCHES; tests/test_abi.py checks
+ *     that the shipped object does not import getenv).
  *
  * Random numbers ("native RNG", used when a noise pointer is NULL)
  *   Philox4x32-10 keyed by `seed`.  For step s (64-bit, = offset + local step index)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Gaussian HMC at dims 32..128 (matrix-core kernel; EBM_GAUSS_ROWS=1 forces the lane-group LDS kernel)."""
+"""[the EBM_* kernel switches need a library built with make CXXFLAGS_EXTRA=-DEBM_AB_SWITCHES] Gaussian HMC at dims 32..128 (matrix-core kernel; EBM_GAUSS_ROWS=1 forces the lane-group LDS kernel)."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torchebm_amd as ta

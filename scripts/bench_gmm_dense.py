@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HMC on mixtures with DENSE means (every column differs): the matrix-layout kernel against the lane-group kernels
+"""[the EBM_* kernel switches need a library built with make CXXFLAGS_EXTRA=-DEBM_AB_SWITCHES] HMC on mixtures with DENSE means (every column differs): the matrix-layout kernel against the lane-group kernels
 (EBM_GMM_ROWS=1), K = 4 .. 32, dim 32 / 64, 2^18 chains, L = 20, 10 transitions per call."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mixture Langevin over dims and component counts: matrix-layout kernel vs (EBM_GMM_ROWS=1) lane-group kernels.
+"""[the EBM_* kernel switches need a library built with make CXXFLAGS_EXTRA=-DEBM_AB_SWITCHES] Mixture Langevin over dims and component counts: matrix-layout kernel vs (EBM_GMM_ROWS=1) lane-group kernels.
 2^18 chains, k = 50, dense means."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -27,6 +27,18 @@ def test_library_is_built_and_exports_every_symbol():
         assert hasattr(handle, name), name
 
 
+def test_library_reads_no_environment():
+    """The kernel-selection switches (EBM_GAUSS_ROWS ...) are compiled out of the shipped library (-DEBM_AB_SWITCHES builds
+    only): no getenv import, no debug entry points -- include/ebm_hip.h promises no process-global state."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    undefined = {line.split()[-1].split("@")[0] for line in out.splitlines() if " U " in line}
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert not any(name.startswith("ebm_debug") for name in exported), exported
+
+
 def test_version_and_error_string():
     lib = _lib.lib()
     assert lib.ebm_version() == _lib.ABI_VERSION

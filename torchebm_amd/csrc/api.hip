@@ -138,8 +138,8 @@ DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32
   const int heun = sampler == EBM_DIAG_LANGEVIN_HEUN;
   if (elementwise && elem_diag_supported(dim, has_noise, has_traj) && elem_diag_plan(n_chains, dim, d)) return kDiagElemFlat;
   // dense Gaussians and mixtures where the matrix-layout kernels run (dims up to 96): records from those kernels
-  static const bool gauss_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
-  static const bool gmm_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+  static const bool gauss_rows = ab_switch("EBM_GAUSS_ROWS");
+  static const bool gmm_rows = ab_switch("EBM_GMM_ROWS");
   const bool forced_rows = (e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows);
   if (!heun && !forced_rows && matrix_langevin_diag_plan(e, n_chains, dim, d)) return kDiagMatrix;
   return rows_langevin_diag_plan(e, heun, n_chains, dim, d) ? kDiagRows : kDiagNone;
@@ -246,7 +246,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
                                       cmax, thin, traj, noise, seed, offset, heun, (hipStream_t)stream);
   if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim)) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
-    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+    static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)
       return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                               clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
@@ -255,7 +255,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
   // one lane per chain with the means as scalar operands
   if (!heun && energy->kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, energy->n_comp) &&
       !(dim == 32 && energy->n_comp <= 8)) {
-    static const bool force_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+    static const bool force_rows = ab_switch("EBM_GMM_ROWS");
     if (!force_rows)
       return launch_langevin_chain_gmm_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                             clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);

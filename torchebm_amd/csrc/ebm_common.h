@@ -15,6 +15,26 @@
 
 namespace ebm {
 
+// A/B switches (EBM_GAUSS_ROWS=1 and friends) exist only in builds made with -DEBM_AB_SWITCHES (make CXXFLAGS_EXTRA=-DEBM_AB_SWITCHES:
+// the comparison runs of scripts/).  The shipped library reads no environment variable and keeps no process-global state.
+#ifdef EBM_AB_SWITCHES
+}  // namespace ebm
+#include <cstdlib>
+namespace ebm {
+inline bool ab_switch(const char* name, char on = '1') {
+  const char* v = getenv(name);
+  return v && v[0] == on;
+}
+inline int ab_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+#else
+constexpr bool ab_switch(const char*, char = '1') { return false; }
+constexpr int ab_int(const char*) { return 0; }
+#endif
+
+
 // ---------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
 template <int NT, bool DIAGM>
 int launch_nt(const GaussHmcArgs& a, hipStream_t st) {
   // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
-  static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
+  static const bool f32_mfma = ab_switch("EBM_GAUSS_F32MFMA");
   return f32_mfma ? launch_nt_b<NT, DIAGM, false>(a, st) : launch_nt_b<NT, DIAGM, true>(a, st);
 }
 

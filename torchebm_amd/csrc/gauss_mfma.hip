@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kWideBlock) void gauss_langevin_bf16x3_fast_wide_ke
 template <int NT>
 int launch_nt(const GaussArgs& a, hipStream_t st) {
   // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
-  static const bool f32_mfma = [] { const char* v = getenv("EBM_GAUSS_F32MFMA"); return v && v[0] == '1'; }();
+  static const bool f32_mfma = ab_switch("EBM_GAUSS_F32MFMA");
   const size_t smem = (f32_mfma ? (size_t)(32 * NT) * (32 * NT) * sizeof(float) : gauss3::aop_bytes(NT)) + 32 * NT * sizeof(float);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first() && smem > 64 * 1024) {
@@ -377,7 +377,7 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   if constexpr (NT == 3) {  // (four tiles: the 256-register cap costs 80 B of scratch and the unhidden half of the RNG -- no gain)
     // A/B switch: EBM_GAUSS_WIDE=0 keeps the 256-thread workgroups (dim 96: 1.81 ms against 1.68)
-    static const bool wide_off = [] { const char* v = getenv("EBM_GAUSS_WIDE"); return v && v[0] == '0'; }();
+    static const bool wide_off = ab_switch("EBM_GAUSS_WIDE", '0');
     if (!f32_mfma && !a.noise && !a.clamp_on && !wide_off) {
       constexpr int HIDE = 2;
       static bool wide_attr = false;
@@ -444,7 +444,7 @@ int launch_gmm_langevin(const GaussArgs& a, hipStream_t st) {
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   // no clamp, no injected noise: the step's normals are drawn in stages behind the MFMAs (as for the Gaussian)
-  static const bool no_fast = [] { const char* v = getenv("EBM_GMM_NOFAST"); return v && v[0] == '1'; }();
+  static const bool no_fast = ab_switch("EBM_GMM_NOFAST");
   // (three tiles: the staged form drops to one wave per SIMD -- 1.54 ms against 1.39 at dim 96 -- and stays off)
   if (NT != 3 && !a.noise && !a.clamp_on && !no_fast)
     hipLaunchKernelGGL((gmm_langevin_bf16x3_fast_kernel<NT, GKR>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);

@@ -41,10 +41,7 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, i
 static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
   if (!pick_geometry(dim, geo)) return false;
   // dim-32 full rows can be re-shaped to (G, NV) = (4,2) | (2,4) | (1,8); EBM_HMC_NV overrides
-  static const int nv_env = [] {
-    const char* s = getenv("EBM_HMC_NV");
-    return s ? atoi(s) : 0;
-  }();
+  static const int nv_env = ab_int("EBM_HMC_NV");
   if (dim == 32 && (nv_env == 2 || nv_env == 4 || nv_env == 8)) geo = Geometry{8 / nv_env, nv_env, true};
   // measured on MI355X (profiles/r01_bench_kernels.jsonl): the small-mixture energy is fastest with
   // ONE lane per chain -- the means become wave-uniform scalar operands (no LDS traffic, no cross-lane
@@ -62,8 +59,8 @@ static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
 // Records from the matrix-layout kernels where they run and their layout does not depend on the mass form (the layout
 // query is not told it): dense Gaussians and mixtures at dims 20 .. 96.
 static bool hmc_matrix_records(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
-  static const bool gauss_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
-  static const bool gmm_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+  static const bool gauss_rows = ab_switch("EBM_GAUSS_ROWS");
+  static const bool gmm_rows = ab_switch("EBM_GMM_ROWS");
   if ((e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows)) return false;
   return matrix_hmc_diag_plan(e, n_chains, dim, d);
 }
@@ -89,7 +86,7 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   // (records beyond those shapes: the lane-group kernels)
   if (!diag_partials && e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
-    static const bool force_rows = [] { const char* v = getenv("EBM_GAUSS_ROWS"); return v && v[0] == '1'; }();
+    static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)
       return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
                                          mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
@@ -102,7 +99,7 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   if (!diag_partials && e.kind == EBM_ENERGY_GMM && gmm_hmc_mfma_supported(dim, e.n_comp, mass_kind) &&
       !(dim == 32 && e.n_comp <= 8)) {
     // A/B switch for tests and profiling: EBM_GMM_ROWS=1 keeps the lane-group kernels
-    static const bool force_rows = [] { const char* v = getenv("EBM_GMM_ROWS"); return v && v[0] == '1'; }();
+    static const bool force_rows = ab_switch("EBM_GMM_ROWS");
     if (!force_rows)
       return launch_hmc_chain_gmm_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
                                        mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);

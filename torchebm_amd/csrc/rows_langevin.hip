@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void energy_grad_wide_row_kernel(const floa
 // diagnostics layout query, which must agree).
 static bool rows_langevin_pair(const ebm_energy_t& e, int32_t dim) {
   // A/B switch for tests and profiling: EBM_NO_PAIR=1 keeps one chain per lane at dim 2
-  static const bool off = [] { const char* v = getenv("EBM_NO_PAIR"); return v && v[0] == '1'; }();
+  static const bool off = ab_switch("EBM_NO_PAIR");
   return !off && dim == 2 && (e.kind == EBM_ENERGY_GAUSSIAN || e.kind == EBM_ENERGY_GMM);
 }
 
