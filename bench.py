@@ -50,12 +50,15 @@ from torchebm_amd import _lib  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy ceiling is measured live next to it
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector (non-matrix) peak
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
 ETA, SIGMA = 0.01, 1.0
 # Issue cost of one Euler-Maruyama step of one float4 group in the lean DoubleWell loop, in units of one plain
 # full-rate VALU op: 18 v_mad_u64_u32 x 2.6 + 20 v_bitop3_b32 + 8 transcendentals x 3.2 + 11 plain + 20 packed-f32 x 1.8
 # (static ISA count of langevin_chain_lean_kernel<DoubleWell>; per-class costs measured by scripts/ubench/valu_rates.hip,
 # profiles/r01_valu_rates.txt)
-LEAN_LOOP_ISSUE_UNITS = 140.0
+LEAN_LOOP_ISSUE_UNITS = 140.0  # round-1 constant, kept as the fallback and printed next to the value measured in the run
+# static instruction mix of the lean loop per float4 group and step (scripts/isa_mix.py on langevin.hip)
+LEAN_LOOP_MIX = {"mad_u64_u32": 18, "bitop3": 20, "transcendental": 8, "packed_f32": 20, "plain": 11}
 
 
 def parse():
@@ -152,7 +155,10 @@ def cpu_baseline(dim: int, k_full: int):
         "kind": "port",
         "sample": f"oracle (torch CPU restatement of the reference loop: randn + autograd gradient + eager update), "
                   f"DoubleWell n=2^16 dim={dim} k={k}, median of {len(times)} runs ({t:.2f} s each) at the fastest of the "
-                  f"probed torch thread counts ({best_threads} of {ncpu} cores); rate is per chain-step",
+                  f"probed torch thread counts ({best_threads} of {ncpu} cores); rate is per chain-step.  BASELINE.md section 4 "
+                  f"sketched os.cpu_count() threads at n=2^17: torch's intra-op pool is SLOWER at {ncpu} threads than at "
+                  f"{best_threads} on ops this small (the probe above measures it), and n=2^16 keeps the default run short -- "
+                  f"the rate per chain-step does not depend on n at these sizes",
     }
 
 
@@ -188,6 +194,115 @@ def plain_valu_rate(device, blocks=256 * 8, iters=4096, reps=5):
     b.record()
     torch.cuda.synchronize(device)
     return blocks * 4 * 8 * iters * reps / (a.elapsed_time(b) * 1e-3)
+
+
+def issue_costs(device, blocks=256 * 8, iters=2048, reps=3):
+    """Issue cost of the instruction classes of the lean loop, in units of one plain VALU op, measured NOW on this box
+    (``ebm_probe_issue_f32``: the same dependent-free stream per class) -> the loop's price per float4 group and step."""
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=device)
+    st = _lib.stream_handle(device)
+
+    def t_of(kind):
+        _lib.call("ebm_probe_issue_f32", out.data_ptr(), blocks, iters, kind, st)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            _lib.call("ebm_probe_issue_f32", out.data_ptr(), blocks, iters, kind, st)
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / reps
+
+    t0 = t_of(0)                      # 8 plain ops per iteration
+    per = t0 / 8.0
+    units = {
+        "mad_u64_u32": t_of(1) / 8.0 / per - 1.0,      # slot = v_mad_u64_u32 + one plain v_xor
+        "transcendental": t_of(2) / 8.0 / per - 1.0,   # slot = v_log_f32 + one plain v_add
+        "packed_f32": t_of(3) / 4.0 / per,             # v_pk_fma_f32 (two fused multiply-adds)
+        "bitop3": t_of(4) / 8.0 / per,
+        "plain": 1.0,
+    }
+    loop = sum(LEAN_LOOP_MIX[k] * units[k] for k in LEAN_LOOP_MIX)
+    return {"units_per_class": {k: round(v, 3) for k, v in units.items()}, "static_mix_per_group_step": LEAN_LOOP_MIX,
+            "issue_units_per_float4_group_step": loop, "round1_constant": LEAN_LOOP_ISSUE_UNITS}
+
+
+def pick_threads(run_once, candidates=(8, 16, 32, 64)):
+    """Fastest torch intra-op thread count for ``run_once`` among a few candidates (bounded: stops at a 5 s probe; the
+    whole-machine count is not probed -- torch's intra-op pool is slower at 256 threads than at 64 on ops this small)."""
+    ncpu = os.cpu_count() or 1
+    best, best_t = 1, float("inf")
+    for th in sorted({min(t, ncpu) for t in candidates}):
+        torch.set_num_threads(th)
+        run_once()
+        t0 = time.perf_counter()
+        run_once()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = th, dt
+        if dt > 5.0:
+            break
+    torch.set_num_threads(best)
+    return best, best_t, ncpu
+
+
+def cpu_config3():
+    """Config 3 on the host: the oracle's HMC (restatement of samplers/hmc.py:243-312 + leapfrog.py:116-187) driving autograd
+    on the mixture forward as the reference's BaseModel.gradient does, n = 2^14 chains, 2 MH transitions of L = 20."""
+    import oracle
+
+    n, dim, T, L = 1 << 14, 32, 2, 20
+    model = ta.core.ring_mixture(8, dim, device="cpu")
+    en = oracle.GaussianMixture(model.means.detach().clone(), float(model.sigma))
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(n, dim, generator=g)
+    p = torch.randn(T, n, dim, generator=g)
+    u = torch.rand(T, n, generator=g)
+    run = lambda: oracle.hmc_chain(en, x0, p, u, [0.1] * T, L)  # noqa: E731
+    th, _, ncpu = pick_threads(run)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    return {"value": n * T / t, "unit": "MH-steps/s", "cores": th, "kind": "port",
+            "sample": f"oracle.hmc_chain (torch CPU restatement), ring mixture K=8 dim=32, n=2^14, {T} transitions of L={L}, "
+                      f"median of 3 ({t:.2f} s each), fastest of the probed thread counts ({th} of {ncpu} cores)"}
+
+
+def cpu_config5():
+    """Config 5's sampler call on the host: 20 Langevin steps of 65 536 chains through the autograd gradient of the
+    2-128-128-1 SiLU network (what the reference's ContrastiveDivergence does per training step)."""
+    import oracle
+    from torch import nn
+
+    n, k = 65536, 20
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(2, 128), nn.SiLU(), nn.Linear(128, 128), nn.SiLU(), nn.Linear(128, 1))
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(n, 2, generator=g)
+
+    def grad(x):
+        x = x.detach().requires_grad_(True)
+        (gx,) = torch.autograd.grad(net(x).sum(), x)
+        return gx
+
+    def run(steps=k):
+        x = x0
+        for _ in range(steps):
+            x = oracle.em_step(x, grad(x), torch.randn(n, 2, generator=g), 0.1, 1.0)
+        return x
+
+    th, _, ncpu = pick_threads(lambda: run(2))
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    return {"value": n * k / t, "unit": "chain-steps/s", "sampler_call_ms": t * 1e3, "cores": th, "kind": "port",
+            "sample": f"autograd gradient of the 2-128-128-1 network + the oracle's eager update, n=65536, k=20, median of 3 "
+                      f"({t:.2f} s each), fastest of the probed thread counts ({th} of {ncpu} cores)"}
 
 
 def read_traffic():
@@ -226,14 +341,16 @@ def kernel_ms_of(entry, fn, reps, device):
 # ---------------------------------------------------------------------------------------
 # the other BASELINE configs, measured in the same run (N = 1, rank 0): `extra`
 # ---------------------------------------------------------------------------------------
-def extra_measurements(device, valu_rate):
+def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=True):
     out = []
 
     def guarded(name, fn):
+        t0 = time.perf_counter()
         try:
             out.append(fn())
         except Exception as exc:  # one failing extra must not take the headline line with it
             out.append({"name": name, "error": f"{type(exc).__name__}: {exc}"[:300]})
+        out[-1]["wall_s_of_this_measurement"] = round(time.perf_counter() - t0, 1)
 
     def c3():
         # BASELINE configs[2]: HMC, L = 20, 8-mode mixture on a radius-4 ring, n = 2^18, dim = 32, eps = 0.1, 50 MH steps per call
@@ -267,6 +384,7 @@ def extra_measurements(device, valu_rate):
             "bound": "valu", "body": "active-column (the ring's means differ in columns 0..1 only)",
             "step_equivalent_GBps": n * T * 8 * dim / t / 1e9,
             "acceptance_rate": float(d["acceptance_rate"][-1]),
+            "cpu_baseline": cpu_config3() if cpu else None,
             "dense_means": {
                 "workload": "same call, 8 random means that differ in every column (general mixture body)",
                 "value": n * T / td, "ms_per_call": td * 1e3, "kernel_ms_per_call": kd,
@@ -284,7 +402,7 @@ def extra_measurements(device, valu_rate):
         fn = lambda: s.sample(x=x0, n_steps=k, generator=gen)  # noqa: E731
         t = timed(fn, reps=3, warm=1, device=device)
         kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 2, device)
-        limit_ms = (n * dim / 4 / 64) * k * LEAN_LOOP_ISSUE_UNITS / valu_rate * 1e3
+        limit_ms = (n * dim / 4 / 64) * k * loop_units / valu_rate * 1e3
         return {
             "name": "config4_shard", "workload": "LangevinDynamics.sample on DoubleWell, one GPU's shard of BASELINE configs[3]: "
             "n_chains=2^20 (of 2^23 over 8 GPUs), dim=128, k=500", "metric": "chain-steps/s per GPU", "value": n * k / t,
@@ -342,7 +460,8 @@ def extra_measurements(device, valu_rate):
             "eager_launches": {"training_steps_per_s": 1 / t_eager, "sampler_ms": t_eager_sample * 1e3},
             "hip_graph_replay": {"training_steps_per_s": 1 / t_graph, "sampler_ms": t_graph_sample * 1e3},
         }
-        # the same energy as the packaged MLPEnergy: forward + input gradient fused on fp32 MFMA
+        # the same energy as the packaged MLPEnergy: forward + input gradient fused, the four contractions on the bf16 matrix
+        # pipe with three-way split operands (fp32 accuracy, 6 bf16 MFMAs per K-block of 16; csrc/mlp_b16.h)
         torch.manual_seed(0)
         fmodel = ta.MLPEnergy(2, device=device)
         fs = ta.LangevinDynamics(fmodel, step_size=0.1, noise_scale=1.0, device=device)
@@ -351,11 +470,16 @@ def extra_measurements(device, valu_rate):
         tf_sample = timed(fn, reps=10, warm=2, device=device)
         kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 5, device)
         mlp_flops = n * k * 2 * (2 * 128 * 128 + 2 * 2 * 128)  # two HxH contractions + the two thin ones, per chain-step
+        issued = n * k * 2 * (2 * 128 * 128 + 2 * 32 * 128) * 6    # bf16 products issued: input width padded to 32, six terms
+        tk = kms * 1e-3 if kms else tf_sample
         res["fused_mlp_kernel"] = {
-            "training_steps_per_s": 1 / tf, "sampler_ms": tf_sample * 1e3, "kernel_ms": kms, "bound": "mfma",
-            "fp32_TFLOPs": mlp_flops / (kms * 1e-3 if kms else tf_sample) / 1e12,
-            "frac_of_fp32_matrix_peak": mlp_flops / (kms * 1e-3 if kms else tf_sample) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "training_steps_per_s": 1 / tf, "sampler_ms": tf_sample * 1e3, "kernel_ms": kms,
+            "bound": "instruction issue at one wave per SIMD (DESIGN.md section 4, Wide MLP); matrix pipe: bf16 split operands",
+            "useful_fp32_TFLOPs": mlp_flops / tk / 1e12,
+            "vs_fp32_matrix_peak": mlp_flops / tk / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "issued_bf16_TFLOPs": issued / tk / 1e12, "frac_of_bf16_matrix_peak": issued / tk / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
         }
+        res["cpu_baseline"] = cpu_config5() if cpu else None
         res["value"] = 1 / (t_graph if default_graph else t_eager)
         res["chain_steps_per_s"] = n * k * res["value"]
         return res
@@ -423,10 +547,14 @@ def extra_measurements(device, valu_rate):
         timed(fn, reps=2, warm=2, device=device)
         kms = kernel_ms_of(sym, fn, 3, device)
         tf = n * evals * 2 * (2 * hidden * hidden + 2 * dim * hidden) / (kms * 1e-3) / 1e12
-        return {"kernel_ms": kms, "evaluations_per_launch": evals, "TFLOPs": tf, "frac": tf / FP32_MATRIX_PEAK_TFLOPS}
+        res = {"kernel_ms": kms, "evaluations_per_launch": evals, "useful_fp32_TFLOPs": tf, "vs_fp32_matrix_peak": tf / FP32_MATRIX_PEAK_TFLOPS,
+               "contraction": "exact-f32 MFMA, weights streamed from L2" if hidden == 256 else "bf16 MFMA, three-way split operands"}
+        if hidden != 256:
+            res["frac_of_bf16_matrix_peak"] = 6 * tf / BF16_MATRIX_PEAK_TFLOPS
+        return res
 
     def mlp_bench_net():
-        # the reference's benchmark network (benchmarks/registry.py:372-387) at dim 32: Langevin chain fused on fp32 MFMA
+        # the reference's benchmark network (benchmarks/registry.py:372-387) at dim 32: Langevin chain fused on the bf16 matrix pipe
         n, k, dim, hidden = 65536, 20, 32, 128
         torch.manual_seed(0)
         m = ta.MLPEnergy(dim, hidden, device=device)
@@ -438,9 +566,12 @@ def extra_measurements(device, valu_rate):
         flops = n * k * 2 * (2 * hidden * hidden + 2 * dim * hidden)
         return {"name": "mlp_benchmark_network_dim32", "workload": "LangevinDynamics.sample on MLPEnergy Linear(32,128)-SiLU-Linear(128,128)-"
                 "SiLU-Linear(128,1) (the reference's benchmarks/registry.py network), n_chains=65536, k=20: forward + input gradient + "
-                "update fused, four contractions on v_mfma_f32_32x32x2_f32", "metric": "TFLOP/s (exact fp32 matrix)", "bound": "mfma",
-                "kernel_ms": kms, "value": flops / (kms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                "frac": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3),
+                "update fused, four contractions on v_mfma_f32_32x32x16_bf16 with three-way split operands (six products per K-block, fp32 "
+                "accuracy)", "metric": "useful fp32-equivalent TFLOP/s", "bound": "instruction issue at one wave per SIMD; bf16 mfma",
+                "kernel_ms": kms, "value": flops / (kms * 1e-3) / 1e12, "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS,
+                "vs_fp32_matrix_peak": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                "issued_bf16_TFLOPs": 6 * flops / (kms * 1e-3) / 1e12, "peak": BF16_MATRIX_PEAK_TFLOPS,
+                "frac": 6 * flops / (kms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3),
                 "hidden_256": wide(256, "langevin"), "hmc_hidden_128": wide(128, "hmc"), "hmc_hidden_256": wide(256, "hmc")}
 
     guarded("config3_hmc_gmm8", c3)
@@ -550,11 +681,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = None
+    kernel_ms, kernel_dist = None, None
     if on_gpu:
         pairs = _lib.timed_events.pop("ebm_langevin_chain_f32")
         if pairs:  # GPU time of the chain kernel per step (the pipelined last step of N > 1 is several launches)
-            kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
+            each = [a.elapsed_time(b) for a, b in pairs]
+            kernel_ms = sum(each) / args.steps
+            if len(each) == args.steps:  # one launch per step: the per-step distribution
+                srt = sorted(each)
+                kernel_dist = {"min": srt[0], "median": srt[len(srt) // 2], "mean": kernel_ms, "max": srt[-1], "launches": len(each)}
 
     if rank == 0:
         chain_steps = world * n * k * args.steps
@@ -566,8 +701,10 @@ def main():
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             traffic = read_traffic()
             valu_rate = plain_valu_rate(device)
+            costs = issue_costs(device)  # per-class issue costs measured in THIS run -> the loop's price
+            loop_units = costs["issue_units_per_float4_group_step"]
             physical = 2 * n * dim * 4  # what the k-fused launch has to move: the state in, the state out
-            issue_limit_ms = (n * dim / 4 / 64) * k * LEAN_LOOP_ISSUE_UNITS / valu_rate * 1e3
+            issue_limit_ms = (n * dim / 4 / 64) * k * loop_units / valu_rate * 1e3
             roof = {
                 # The kernel keeps the state in registers for all k steps, so it is NOT memory-shaped: the physical
                 # limiter is VALU issue (Philox-10 + Box-Muller).  `achieved`/`peak`/`frac` keep BASELINE.json's
@@ -580,7 +717,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "definition": "step-equivalent: n_chains*k*8*dim bytes / kernel time (BASELINE.md section 3)",
                 "valu": {
-                    "issue_units_per_float4_group_step": LEAN_LOOP_ISSUE_UNITS,
+                    "issue_units_per_float4_group_step": loop_units,
+                    "issue_costs_measured_in_run": costs,
                     "plain_valu_wave_instr_per_s": valu_rate,
                     "issue_limit_ms": issue_limit_ms,
                     "frac_of_issue_limit": issue_limit_ms / kernel_ms,
@@ -595,6 +733,7 @@ def main():
                 "traffic_source": None if not traffic else traffic.get("source"),
                 "kernel": "langevin_chain_lean_kernel<DoubleWell> (ebm_langevin_chain_f32)",
                 "kernel_ms": kernel_ms,
+                "kernel_ms_per_step": kernel_dist,
                 "algorithmic_bytes_per_launch": algo_bytes,
             }
         line = {
@@ -629,7 +768,9 @@ def main():
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dim, k),
         }
         if on_gpu and world == 1 and not args.no_extra:
-            line["extra"] = extra_measurements(device, valu_rate or plain_valu_rate(device))
+            line["extra"] = extra_measurements(device, valu_rate or plain_valu_rate(device),
+                                               (roof or {}).get("valu", {}).get("issue_units_per_float4_group_step") or LEAN_LOOP_ISSUE_UNITS,
+                                               cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
 
     if world > 1:

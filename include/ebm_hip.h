@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 2
+#define EBM_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -317,6 +317,14 @@ EBM_API int ebm_diag_finish_f32(const float* diag_partials, int32_t n_kept, int6
  * issue rate of this chip at its current clock, against which the VALU-bound chain kernels are priced.
  * `out` = float[blocks * 256] (keeps the arithmetic alive). */
 EBM_API int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream);
+
+/* The same stream shape with the instruction classes the in-kernel RNG is made of, so that bench.py can price the
+ * Langevin loop from costs measured in the run instead of constants: per lane and iteration,
+ *   kind 0: 8 v_fma_f32 (= ebm_probe_valu_f32)          kind 1: 8 x (v_mad_u64_u32 + v_xor_b32)
+ *   kind 2: 8 x (v_log_f32 + v_add_f32)                 kind 3: 4 v_pk_fma_f32 (8 fused multiply-adds)
+ *   kind 4: 8 v_bitop3_b32
+ * independent across the eight slots.  Since ABI version 3. */
+EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,12 +60,13 @@ def hmc_chain(
     thin: int = 1,
     want_traj: bool = False,
     want_diag: bool = False,
+    want_margins: bool = False,
 ):
     """T = len(eps_values) transitions; ``p_noise[t]`` are the standard normals of transition
     t (scaled by sqrt(mass) here, hmc.py:118-133), ``u[t]`` the accept uniforms.
 
     Returns a dict: ``x`` final state, ``accepted`` bool [T, n], ``margin`` = min |u - a| over
-    all decisions (how far the closest accept/reject call was from flipping), optional
+    all decisions (how far the closest accept/reject call was from flipping; ``margins`` [T, n]: per decision), optional
     ``trajectory`` [n, T // thin, dim] and ``diagnostics`` (mean, var, energy, acceptance_rate).
     """
     x = x0.clone()
@@ -73,6 +74,7 @@ def hmc_chain(
     T = len(eps_values)
     n_kept = T // thin
     accepted_all = torch.empty(T, n, dtype=torch.bool)
+    margins_all = torch.full((T, n), float("inf"), dtype=torch.float64) if want_margins else None  # |u - a| of every decision
     margin = float("inf")
     traj = torch.empty(n, n_kept, dim, dtype=x.dtype) if want_traj else None
     diag: Optional[Dict[str, torch.Tensor]] = None
@@ -101,6 +103,8 @@ def hmc_chain(
         if bool(finite.any()):
             margin = min(margin, float((u[t][finite] - a[finite]).abs().min()))
         accepted_all[t] = acc
+        if margins_all is not None:
+            margins_all[t] = torch.where(finite, (u[t] - a).abs().double(), torch.zeros((), dtype=torch.float64))
         x = torch.where(acc.view(-1, 1), xp, x)
         if (t + 1) % thin == 0:
             if traj is not None:
@@ -113,4 +117,4 @@ def hmc_chain(
                 diag["energy"][keep] = energy.energy(x).clamp_(min=-1e10, max=1e10).mean()
                 diag["acceptance_rate"][keep] = acc.float().mean()
             keep += 1
-    return {"x": x, "accepted": accepted_all, "margin": margin, "trajectory": traj, "diagnostics": diag}
+    return {"x": x, "accepted": accepted_all, "margin": margin, "margins": margins_all, "trajectory": traj, "diagnostics": diag}

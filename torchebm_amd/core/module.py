@@ -110,22 +110,113 @@ class TorchEBMModule(nn.Module):
         return contextlib.nullcontext()
 
 
+_BLIND = object()
+_MODULE_INTERNALS = None
+
+
+def _plain(val):
+    """A hashable stand-in for an attribute value a captured graph may have frozen, or ``_BLIND``."""
+    import torch
+
+    if isinstance(val, (bool, int, float, complex, str, bytes, type(None), torch.device, torch.dtype, torch.Size)):
+        return val
+    if torch.is_tensor(val):
+        return ("tensor", val.data_ptr(), val._version, tuple(val.shape), val.dtype)
+    if isinstance(val, (tuple, list)):
+        parts = tuple(_plain(v) for v in val)
+        return _BLIND if any(p is _BLIND for p in parts) else (type(val).__name__,) + parts
+    if isinstance(val, dict):
+        try:
+            parts = tuple(sorted((str(k), _plain(v)) for k, v in val.items()))
+        except TypeError:
+            return _BLIND
+        return _BLIND if any(p[1] is _BLIND for p in parts) else ("dict",) + parts
+    if isinstance(val, type) or callable(val) and not isinstance(val, torch.nn.Module) and not hasattr(val, "__dict__"):
+        return ("callable", id(val))
+    import types
+
+    if isinstance(val, (types.FunctionType, types.BuiltinFunctionType, types.MethodType)):
+        return ("callable", id(val))
+    return _BLIND
+
+
+def _module_attributes(model):
+    """(module name, attribute name, value) of every attribute a user put on a submodule (torch's own bookkeeping --
+    ``_parameters``, hooks ... -- is skipped: parameters and buffers enter the key through their storages)."""
+    import torch
+
+    global _MODULE_INTERNALS
+    if _MODULE_INTERNALS is None:
+        _MODULE_INTERNALS = frozenset(vars(torch.nn.Module()).keys())
+    for name, mod in model.named_modules():
+        for attr, val in vars(mod).items():
+            if attr in _MODULE_INTERNALS or attr == "_where":  # _where: DeviceMixin's own (device, dtype) cache
+                continue
+            yield name, attr, val
+
+
 def graph_state_key(model) -> tuple:
     """What a captured HIP graph of ``model``'s forward / backward has frozen, as a hashable key: the storage of
     every parameter and buffer (in-place updates -- an optimiser step -- are seen by a replay, a REPLACED tensor is
-    not) and every plain Python attribute of every submodule (``training``, a temperature, a flag: a replay cannot
-    see a changed value).  The samplers re-capture when the key of the model they are about to replay differs."""
+    not); every Python attribute of every submodule, ``_``-prefixed ones included -- numbers, strings, flags, tuples /
+    lists / dicts of those, functions by identity, and tensors kept as plain attributes (``self.scale = torch.tensor(..)``:
+    storage, in-place version, shape); ``training``; and whether autocast is on.  The samplers re-capture when the key of
+    the model they are about to replay differs.  Attributes it cannot hash are listed by ``graph_blind_spots``."""
     import torch
 
     items = []
+    for name, attr, val in _module_attributes(model):
+        k = _plain(val)
+        items.append((name, attr, "<unhashable>" if k is _BLIND else k))  # the PRESENCE of a blind spot is part of the key
     for name, mod in model.named_modules():
-        for attr, val in vars(mod).items():
-            if attr.startswith("_"):
-                continue
-            if isinstance(val, (bool, int, float, str, type(None))):
-                items.append((name, attr, val))
-            elif isinstance(val, (tuple, list)) and all(isinstance(v, (bool, int, float, str)) for v in val):
-                items.append((name, attr, tuple(val)))
         items.append((name, "training", mod.training))
     tensors = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in list(model.parameters()) + list(model.buffers()))
-    return (tuple(items), tensors)
+    return (tuple(items), tensors, torch.is_autocast_enabled())
+
+
+def graph_blind_spots(model) -> list:
+    """Attributes ``graph_state_key`` cannot see into (an arbitrary object, a container holding one): a replay would not
+    notice a change behind them, so the samplers do not capture BY DEFAULT when a model has any (``capture_graph = True``
+    overrides)."""
+    return [f"{name or type(model).__name__}.{attr}" for name, attr, val in _module_attributes(model) if _plain(val) is _BLIND]
+
+
+class ForwardProbe:
+    """What ONE eager iteration of the step route did besides computing: taken around the first (real) step of a call,
+    it tells whether the model's forward has side effects a replayed graph would not reproduce the way eager launches
+    do -- a buffer written under ``forward`` (BatchNorm running statistics in training mode), random numbers drawn from
+    the default CUDA or CPU generator (dropout, ``torch.rand`` in the forward), a Python attribute that changed (a call
+    counter).  The samplers capture by default only when it reports nothing."""
+
+    def __init__(self, model, device):
+        import torch
+
+        self.model, self.device = model, device
+        self.buffers = tuple(b._version for b in model.buffers())
+        self.cuda_offset = self._cuda_offset()
+        self.cpu_state = torch.get_rng_state()
+        self.key = graph_state_key(model)
+
+    def _cuda_offset(self):
+        import torch
+
+        if self.device.type != "cuda":
+            return None
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        return torch.cuda.default_generators[idx].get_offset()
+
+    def side_effects(self) -> list:
+        import torch
+
+        found = []
+        if tuple(b._version for b in self.model.buffers()) != self.buffers:
+            found.append("the forward writes a buffer (running statistics in training mode?)")
+        if self._cuda_offset() != self.cuda_offset:
+            found.append("the forward draws from the default CUDA generator (dropout?)")
+        if not torch.equal(torch.get_rng_state(), self.cpu_state):
+            found.append("the forward draws from the default CPU generator")
+        if graph_state_key(self.model) != self.key:
+            found.append("the forward changes an attribute of the model")
+        return found
+
+

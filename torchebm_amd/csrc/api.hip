@@ -57,6 +57,7 @@ int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
+int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
 bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
@@ -502,6 +503,13 @@ int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream) 
   const char* who = "ebm_probe_valu_f32";
   if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
   return launch_probe_valu(out, blocks, iters, (hipStream_t)stream);
+}
+
+int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream) {
+  const char* who = "ebm_probe_issue_f32";
+  if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
+  if (kind < 0 || kind > 4) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3)", who, kind);
+  return launch_probe_issue(out, blocks, iters, kind, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -557,6 +557,74 @@ int launch_diag_finish(const float* partials, int32_t n_kept, int64_t n_blocks, 
   return check_launch("ebm_diag_finish_f32");
 }
 
+// Per-class issue probes (bench.py prices the lean Langevin loop with them, in the run, on the box): the same
+// dependent-free shape as probe_valu_kernel with the op under test in the stream.
+//   kind 1: v_mad_u64_u32 + v_xor_b32 per slot (the Philox multiply)      kind 2: v_log_f32 + v_add_f32 (a transcendental)
+//   kind 3: v_pk_fma_f32, two slots per instruction                        kind 4: v_bitop3_b32 (the three-input xor)
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void probe_issue_kernel(float* __restrict__ out, int iters) {
+  if constexpr (KIND == 1 || KIND == 4) {
+    uint32_t a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 2654435761u + j;
+    uint32_t k1 = 0x9E3779B9u + blockIdx.x, k2 = 0xBB67AE85u + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (KIND == 1) {
+          const uint64_t p = (uint64_t)0xD2511F53u * a[j];
+          a[j] = (uint32_t)(p >> 32) ^ (uint32_t)p;
+        } else {
+          a[j] = __builtin_amdgcn_bitop3_b32(a[j], k1, k2, 0x96);
+          asm volatile("" : "+v"(a[j]));  // keep one instruction per slot (x ^ k1 ^ k2 twice is x)
+        }
+      }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j];
+    out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = __builtin_bit_cast(float, s);
+  } else if constexpr (KIND == 2) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.3f + threadIdx.x * 1e-4f + j * 0.01f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = __builtin_amdgcn_logf(a[j]) + 2.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j];
+    out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
+  } else {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = (f32x2){threadIdx.x * 1e-3f + j, threadIdx.x * 2e-3f + j};
+    const f32x2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = __builtin_elementwise_fma(a[j], m, c);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += a[j].x + a[j].y;
+    out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
+  }
+}
+
+int launch_probe_issue(float* out, int32_t blocks, int32_t iters, int32_t kind, hipStream_t st) {
+  const dim3 g((unsigned)blocks), b(kBlock);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(probe_valu_kernel, g, b, 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(probe_issue_kernel<1>, g, b, 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(probe_issue_kernel<2>, g, b, 0, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(probe_issue_kernel<3>, g, b, 0, st, out, iters); break;
+    default: hipLaunchKernelGGL(probe_issue_kernel<4>, g, b, 0, st, out, iters); break;
+  }
+  return check_launch("ebm_probe_issue_f32");
+}
+
 int launch_probe_valu(float* out, int32_t blocks, int32_t iters, hipStream_t st) {
   hipLaunchKernelGGL(probe_valu_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, out, iters);
   return check_launch("ebm_probe_valu_f32");

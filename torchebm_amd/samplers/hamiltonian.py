@@ -27,6 +27,7 @@ from .. import _lib, _rng
 from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSymplecticIntegrator
 from ..core.module import graph_state_key, warn_once
+from .langevin import _replay_or_step
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler
 from ..integrators.registry import resolve_integrator
@@ -198,15 +199,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         traj, diag = self._new_outputs(n, dim, n_kept, want_traj, want_diag)
         drift = lambda x_, t_: -self._model_gradient(x_, model_kwargs)  # noqa: E731
         if hip and n > 0 and self._use_graph(model_kwargs, n_steps):
-            try:
-                return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
-            except RuntimeError as exc:  # the model's forward cannot be captured (host sync, data-dependent control flow ...)
-                if "ebm_" in str(exc):
-                    raise
-                warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
-                          "continuing with the eager step route.", UserWarning)
-                self.capture_graph = False
-                self._step_graph = None
+            return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
         if hip:
             x = _lib.dense_f32(x)
             seed, step0 = _rng.reserve(generator, x.device, 2 * n_steps)
@@ -285,8 +278,10 @@ class HamiltonianMonteCarlo(BaseSampler):
     #: (``ebm_noise_fill_dev_f32`` at +0, ``ebm_hmc_accept_dev_f32`` at +1), so the generator contract and
     #: the noise field are those of the eager step route, bit for bit.  Requirements: constant step
     #: size, no conditioning, a model whose forward is static-shape and free of host-side randomness.
-    #: ``None`` (default): replay whenever eligible and the call has at least ``GRAPH_MIN_STEPS`` transitions;
-    #: ``True``: whenever eligible; ``False``: never.  See ``LangevinDynamics.capture_graph`` for the rules.
+    #: ``None`` (default): replay whenever eligible, the call has at least ``GRAPH_MIN_STEPS`` transitions and the first
+    #: (eager) transition showed no side effect of the model's forward; ``True``: whenever eligible; ``False``: never.
+    #: See ``LangevinDynamics.capture_graph`` for the rules (first transition eager = the warm-up, thread-local capture,
+    #: per-configuration refusal).
     capture_graph: Optional[bool] = None
     GRAPH_MIN_STEPS = 4
     #: Step route only (the fused kernels always do this, bit-identically): reuse the force a leapfrog step ends on as
@@ -341,17 +336,7 @@ class HamiltonianMonteCarlo(BaseSampler):
             )
             rng[1:2].add_(2)
 
-        state.copy_(x)
-        side = torch.cuda.Stream(device=x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side):                                      # warm-up off the capture stream
-            for _ in range(2):
-                body()
-        torch.cuda.current_stream(x.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            body()
-        self._step_graph = {"key": key, "graph": graph, "state": state, "rng": rng, "mask": mask}
+        self._step_graph = {"key": key, "graph": None, "state": state, "rng": rng, "mask": mask, "body": body}
         return self._step_graph
 
     def _sample_graph(self, x, n_steps, thin, traj, diag, want_traj, want_diag, generator):
@@ -364,7 +349,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         g["rng"].copy_(torch.tensor([as_i64(seed), as_i64(step0)], dtype=torch.int64), non_blocking=True)
         state, keep = g["state"], 0
         for i in range(n_steps):
-            g["graph"].replay()
+            _replay_or_step(self, g, first=(i == 0), more=(i + 1 < n_steps))
             if (i + 1) % thin == 0:
                 if traj is not None:
                     traj[:, keep, :] = state

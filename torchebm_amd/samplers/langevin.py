@@ -27,7 +27,7 @@ import torch
 from .. import _lib, _rng
 from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSDERungeKuttaIntegrator
-from ..core.module import graph_state_key, warn_once
+from ..core.module import ForwardProbe, graph_blind_spots, graph_state_key, warn_once
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler
 from ..integrators.em import EulerMaruyamaIntegrator, HeunIntegrator
@@ -39,6 +39,48 @@ def em_coefficients(eta: float, sigma: float) -> Tuple[float, float, float]:
     reference's Python-float arithmetic does (base_integrator.py:728-729): they are cast to
     fp32 only when they enter the tensor ops / the kernel."""
     return eta, eta**0.5, (2.0 * sigma**2) ** 0.5
+
+
+def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
+    """One iteration of the graph route: a replay once the graph exists; until then the step body runs eagerly (a real
+    step), and behind the FIRST one of a call the graph is captured -- unless, by default, that step showed side effects
+    (``ForwardProbe``) or the model has attributes the cache key cannot see into.  Shared by the Langevin and HMC samplers
+    (``sampler.capture_graph``, ``sampler._graph_refused``)."""
+    if g["graph"] is not None:
+        g["graph"].replay()
+        return
+    refused = getattr(sampler, "_graph_refused", None)
+    if refused is None:
+        refused = sampler._graph_refused = {}
+    prior = refused.get(g["key"])  # ("probe" | "failed", reasons): a default-mode refusal does not bind capture_graph = True
+    decide = first and more and (prior is None or (sampler.capture_graph is True and prior[0] == "probe"))
+    probe = ForwardProbe(sampler.model, g["state"].device) if decide and sampler.capture_graph is not True else None
+    g["body"]()
+    if not decide:
+        return
+    why = []
+    if probe is not None:
+        why = probe.side_effects()
+        blind = graph_blind_spots(sampler.model)
+        if blind:
+            why.append("attributes the cache key cannot see into: " + ", ".join(blind[:4]))
+    if not why:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                g["body"]()
+            g["graph"] = graph
+            return
+        except RuntimeError as exc:  # the forward cannot be captured (host sync, data-dependent control flow ...)
+            if "ebm_" in str(exc):
+                raise
+            warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
+                      "continuing with eager launches.", UserWarning)
+            probe, why = None, [f"capture failed: {exc}"]
+    refused.pop(g["key"], None)
+    if len(refused) >= 8:
+        refused.pop(next(iter(refused)))
+    refused[g["key"]] = ("failed" if probe is None else "probe", why)
 
 
 class LangevinDynamics(BaseSampler):
@@ -179,15 +221,7 @@ class LangevinDynamics(BaseSampler):
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         keep = 0
         if hip and self._use_graph(model_kwargs, n_steps):
-            try:
-                return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
-            except RuntimeError as exc:  # the model's forward cannot be captured (host sync, data-dependent control flow ...)
-                if "ebm_" in str(exc):
-                    raise
-                warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
-                          "continuing with the eager step route.", UserWarning)
-                self.capture_graph = False
-                self._step_graph = None
+            return self._sample_graph(x, n_steps, thin, traj, diag, want_traj, want_diag, generator)
         if hip:
             x = _lib.dense_f32(x)
             seed, step0 = _rng.reserve(generator, x.device, n_steps)
@@ -241,16 +275,25 @@ class LangevinDynamics(BaseSampler):
     #: coordinates live in a device buffer advanced inside the graph (``ebm_langevin_step_dev_f32``), so
     #: every replay draws fresh noise and the generator contract is unchanged; the result is bit-identical
     #: to the eager step route.
-    #:   ``None`` (default)  replay whenever the call is eligible: constant step size / noise scale, no
-    #:                       conditioning, no autocast, at least ``GRAPH_MIN_STEPS`` steps.  The graph is kept
-    #:                       for the next call and re-captured when the batch shape, the coefficients or the
-    #:                       model's state key (``core.module.graph_state_key``: parameter / buffer storages and
-    #:                       plain Python attributes of every submodule) change.  A forward that cannot be
-    #:                       captured (host sync, data-dependent control flow) falls back to eager launches
-    #:                       with a one-time warning.
-    #:   ``True``            as above, without the minimum step count.
-    #:   ``False``           always eager launches (what a model with host-side randomness, or with state a
-    #:                       replay cannot see, needs).
+    #:   ``None`` (default)  replay whenever the call is eligible -- constant step size / noise scale, no conditioning, no
+    #:                       autocast, at least ``GRAPH_MIN_STEPS`` steps -- AND capturing has no observable side effect:
+    #:                       the first step of the call runs eagerly (it is the warm-up; nothing is evaluated that the
+    #:                       eager route would not evaluate), and the graph is captured behind it only if that step
+    #:                       wrote no buffer of the model (BatchNorm statistics in training mode), drew nothing from the
+    #:                       default CUDA / CPU generators (dropout) and changed no attribute (``core.module.ForwardProbe``),
+    #:                       and the model holds no attribute the cache key cannot see into
+    #:                       (``core.module.graph_blind_spots``); otherwise the call continues with eager launches.
+    #:                       The graph is kept for the next call and re-captured when the batch shape, the coefficients
+    #:                       or the model's state key (``core.module.graph_state_key``: parameter / buffer storages, every
+    #:                       hashable attribute of every submodule incl. tensor-valued ones, ``training``, autocast)
+    #:                       change.  A forward that cannot be captured (host sync, data-dependent control flow) continues
+    #:                       with eager launches with a one-time warning; only THAT configuration is remembered as
+    #:                       uncapturable.  Capture uses ``capture_error_mode="thread_local"``: work other threads
+    #:                       submit meanwhile (a DataLoader's pinning thread) neither breaks it nor is broken by it.
+    #:                       Blind spots that remain: state reached through a closure or a global, tensors replaced
+    #:                       inside containers the key hashes by storage, side effects outside the model.
+    #:   ``True``            capture whenever eligible, without the minimum step count and without the side-effect checks.
+    #:   ``False``           always eager launches.
     capture_graph: Optional[bool] = None
     GRAPH_MIN_STEPS = 8
 
@@ -268,6 +311,8 @@ class LangevinDynamics(BaseSampler):
         )
 
     def _graph_for(self, x: torch.Tensor):
+        """The replay state for this (batch shape, coefficients, model state): static buffers + the step body; the graph
+        itself is captured by ``_sample_graph`` behind the first eager step."""
         a, sq, coef = em_coefficients(self.get_scheduled_value("step_size"), self.get_scheduled_value("noise_scale"))
         key = (
             tuple(x.shape), x.device, (a, sq, coef), self._clamp_args(),
@@ -289,17 +334,7 @@ class LangevinDynamics(BaseSampler):
             )
             rng[1:2].add_(1)
 
-        state.copy_(x)
-        side = torch.cuda.Stream(device=x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side):                                      # warm-up off the capture stream
-            for _ in range(3):
-                body()
-        torch.cuda.current_stream(x.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            body()
-        self._step_graph = {"key": key, "graph": graph, "state": state, "rng": rng}
+        self._step_graph = {"key": key, "graph": None, "state": state, "rng": rng, "body": body}
         return self._step_graph
 
     def _sample_graph(self, x, n_steps, thin, traj, diag, want_traj, want_diag, generator):
@@ -312,7 +347,7 @@ class LangevinDynamics(BaseSampler):
         g["rng"].copy_(torch.tensor([as_i64(seed), as_i64(step0)], dtype=torch.int64), non_blocking=True)
         state, keep = g["state"], 0
         for i in range(n_steps):
-            g["graph"].replay()
+            _replay_or_step(self, g, first=(i == 0), more=(i + 1 < n_steps))
             if (i + 1) % thin == 0:
                 if traj is not None:
                     traj[:, keep] = state
