@@ -60,6 +60,9 @@ if os.path.exists(trace):
             f.write(",".join(str(k) for k in key) + f",{len(v)},{sum(v)/len(v):.4f},{min(v):.4f},{max(v):.4f}\n")
     print(open(os.path.join(dst, f"{tag}_kernel_stats_by_grid.csv")).read())
 
+# keyed by kernel AND launch grid (workgroups): the default run uses some kernels at several shapes (the lean chain kernel at
+# config 2 and at config 4's shard; the per-step kernel at 2^26 elements and at config 5's 2^17), and a mean over all of
+# them describes none
 pmc = {}
 for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     path = os.path.join(src, sub, "bench_counter_collection.csv")
@@ -67,8 +70,9 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == counter and "ebm::" in r["Kernel_Name"]:
+            wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+            agg[f"{short(r['Kernel_Name'])} @ {wgs} workgroups"].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter + "_KiB_mean"] = sum(v) / len(v)
         pmc[k][counter + "_launches"] = len(v)
@@ -80,8 +84,11 @@ for k, d in pmc.items():
     d["hbm_bytes_per_launch"] = fetch + write
 json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 
-for k, d in pmc.items():
-    if dominant in k:
+# the dominant kernel at the headline shape = its most frequent grid in the run
+dom = sorted((k for k in pmc if dominant in k), key=lambda k: -pmc[k].get("FETCH_SIZE_launches", 0))[:1]
+for k in dom:
+    d = pmc[k]
+    if True:
         json.dump(
             {
                 "kernel": k,
