@@ -291,7 +291,10 @@ EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, con
  * At every kept step each workgroup of a chain launch stores ONE record of its chains' per-column partials
  * (sum, M2 about the block mean), its energy sum and its accept count; ebm_diag_finish_f32 merges the records of
  * all kept steps into the reference's diagnostics tensors.  return_diagnostics=True is therefore one chain launch
- * plus one small merge launch, with no extra pass over the state.
+ * plus one small merge launch, with no extra pass over the state.  (The matrix-layout MLP kernels store one record per
+ * WAVEFRONT of 32 chains -- the state lives in the MFMA accumulator layout, a column statistic is a sum over 32 lanes, no
+ * LDS tile -- and write a Langevin record's energy share one evaluation late, when the energy of the kept state exists;
+ * a kept last step costs one forward pass more.  Since ABI version 3.)
  *
  * ebm_diag_layout: the record geometry the chain entry WOULD use for this energy / shape --
  *   sampler: EBM_DIAG_LANGEVIN / EBM_DIAG_LANGEVIN_HEUN / EBM_DIAG_HMC;  injected_noise / with_traj: whether the

@@ -263,7 +263,8 @@ def test_c_abi_layout_and_injected_noise_records(cuda_device):
     assert _lib.diag_layout(c, _lib.DIAG_LANGEVIN, 10, 5000) is None                       # neither divides: no in-kernel form
     assert _lib.diag_layout(c, _lib.DIAG_HMC, 10, 2000) is None
     mlp = ta.MLPEnergy(2, device=cuda_device).fused_spec().to_c()
-    assert _lib.diag_layout(mlp, _lib.DIAG_LANGEVIN, 100, 2) is None
+    assert _lib.diag_layout(mlp, _lib.DIAG_LANGEVIN, 100, 2) == (4, 2, 64)                 # MLP kernels: one record per wave of 32 chains
+    assert _lib.diag_layout(mlp, _lib.DIAG_LANGEVIN_HEUN, 100, 2) is None                  # no fused Heun kernel for this energy
     n, dim, k = 500, 64, 6
     x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(0)).clamp_(-2, 2)
     noise = torch.randn(k, n, dim, generator=torch.Generator().manual_seed(1))

@@ -363,3 +363,50 @@ def test_wide_hmc_edge_shapes_schedule_and_prefix_identity(cuda_device, in_dim, 
     # the kept states are transitions 2 and 4; the final state (after 5) differs from the last kept one for most chains
     assert (last != full[:, -1]).any(dim=1).float().mean().item() > 0.5
     assert torch.equal(x0, x0.clone())                                # the caller's tensor is not the in/out buffer
+
+
+@pytest.mark.parametrize("in_dim,hidden,n", [(2, 128, 4099), (32, 128, 1000), (64, 128, 515), (33, 64, 777), (32, 256, 300), (100, 128, 257)])
+def test_langevin_diagnostics_come_from_records_of_the_one_chain_launch(cuda_device, in_dim, hidden, n):
+    """return_diagnostics=True on the MLP energy stays ONE chain launch -- every wave stores the record
+    of its 32 chains at the kept steps (the energy share one evaluation later), ebm_diag_finish_f32 merges them -- and
+    equals the torch reductions of the stored trajectory (langevin_dynamics.py:170-185)."""
+    torch.manual_seed(in_dim)
+    model = ta.MLPEnergy(in_dim, hidden, device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    x0 = torch.randn(n, in_dim, device=cuda_device)
+    for k, thin in ((12, 3), (10, 4), (5, 1)):   # kept last step; unkept tail; every step
+        c0, f0 = hip_calls("ebm_langevin_chain_f32"), hip_calls("ebm_diag_finish_f32")
+        traj, diag = s.sample(x=x0, n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True,
+                              generator=torch.Generator(device=cuda_device).manual_seed(5))
+        assert hip_calls("ebm_langevin_chain_f32") == c0 + 1 and hip_calls("ebm_diag_finish_f32") == f0 + 1
+        plain = s.sample(x=x0, n_steps=k, thin=thin, return_trajectory=True, generator=torch.Generator(device=cuda_device).manual_seed(5))
+        assert torch.equal(traj, plain)                      # the records do not touch the chains
+        t64 = traj.double()
+        torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False).clamp(1e-10, 1e10), rtol=1e-4, atol=1e-7)
+        want_e = torch.stack([model(traj[:, j]).double().mean() for j in range(traj.shape[1])])
+        torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("in_dim,hidden,mass", [(2, 128, None), (32, 128, 1.7), (48, 64, "diag"), (32, 256, None)])
+def test_hmc_diagnostics_come_from_records_of_the_one_chain_launch(cuda_device, in_dim, hidden, mass):
+    torch.manual_seed(3 + in_dim)
+    model = ta.MLPEnergy(in_dim, hidden, device=cuda_device)
+    if mass == "diag":
+        mass = torch.rand(in_dim, device=cuda_device) + 0.5
+    h = ta.HamiltonianMonteCarlo(model, step_size=0.1, n_leapfrog_steps=4, mass=mass, device=cuda_device)
+    n = 1234
+    x0 = torch.randn(n, in_dim, device=cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    traj, diag = h.sample(x=x0, n_steps=6, thin=1, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(2))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    t64 = traj.double()
+    torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False).clamp(1e-10, 1e10), rtol=1e-4, atol=1e-7)
+    want_e = torch.stack([model(traj[:, j]).double().clamp(-1e10, 1e10).mean() for j in range(6)])
+    torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-5)
+    prev = torch.cat([x0.unsqueeze(1), traj[:, :-1]], dim=1)
+    moved = (traj != prev).any(dim=2).double().mean(dim=0)     # an accepted proposal moves the chain
+    torch.testing.assert_close(diag["acceptance_rate"].double(), moved, rtol=0, atol=1e-6)
+    assert 0.2 < float(diag["acceptance_rate"].mean()) <= 1.0

@@ -32,7 +32,8 @@ int launch_diag_finish(const float*, int32_t, int64_t, int32_t, int32_t, int64_t
                        double*, hipStream_t);
 int launch_hmc_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
                          double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
-                         uint64_t, uint64_t, hipStream_t);
+                         uint64_t, uint64_t, float*, hipStream_t);
+bool mlp_diag_plan(const ebm_energy_t&, bool hmc, int64_t, int32_t, diag::DiagArgs&);  // mlp.hip
 int launch_hmc_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float,
                      const float*, int32_t, double, const float*, int32_t, float*, uint8_t*,
                      uint32_t*, const float*, const float*, uint64_t, uint64_t, float* diag_partials, hipStream_t);
@@ -54,7 +55,7 @@ int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, 
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
-                              int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, hipStream_t);
+                              int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
@@ -129,11 +130,12 @@ int reject_mlp(const ebm_energy_t* en, const char* who) {
 
 // Which kernel family serves a chain call that asks for diagnostics records, and with what record geometry.
 // One function for the layout query and for the dispatch, so the two cannot disagree.
-enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows, kDiagMatrix };
+enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows, kDiagMatrix, kDiagMlp };
 
 DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32_t dim, bool has_noise, bool has_traj,
                      diag::DiagArgs& d) {
-  if (e.kind == EBM_ENERGY_MLP) return kDiagNone;  // matrix-layout kernels: statistics from the state between launches
+  if (e.kind == EBM_ENERGY_MLP)  // matrix-layout kernels: one record per wave of 32 chains (mlp_wide_body.h); no Heun kernel
+    return (sampler != EBM_DIAG_LANGEVIN_HEUN && mlp_diag_plan(e, sampler == EBM_DIAG_HMC, n_chains, dim, d)) ? kDiagMlp : kDiagNone;
   const bool elementwise = e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC;
   if (sampler == EBM_DIAG_HMC) return hmc_diag_plan(e, n_chains, dim, d) ? kDiagHmcRows : kDiagNone;
   const int heun = sampler == EBM_DIAG_LANGEVIN_HEUN;
@@ -232,6 +234,9 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (fam == kDiagRows)
       return launch_langevin_chain_rows(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
                                         cmax, thin, traj, noise, seed, offset, heun, diag_partials, (hipStream_t)stream);
+    if (fam == kDiagMlp)
+      return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
+                                       thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
     if (fam == kDiagMatrix)
       return launch_langevin_chain_matrix_diag(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on,
                                                cmin, cmax, thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
@@ -240,7 +245,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
   }
   if (energy->kind == EBM_ENERGY_MLP)
     return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
-                                     clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+                                     clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
   if (energy->kind == EBM_ENERGY_DOUBLE_WELL || energy->kind == EBM_ENERGY_HARMONIC)
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
@@ -305,13 +310,14 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
   if (n_mh / thin == 0) diag_partials = nullptr;
   if (diag_partials) {
     diag::DiagArgs d;
-    if (plan_diag(*energy, EBM_DIAG_HMC, n_chains, dim, p_noise != nullptr, traj != nullptr, d) != kDiagHmcRows)
+    const DiagFamily fam = plan_diag(*energy, EBM_DIAG_HMC, n_chains, dim, p_noise != nullptr, traj != nullptr, d);
+    if (fam != kDiagHmcRows && fam != kDiagMlp)
       return fail(energy->kind == EBM_ENERGY_MLP ? EBM_EKIND : EBM_EDIM,
                   "%s: no in-kernel diagnostics for this energy / dim %d (see ebm_diag_layout)", who, dim);
   }
   if (energy->kind == EBM_ENERGY_MLP)
     return launch_hmc_chain_mlp(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset,
+                                mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials,
                                 (hipStream_t)stream);
   return launch_hmc_chain(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind,
                           mass_scalar, mass_diag, thin, traj, accept_mask, accept_count, p_noise, u,

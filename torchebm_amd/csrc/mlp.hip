@@ -7,6 +7,7 @@
 // where it took 0.91 (65 536 chains x 20 steps) and 3.0 ms where it took 4.4 (HMC, L = 10, 10 transitions), so it is gone.
 // Reference shape: examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31 (the energy),
 // torchebm/samplers/langevin_dynamics.py:154-185 (the loop), core/base_integrator.py:711-731 (the update).
+#include "diag.h"
 #include "ebm_common.h"
 
 namespace ebm {
@@ -16,11 +17,12 @@ bool mlp_wide_hmc_supported(int32_t hidden, int32_t dim);  // mlp_wide_hmc.hip
 int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
                               int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
                               const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
-                              const float* p_noise, const float* u, uint64_t seed, uint64_t offset, hipStream_t st, const char* who);
+                              const float* p_noise, const float* u, uint64_t seed, uint64_t offset, float* diag_partials,
+                              hipStream_t st, const char* who);
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
-                    float* grad_out, hipStream_t st, const char* who);
+                    float* grad_out, float* diag_partials, hipStream_t st, const char* who);
 
 namespace {
 
@@ -34,24 +36,30 @@ int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool hmc) {
 
 }  // namespace
 
+// Records of the matrix-layout MLP kernels (mlp_wide_body.h): a wave of 32 chains is a "block" of the record geometry.
+bool mlp_diag_plan(const ebm_energy_t& e, bool hmc, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  if (!e.dev0 || (hmc ? !mlp_wide_hmc_supported(e.n_comp, dim) : !mlp_wide_supported(e.n_comp, dim))) return false;
+  return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
+}
+
 int launch_langevin_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                               float eta, float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on,
                               float cmin, float cmax, int32_t thin, float* traj, const float* noise, uint64_t seed,
-                              uint64_t offset, hipStream_t st) {
+                              uint64_t offset, float* diag_partials, hipStream_t st) {
   const char* who = "ebm_langevin_chain_f32";
   if (int r = mlp_check(e, dim, who, false)) return r;
   return launch_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
-                         thin, traj, noise, seed, offset, nullptr, nullptr, st, who);
+                         thin, traj, noise, seed, offset, nullptr, nullptr, diag_partials, st, who);
 }
 
 int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh, int32_t n_leapfrog,
                          float eps, const float* eps_table, int32_t mass_kind, double mass_scalar, const float* mass_diag,
                          int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
-                         const float* u, uint64_t seed, uint64_t offset, hipStream_t st) {
+                         const float* u, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   const char* who = "ebm_hmc_chain_f32";
   if (int r = mlp_check(e, dim, who, true)) return r;
   return launch_hmc_chain_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                   mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st, who);
+                                   mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st, who);
 }
 
 int launch_energy_grad_mlp(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* e_out,
@@ -59,7 +67,7 @@ int launch_energy_grad_mlp(const ebm_energy_t& e, const float* x, int64_t n_chai
   const char* who = "ebm_energy_grad_f32";
   if (int r = mlp_check(e, dim, who, false)) return r;
   return launch_mlp_wide(e.n_comp, e.dev0, const_cast<float*>(x), n_chains, dim, 0, 0.0f, 0.0f, 0.0f, nullptr, 0, 0.0f, 0.0f, 1,
-                         nullptr, nullptr, 0, 0, e_out, g_out, st, who);
+                         nullptr, nullptr, 0, 0, e_out, g_out, nullptr, st, who);
 }
 
 }  // namespace ebm

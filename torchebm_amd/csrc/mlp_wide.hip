@@ -41,7 +41,7 @@ bool mlp_wide_supported(int32_t hidden, int32_t dim) {
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
-                    float* grad_out, hipStream_t st, const char* who) {
+                    float* grad_out, float* diag_partials, hipStream_t st, const char* who) {
   WideArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
@@ -50,6 +50,7 @@ int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_cha
   a.thin = thin; a.n_kept = thin > 0 ? k_steps / thin : 0; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.params = params; a.energy_out = energy_out; a.grad_out = grad_out;
+  a.diag_partials = diag_partials; a.diag_blocks = ceil_div64(n_chains, 32);
   const int dt = (dim + 31) / 32;
 #define EBM_WIDE(HTV)                                    \
   switch (dt) {                                          \

@@ -6,6 +6,7 @@
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"  // static_for
 #include "mlp_b16.h"
+#include "diag.h"
 
 namespace ebm {
 namespace widemlp {
@@ -50,9 +51,62 @@ struct WideArgs {
   const float* params;   // packed W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1]
   float* energy_out;     // k_steps == 0: E(x)[n]
   float* grad_out;       // k_steps == 0: dE/dx[n, dim]
+  float* diag_partials;  // in-kernel diagnostics records (one per WAVE: 32 chains), or null
+  int64_t diag_blocks;   // records per kept step = ceil(n_chains / 32)
 };
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+
+// ------------------------------------------------------------------------------------------------------------------
+// In-kernel diagnostics records of the matrix-layout MLP kernels (diag.h).  The state of a wave's 32 chains sits in the
+// C/D layout -- lane (m, h), register r of tile td = coordinate 32 td + row_of(r, h) of chain m -- so a column statistic
+// is a sum over the 32 lanes of a K-half: no LDS tile (the images leave none), no barrier.  A WAVE is a "block" of the
+// record geometry: E = 32 dim flat elements, S = dim slots, n_blocks = ceil(n / 32); diag_finish_kernel merges them like
+// any other layout.  Two passes (sum -> wave mean -> squared deviations), as in diag::emit: no cancellation.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_sum(float v) {  // over the 32 lanes that share this lane's h
+#pragma unroll
+  for (int msk = 16; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
+  return v;
+}
+__device__ __forceinline__ constexpr int diag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// sums and centred second moments of the wave's chains at kept step `keep`; the energy / accept shares follow through
+// wave_record_tail() (Langevin: one evaluation later, when the energy of the kept state exists)
+template <int DT>
+__device__ __noinline__ void wave_record(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, const float (&xs)[DT][16],
+                                         bool active, int lane) {
+  if (wave_id >= n_blocks) return;  // a wave past the last chain has no record (wave-uniform)
+  const int h = lane >> 5;
+  const int valid = __popcll(__ballot(active)) >> 1;  // both K-halves of a chain vote
+  const float inv = valid > 0 ? 1.0f / (float)valid : 0.0f;
+  float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)diag::record_floats(dim);
+#pragma unroll
+  for (int td = 0; td < DT; ++td)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = active ? xs[td][r] : 0.0f;
+      const float sum = half_wave_sum(v);
+      const float dv = active ? v - sum * inv : 0.0f;
+      const float m2 = half_wave_sum(dv * dv);
+      const int c = 32 * td + diag_row(r, h);
+      if ((lane & 31) == 0 && c < dim) {
+        rec[c] = sum;
+        rec[dim + c] = m2;
+      }
+    }
+}
+__device__ __forceinline__ void wave_record_tail(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, float energy,
+                                                 bool active, bool accepted, int lane) {
+  if (wave_id >= n_blocks) return;
+  float e = (active && lane < 32) ? energy : 0.0f;  // one K-half speaks for the chain
+  e = diag::wave_sum(e);
+  const int acc = __popcll(__ballot(accepted && lane < 32));
+  if (lane < 8) {
+    float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)diag::record_floats(dim);
+    rec[2 * dim + lane] = lane == 0 ? e : (lane == 4 ? (float)acc : 0.0f);
+  }
+}
 
 // -DEBM_PHASE_TIMES (scripts/mlp_phase_times.py only): wave 0 of workgroup 0 logs the shader clock at the phase boundaries of
 // every evaluation (stamps cost a drained LDS queue each: read the phases relative to each other, not against a plain run).
@@ -197,14 +251,26 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
   int until_keep = a.thin;
   int64_t keep_off = 0;
-  const int n_evals = a.k_steps > 0 ? a.k_steps : 1;
+  // Diagnostics: the reference reports the mean energy of the KEPT state, i.e. of x after the update; that energy is what
+  // the NEXT step's evaluation computes anyway, so the record's energy share is written one evaluation late and only a
+  // kept LAST step costs an evaluation of its own (the loop runs one more time, without an update).
+  const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  int diag_keep = 0, diag_pending = -1;
+  const bool diag_tail = a.diag_partials && a.k_steps > 0 && a.thin > 0 && a.k_steps % a.thin == 0;
+  const int n_evals = a.k_steps > 0 ? a.k_steps + (diag_tail ? 1 : 0) : 1;
 
 #ifdef EBM_PHASE_TIMES
   int stamp_n_ = 0;
 #endif
   for (int step = 0; step < n_evals; ++step) {
     EBM_STAMP();
+    const bool eval_energy_only = a.k_steps > 0 && step >= a.k_steps;  // the extra evaluation of a kept last step
 #include "mlp_wide_eval.inc"
+    if (diag_pending >= 0) {
+      wave_record_tail(a.diag_partials, a.diag_blocks, diag_pending, wave_id, dim, energy, active, false, lane);
+      diag_pending = -1;
+    }
+    if (a.k_steps > 0 && step >= a.k_steps) break;  // the extra evaluation of a kept last step
 
     if (a.k_steps == 0) {  // evaluation only
       if (active) {
@@ -270,9 +336,9 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
           xr[td][r] = (c0 + i < dim) ? nv : 0.0f;
         }
       }
-    if (a.traj && --until_keep == 0) {
+    if ((a.traj || a.diag_partials) && --until_keep == 0) {
       until_keep = a.thin;
-      if (active) {
+      if (a.traj && active) {
         float* dst = a.traj + smp * (int64_t)a.n_kept * dim + keep_off;
 #pragma unroll
         for (int td = 0; td < DT; ++td)
@@ -283,6 +349,10 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
           }
       }
       keep_off += dim;
+      if (a.diag_partials) {
+        wave_record<DT>(a.diag_partials, a.diag_blocks, diag_keep, wave_id, dim, xr, active, lane);
+        diag_pending = diag_keep++;
+      }
     }
   }
   if (active) {

@@ -26,7 +26,8 @@ bool mlp_wide_hmc_supported(int32_t hidden, int32_t dim) {
 int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
                               int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
                               const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
-                              const float* p_noise, const float* u, uint64_t seed, uint64_t offset, hipStream_t st, const char* who) {
+                              const float* p_noise, const float* u, uint64_t seed, uint64_t offset, float* diag_partials,
+                              hipStream_t st, const char* who) {
   widemlp::WideHmcArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
@@ -37,6 +38,7 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
   a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.params = params;
+  a.diag_partials = diag_partials; a.diag_blocks = ceil_div64(n_chains, 32);
   const int dt = (dim + 31) / 32;
 #define EBM_WIDE_HMC(HTV)                                               \
   switch (dt) {                                                         \

@@ -25,6 +25,8 @@ struct WideHmcArgs {
   RngKey key;
   uint64_t step0;
   const float* params;
+  float* diag_partials;  // in-kernel diagnostics records (mlp_wide_body.h: one per wave), or null
+  int64_t diag_blocks;
 };
 
 template <int HT, int DT, int MODE, bool DIAGM>
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
     for (int td = 0; td < DT; ++td)
 #pragma unroll
       for (int r = 0; r < 16; ++r) f[td][r] = 0.0f;
-    float h0 = 0.0f, e_last = 0.0f;
+    float h0 = 0.0f, e_last = 0.0f, e_start = 0.0f;
     int done = 0, mode = 0;  // wave-uniform
     while (done <= a.n_leapfrog) {
       if (mode == 1) {  // first half kick + drift
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
             xr[td][r] = (32 * td + row_of(r, h) < dim) ? xn : 0.0f;
           }
       }
+      constexpr bool eval_energy_only = false;
 #include "mlp_wide_eval.inc"
       if (mode == 0) {  // H0 and the first (clamped) force
         h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
 #pragma unroll
           for (int r = 0; r < 16; ++r) f[td][r] = clamp_nanprop(-g[td][r], -1e6f, 1e6f);
         e_last = energy;
+        e_start = energy;
         mode = 1;
         ++done;
       } else if (mode == 1) {
@@ -236,10 +240,17 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
       const unsigned long long b = __ballot(accept && leader);
       if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
     }
-    if (a.traj && --until_keep == 0) {
+    if ((a.traj || a.diag_partials) && --until_keep == 0) {
       until_keep = a.thin;
-      if (active) {
-        if (!accept) load_state(xr, smp);  // a rejected chain records the position it stays at
+      if (active && !accept) load_state(xr, smp);  // a rejected chain records the position it stays at
+      if (a.diag_partials) {  // hmc.py:294-310: statistics of the state after the accept step, its (clamped) energy, the accept rate
+        const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        const int kept = (int)(keep_off / dim);
+        wave_record<DT>(a.diag_partials, a.diag_blocks, kept, wave_id, dim, xr, active, lane);
+        wave_record_tail(a.diag_partials, a.diag_blocks, kept, wave_id, dim, clamp_nanprop(accept ? e_last : e_start, -1e10f, 1e10f),
+                         active, accept, lane);
+      }
+      if (a.traj && active) {
         float* dst = a.traj + smp * (int64_t)a.n_kept * dim + keep_off;
 #pragma unroll
         for (int td = 0; td < DT; ++td)

@@ -65,8 +65,15 @@ def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
         if blind:
             why.append("attributes the cache key cannot see into: " + ", ".join(blind[:4]))
     if not why:
+        # The cyclic collector must not run inside the capture: finalising a dead sampler's CUDAGraph (or any tensor whose
+        # storage goes back to the driver) while this stream records aborts the process.  torch.cuda.graph() collects
+        # once on entry; what becomes garbage during the body waits until the capture has ended.
+        import gc
+
+        gc_was_on = gc.isenabled()
         try:
             graph = torch.cuda.CUDAGraph()
+            gc.disable()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g["body"]()
             g["graph"] = graph
@@ -77,6 +84,9 @@ def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
             warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
                       "continuing with eager launches.", UserWarning)
             probe, why = None, [f"capture failed: {exc}"]
+        finally:
+            if gc_was_on:
+                gc.enable()
     refused.pop(g["key"], None)
     if len(refused) >= 8:
         refused.pop(next(iter(refused)))
