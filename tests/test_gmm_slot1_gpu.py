@@ -119,3 +119,22 @@ def test_energy_and_diagnostics_and_safe_mode(cuda_device):
     assert _mask_of(model) == 0b101
     out2 = s.sample(x=x0, n_steps=2, generator=torch.Generator(device=cuda_device).manual_seed(3))
     assert torch.isfinite(out2).all()
+
+
+def test_means_written_through_data_do_not_leave_a_stale_hint(cuda_device):
+    """``means.data.copy_(..)`` keeps the tensor's storage and version; the active-column hint is recomputed at
+    every call, so a ring mixture turned into a dense one runs the dense body (same chains as a freshly built model)."""
+    dim, k = 32, 8
+    ring = ta.core.ring_mixture(k, dim, device=cuda_device)
+    dense_means = torch.randn(k, dim, generator=torch.Generator().manual_seed(3)) * 2.0
+    fresh = ta.GaussianMixtureModel(dense_means, sigma=1.0, device=cuda_device)
+    x0 = torch.randn(4096, dim, device=cuda_device)
+    h = ta.HamiltonianMonteCarlo(ring, step_size=0.1, n_leapfrog_steps=5, device=cuda_device)
+    h.sample(x=x0, n_steps=2)                                    # the hint of the ring has been used
+    assert int(ring.fused_spec().aux.item()) == 1
+    ring.means.data.copy_(dense_means.to(cuda_device))
+    assert int(ring.fused_spec().aux.item()) == 0xFF
+    a = h.sample(x=x0, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(4))
+    b = ta.HamiltonianMonteCarlo(fresh, step_size=0.1, n_leapfrog_steps=5, device=cuda_device).sample(
+        x=x0, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(4))
+    assert torch.equal(a, b)

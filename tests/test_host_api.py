@@ -556,6 +556,22 @@ def test_sample_and_gather_single_process_contract():
     assert torch.equal(loc, want)
     with pytest.raises(ValueError, match="equal blocks"):
         sample_and_gather(s, x, 4, pieces=5)
+    # the default adapts to the shard size, and every block runs at the same point of the schedules
+    odd = torch.randn(7, 3, generator=torch.Generator().manual_seed(2))
+    loc, gat = sample_and_gather(s, odd, 4, generator=torch.Generator().manual_seed(1))
+    assert gat.shape == (1, 1, 7, 3) and torch.equal(loc, s.sample(x=odd, n_steps=4, generator=torch.Generator().manual_seed(1)))
+    from torchebm_amd.core.schedules import LinearScheduler
+
+    sched = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=LinearScheduler(0.02, 0.002, 8))
+    loc, _ = sample_and_gather(sched, x, 4, pieces=3, generator=torch.Generator().manual_seed(1))
+    assert sched.schedulers["step_size"].get_value() == pytest.approx(LinearScheduler(0.02, 0.002, 8).preview(5)[4])  # advanced by 4, once
+    fresh = ta.LangevinDynamics(ta.DoubleWellModel(), step_size=LinearScheduler(0.02, 0.002, 8))
+    gen = torch.Generator().manual_seed(1)
+    want = []
+    for i in range(3):
+        fresh.reset_schedulers()
+        want.append(fresh.sample(x=x[4 * i : 4 * (i + 1)], n_steps=4, generator=gen))
+    assert torch.equal(loc, torch.cat(want))
 
 
 def test_width_mismatch_raises_like_the_reference():

@@ -309,19 +309,19 @@ class GaussianMixtureModel(BaseModel):
 
     def _active_column_mask(self) -> Optional[torch.Tensor]:
         """Device int32[1]: bit v set when the component means differ somewhere in columns 4v..4v+3 (the `aux` hint
-        of EBM_ENERGY_GMM).  Computed on the device -- no host read -- and kept until the means change."""
+        of EBM_ENERGY_GMM).  Computed on the device -- no host read -- at EVERY call (four tiny device ops): a cache keyed on
+        the tensor's storage and version would survive a write through ``.data`` (``means.data.copy_(new)`` keeps both),
+        and a stale hint sends a mixture whose components now differ elsewhere to the active-column body."""
         m = self.means
         k, d = m.shape
         if not m.is_cuda or d % 4 != 0 or d // 4 > 8:
             return None
-        key = (m.data_ptr(), m._version)
-        cached = getattr(self, "_mask_cache", None)
-        if cached is None or cached[0] != key:
-            differs = (m != m[:1]).any(dim=0).view(d // 4, 4).any(dim=1)
+        weights = getattr(self, "_mask_weights", None)
+        if weights is None or weights.device != m.device or weights.numel() != d // 4:
             weights = torch.ones(d // 4, dtype=torch.int32, device=m.device) << torch.arange(d // 4, dtype=torch.int32, device=m.device)
-            cached = (key, (differs.to(torch.int32) * weights).sum().to(torch.int32).reshape(1))
-            self._mask_cache = cached
-        return cached[1]
+            self._mask_weights = weights
+        differs = (m != m[:1]).any(dim=0).view(d // 4, 4).any(dim=1)
+        return (differs.to(torch.int32) * weights).sum().to(torch.int32).reshape(1)
 
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(GaussianMixtureModel) or self.means.dtype != torch.float32:

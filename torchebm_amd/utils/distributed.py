@@ -41,7 +41,7 @@ def all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
-def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: int = 4, generator=None, group=None):
+def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: Optional[int] = None, generator=None, group=None):
     """This rank's shard through ``sampler.sample`` AND the read-back all-gather, pipelined: the shard
     is processed in ``pieces`` row blocks, and the all-gather of block i is in flight (RCCL's own
     stream, ``async_op=True``) while block i+1 is being sampled, so only the last block's gather is
@@ -54,24 +54,37 @@ def sample_and_gather(sampler, x: torch.Tensor, n_steps: int, *, pieces: int = 4
     chip's copy rate, against 282 ms of sampling per call).
     With one process the same ``pieces`` ``sampler.sample`` calls are made (so a rank's chains do not depend
     on how many other ranks exist) and ``gathered`` is the ``[1, pieces, n // pieces, ...]`` view of the
-    local result -- the indexing contract does not depend on the world size.  ``n`` must be divisible by
-    ``pieces`` in every case."""
+    local result -- the indexing contract does not depend on the world size.  An explicit ``pieces`` must divide
+    ``n``; the default (``None``) takes the largest of 4, 3, 2, 1 that does, so any shard size works.
+    Every block runs at the SAME point of the sampler's schedules (step size, noise scale ...): the schedulers are
+    rewound before each block and end up advanced by ``n_steps`` once, as after one ``sample()`` call over the shard
+    -- ``pieces`` is a pipelining choice, not a change of the dynamics."""
     n = x.shape[0]
     world = get_world_size(group)
+    if pieces is None:
+        pieces = next(p for p in (4, 3, 2, 1) if n % p == 0)
     if pieces < 1 or n % pieces != 0:
         raise ValueError(f"n = {n} chains cannot be split into {pieces} equal blocks")
     block = n // pieces
     tail = tuple(x.shape[1:])
     local = torch.empty_like(x)
+    scheds = list(sampler._subtree_schedulers()) if hasattr(sampler, "_subtree_schedulers") else []
+    start = [s.state_dict() for s in scheds]
+
+    def sample_block(i):
+        if i > 0:
+            for s, st in zip(scheds, start):
+                s.load_state_dict(st)
+        return sampler.sample(x=x[i * block : (i + 1) * block], n_steps=n_steps, generator=generator)
+
     if world == 1:
         for i in range(pieces):
-            local[i * block : (i + 1) * block] = sampler.sample(x=x[i * block : (i + 1) * block], n_steps=n_steps,
-                                                                generator=generator)
+            local[i * block : (i + 1) * block] = sample_block(i)
         return local, local.view((1, pieces, block) + tail)
     store = torch.empty((pieces, world, block) + tail, dtype=x.dtype, device=x.device)
     pending = []
     for i in range(pieces):
-        out = sampler.sample(x=x[i * block : (i + 1) * block], n_steps=n_steps, generator=generator)
+        out = sample_block(i)
         local[i * block : (i + 1) * block] = out
         pending.append(dist.all_gather_into_tensor(store[i].view((world * block,) + tail), out.contiguous(),
                                                    group=group, async_op=True))
