@@ -255,7 +255,8 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   // the NEXT step's evaluation computes anyway, so the record's energy share is written one evaluation late and only a
   // kept LAST step costs an evaluation of its own (the loop runs one more time, without an update).
   const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  int diag_keep = 0, diag_pending = -1;
+  [[maybe_unused]] int diag_keep = 0;
+  int diag_pending = -1;
   const bool diag_tail = a.diag_partials && a.k_steps > 0 && a.thin > 0 && a.k_steps % a.thin == 0;
   const int n_evals = a.k_steps > 0 ? a.k_steps + (diag_tail ? 1 : 0) : 1;
 
@@ -349,10 +350,12 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
           }
       }
       keep_off += dim;
+#ifndef EBM_MLP_NO_DIAG  // A/B builds only: what the records cost the plain call
       if (a.diag_partials) {
         wave_record<DT>(a.diag_partials, a.diag_blocks, diag_keep, wave_id, dim, xr, active, lane);
         diag_pending = diag_keep++;
       }
+#endif
     }
   }
   if (active) {
