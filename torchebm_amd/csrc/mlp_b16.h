@@ -142,6 +142,16 @@ struct NoFill {
   __device__ __forceinline__ void operator()(O) const {}
 };
 
+// A never-taken branch on an opaque scalar: it ends the basic block.  The evaluation is otherwise ONE block of ~4 000
+// instructions, over which the scheduler stretches live ranges until a 512-register wave spills; cut into its four phases the
+// same code needs ~380 registers (scripts/kernel_regs.py).  Two scalar instructions per cut.
+#define EBM_BLOCK_CUT()                         \
+  do {                                          \
+    int never_ = 0;                             \
+    asm volatile("" : "+s"(never_));            \
+    if (never_ != 0) __builtin_trap();          \
+  } while (0)
+
 #define EBM_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f) /* lgkmcnt(0), vmcnt / expcnt untouched */
 
 // The A operands of the two walks over an image of width C with R rows (split stride R 2 C).  Every address is ONE lane

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
             xr[td][r] = (32 * td + row_of(r, h) < dim) ? xn : 0.0f;
           }
       }
-      constexpr bool eval_energy_only = false;
+      constexpr bool eval_energy_only = false, eval_block_cuts = false;
 #include "mlp_wide_eval.inc"
       if (mode == 0) {  // H0 and the first (clamped) force
         h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
