@@ -29,7 +29,10 @@ struct WideHmcArgs {
   int64_t diag_blocks;
 };
 
-template <int HT, int DT, int MODE, bool DIAGM>
+// FAST: the plain call only -- in-kernel momenta and uniforms, no diagnostics records, dim % 4 == 0 or dim == 2 -- with the
+// injected-noise and per-element Philox paths and the record code compiled out and the evaluation cut into basic blocks
+// (mlp_wide_body.h); instantiated for the MODE 2 shapes without a diagonal mass in mlp_wide_hmc_fast.hip.
+template <int HT, int DT, int MODE, bool DIAGM, bool FAST = false>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) {
 #include "mlp_wide_setup.inc"
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
         const int c0 = 32 * td + 8 * q + 4 * h;
         float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (c0 < dim) {
-          if (a.p_noise) {
+          if (!FAST && a.p_noise) {
             if (active)
 #pragma unroll
               for (int i = 0; i < 4; ++i)
@@ -101,6 +104,13 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
             const F4 nrm = normal4_at(a.key, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, a.step0 + 2ull * (uint64_t)tr);
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = nrm.v[i];
+          } else if constexpr (FAST) {  // dim == 2: a chain's two elements are half a Philox counter
+            if (td == 0 && q == 0) {
+              const F4 nrm = normal4_at(a.key, (uint64_t)smp >> 1, a.step0 + 2ull * (uint64_t)tr);
+              const bool odd = (smp & 1) != 0;
+              z[0] = odd ? nrm.v[2] : nrm.v[0];
+              z[1] = odd ? nrm.v[3] : nrm.v[1];
+            }
           } else {
             uint64_t have = ~0ull;
             F4 nrm;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
     float acc_p = expf(dlt);
     acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
     float uu;
-    if (a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + smp] : 2.0f;
+    if (!FAST && a.u) uu = active ? a.u[(int64_t)tr * a.n_chains + smp] : 2.0f;
     else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)smp >> 2, a.step0 + 2ull * (uint64_t)tr + 1ull), (int)(smp & 3)));
     const bool accept = active && (uu < acc_p);
     if (accept) {
@@ -240,10 +250,10 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
       const unsigned long long b = __ballot(accept && leader);
       if (lane == 0 && b) atomicAdd(a.accept_count + tr, (uint32_t)__popcll(b));
     }
-    if ((a.traj || a.diag_partials) && --until_keep == 0) {
+    if ((a.traj || (!FAST && a.diag_partials)) && --until_keep == 0) {
       until_keep = a.thin;
       if (active && !accept) load_state(xr, smp);  // a rejected chain records the position it stays at
-      if (a.diag_partials) {  // hmc.py:294-310: statistics of the state after the accept step, its (clamped) energy, the accept rate
+      if (!FAST && a.diag_partials) {  // hmc.py:294-310: statistics of the state after the accept step, its (clamped) energy, the accept rate
         const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
         const int kept = (int)(keep_off / dim);
         wave_record<DT>(a.diag_partials, a.diag_blocks, kept, wave_id, dim, xr, active, lane);
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
   }
 }
 
-template <int HT, int DT, bool DIAGM>
-int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
+template <int HT, int DT, bool DIAGM, bool FAST>
+int launch_hmc_variant(const WideHmcArgs& a, hipStream_t st, const char* who) {
   constexpr int MODE = wide_mode(HT, DT);
   constexpr bool STREAM = MODE == 1;
   const size_t smem = wide_smem_bytes(HT, DT);
@@ -274,13 +284,28 @@ int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM, FAST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
-  hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  hipLaunchKernelGGL((mlp_wide_hmc_kernel<HT, DT, MODE, DIAGM, FAST>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch(who);
+}
+
+// the FAST instantiations live in mlp_wide_hmc_fast.hip
+template <int HT, int DT>
+int launch_hmc_fast(const WideHmcArgs& a, hipStream_t st, const char* who);
+#define EBM_HMC_FAST_DECL(HTV, DTV) template <> int launch_hmc_fast<HTV, DTV>(const WideHmcArgs& a, hipStream_t st, const char* who);
+EBM_HMC_FAST_DECL(2, 1) EBM_HMC_FAST_DECL(2, 2) EBM_HMC_FAST_DECL(2, 3) EBM_HMC_FAST_DECL(2, 4) EBM_HMC_FAST_DECL(4, 1) EBM_HMC_FAST_DECL(4, 2)
+#undef EBM_HMC_FAST_DECL
+
+template <int HT, int DT, bool DIAGM>
+int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
+  if constexpr (wide_mode(HT, DT) == 2 && !DIAGM) {
+    if (!a.p_noise && !a.u && !a.diag_partials && ((a.dim & 3) == 0 || a.dim == 2)) return launch_hmc_fast<HT, DT>(a, st, who);
+  }
+  return launch_hmc_variant<HT, DT, DIAGM, false>(a, st, who);
 }
 
 }  // namespace widemlp
