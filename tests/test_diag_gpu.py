@@ -204,7 +204,7 @@ def test_matrix_layout_kernels_emit_records(cuda_device, kind, dim):
     else:
         model = ta.GaussianMixtureModel(torch.randn(int(kind[3:]), dim, generator=g) * 2, sigma=0.9, device=cuda_device)
     n = 1001
-    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim) == ((n + 127) // 128, dim, 128 * dim)
+    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim) == ((n + 31) // 32, dim, 32 * dim)  # one record per wave of 32 chains
     s = ta.LangevinDynamics(model, step_size=0.02, noise_scale=0.8, clamp=(-3.0, 3.5), device=cuda_device)
     x0 = torch.randn(n, dim, generator=g).to(cuda_device)
     c0 = hip_calls("ebm_langevin_chain_f32")
@@ -235,7 +235,7 @@ def test_matrix_layout_hmc_kernels_emit_records(cuda_device, kind, dim, mass):
     if mass == "diag":
         mass = torch.rand(dim, generator=g) + 0.5
     n, T, L, thin = 700, 6, 4, 2
-    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_HMC, n, dim) == ((n + 127) // 128, dim, 128 * dim)
+    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_HMC, n, dim) == ((n + 31) // 32, dim, 32 * dim)  # one record per wave of 32 chains
     s = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass,
                                  device=cuda_device)
     x0 = torch.randn(n, dim, generator=g).clamp_(-1.5, 1.5).to(cuda_device)
@@ -318,3 +318,28 @@ def test_config2_with_diagnostics_is_one_launch_at_full_size(cuda_device):
     torch.testing.assert_close(diag["mean"][3].double(), xs.mean(dim=0), rtol=1e-4, atol=2e-6)
     torch.testing.assert_close(diag["var"][3].double(), xs.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(diag["energy"][3].double(), model(out).double().mean(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind,dim", [("gauss", 100), ("gauss", 128), ("gmm", 64), ("gmm", 128)])
+def test_asking_for_diagnostics_does_not_change_the_chains(cuda_device, kind, dim):
+    """records come from the SAME kernel family as the plain call at every dim the matrix-layout kernels take
+    (one record per wave of 32 chains, no LDS tile), so sample(return_diagnostics=True) returns the chains of sample()."""
+    g = torch.Generator().manual_seed(dim)
+    if kind == "gauss":
+        a = torch.randn(dim, dim, generator=g)
+        model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=cuda_device)
+    else:
+        model = ta.GaussianMixtureModel(torch.randn(12, dim, generator=g) * 1.5, sigma=1.0, device=cuda_device)
+    x0 = torch.randn(1000, dim, device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
+    plain = s.sample(x=x0, n_steps=12, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    with_d, d = s.sample(x=x0, n_steps=12, thin=4, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(1))
+    assert torch.equal(plain, with_d)
+    torch.testing.assert_close(d["mean"][-1], with_d.mean(dim=0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(d["energy"][-1], model(with_d).mean(), rtol=1e-4, atol=1e-4)
+    if kind == "gauss" or dim <= 96:
+        h = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=4, device=cuda_device)
+        plain = h.sample(x=x0, n_steps=6, generator=torch.Generator(device=cuda_device).manual_seed(2))
+        with_d, d = h.sample(x=x0, n_steps=6, thin=2, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(2))
+        assert torch.equal(plain, with_d)
+        torch.testing.assert_close(d["mean"][-1], with_d.mean(dim=0), rtol=1e-5, atol=1e-6)

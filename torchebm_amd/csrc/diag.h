@@ -195,6 +195,56 @@ __device__ __forceinline__ void emit_flat_fast(const DiagArgs d, int keep, float
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Records of the MATRIX-LAYOUT kernels (dense Gaussian / mixture / MLP on the matrix cores).  The state of a wave's 32 chains
+// sits in the 32x32 C/D layout -- lane (m, h), register r of tile t = coordinate 32 t + (r & 3) + 8 (r >> 2) + 4 h of chain m
+// -- so a column statistic is a sum over the 32 lanes of a K-half: no LDS tile, no barrier.  A WAVE is a "block" of the record
+// geometry: E = 32 dim flat elements, S = dim slots, n_blocks = ceil(n / 32); diag_finish_kernel merges them like any other
+// layout.  Two passes (sum -> wave mean -> squared deviations), as in emit(): no cancellation.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_sum(float v) {  // over the 32 lanes that share this lane's h
+#pragma unroll
+  for (int msk = 16; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
+  return v;
+}
+
+// sums and centred second moments of the wave's chains at kept step `keep`; at(t, r): register r of tile t of this lane.
+// The energy / accept shares follow through wave_record_tail() (the MLP Langevin kernel: one evaluation later).
+template <int NT, class At>
+__device__ __forceinline__ void wave_record(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, At at, bool active,
+                                            int lane) {
+  if (wave_id >= n_blocks) return;  // a wave past the last chain has no record (wave-uniform)
+  const int h = lane >> 5;
+  const int valid = __popcll(__ballot(active)) >> 1;  // both K-halves of a chain vote
+  const float inv = valid > 0 ? 1.0f / (float)valid : 0.0f;
+  float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)record_floats(dim);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = active ? at(t, r) : 0.0f;
+      const float sum = half_wave_sum(v);
+      const float dv = active ? v - sum * inv : 0.0f;
+      const float m2 = half_wave_sum(dv * dv);
+      const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if ((lane & 31) == 0 && c < dim) {
+        rec[c] = sum;
+        rec[dim + c] = m2;
+      }
+    }
+}
+__device__ __forceinline__ void wave_record_tail(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, float energy,
+                                                 bool active, bool accepted, int lane) {
+  if (wave_id >= n_blocks) return;
+  float e = (active && lane < 32) ? energy : 0.0f;  // one K-half speaks for the chain
+  e = wave_sum(e);
+  const int acc = __popcll(__ballot(accepted && lane < 32));
+  if (lane < 8) {
+    float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)record_floats(dim);
+    rec[2 * dim + lane] = lane == 0 ? e : (lane == 4 ? (float)acc : 0.0f);
+  }
+}
+
 // host side: the layout of a launch that covers `block_elems` flat elements per workgroup
 inline bool plan(int64_t n_chains, int32_t dim, int64_t block_elems, DiagArgs& d) {
   if (block_elems <= 0) return false;

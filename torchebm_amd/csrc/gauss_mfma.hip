@@ -276,18 +276,10 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       }
       keep_off += dim;
       if constexpr (DIAG) {
-        // langevin_dynamics.py:170-185: population mean / var per coordinate, mean energy of the kept state
-        float* tile = gauss_smem + a.diag_offset_floats;
-        const int cib = (threadIdx.x >> 6) * 32 + m;  // chain inside the workgroup
-        if (active) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (32 * t + 8 * q + 4 * h < dim)
-                *reinterpret_cast<float4*>(tile + cib * dim + 32 * t + 8 * q + 4 * h) =
-                    make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
-        }
+        // langevin_dynamics.py:170-185: population mean / var per coordinate, mean energy of the kept state -- one record
+        // per WAVE of 32 chains straight from the C/D registers (diag::wave_record: no LDS tile, every dim the kernels take)
+        const int64_t wave_id = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+        diag::wave_record<NT>(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, [&](int t, int r) { return x[t][r]; }, active, lane);
         float e_now;
         if constexpr (GKR > 0) {
           e_now = Mix::energy(a.gm, gauss_smem, x, lane);
@@ -308,9 +300,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           acc += __shfl_xor(acc, 32);
           e_now = 0.5f * acc;
         }
-        const int64_t left = a.n_chains - (int64_t)blockIdx.x * (BLOCK / 2);
-        const int valid = (left >= BLOCK / 2 ? BLOCK / 2 : (left > 0 ? (int)left : 0)) * dim;
-        diag::emit(a.diag, keep, tile, tile + a.diag.E, valid, dim, (active && h == 0) ? e_now : 0.0f, 0.0f);
+        diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, e_now, active, false, lane);
         ++keep;
       }
     }
@@ -483,14 +473,15 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
 }
 
 // ---------------------------------------------------------------------------------
-// Diagnostics records on the matrix-layout Langevin kernels (dense Gaussian, mixtures): dims up to 96 -- the tile of a
-// workgroup's 128 chains next to the split matrix does not fit LDS beyond that; the lane-group kernels take the rest.
+// Diagnostics records on the matrix-layout Langevin kernels (dense Gaussian, mixtures): every dim they take -- one record per
+// wave of 32 chains from the C/D registers (round 3; rounds 1-2 went through an LDS tile of the workgroup's chains, which did
+// not fit beyond dim 96: a call WITH records then ran on another kernel family than the same call without).
 // ---------------------------------------------------------------------------------
 bool matrix_langevin_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
   const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim);
   const bool mix = e.kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, e.n_comp) && !(dim == 32 && e.n_comp <= 8);
-  if (!(gauss || mix) || dim > 96) return false;
-  return diag::plan(n_chains, dim, (int64_t)(kBlock / 2) * dim, d);
+  if (!(gauss || mix)) return false;
+  return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
 }
 
 namespace {
@@ -498,8 +489,7 @@ template <int NT, int GKR>
 int launch_matrix_diag(GaussArgs& a, hipStream_t st) {
   const size_t energy_floats = GKR > 0 ? (size_t)gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>::kLdsFloats
                                        : gauss3::aop_bytes(NT) / sizeof(float) + 32 * NT;
-  a.diag_offset_floats = (int)energy_floats;
-  const size_t smem = (energy_floats + (size_t)diag::lds_floats(a.diag.E, a.diag.S)) * sizeof(float);
+  const size_t smem = energy_floats * sizeof(float);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first() && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_langevin_diag_kernel<NT, GKR>),
@@ -540,7 +530,8 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
   switch ((dim + 31) / 32) {
     case 1: return launch_matrix_diag_nt<1>(a, mixture, st);
     case 2: return launch_matrix_diag_nt<2>(a, mixture, st);
-    default: return launch_matrix_diag_nt<3>(a, mixture, st);
+    case 3: return launch_matrix_diag_nt<3>(a, mixture, st);
+    default: return launch_matrix_diag_nt<4>(a, mixture, st);
   }
 }
 

@@ -1,7 +1,7 @@
-// The matrix-layout HMC kernels with in-kernel diagnostics records (mfma_hmc_body.h: DIAG).  Dense Gaussians and
-// mixtures at dims 20 .. 96 -- shapes that run here under every mass form, which the layout query (ebm_diag_layout) is not
-// told, and whose tile fits LDS next to the operands and the parked force; beyond them the lane-group kernels take a run
-// with records.
+// The matrix-layout HMC kernels with in-kernel diagnostics records (mfma_hmc_body.h: DIAG; one record per wave of 32
+// chains, diag::wave_record).  Dense Gaussians at every dim the kernels take (20 .. 128) and mixtures at dims 20 .. 96 -- the
+// shapes that run here under EVERY mass form, which the layout query (ebm_diag_layout) is not told; a mixture beyond 96
+// takes a run with records on the lane-group kernels.
 #include "mfma_hmc_body.h"
 
 namespace ebm {
@@ -9,11 +9,11 @@ namespace ebm {
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
 
 bool matrix_hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
-  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, EBM_MASS_NONE) && dim <= 96;
+  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, EBM_MASS_NONE);
   const bool mix = e.kind == EBM_ENERGY_GMM && dim >= 20 && dim <= 96 && dim % 4 == 0 && e.n_comp >= 1 && e.n_comp <= 32 &&
                    !(dim == 32 && e.n_comp <= 8);
   if (!gauss && !mix) return false;
-  return diag::plan(n_chains, dim, (int64_t)(kBlock / 2) * dim, d);
+  return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
 }
 
 namespace {
@@ -33,7 +33,8 @@ int launch_diag(const GaussHmcArgs& a, bool mixture, hipStream_t st) {
   if (mixture) return nt == 1 ? launch_gmm_diag<1, DIAGM>(a, st) : (nt == 2 ? launch_gmm_diag<2, DIAGM>(a, st) : launch_gmm_diag<3, DIAGM>(a, st));
   if (nt == 1) return launch_gauss_diag<1, DIAGM>(a, st);
   if (nt == 2) return launch_gauss_diag<2, DIAGM>(a, st);
-  return launch_gauss_diag<3, DIAGM>(a, st);
+  if (nt == 3) return launch_gauss_diag<3, DIAGM>(a, st);
+  return launch_gauss_diag<4, DIAGM>(a, st);
 }
 }  // namespace
 

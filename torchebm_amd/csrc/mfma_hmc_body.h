@@ -159,8 +159,8 @@ struct GmmE {
 
 // DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
 // E: the energy (GaussE / GmmE above).
-// DIAG: emit the in-kernel diagnostics records (diag.h) at the kept transitions: the workgroup's 128 chains go to an LDS
-// tile in flat order; the energy is the carried one, the accept share the decision just taken.
+// DIAG: emit the in-kernel diagnostics records (diag.h: wave_record, one per wave of 32 chains, straight from the C/D
+// registers) at the kept transitions; the energy is the carried one, the accept share the decision just taken.
 // CARRY off (E::kCarry: the four-tile Gaussian on the split contraction, whose 96 KB of operands leave no LDS for the parked
 // force): energy and force are evaluated at the top of every transition, as the reference does.
 template <int NT, bool DIAGM, class E, bool DIAG = false>
@@ -440,12 +440,10 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       if constexpr (DIAG) {
         // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain holds now,
         // acceptance rate of this transition
-        float* tile = fpark_base + (CARRY ? 16 * NT * kBlock : 0);
-        store_rows(tile, (int64_t)((threadIdx.x >> 6) * 32 + m) * dim, x);
-        const int64_t left = a.n_chains - (int64_t)blockIdx.x * (kBlock / 2);
-        const int valid = (left >= kBlock / 2 ? kBlock / 2 : (left > 0 ? (int)left : 0)) * dim;
-        diag::emit(a.diag, keep, tile, tile + a.diag.E, valid, dim, leader ? clamp_nanprop(e_cur, -1e10f, 1e10f) : 0.0f,
-                   (accept && leader) ? 1.0f : 0.0f);
+        const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        diag::wave_record<NT>(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, [&](int t, int r) { return x.t[t][r]; }, active, lane);
+        diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, clamp_nanprop(e_cur, -1e10f, 1e10f), active,
+                               accept && leader, lane);
         ++keep;
       }
     }
@@ -471,10 +469,8 @@ __global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcAr
 // WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
 template <int NT, bool DIAGM, class E, int WAVES, bool DIAG = false>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
-  // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register),
-  // and with records the tile + scratch rows of diag::emit
-  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + (E::kCarry ? 16 * NT * kBlock : 0) +
-                               (DIAG ? diag::lds_floats(a.diag.E, a.diag.S) : 0)) * sizeof(float);
+  // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register)
+  const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + (E::kCarry ? 16 * NT * kBlock : 0)) * sizeof(float);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first() && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG>),

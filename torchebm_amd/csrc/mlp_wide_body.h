@@ -57,56 +57,13 @@ struct WideArgs {
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
 
-// ------------------------------------------------------------------------------------------------------------------
-// In-kernel diagnostics records of the matrix-layout MLP kernels (diag.h).  The state of a wave's 32 chains sits in the
-// C/D layout -- lane (m, h), register r of tile td = coordinate 32 td + row_of(r, h) of chain m -- so a column statistic
-// is a sum over the 32 lanes of a K-half: no LDS tile (the images leave none), no barrier.  A WAVE is a "block" of the
-// record geometry: E = 32 dim flat elements, S = dim slots, n_blocks = ceil(n / 32); diag_finish_kernel merges them like
-// any other layout.  Two passes (sum -> wave mean -> squared deviations), as in diag::emit: no cancellation.
-// ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_wave_sum(float v) {  // over the 32 lanes that share this lane's h
-#pragma unroll
-  for (int msk = 16; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
-  return v;
-}
-__device__ __forceinline__ constexpr int diag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// sums and centred second moments of the wave's chains at kept step `keep`; the energy / accept shares follow through
-// wave_record_tail() (Langevin: one evaluation later, when the energy of the kept state exists)
+// In-kernel diagnostics records: diag::wave_record / diag::wave_record_tail (diag.h) -- one record per WAVE of 32 chains.
 template <int DT>
 __device__ __noinline__ void wave_record(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, const float (&xs)[DT][16],
                                          bool active, int lane) {
-  if (wave_id >= n_blocks) return;  // a wave past the last chain has no record (wave-uniform)
-  const int h = lane >> 5;
-  const int valid = __popcll(__ballot(active)) >> 1;  // both K-halves of a chain vote
-  const float inv = valid > 0 ? 1.0f / (float)valid : 0.0f;
-  float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)diag::record_floats(dim);
-#pragma unroll
-  for (int td = 0; td < DT; ++td)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = active ? xs[td][r] : 0.0f;
-      const float sum = half_wave_sum(v);
-      const float dv = active ? v - sum * inv : 0.0f;
-      const float m2 = half_wave_sum(dv * dv);
-      const int c = 32 * td + diag_row(r, h);
-      if ((lane & 31) == 0 && c < dim) {
-        rec[c] = sum;
-        rec[dim + c] = m2;
-      }
-    }
+  diag::wave_record<DT>(partials, n_blocks, keep, wave_id, dim, [&](int td, int r) { return xs[td][r]; }, active, lane);
 }
-__device__ __forceinline__ void wave_record_tail(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, float energy,
-                                                 bool active, bool accepted, int lane) {
-  if (wave_id >= n_blocks) return;
-  float e = (active && lane < 32) ? energy : 0.0f;  // one K-half speaks for the chain
-  e = diag::wave_sum(e);
-  const int acc = __popcll(__ballot(accepted && lane < 32));
-  if (lane < 8) {
-    float* rec = partials + ((int64_t)keep * n_blocks + wave_id) * (int64_t)diag::record_floats(dim);
-    rec[2 * dim + lane] = lane == 0 ? e : (lane == 4 ? (float)acc : 0.0f);
-  }
-}
+using diag::wave_record_tail;
 
 // -DEBM_PHASE_TIMES (scripts/mlp_phase_times.py only): wave 0 of workgroup 0 logs the shader clock at the phase boundaries of
 // every evaluation (stamps cost a drained LDS queue each: read the phases relative to each other, not against a plain run).
