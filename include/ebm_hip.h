@@ -301,7 +301,13 @@ EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, con
  *   chain call will pass a noise / trajectory pointer (they select the kernel family);
  *   outputs: n_blocks (records per kept step), slots S and block_elems E.  The caller allocates
  *   diag_partials = float[n_kept][n_blocks][2*S + 8] and work = double[n_kept][3*dim + 3] (zeroed once; the merge
- *   leaves it zeroed).  Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
+ *   leaves it zeroed; 3*max(S, dim) + 3 doubles per kept step when S > dim, below).  S > dim means PACKED rows: a dense
+ *   Gaussian whose width the matrix-layout kernel does not take as is (below 20, or not a multiple of 4) runs S / dim
+ *   consecutive chains as one row of width S (block-diagonal precision; same element order, same random field), and
+ *   the records are those of n_chains * dim / S rows: call ebm_diag_finish_f32 with (n_chains * dim / S, S) and fold
+ *   the S columns onto the dim coordinates -- mean = average of the S / dim column means of a coordinate, var = average
+ *   of their variances + the (biased) variance of those column means, energy divided by S / dim
+ *   (torchebm_amd/samplers/langevin.py, _fused_with_records).  Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
  *   statistics from the state with ebm_chain_stats_f32 / ebm_energy_grad_f32 between launches).
  * ebm_diag_finish_f32: mean_out / var_out = float[n_kept][dim] (biased variance clamped to [1e-10, 1e10], zero for a
  *   single chain), energy_out = float[n_kept] (mean per-chain energy), accept_out = NULL or float[n_kept]

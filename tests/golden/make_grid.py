@@ -108,5 +108,16 @@ def main():
             hmc(f"hmc20_{tag}_{dim}", en, dim, 20, step20, seed + 200, scale, mass=mass)
 
 
+def extra():
+    """Round 3: dense Gaussians at widths the matrix-layout kernel does not take as is (below 20, not a multiple of 4) --
+    it runs them as PACKED rows (csrc/gauss_mfma.hip: gauss_pack_factor).  Langevin only; new files, the grid above is
+    not rewritten."""
+    seed = 9000
+    for dim in (5, 8, 12, 30, 50):
+        seed += 1
+        en = energies(dim)["gauss"]
+        langevin(f"ld_gauss_{dim}", en, dim, 0.02, 0.8, seed, 1.0)
+
+
 if __name__ == "__main__":
-    main()
+    extra() if "--extra" in sys.argv else main()

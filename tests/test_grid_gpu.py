@@ -21,18 +21,27 @@ def _records(desc, sampler, n, dim, n_kept, dev, injected=True):
     assert layout is not None
     nb, S, E = layout
     rec = torch.empty(n_kept * nb * (2 * S + 8), device=dev)
-    work = torch.zeros(n_kept * (3 * dim + 3), dtype=torch.float64, device=dev)
+    work = torch.zeros(n_kept * (3 * max(S, dim) + 3), dtype=torch.float64, device=dev)
     return layout, rec, work
 
 
 def _finish(layout, rec, work, n, dim, n_kept, dev, with_accept):
     nb, S, E = layout
-    out = {"mean": torch.empty(n_kept, dim, device=dev), "var": torch.empty(n_kept, dim, device=dev),
+    # S > dim: PACKED rows (include/ebm_hip.h, ebm_diag_layout): the records are those of n / pack rows of width pack * dim,
+    # merged as such; the `pack` columns of every coordinate are pooled afterwards (within + between-group variance)
+    pack = S // dim if S > dim else 1
+    m_n, m_dim = n // pack, dim * pack
+    out = {"mean": torch.empty(n_kept, m_dim, device=dev), "var": torch.empty(n_kept, m_dim, device=dev),
            "energy": torch.empty(n_kept, device=dev)}
     if with_accept:
         out["acceptance_rate"] = torch.empty(n_kept, device=dev)
-    _lib.call("ebm_diag_finish_f32", rec.data_ptr(), n_kept, nb, S, E, n, dim, out["mean"].data_ptr(), out["var"].data_ptr(),
+    _lib.call("ebm_diag_finish_f32", rec.data_ptr(), n_kept, nb, S, E, m_n, m_dim, out["mean"].data_ptr(), out["var"].data_ptr(),
               out["energy"].data_ptr(), _lib.ptr(out.get("acceptance_rate")), work.data_ptr(), _lib.stream_handle(dev))
+    if pack > 1:
+        gm = out["mean"].view(n_kept, pack, dim).double()
+        mean = gm.mean(dim=1)
+        var = out["var"].view(n_kept, pack, dim).double().mean(dim=1) + (gm - mean.unsqueeze(1)).square().mean(dim=1)
+        out["mean"], out["var"], out["energy"] = mean.float(), var.float().clamp(1e-10, 1e10), out["energy"] / pack
     return {k: v.cpu() for k, v in out.items()}
 
 

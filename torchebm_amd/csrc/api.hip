@@ -60,6 +60,7 @@ int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, 
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
+int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 as is, > 1 packed rows, 0 no matrix-layout form
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
 bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -250,7 +251,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
                                       cmax, thin, traj, noise, seed, offset, heun, (hipStream_t)stream);
-  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim)) {
+  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_pack_factor(dim, n_chains) >= 1) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)

@@ -37,8 +37,10 @@ struct GaussArgs {
   const float* noise;
   RngKey key;
   uint64_t step0;
-  const float* mean;  // [dim]
-  const float* prec;  // [dim, dim], symmetric
+  const float* mean;  // [sub_dim]
+  const float* prec;  // [sub_dim, sub_dim], symmetric
+  int32_t sub_dim;    // PACKED rows: dim = pack * sub_dim -- `pack` consecutive chains of a sub_dim-dimensional Gaussian are ONE
+  int32_t pack;       // row of the block-diagonal Gaussian kron(I_pack, Ps) (n_chains counts packed rows); else sub_dim = dim
   gmm3::Params gm;    // the mixture kernels (GKR > 0 below)
   diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept steps (DIAG kernels)
   int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
@@ -76,16 +78,25 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   const int dim = a.dim;
   if constexpr (GKR > 0) {
     Mix::stage(a.gm, gauss_smem, BLOCK);
-  } else if constexpr (B3) {
-    gauss3::stage_split_precision<NT>(a.prec, dim, aop, BLOCK);
   } else {
-    for (int i = threadIdx.x; i < DIM * DIM; i += BLOCK) {
-      const int r = i / DIM, c = i - r * DIM;
-      Ps[i] = (r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+    // the precision of the (possibly packed) row: block-diagonal copies of the sub_dim x sub_dim matrix
+    const int sd = a.sub_dim;
+    const auto ps_at = [&](int r, int c) {
+      if (r >= dim || c >= dim) return 0.0f;
+      const int br = r / sd, bc = c / sd;
+      return br == bc ? a.prec[(r - br * sd) * sd + (c - bc * sd)] : 0.0f;
+    };
+    if constexpr (B3) {
+      gauss3::stage_split_matrix<NT, 2 * NT>(ps_at, aop, BLOCK);
+    } else {
+      for (int i = threadIdx.x; i < DIM * DIM; i += BLOCK) {
+        const int r = i / DIM, c = i - r * DIM;
+        Ps[i] = ps_at(r, c);
+      }
     }
   }
   if constexpr (GKR == 0)
-    for (int i = threadIdx.x; i < DIM; i += BLOCK) mus[i] = i < dim ? a.mean[i] : 0.0f;
+    for (int i = threadIdx.x; i < DIM; i += BLOCK) mus[i] = i < dim ? a.mean[i % a.sub_dim] : 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -266,13 +277,28 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
     if ((a.traj || DIAG) && --until_keep == 0) {
       until_keep = a.thin;
       if (a.traj && active) {
+        if (a.pack > 1) {  // packed rows: element j of the row is coordinate j % sub_dim of chain pack * row + j / sub_dim
+          const int sd = a.sub_dim;
+          const int64_t kept = keep_off / dim;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (32 * t + 8 * q + 4 * h < dim)
-              *reinterpret_cast<float4*>(a.traj + traj_row + keep_off + 32 * t + 8 * q + 4 * h) =
-                  make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+            for (int r = 0; r < 16; ++r) {
+              const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (j < dim) {
+                const int sub = j / sd;
+                a.traj[((chain * a.pack + sub) * (int64_t)a.n_kept + kept) * sd + (j - sub * sd)] = x[t][r];
+              }
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (32 * t + 8 * q + 4 * h < dim)
+                *reinterpret_cast<float4*>(a.traj + traj_row + keep_off + 32 * t + 8 * q + 4 * h) =
+                    make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+        }
       }
       keep_off += dim;
       if constexpr (DIAG) {
@@ -393,11 +419,31 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
 // matrix cores (measured: scripts/bench_gauss_dims.py), those stay on the lane-group kernel
 bool gauss_mfma_supported(int32_t dim) { return dim >= 20 && dim <= 128 && (dim % 4) == 0; }
 
+// Other widths (below 20, or not a multiple of 4) PACKED: `pack` consecutive chains of the row-major state are one row of
+// width pack * dim, whose Gaussian is block diagonal -- kron(I, Ps), the mean repeated.  The flat element order, hence the
+// Philox field and the update of every element, is unchanged; the kernel only stages the block-diagonal matrix (and scatters
+// trajectory rows).  1: no packing needed; 0: no packing possible (n not divisible, or no factor lands in 20 .. 128, % 4).
+// Langevin only: an HMC accept decision is per chain.  dim 2 keeps its two-chains-per-lane kernel.
+int32_t gauss_pack_factor(int32_t dim, int64_t n_chains) {
+  if (gauss_mfma_supported(dim)) return 1;
+  if (dim < 3) return 0;
+  for (int32_t g = 2; g <= 16; g *= 2) {
+    const int32_t d = g * dim;
+    if (d > 128) break;
+    if (d >= 20 && d % 4 == 0 && n_chains % g == 0) return g;
+  }
+  return 0;
+}
+
 int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                                      float eta, float sqrt_eta, float noise_coef, const float* coef_table,
                                      int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                      const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
   GaussArgs a;
+  const int32_t pack = gauss_pack_factor(dim, n_chains);
+  if (pack < 1) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout form for a Gaussian of dim %d over %lld chains", dim, (long long)n_chains);
+  a.sub_dim = dim; a.pack = pack;
+  n_chains /= pack; dim *= pack;  // the packed geometry from here on
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
   a.table = reinterpret_cast<const float4*>(coef_table);
@@ -478,9 +524,11 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
 // not fit beyond dim 96: a call WITH records then ran on another kernel family than the same call without).
 // ---------------------------------------------------------------------------------
 bool matrix_langevin_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
-  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_mfma_supported(dim);
+  const int32_t pack = e.kind == EBM_ENERGY_GAUSSIAN ? gauss_pack_factor(dim, n_chains) : 0;
   const bool mix = e.kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, e.n_comp) && !(dim == 32 && e.n_comp <= 8);
-  if (!(gauss || mix)) return false;
+  if (!(pack >= 1 || mix)) return false;
+  if (pack > 1)  // packed rows: the records are those of n / pack rows of width pack * dim (S > dim tells the caller to fold)
+    return diag::plan(n_chains / pack, pack * dim, 32 * (int64_t)pack * dim, d);
   return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
 }
 
@@ -514,6 +562,12 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
                                       int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                       const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   GaussArgs a;
+  if (!matrix_langevin_diag_plan(e, n_chains, dim, a.diag))
+    return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout diagnostics records for this energy / dim %d", dim);
+  const bool mixture = e.kind == EBM_ENERGY_GMM;
+  const int32_t pack = mixture ? 1 : gauss_pack_factor(dim, n_chains);
+  a.sub_dim = dim; a.pack = pack;
+  n_chains /= pack; dim *= pack;  // the packed geometry from here on
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
   a.table = reinterpret_cast<const float4*>(coef_table);
@@ -521,11 +575,8 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
-  const bool mixture = e.kind == EBM_ENERGY_GMM;
   a.mean = mixture ? nullptr : e.dev0; a.prec = mixture ? nullptr : e.dev1;
   a.gm = mixture ? gmm3::Params{e.dev0, e.dev1, e.n_comp, dim, e.s[0], e.s[1]} : gmm3::Params{nullptr, nullptr, 0, dim, 0.0f, 0.0f};
-  if (!matrix_langevin_diag_plan(e, n_chains, dim, a.diag))
-    return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout diagnostics records for this energy / dim %d", dim);
   a.diag.partials = diag_partials;
   switch ((dim + 31) / 32) {
     case 1: return launch_matrix_diag_nt<1>(a, mixture, st);

@@ -459,10 +459,19 @@ class LangevinDynamics(BaseSampler):
         ``DIAG_RECORD_BYTES``)."""
         n_blocks, slots, block_elems = layout
         n_kept = n_steps // thin
+        # slots > dim: PACKED rows (a Gaussian whose width the matrix-layout kernel does not take as is: csrc/gauss_mfma.hip,
+        # gauss_pack_factor) -- `pack` consecutive chains are one row of width pack * dim; the records and the merge are those of
+        # n / pack rows, and the `pack` columns of every coordinate are pooled afterwards
+        pack = slots // dim if slots > dim else 1
+        m_n, m_dim = n // pack, dim * pack
         rec_floats = n_blocks * (2 * slots + 8)
         chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
         records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
-        work = torch.zeros(chunk * (3 * dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        work = torch.zeros(chunk * (3 * m_dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        if pack > 1:
+            p_mean = torch.empty(chunk, m_dim, dtype=torch.float32, device=state.device)
+            p_var = torch.empty_like(p_mean)
+            p_energy = torch.empty(chunk, dtype=torch.float32, device=state.device)
         done_keep, done_steps = 0, 0
         while done_keep < n_kept:
             kk = min(chunk, n_kept - done_keep)
@@ -475,11 +484,24 @@ class LangevinDynamics(BaseSampler):
                                records=records)
             if traj is not None and not whole:
                 traj[:, done_keep : done_keep + kk] = piece
-            _lib.call(
-                "ebm_diag_finish_f32", _lib.ptr(records), kk, n_blocks, slots, block_elems, n, dim,
-                _lib.ptr(diag["mean"][done_keep : done_keep + kk]), _lib.ptr(diag["var"][done_keep : done_keep + kk]),
-                _lib.ptr(diag["energy"][done_keep : done_keep + kk]), None, _lib.ptr(work), stream,
-            )
+            sl = slice(done_keep, done_keep + kk)
+            if pack == 1:
+                _lib.call(
+                    "ebm_diag_finish_f32", _lib.ptr(records), kk, n_blocks, slots, block_elems, n, dim,
+                    _lib.ptr(diag["mean"][sl]), _lib.ptr(diag["var"][sl]), _lib.ptr(diag["energy"][sl]), None, _lib.ptr(work), stream,
+                )
+            else:
+                _lib.call(
+                    "ebm_diag_finish_f32", _lib.ptr(records), kk, n_blocks, slots, block_elems, m_n, m_dim,
+                    _lib.ptr(p_mean), _lib.ptr(p_var), _lib.ptr(p_energy), None, _lib.ptr(work), stream,
+                )
+                # pool the `pack` equally sized groups of every coordinate: within-group variance + variance of the group means
+                gm = p_mean[:kk].view(kk, pack, dim).double()
+                mean = gm.mean(dim=1)
+                var = p_var[:kk].view(kk, pack, dim).double().mean(dim=1) + (gm - mean.unsqueeze(1)).square().mean(dim=1)
+                diag["mean"][sl] = mean.to(torch.float32)
+                diag["var"][sl] = var.to(torch.float32).clamp_(min=1e-10, max=1e10)
+                diag["energy"][sl] = p_energy[:kk] / pack  # a packed row's energy is the sum of its chains'
             done_keep += kk
             done_steps += steps
 
