@@ -15,7 +15,8 @@ def test_the_grid_is_complete():
         for tag in ("dw", "har", "gauss", "gmm8"):
             for kind in ("ld", "hmc5", "hmc20"):
                 assert f"{kind}_{tag}_{dim}" in names
-    assert {"ld_gmmd_32", "hmc5_gmmd_32", "hmc20_gmmd_32"} <= names and len(names) == 51
+    assert {"ld_gmmd_32", "hmc5_gmmd_32", "hmc20_gmmd_32"} <= names
+    assert {f"ld_gauss_{d}" for d in (5, 8, 12, 30, 50)} <= names and len(names) == 56   # round 3: the packed-row widths
 
 
 @pytest.mark.parametrize("name", grid_names("ld_"))
