@@ -217,7 +217,8 @@ def issue_costs(device, blocks=256 * 8, iters=2048, reps=3):
     units = {
         "mad_u64_u32": t_of(1) / 8.0 / per - 1.0,      # slot = v_mad_u64_u32 + one plain v_xor
         "transcendental": t_of(2) / 8.0 / per - 1.0,   # slot = v_log_f32 + one plain v_add
-        "packed_f32": t_of(3) / 4.0 / per,             # v_pk_fma_f32 (two fused multiply-adds)
+        "packed_f32": t_of(3) / 8.0 / per,             # v_pk_fma_f32 (two fused multiply-adds), SGPR-pair multiplicand
+        "packed_f32_vgpr": t_of(5) / 8.0 / per, "packed_mul_f32": t_of(6) / 8.0 / per,
         "bitop3": t_of(4) / 8.0 / per,
         "plain": 1.0,
     }

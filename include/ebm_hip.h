@@ -330,9 +330,10 @@ EBM_API int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* 
 /* The same stream shape with the instruction classes the in-kernel RNG is made of, so that bench.py can price the
  * Langevin loop from costs measured in the run instead of constants: per lane and iteration,
  *   kind 0: 8 v_fma_f32 (= ebm_probe_valu_f32)          kind 1: 8 x (v_mad_u64_u32 + v_xor_b32)
- *   kind 2: 8 x (v_log_f32 + v_add_f32)                 kind 3: 4 v_pk_fma_f32 (8 fused multiply-adds)
- *   kind 4: 8 v_bitop3_b32
- * independent across the eight slots.  Since ABI version 3. */
+ *   kind 2: 8 x (v_log_f32 + v_add_f32)                 kind 3: 8 v_pk_fma_f32 (16 fused multiply-adds; SGPR-pair multiplicand)
+ *   kind 4: 8 v_bitop3_b32                              kind 5: 8 v_pk_fma_f32, every operand a VGPR pair
+ *   kind 6: 8 v_pk_mul_f32
+ * independent across the eight slots (`iters` a multiple of 4 for kinds 3 / 5 / 6).  Since ABI version 3. */
 EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,118 @@
+"""Dense Gaussians at dims 132 .. 512 (multiples of 4): the tiled per-step kernel (csrc/gauss_big.hip) -- the state goes through
+HBM once per step, Ps through LDS as three bf16 splits per K-slab, the update is the contraction's epilogue.  Checked against
+the oracle's chain (reference op order, fp32) and an fp64 referee on the same injected noise, and -- native RNG -- against
+the kernel fed the materialised Philox field (bit for bit: same arithmetic, the field depends on (seed, step, element) only)."""
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd import _lib
+from torchebm_amd.samplers.langevin import em_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dim, device, seed=0):
+    g = torch.Generator().manual_seed(seed + dim)
+    a = torch.randn(dim, dim, generator=g)
+    cov = a @ a.t() / dim + 0.5 * torch.eye(dim)
+    mean = torch.randn(dim, generator=g) * 0.5
+    return ta.GaussianModel(mean, cov, device=device), oracle.Gaussian(mean, cov)
+
+
+def _call(spec, x, k, rows, clamp=None, thin=1, traj=None, noise=None, seed=0, step=0):
+    n, dim = x.shape
+    a, sq, coef = rows[0]
+    table = None
+    if len(rows) > 1:
+        table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=x.device)
+    clamp_on, cmin, cmax = (0, 0.0, 0.0) if clamp is None else (1, clamp[0], clamp[1])
+    _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, dim, k, a, sq, coef, _lib.ptr(table), clamp_on, cmin, cmax,
+              thin, _lib.ptr(traj), None, _lib.ptr(noise), seed, step, _lib.stream_handle(x.device))
+
+
+def _f64_chain(model, x0, noise, etas, sigmas):
+    prec = model.cov_inv.double()
+    mean = model.mean.double()
+    x = x0.double()
+    for i, (eta, sigma) in enumerate(zip(etas, sigmas)):
+        x = x - eta * ((x - mean) @ prec) + sigma * (noise[i].double() * eta ** 0.5)
+    return x
+
+
+@pytest.mark.parametrize("dim,n", [(132, 300), (160, 257), (200, 128), (256, 515), (260, 200), (320, 129), (384, 130), (500, 77), (512, 260)])
+def test_injected_noise_matches_the_oracle_and_the_fp64_referee(cuda_device, dim, n):
+    model, ref = _model(dim, cuda_device)
+    k = 6
+    etas = [0.02 * (0.9 ** i) for i in range(k)]
+    sigmas = [1.0 - 0.05 * i for i in range(k)]
+    gen = torch.Generator().manual_seed(dim)
+    x0 = torch.randn(n, dim, generator=gen)
+    noise = torch.randn(k, n, dim, generator=gen)
+    want, wtraj, _ = oracle.langevin_chain(ref, x0, noise, etas, sigmas, thin=2, want_traj=True)
+    f64 = _f64_chain(ref, x0, noise, etas, sigmas)
+    x = x0.to(cuda_device)
+    traj = torch.full((n, k // 2, dim), float("nan"), device=cuda_device)
+    rows = [em_coefficients(e, s) for e, s in zip(etas, sigmas)]
+    _call(model.fused_spec(), x, k, rows, thin=2, traj=traj, noise=noise.to(cuda_device))
+    got = x.cpu()
+    # the oracle itself (torch fp32 bmm) is a few ulp of |P||d| from the fp64 chain; the split-operand contraction is the same class
+    err_ref = (want.double() - f64).abs().max().item()
+    err_hip = (got.double() - f64).abs().max().item()
+    assert err_hip <= 4.0 * err_ref + 1e-6, (err_hip, err_ref)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(traj.cpu(), wtraj, rtol=2e-5, atol=2e-5)
+    assert torch.equal(traj[:, -1].cpu(), got)
+
+
+@pytest.mark.parametrize("dim,n", [(160, 1000), (256, 300), (448, 257)])
+def test_native_rng_equals_the_materialised_field_and_clamp(cuda_device, dim, n):
+    model, _ = _model(dim, cuda_device, seed=3)
+    k, seed, step0 = 5, 0x1234ABCD77, 40
+    rows = [em_coefficients(0.01, 1.0)]
+    x0 = torch.randn(n, dim, device=cuda_device) * 2.0
+    noise = torch.empty(k, n, dim, device=cuda_device)
+    for i in range(k):
+        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * dim, _lib.NOISE_NORMAL, seed, step0 + i, _lib.stream_handle(cuda_device))
+    for clamp in (None, (-1.5, 1.5)):
+        xa, xb = x0.clone(), x0.clone()
+        _call(model.fused_spec(), xa, k, rows, clamp=clamp, seed=seed, step=step0)
+        _call(model.fused_spec(), xb, k, rows, clamp=clamp, noise=noise)
+        assert torch.equal(xa, xb)
+        assert not torch.equal(xa, x0)
+        if clamp:
+            assert xa.min().item() >= -1.5 and xa.max().item() <= 1.5
+
+
+def test_sampler_route_is_one_launch_and_recovers_the_moments(cuda_device):
+    dim, n = 256, 8192
+    g = torch.Generator().manual_seed(1)
+    q, _ = torch.linalg.qr(torch.randn(dim, dim, generator=g))
+    var = torch.linspace(0.5, 2.0, dim)
+    cov = (q * var) @ q.t()
+    mean = torch.randn(dim, generator=g)
+    model = ta.GaussianModel(mean, cov, device=cuda_device)
+    s = ta.LangevinDynamics(model, step_size=0.05, device=cuda_device)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    out = s.sample(x=torch.randn(n, dim, device=cuda_device), n_steps=400, generator=torch.Generator(device=cuda_device).manual_seed(2))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    # Euler-Maruyama's stationary law is N(mean, cov (I - eta P / 2)^-1): the discretisation inflates cov by <= 5 % here
+    emp_mean = out.mean(dim=0).cpu()
+    emp_cov = torch.cov(out.t().cpu())
+    assert (emp_mean - mean).abs().max().item() < 0.08
+    rel = torch.linalg.norm(emp_cov - cov) / torch.linalg.norm(cov)
+    assert rel.item() < 0.2, rel.item()
+
+
+def test_dims_it_does_not_take_keep_the_lane_group_kernel(cuda_device):
+    for dim in (130, 516):
+        model, ref = _model(dim, cuda_device)
+        x0 = torch.randn(64, dim)
+        noise = torch.randn(2, 64, dim)
+        want, _, _ = oracle.langevin_chain(ref, x0, noise, [0.01, 0.01], [1.0, 1.0])
+        x = x0.to(cuda_device)
+        _call(model.fused_spec(), x, 2, [em_coefficients(0.01, 1.0)], noise=noise.to(cuda_device))
+        torch.testing.assert_close(x.cpu(), want, rtol=2e-5, atol=2e-5)

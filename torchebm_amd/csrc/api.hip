@@ -61,6 +61,10 @@ int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
 int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 as is, > 1 packed rows, 0 no matrix-layout form
+bool gauss_big_supported(int32_t dim);                      // gauss_big.hip: dims 132 .. 512 in steps of 4, tiled per step
+int launch_langevin_chain_gauss_big(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
+                                    hipStream_t);
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
 bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -257,6 +261,12 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (!force_rows)
       return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                               clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  }
+  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_big_supported(dim)) {
+    static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
+    if (!force_rows)
+      return launch_langevin_chain_gauss_big(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                             clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
   }
   // mixtures of up to 32 components on the matrix layout (gauss_mfma.hip / gmm_bf16x3.h); dims 16 / 32 with K <= 8 keep
   // one lane per chain with the means as scalar operands
@@ -515,7 +525,7 @@ int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream) 
 int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream) {
   const char* who = "ebm_probe_issue_f32";
   if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
-  if (kind < 0 || kind > 4) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3)", who, kind);
+  if (kind < 0 || kind > 6) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3 | 5 pk_fma, VGPR operands | 6 pk_mul)", who, kind);
   return launch_probe_issue(out, blocks, iters, kind, (hipStream_t)stream);
 }
 

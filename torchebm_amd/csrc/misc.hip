@@ -560,7 +560,7 @@ int launch_diag_finish(const float* partials, int32_t n_kept, int64_t n_blocks, 
 // Per-class issue probes (bench.py prices the lean Langevin loop with them, in the run, on the box): the same
 // dependent-free shape as probe_valu_kernel with the op under test in the stream.
 //   kind 1: v_mad_u64_u32 + v_xor_b32 per slot (the Philox multiply)      kind 2: v_log_f32 + v_add_f32 (a transcendental)
-//   kind 3: v_pk_fma_f32, two slots per instruction                        kind 4: v_bitop3_b32 (the three-input xor)
+//   kind 3: v_pk_fma_f32, two slots per instruction (5: all-VGPR operands, 6: v_pk_mul_f32)   kind 4: v_bitop3_b32 (the three-input xor)
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void probe_issue_kernel(float* __restrict__ out, int iters) {
   if constexpr (KIND == 1 || KIND == 4) {
@@ -597,18 +597,30 @@ __global__ __launch_bounds__(kBlock) void probe_issue_kernel(float* __restrict__
     for (int j = 0; j < 8; ++j) s += a[j];
     out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
   } else {
+    // packed f32: EIGHT independent chains, 32 instructions per trip of the loop (the trip's scalar bookkeeping and the
+    // dependent-issue distance are then out of the measurement).  kind 3: multiplicand in an SGPR pair (how the mixture
+    // kernels feed their means), kind 5: every operand a VGPR pair, kind 6: v_pk_mul_f32.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 a[4];
+    f32x2 a[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = (f32x2){threadIdx.x * 1e-3f + j, threadIdx.x * 2e-3f + j};
-    const f32x2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
-    for (int it = 0; it < iters; ++it) {
+    for (int j = 0; j < 8; ++j) a[j] = (f32x2){threadIdx.x * 1e-3f + j, threadIdx.x * 2e-3f + j};
+    f32x2 ms = {1.0001f, 0.9999f};
+    asm volatile("" : "+s"(ms));
+    f32x2 mv = {1.0001f + threadIdx.x * 1e-9f, 0.9999f}, cv = {0.5f, 0.25f + threadIdx.x * 1e-9f};
+    asm volatile("" : "+v"(mv), "+v"(cv));
+    for (int it = 0; it < iters; it += 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = __builtin_elementwise_fma(a[j], m, c);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if constexpr (KIND == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "s"(ms), "v"(cv));
+          else if constexpr (KIND == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(mv), "v"(cv));
+          else asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[j]) : "v"(mv));
+        }
     }
     float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += a[j].x + a[j].y;
+    for (int j = 0; j < 8; ++j) s += a[j].x + a[j].y;
     out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s;
   }
 }
@@ -620,7 +632,10 @@ int launch_probe_issue(float* out, int32_t blocks, int32_t iters, int32_t kind, 
     case 1: hipLaunchKernelGGL(probe_issue_kernel<1>, g, b, 0, st, out, iters); break;
     case 2: hipLaunchKernelGGL(probe_issue_kernel<2>, g, b, 0, st, out, iters); break;
     case 3: hipLaunchKernelGGL(probe_issue_kernel<3>, g, b, 0, st, out, iters); break;
-    default: hipLaunchKernelGGL(probe_issue_kernel<4>, g, b, 0, st, out, iters); break;
+    case 4: hipLaunchKernelGGL(probe_issue_kernel<4>, g, b, 0, st, out, iters); break;
+    case 5: hipLaunchKernelGGL(probe_issue_kernel<5>, g, b, 0, st, out, iters); break;
+    case 6: hipLaunchKernelGGL(probe_issue_kernel<6>, g, b, 0, st, out, iters); break;
+    default: return fail(EBM_EKIND, "ebm_probe_issue_f32: kind %d", kind);
   }
   return check_launch("ebm_probe_issue_f32");
 }
