@@ -116,3 +116,50 @@ def test_dims_it_does_not_take_keep_the_lane_group_kernel(cuda_device):
         x = x0.to(cuda_device)
         _call(model.fused_spec(), x, 2, [em_coefficients(0.01, 1.0)], noise=noise.to(cuda_device))
         torch.testing.assert_close(x.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_diagnostics_come_from_state_passes_between_launches(cuda_device):
+    """No in-kernel records on these kernels (ebm_diag_layout says so): the sampler launches `thin` steps at a time and takes
+    the column statistics / energies from the state -- same numbers as torch reductions of the stored trajectory."""
+    dim, n = 160, 1000
+    model, _ = _model(dim, cuda_device, seed=5)
+    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim) is None
+    s = ta.LangevinDynamics(model, step_size=0.02, device=cuda_device)
+    x0 = torch.randn(n, dim, device=cuda_device)
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    traj, diag = s.sample(x=x0, n_steps=12, thin=4, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(3))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 3
+    plain = s.sample(x=x0, n_steps=12, generator=torch.Generator(device=cuda_device).manual_seed(3))
+    assert torch.equal(traj[:, -1], plain)
+    t64 = traj.double()
+    torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)
+    want_e = torch.stack([model(traj[:, j]).double().mean() for j in range(3)])
+    torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dim", [130, 1024])
+def test_widths_without_a_matrix_chain_kernel_take_the_gemm_step_route(cuda_device, dim):
+    """dim 130 (not a multiple of 4) / 1024 (above 512): the sampler runs the per-step route -- the gradient as one library
+    GEMM (GaussianModel's closed form above 128 dims), the update kernel on the native field -- not the lane-group chain
+    kernel; same chains as that kernel on the same seed (shared (seed, step, element) field), to fp32 round-off."""
+    n, k = 512, 5
+    model, _ = _model(dim, cuda_device, seed=7)
+    s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
+    x0 = torch.randn(n, dim, device=cuda_device)
+    c_chain, c_step = hip_calls("ebm_langevin_chain_f32"), hip_calls("ebm_langevin_step_f32") + hip_calls("ebm_langevin_step_dev_f32")
+    out = s.sample(x=x0, n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(11))
+    assert hip_calls("ebm_langevin_chain_f32") == c_chain
+    assert hip_calls("ebm_langevin_step_f32") + hip_calls("ebm_langevin_step_dev_f32") > c_step
+    # the closed-form gradient against autograd through the reference's forward
+    g_fast = model.gradient(x0)
+    leaf = x0.clone().requires_grad_(True)
+    (g_auto,) = torch.autograd.grad(model(leaf).sum(), leaf)
+    torch.testing.assert_close(g_fast, g_auto, rtol=2e-5, atol=2e-5)
+    # the lane-group chain kernel on the same seed / offsets
+    from torchebm_amd import _rng
+    seed, first = _rng.reserve(torch.Generator(device=cuda_device).manual_seed(11), cuda_device, k)
+    xb = x0.clone()
+    _call(model.fused_spec(), xb, k, [em_coefficients(0.01, 1.0)], seed=seed, step=first)
+    torch.testing.assert_close(out, xb, rtol=5e-5, atol=5e-5)

@@ -247,6 +247,21 @@ class GaussianModel(BaseModel):
             return 0.5 * torch.bmm(delta.unsqueeze(1), p_delta).squeeze(-1).squeeze(-1)
         return 0.5 * torch.sum(delta * torch.matmul(delta, prec), dim=-1)
 
+    #: widths above which ``gradient()`` is the closed form ``(x - mu) @ sym(P)`` -- ONE library GEMM -- instead of autograd
+    #: through ``forward``'s batched form (base_model.py:199-206 expands P to n matrices: at dim 1024 that is n mat-vecs of
+    #: 4 MB each).  Same value up to fp32 rounding of the two contraction orders; below, autograd as in the reference.
+    CLOSED_FORM_GRADIENT_ABOVE = 128
+
+    def _hip_gradient(self, x: torch.Tensor, model_kwargs: Optional[dict]) -> Optional[torch.Tensor]:
+        spec = None
+        if (not model_kwargs and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] > 1
+                and x.shape[1] > self.CLOSED_FORM_GRADIENT_ABOVE and not torch.is_autocast_enabled()
+                and not getattr(self, "use_mixed_precision", False)):
+            spec = self.fused_spec()
+        if spec is None:
+            return None
+        return torch.mm(x.detach() - spec.dev0, spec.dev1)  # dev1 = sym(P): symmetric, no transpose needed
+
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(GaussianModel) or self.cov_inv.dtype != torch.float32:
             return None

@@ -150,6 +150,9 @@ DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32
   static const bool gmm_rows = ab_switch("EBM_GMM_ROWS");
   const bool forced_rows = (e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows);
   if (!heun && !forced_rows && matrix_langevin_diag_plan(e, n_chains, dim, d)) return kDiagMatrix;
+  // dense Gaussians above 128 dims run on the streamed-Ps kernels (gauss_big.hip), which keep no records: statistics
+  // between launches (the lane-group kernel that has them is 5 - 40x slower than those kernels plus the state passes)
+  if (!heun && !forced_rows && e.kind == EBM_ENERGY_GAUSSIAN && gauss_big_supported(dim)) return kDiagNone;
   return rows_langevin_diag_plan(e, heun, n_chains, dim, d) ? kDiagRows : kDiagNone;
 }
 

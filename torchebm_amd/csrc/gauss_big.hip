@@ -1,29 +1,31 @@
-// k-fused Langevin chain for the dense Gaussian energy at dims 129 .. 512 (multiples of 4) on the bf16 matrix pipe.
+// k-fused Langevin chain for the dense Gaussian energy at dims 132 .. 512 (multiples of 4) on the bf16 matrix pipe.
 //
 //   reference: torchebm/samplers/langevin_dynamics.py:150-185 (the step loop), torchebm/core/base_model.py (GaussianModel:
 //   E = 0.5 (x - mu)^T P (x - mu), gradient P (x - mu))
 //
 // Below 129 the chain state lives in registers for the whole call and the three bf16 splits of Ps are resident in LDS
-// (gauss_mfma.hip).  Neither fits here: a row is 0.5 - 2 KB and the splits of Ps are 0.4 - 1.5 MB.  So a step is one pass
-// of a tiled GEMM over the state,  g^T = Ps (x - mu)^T,  with the Euler-Maruyama update as its epilogue:
+// (gauss_mfma.hip).  Here the splits of Ps are 0.4 - 1.5 MB: Ps STREAMS -- per stage of two K-blocks the workgroup loads the
+// [32 OT] x 32 slab of Ps (fp32, symmetric), splits it into three bf16 pieces and writes them operand-ready to LDS
+// (double-buffered, one barrier per stage); every wave reads each image with one ds_read_b128 per (tile, K-block).  Six
+// products per (out tile, chain tile, K-block) as in gauss_bf16x3.h, smallest first, two independent accumulators
+// alternating; fp32 accumulation.  Two kernels:
 //
-//   * a workgroup (4 waves, one per SIMD) owns 128 CTW chains for the whole call; wave w owns CTW chain tiles of 32.
-//     The state goes through HBM / L2 once per step (read as the B operand, read again by the epilogue, written once):
-//     8 dim bytes per chain-step = one step-equivalent, the same accounting as every other chain kernel.
-//   * B operand (x - mu, K x chains): PRIVATE to the wave -- lane (m, h) loads the eight coordinates 16 kb + 8 h .. + 7
-//     of chain m as two float4 (a 32 B run of the chain's row), subtracts mu and splits into three bf16x8 in registers.
-//   * A operand (Ps, out-rows x K): SHARED by the four waves -- per stage of two K-blocks the workgroup loads the
-//     [32 OT] x 32 slab of Ps once (lane-operand units of 8 consecutive fp32 of a row; Ps is symmetric), splits it and
-//     writes the three operand-ready images to LDS (double-buffered: one barrier per stage); every wave reads each image
-//     with one ds_read_b128 per (tile, K-block).  Ps therefore crosses L2 -> CU once per 128 CTW chains and step.
-//   * six products per (out tile, chain tile, K-block) as in gauss_bf16x3.h, smallest first, two independent
-//     accumulators alternating; fp32 accumulation.
-//   * out-dims beyond 256 are done in two SLICES of <= 8 tiles; the updated first slice waits in registers until the
-//     second slice has read the old state (in place, no second state buffer).
-//   * epilogue in the C/D layout (lane = chain m, registers = 4 consecutive coordinates per quad): one Philox counter and
-//     one float4 of old state per quad, the update in the reference's op order, float4 store.
+//   gauss_res_langevin_kernel<OT>  (dims up to 224)   the state STAYS IN REGISTERS (C/D layout, 16 OT registers + 16 OT
+//     accumulators, one wave per SIMD, 128 chains per workgroup): no HBM traffic in the step loop; the B operand of a
+//     K-block is eight state registers; the split work (B operands, next slab) sits in slots behind the MFMAs.
+//   gauss_big_langevin_kernel<OT, NS>  (dims 228 .. 512)   a step is one pass of a tiled GEMM over the state, the
+//     Euler-Maruyama update its epilogue: the state goes through HBM / L2 once per step (read as the B operand -- lane (m, h)
+//     loads eight coordinates of chain m as two 16 B pieces --, read again by the epilogue, written once).  Up to 256
+//     out-dims: eight waves of one chain tile each (two per SIMD, 256 registers: one's VALU work issues while the other's
+//     MFMAs run), 256 chains per workgroup.  Beyond: two SLICES of <= 8 out tiles, four waves; the updated first slice
+//     waits in registers until the second slice has read the old state (in place, no second state buffer).
 //
-// Registers: 16 OT CTW accumulators per slice (<= 256), one wave per SIMD.  LDS: 2 x 3 x OT x 2 KB of slabs + mu.
+// Where the time goes (MI355X, 2^17 chains x 256 dims x 20 steps; scripts/ab_big.sh removes one phase at a time): the
+// MFMAs alone 1.46 ms (= the bf16 peak for 6 products), Philox + Box-Muller + update 0.85 - 1.0 ms, the slab path (loads of Ps,
+// split, LDS write) 0.7 - 1.5 ms, not overlapped.  3.0 ms as shipped (round 2's lane-group kernel: 17.9 ms; the same chain as
+// torch ops -- a GEMM and four element-wise kernels per step -- 8.3 ms).  Open: the slab loads take ~2 stages to land (every
+// workgroup asks L2 for the same lines of Ps at the same time) -- a deeper prefetch needs 32 more registers; the normals could
+// be drawn behind the MFMAs as in gauss_mfma.hip's FAST body if 16 OT more registers were free.
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"
 #include "mlp_b16.h"  // EBM_BLOCK_CUT
@@ -36,7 +38,15 @@ using gauss3::f32x16;
 using gauss3::f32x8;
 using gauss3::static_for;
 
-constexpr int kBigBlock = 256;
+#ifndef EBM_BIG_WAVES1
+#define EBM_BIG_WAVES1 8  /* waves per workgroup of the one-slice kernels: 8 = two per SIMD, one chain tile each; 4 = see EBM_BIG_TWO_WG */
+#endif
+#ifndef EBM_BIG_TWO_WG
+#define EBM_BIG_TWO_WG 0  /* with 4 waves: 1 = one chain tile per wave, one K-block per stage, TWO workgroups per CU; 0 = two tiles per wave */
+#endif
+#ifndef EBM_BIG_EXP
+#define EBM_BIG_EXP 0  /* timing experiments (scripts/ab_big.sh): 1 no MFMA, 2 no Philox, 4 no loads in the K loop, 8 no slab writes */
+#endif
 
 struct BigArgs {
   float* x;
@@ -71,32 +81,33 @@ __device__ __forceinline__ Tri split8(const f32x8 d) {
 // (native vectors throughout: a conditional on HIP's float4 STRUCT is compiled through a stack slot)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x8 join8(const f32x4 a, const f32x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-// *p when ok, zeros otherwise -- the load is unconditional from an always-valid address (the caller's fallback)
-__device__ __forceinline__ f32x4 load4_or_zero(const float* p, const float* fallback, bool ok) {
-  const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p : fallback);
-  const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-  return ok ? v : z;
-}
-
 template <int OT, int NS>
 struct BigCfg {
-  static constexpr int CTW = NS == 1 ? 2 : 1;            // chain tiles per wave
-  static constexpr int CHAINS = 128 * CTW;               // per workgroup
-  static constexpr int UNITS = OT * 128;                 // lane-operand units of a slab: [OT][2 K-blocks][64 lanes]
-  static constexpr int UPT = (UNITS + kBigBlock - 1) / kBigBlock;
+  // One slice: EIGHT waves of one chain tile each -- two waves per SIMD, 256 registers each (128 accumulators), so that one wave's
+  // VALU work (splits, Philox, update) issues while the other's MFMAs run; a single wave per SIMD issues VALU work at ~40 % of
+  // the rate and nothing overlaps (scripts/ab_big.sh: the phases add up).  Two slices need 256 accumulator registers: four waves.
+  static constexpr int WAVES = NS == 1 ? EBM_BIG_WAVES1 : 4;
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr bool TWO_WG = NS == 1 && WAVES == 4 && EBM_BIG_TWO_WG;
+  static constexpr int CTW = NS == 1 && !TWO_WG ? 8 / WAVES : 1;  // chain tiles per wave
+  static constexpr int KBS = TWO_WG ? 1 : 2;              // K-blocks (of 16 columns) per stage
+  static constexpr int CHAINS = 32 * WAVES * CTW;         // per workgroup
+  static constexpr int UNITS = OT * 64 * KBS;            // lane-operand units of a slab: [OT][KBS K-blocks][64 lanes]
+  static constexpr int UPT = (UNITS + THREADS - 1) / THREADS;
   static constexpr size_t SLAB = (size_t)3 * UNITS * 16;  // bytes of one buffer (three splits)
   static constexpr size_t SMEM = 2 * SLAB + 512 * sizeof(float);
 };
 
 template <int OT, int NS>
-__global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a) {
+__global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG ? 2 : 1)) void gauss_big_langevin_kernel(BigArgs a) {
   using C = BigCfg<OT, NS>;
-  constexpr int CTW = C::CTW, UNITS = C::UNITS, UPT = C::UPT;
+  constexpr int kBigBlock = C::THREADS;
+  constexpr int CTW = C::CTW, UNITS = C::UNITS, UPT = C::UPT, KBS = C::KBS, KW = 16 * KBS;
   extern __shared__ __align__(16) unsigned char big_smem[];
   bf16x8* slab = reinterpret_cast<bf16x8*>(big_smem);                   // [2][3][UNITS]
   float* mus = reinterpret_cast<float*>(big_smem + 2 * C::SLAB);        // [d32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
-  const int dim = a.dim, d32 = (dim + 31) & ~31, n_stage = d32 >> 5;
+  const int dim = a.dim, d32 = (dim + 31) & ~31, n_stage = d32 / KW;
   for (int i = tid; i < d32; i += kBigBlock) mus[i] = i < dim ? a.mean[i] : 0.0f;
 
   int64_t chain[CTW];
@@ -115,29 +126,48 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
   int until_keep = a.thin;
   int64_t kept = 0;
 
-  // one lane-operand unit of the slab of slice rows `row0`, stage s: eight fp32 of a row of Ps
-  auto load_a = [&](int row0, int s, int j, f32x4& v0, f32x4& v1) {
+  // One lane-operand unit of the slab of slice rows `row0`, stage s: eight fp32 of a row of Ps.  Loads are UNCONDITIONAL from
+  // an always-valid address and the padding is zeroed where the value is consumed, a stage later (mask_*): a select right
+  // behind the load makes the compiler wait for every load before it issues the next one.
+  auto a_ok = [&](int row0, int s, int j, bool& ok0, bool& ok1, int& row, int& kcol) {
     const int u = tid + kBigBlock * j;
-    const int it = u >> 7, kb2 = (u >> 6) & 1, ul = u & 63;
-    const int row = row0 + 32 * it + (ul & 31), kcol = 32 * s + 16 * kb2 + 8 * (ul >> 5);
+    const int it = u / (64 * KBS), kb2 = (u >> 6) % KBS, ul = u & 63;
+    row = row0 + 32 * it + (ul & 31);
+    kcol = KW * s + 16 * kb2 + 8 * (ul >> 5);
     const bool ok = u < UNITS && row < dim;
-    const float* p = a.prec + (int64_t)(ok ? row : 0) * dim + kcol;
-    v0 = load4_or_zero(p, a.prec, ok && kcol < dim);
-    v1 = load4_or_zero(p + 4, a.prec, ok && kcol + 4 < dim);
+    ok0 = ok && kcol < dim;
+    ok1 = ok && kcol + 4 < dim;
   };
-  auto store_a = [&](int buf, int j, const f32x4& v0, const f32x4& v1) {
+  auto load_a = [&](int row0, int s, int j, f32x4& v0, f32x4& v1) {
+    bool ok0, ok1;
+    int row, kcol;
+    a_ok(row0, s, j, ok0, ok1, row, kcol);
+    const float* p = a.prec + (int64_t)row * dim + kcol;
+    v0 = *reinterpret_cast<const f32x4*>(ok0 ? p : a.prec);
+    v1 = *reinterpret_cast<const f32x4*>(ok1 ? p + 4 : a.prec);
+  };
+  auto store_a = [&](int buf, int row0, int s, int j, const f32x4& v0, const f32x4& v1) {  // (row0, s): what was loaded
     const int u = tid + kBigBlock * j;
     if (u < UNITS) {
-      const Tri t = split8(join8(v0, v1));
+      bool ok0, ok1;
+      int row, kcol;
+      a_ok(row0, s, j, ok0, ok1, row, kcol);
+      const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+      const Tri t = split8(join8(ok0 ? v0 : z, ok1 ? v1 : z));
       bf16x8* dst = slab + (size_t)buf * 3 * UNITS + u;
       dst[0] = t.h; dst[UNITS] = t.m; dst[2 * UNITS] = t.l;
     }
   };
   auto load_b = [&](int c, int s, int kb2, f32x4& v0, f32x4& v1) {
-    const int kcol = 32 * s + 16 * kb2 + 8 * h;
+    const int kcol = KW * s + 16 * kb2 + 8 * h;
     const float* p = a.x + xoff[c] + kcol;
-    v0 = load4_or_zero(p, a.x, active[c] && kcol < dim);
-    v1 = load4_or_zero(p + 4, a.x, active[c] && kcol + 4 < dim);
+    v0 = *reinterpret_cast<const f32x4*>(kcol < dim ? p : a.x);
+    v1 = *reinterpret_cast<const f32x4*>(kcol + 4 < dim ? p + 4 : a.x);
+  };
+  auto masked_b = [&](int c, int s, int kb2, const f32x4& v0, const f32x4& v1) {
+    const int kcol = KW * s + 16 * kb2 + 8 * h;
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    return join8((active[c] && kcol < dim) ? v0 : z, (active[c] && kcol + 4 < dim) ? v1 : z);
   };
 
   for (int step = 0; step < a.k_steps; ++step) {
@@ -168,36 +198,39 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
       });
 
       // ---- stage 0 of the slice: its slab and this wave's B operands
-      f32x4 ra[UPT][2], rb[CTW][2][2];
+      f32x4 ra[UPT][2], rb[CTW][KBS][2];
       static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, 0, j, ra[j][0], ra[j][1]); });
-      static_for<CTW * 2>([&](auto ic) {
-        constexpr int c = decltype(ic)::value >> 1, kb2 = decltype(ic)::value & 1;
+      static_for<CTW * KBS>([&](auto ic) {
+        constexpr int c = decltype(ic)::value / KBS, kb2 = decltype(ic)::value % KBS;
         load_b(c, 0, kb2, rb[c][kb2][0], rb[c][kb2][1]);
       });
-      static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, j, ra[j][0], ra[j][1]); });
+      static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, row0, 0, j, ra[j][0], ra[j][1]); });
       __syncthreads();
 
       for (int s = 0; s < n_stage; ++s) {
         const int buf = s & 1;
         const bool more = s + 1 < n_stage;
-        f32x4 rbn[CTW][2][2];
-        if (more) {  // the next stage's operands: a whole stage of matrix work for them to land
+        // this stage's B operands first (their loads had the previous stage to land), THEN the next stage's loads: the
+        // compiler's wait for a loop-carried load is counted from the newest one in flight
+        Tri ball[KBS][CTW];
+        static_for<KBS * CTW>([&](auto ic) {
+          constexpr int kb2 = decltype(ic)::value / CTW, c = decltype(ic)::value % CTW;
+          const f32x4 m0 = *reinterpret_cast<const f32x4*>(mus + KW * s + 16 * kb2 + 8 * h);
+          const f32x4 m1 = *reinterpret_cast<const f32x4*>(mus + KW * s + 16 * kb2 + 8 * h + 4);
+          ball[kb2][c] = split8(masked_b(c, s, kb2, rb[c][kb2][0], rb[c][kb2][1]) - join8(m0, m1));
+        });
+        if (more && !(EBM_BIG_EXP & 4)) {  // a whole stage of matrix work for them to land
           static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, s + 1, j, ra[j][0], ra[j][1]); });
-          static_for<CTW * 2>([&](auto ic) {
-            constexpr int c = decltype(ic)::value >> 1, kb2 = decltype(ic)::value & 1;
-            load_b(c, s + 1, kb2, rbn[c][kb2][0], rbn[c][kb2][1]);
+          static_for<CTW * KBS>([&](auto ic) {
+            constexpr int c = decltype(ic)::value / KBS, kb2 = decltype(ic)::value % KBS;
+            load_b(c, s + 1, kb2, rb[c][kb2][0], rb[c][kb2][1]);
           });
         }
+        __builtin_amdgcn_sched_barrier(0);
         const bf16x8* sb = slab + (size_t)buf * 3 * UNITS + lane;
-        static_for<2>([&](auto kc) {
+        static_for<KBS>([&](auto kc) {
           constexpr int kb2 = decltype(kc)::value;
-          Tri b[CTW];
-          const f32x4 m0 = *reinterpret_cast<const f32x4*>(mus + 32 * s + 16 * kb2 + 8 * h);
-          const f32x4 m1 = *reinterpret_cast<const f32x4*>(mus + 32 * s + 16 * kb2 + 8 * h + 4);
-          static_for<CTW>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            b[c] = split8(join8(rb[c][kb2][0], rb[c][kb2][1]) - join8(m0, m1));
-          });
+          const Tri (&b)[CTW] = ball[kb2];
           // pairs of independent accumulators alternate: (two chain tiles, one A triple) or (one chain tile, two out tiles)
           constexpr int PAIRS = CTW == 2 ? OT : (OT + 1) / 2;
           // the A triples of pair p + 1 are requested before the twelve MFMAs of pair p (fenced: left alone, the scheduler
@@ -205,9 +238,9 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
           auto read_a = [&](auto pc, bf16x8 (&a6)[6]) {
             constexpr int pi = decltype(pc)::value;
             constexpr int ot0 = CTW == 2 ? pi : 2 * pi, ot1 = CTW == 2 ? pi : (2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi);
-            a6[0] = sb[2 * UNITS + ot0 * 128 + kb2 * 64]; a6[1] = sb[UNITS + ot0 * 128 + kb2 * 64]; a6[2] = sb[ot0 * 128 + kb2 * 64];
+            a6[0] = sb[2 * UNITS + ot0 * (64 * KBS) + kb2 * 64]; a6[1] = sb[UNITS + ot0 * (64 * KBS) + kb2 * 64]; a6[2] = sb[ot0 * (64 * KBS) + kb2 * 64];
             if constexpr (CTW == 1 && ot1 != ot0) {
-              a6[3] = sb[2 * UNITS + ot1 * 128 + kb2 * 64]; a6[4] = sb[UNITS + ot1 * 128 + kb2 * 64]; a6[5] = sb[ot1 * 128 + kb2 * 64];
+              a6[3] = sb[2 * UNITS + ot1 * (64 * KBS) + kb2 * 64]; a6[4] = sb[UNITS + ot1 * (64 * KBS) + kb2 * 64]; a6[5] = sb[ot1 * (64 * KBS) + kb2 * 64];
             } else {
               a6[3] = a6[0]; a6[4] = a6[1]; a6[5] = a6[2];
             }
@@ -226,6 +259,7 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
             if constexpr (two) g1 = res[sl][c1][ot1];
             const Tri& b0 = b[0];
             const Tri& b1 = b[c1];
+            if constexpr (!(EBM_BIG_EXP & 1)) {
             g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[0], b0.h, g0, 0, 0, 0);
             if constexpr (two) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3], b1.h, g1, 0, 0, 0);
             g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[1], b0.m, g0, 0, 0, 0);
@@ -238,6 +272,10 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
             if constexpr (two) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[5], b1.m, g1, 0, 0, 0);
             g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[2], b0.h, g0, 0, 0, 0);
             if constexpr (two) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[5], b1.h, g1, 0, 0, 0);
+            } else {
+              g0[0] += (float)acur[0][0] * (float)b0.h[0] + (float)acur[1][0] * (float)b0.m[0] + (float)acur[2][0] * (float)b0.l[0];
+              if constexpr (two) g1[0] += (float)acur[3][0] * (float)b1.h[0] + (float)acur[4][0] * (float)b1.m[0] + (float)acur[5][0] * (float)b1.l[0];
+            }
             res[sl][0][ot0] = g0;
             if constexpr (two) res[sl][c1][ot1] = g1;
             __builtin_amdgcn_sched_barrier(0);
@@ -247,35 +285,46 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
             }
           });
         });
-        if (more) {
-          static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(buf ^ 1, j, ra[j][0], ra[j][1]); });
-          static_for<CTW * 2>([&](auto ic) {
-            constexpr int c = decltype(ic)::value >> 1, kb2 = decltype(ic)::value & 1;
-            rb[c][kb2][0] = rbn[c][kb2][0];
-            rb[c][kb2][1] = rbn[c][kb2][1];
-          });
+        if (more && !(EBM_BIG_EXP & 8)) {
+          static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(buf ^ 1, row0, s + 1, j, ra[j][0], ra[j][1]); });
         }
         __syncthreads();  // the next slab is written, this one is read by everyone
       }
 
-      // ---- Euler-Maruyama update of the slice in the reference's op order (one Philox counter per register quad)
-      static_for<CTW * OT>([&](auto ic) {
-        constexpr int c = decltype(ic)::value / OT, ot = decltype(ic)::value % OT;
+      // ---- Euler-Maruyama update of the slice in the reference's op order (one Philox counter per register quad).
+      // The old state of tile t + 2 is requested while tile t is updated: a quad's load alone is an HBM round trip.
+      constexpr int TILES = CTW * OT, AHEAD = 2;
+      f32x4 xold[AHEAD + 1][4];
+      auto request = [&](auto tc) {
+        constexpr int t = decltype(tc)::value, c = t / OT, ot = t % OT;
+        static_for<4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const int d0 = row0 + 32 * ot + 8 * q + h4;
+          int off = (active[c] && d0 < dim) ? d0 : 0;
+          asm volatile("" : "+v"(off));  // pins the load here (volatile asm keeps its order: the block cuts, the other quads)
+          xold[t % (AHEAD + 1)][q] = *reinterpret_cast<const f32x4*>(a.x + xoff[c] + off);  // (not ok: some valid word, never stored)
+        });
+      };
+      static_for<(AHEAD < TILES ? AHEAD : TILES)>([&](auto tc) { request(tc); });
+      static_for<TILES>([&](auto ic) {
+        constexpr int t = decltype(ic)::value, c = t / OT, ot = t % OT;
         const uint64_t e_row = e_rows[c];
+        if constexpr (t + AHEAD < TILES) request(std::integral_constant<int, t + AHEAD>{});
         static_for<4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const int d0 = row0 + 32 * ot + 8 * q + h4;
           const bool ok = active[c] && d0 < dim;
-          int off = ok ? d0 : 0;
-          asm volatile("" : "+v"(off));  // pins the quad's loads here (volatile asm keeps its order: the block cuts, the next quad)
-          const f32x4 xo = *reinterpret_cast<const f32x4*>(a.x + xoff[c] + off);  // (lanes that are not ok: some valid word, never stored)
+          const int off = ok ? d0 : 0;
           f32x4 eps;
-          if (a.noise) {
+          if constexpr (EBM_BIG_EXP & 2) {
+            eps = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+          } else if (a.noise) {
             eps = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)step * a.n_chains * dim + (active[c] ? (int64_t)e_row : 0) + off);
           } else {
             const F4 n4 = normal4_at(a.key, (e_row + (uint64_t)d0) >> 2, a.step0 + (uint64_t)step);
             eps = f32x4{n4.v[0], n4.v[1], n4.v[2], n4.v[3]};
           }
+          const f32x4 xo = xold[t % (AHEAD + 1)][q];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float x1 = xo[i] - eta * res[sl][c][ot][4 * q + i];
@@ -325,6 +374,314 @@ __global__ __launch_bounds__(kBigBlock) void gauss_big_langevin_kernel(BigArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------
+// dims 132 .. 256: the chain state stays in registers for the whole call (as below 129: C/D layout, quad q of tile t =
+// coordinates 32 t + 8 q + 4 h .. + 3 of chain m) and only Ps streams -- per stage of two K-blocks the workgroup stages the
+// [32 OT] x 32 slab of Ps as three operand-ready bf16 images in LDS (double-buffered, one barrier per stage); the B operand
+// of K-block kb is eight consecutive state registers (gauss_bf16x3.h: lane half h supplies coordinates
+// 16 kb + 8 (j >> 2) + 4 h + (j & 3), and the slab unit of lane (row, h) holds Ps[row] at the same columns).  No HBM
+// traffic in the step loop: the state is read once and written once per call (plus the kept rows of a trajectory);
+// Ps crosses L2 -> CU once per workgroup (128 chains) and step.  One wave per SIMD: 16 OT state + 16 OT accumulator registers.
+// ---------------------------------------------------------------------------------
+// A three-way split of eight values in EIGHT steps of five / six instructions (mlp_b16.h: pair p = elements 2 p, 2 p + 1 = one
+// packed dword of each piece): step 2 p forms the hi piece of pair p and its residual, step 2 p + 1 the mid and lo pieces.
+struct SplitJob {
+  f32x8 d;
+  mlpb16::f32x2 r;
+  mlpb16::Split8p t;
+  template <class K>
+  __device__ __forceinline__ void step(K) {
+    constexpr int k = K::value, pr = k >> 1;
+    if constexpr ((k & 1) == 0) {
+      mlpb16::pair_split_a<pr>(t, r, mlpb16::f32x2{d[2 * pr], d[2 * pr + 1]});
+    } else {
+      mlpb16::pair_split_b<pr>(t, r);
+      mlpb16::pair_split_c<pr>(t, r);
+    }
+  }
+  __device__ __forceinline__ Tri tri() const {
+    Tri o;
+    o.h = __builtin_bit_cast(bf16x8, t.h); o.m = __builtin_bit_cast(bf16x8, t.m); o.l = __builtin_bit_cast(bf16x8, t.l);
+    return o;
+  }
+};
+
+template <int OT>
+struct ResCfg {
+  static constexpr int THREADS = 256;
+  static constexpr int UNITS = OT * 128;                  // [OT][2 K-blocks][64 lanes]
+  static constexpr int UPT = 4;                           // thread = row of Ps: the four lane-operand units of its 128 B per stage
+  static constexpr int SLABU = 8 * 128;                   // units allocated per image: every thread writes its four, no tail test
+  static constexpr size_t SLAB = (size_t)3 * SLABU * 16;
+  static constexpr size_t SMEM = 2 * SLAB + 256 * sizeof(float);
+};
+
+template <int OT>
+__global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
+  using C = ResCfg<OT>;
+  constexpr int UPT = C::UPT, SLABU = C::SLABU;
+  extern __shared__ __align__(16) unsigned char big_smem[];
+  bf16x8* slab = reinterpret_cast<bf16x8*>(big_smem);                   // [2][3][UNITS]
+  float* mus = reinterpret_cast<float*>(big_smem + 2 * C::SLAB);        // [32 OT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+  const int dim = a.dim;
+  for (int i = tid; i < 32 * OT; i += 256) mus[i] = i < dim ? a.mean[i] : 0.0f;
+  const int64_t chain = ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
+  const bool active = chain < a.n_chains;
+  const int64_t row = active ? chain * (int64_t)dim : 0;
+
+  f32x16 x[OT];
+  static_for<OT * 4>([&](auto ic) {
+    constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
+    const int k0 = 32 * t + 8 * q + 4 * h;
+    const bool ok = active && k0 < dim;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + row + (ok ? k0 : 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[t][4 * q + i] = ok ? v[i] : 0.0f;  // padding stays exactly 0: zero rows / columns of Ps, never stored
+  });
+
+  // Slab units.  Thread t stages row t of Ps: per stage the 32 columns = ONE 128 B line, as the four lane-operand units
+  // (kb2, h') = (j >> 1, j & 1) -- unit (row, kb2, h') holds the eight columns that lane half h' pairs with its B registers in
+  // K-block 2 s + kb2: 32 s + 16 kb2 + 4 h' + {0..3} and + 8.  (Row-per-thread keeps a line's eight 16 B pieces in one
+  // thread, back to back: one L2 request per line.  Spread over waves -- unit u = tid + 256 j -- every piece was its own
+  // request, all 256 CUs asking for the same lines at the same time: the loads took ~2 stages to land, 40 % of the step.)
+  auto a_cols = [&](int s, int j, bool& ok0, bool& ok1, int& rowi, int& c0) {
+    rowi = tid;
+    c0 = 32 * s + 16 * (j >> 1) + 4 * (j & 1);
+    const bool ok = rowi < dim;
+    ok0 = ok && c0 < dim;
+    ok1 = ok && c0 + 8 < dim;
+  };
+  auto unit_of = [&](int j) { return (tid >> 5) * 128 + (j >> 1) * 64 + (j & 1) * 32 + (tid & 31); };
+  auto load_a = [&](int s, int j, f32x4& v0, f32x4& v1) {
+    bool ok0, ok1;
+    int rowi, c0;
+    a_cols(s, j, ok0, ok1, rowi, c0);
+    const float* p = a.prec + (int64_t)rowi * dim + c0;
+    v0 = *reinterpret_cast<const f32x4*>(ok0 ? p : a.prec);
+    v1 = *reinterpret_cast<const f32x4*>(ok1 ? p + 8 : a.prec);
+  };
+  auto store_a = [&](int buf, int s, int j, const f32x4& v0, const f32x4& v1) {
+    bool ok0, ok1;
+    int rowi, c0;
+    a_cols(s, j, ok0, ok1, rowi, c0);
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const Tri t = split8(join8(ok0 ? v0 : z, ok1 ? v1 : z));
+    bf16x8* dst = slab + (size_t)buf * 3 * SLABU + unit_of(j);
+    dst[0] = t.h; dst[SLABU] = t.m; dst[2 * SLABU] = t.l;
+  };
+
+  auto mask_a = [&](int s, int j, const f32x4& v0, const f32x4& v1, f32x8& d) {
+    bool ok0, ok1;
+    int rowi, c0;
+    a_cols(s, j, ok0, ok1, rowi, c0);
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    d = join8(ok0 ? v0 : z, ok1 ? v1 : z);
+  };
+  auto write_a = [&](int buf, int j, const Tri& t) {  // (unconditional: behind a branch the compiler gathers the whole unit's split there)
+    bf16x8* dst = slab + (size_t)buf * 3 * SLABU + unit_of(j);
+    dst[0] = t.h; dst[SLABU] = t.m; dst[2 * SLABU] = t.l;
+  };
+
+  float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
+  int until_keep = a.thin;
+  int64_t kept = 0;
+  Tri b0;  // the B operand of the next K-block 0
+  int gstage = 0;  // stages done so far: its parity is the LDS buffer (OT may be odd, the pipeline runs across steps)
+
+  // the first slab
+  f32x4 ra[UPT][2];
+  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(0, j, ra[j][0], ra[j][1]); });
+  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, 0, j, ra[j][0], ra[j][1]); });
+  __syncthreads();
+
+  for (int step = 0; step < a.k_steps; ++step) {
+    if (a.table) {
+      const float4 tb = a.table[step];
+      eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
+    }
+    f32x16 g[OT];
+    static_for<OT>([&](auto tc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[decltype(tc)::value][r] = 0.0f;
+    });
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));  // (per step: the slab addresses are not hoisted out of the step loop and spilled)
+    // B operand of K-block (tile t, half kb2): d = x[t][8 kb2 ..] - mu, then its three-way split in five small steps -- the
+    // steps are SLOTS behind the MFMAs (one wave per SIMD: work placed between two MFMAs issues while the first one runs;
+    // placed before or after the MFMA block it adds its full issue time, ~40 % of the step as measured by scripts/ab_big.sh)
+    auto b_init = [&](SplitJob& jb, auto tc, auto kc, auto hc) {  // half hc of the eight differences
+      constexpr int t = decltype(tc)::value, kb2 = decltype(kc)::value, hf = decltype(hc)::value;
+      const f32x4 mm = *reinterpret_cast<const f32x4*>(mus + 32 * t + 16 * kb2 + 8 * hf + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) jb.d[4 * hf + j] = x[t][8 * kb2 + 4 * hf + j] - mm[j];
+    };
+    {  // K-block 0 of the step: its state registers were written by the previous update
+      SplitJob j0;
+      b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+      static_for<8>([&](auto kc) { j0.step(kc); });
+      b0 = j0.tri();
+    }
+    static_for<OT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, sn = (s + 1) % OT;  // the stage after the last one is stage 0 of the next step
+      constexpr int HALF = 6 * OT;                                // MFMAs per K-block
+      const int buf = gstage & 1;
+      if constexpr (!(EBM_BIG_EXP & 4)) static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(sn, j, ra[j][0], ra[j][1]); });
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8* sb = slab + (size_t)buf * 3 * SLABU + lane;
+      SplitJob jb1, jb0n, ja;
+      // Slots: one behind every MFMA, each <= 6 .. 8 instructions (what fits a 32-cycle MFMA; more delays the next one).
+      //   behind K-block 0 (HALF slots): the B operands of K-block 1 and of the next stage's K-block 0, alternating --
+      //   2 init + 8 split steps each;   behind K-block 1: the next slab (its loads were issued at the top of the stage) --
+      //   per unit 1 mask step, 8 split steps, the LDS write with the last one
+      constexpr int A_STEPS = 9 * UPT, B_STEPS = 10;
+      constexpr int A_PER = (A_STEPS + HALF - 1) / HALF;  // (five tiles: 36 steps behind 30 MFMAs -- two per slot until they are done)
+      static_assert(2 * B_STEPS <= HALF, "the split work of a stage fits behind its MFMAs");
+      auto b_job = [&](SplitJob& jb, auto tc, auto kc, auto kk) {  // step kk of 10 of a B operand
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < 2) b_init(jb, tc, kc, std::integral_constant<int, k>{});
+        else jb.step(std::integral_constant<int, k - 2>{});
+      };
+      auto a_job = [&](auto kk) {  // step kk of 9 UPT of the next slab
+        constexpr int k = decltype(kk)::value, j = k / 9, st = k % 9;
+        if constexpr (st == 0) {
+          if constexpr (EBM_BIG_EXP & 64) { ja.d = f32x8{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, (float)tid}; }
+          else mask_a(sn, j, ra[j][0], ra[j][1], ja.d);
+        } else {
+          ja.step(std::integral_constant<int, st - 1>{});
+          if constexpr (st == 8 && !(EBM_BIG_EXP & 128)) write_a(buf ^ 1, j, ja.tri());
+        }
+      };
+      auto slot = [&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        if constexpr (o < HALF) {
+          if constexpr (EBM_BIG_EXP & 32) {
+          } else if constexpr (o % 2 == 0 && o / 2 < B_STEPS) {
+            b_job(jb1, sc, std::integral_constant<int, 1>{}, std::integral_constant<int, o / 2>{});
+          } else if constexpr (o % 2 == 1 && o / 2 < B_STEPS && s + 1 < OT) {
+            b_job(jb0n, std::integral_constant<int, (s + 1 < OT ? s + 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, o / 2>{});
+          }
+        } else {
+          constexpr int ak = (o - HALF) * A_PER;
+          static_for<A_PER>([&](auto ic) {
+            if constexpr (ak + decltype(ic)::value < A_STEPS && !(EBM_BIG_EXP & 8)) a_job(std::integral_constant<int, ak + decltype(ic)::value>{});
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      static_for<2>([&](auto kc) {
+        constexpr int kb2 = decltype(kc)::value;
+        constexpr int PAIRS = (OT + 1) / 2;
+        const Tri bb = kb2 == 0 ? b0 : jb1.tri();
+        auto read_a = [&](auto pc, bf16x8 (&a6)[6]) {
+          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
+          a6[0] = sb[2 * SLABU + ot0 * 128 + kb2 * 64]; a6[1] = sb[SLABU + ot0 * 128 + kb2 * 64]; a6[2] = sb[ot0 * 128 + kb2 * 64];
+          if constexpr (ot1 != ot0) {
+            a6[3] = sb[2 * SLABU + ot1 * 128 + kb2 * 64]; a6[4] = sb[SLABU + ot1 * 128 + kb2 * 64]; a6[5] = sb[ot1 * 128 + kb2 * 64];
+          }
+        };
+        bf16x8 acur[6];
+        read_a(std::integral_constant<int, 0>{}, acur);
+        static_for<PAIRS>([&](auto pc) {
+          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
+          constexpr bool two = ot1 != ot0;
+          constexpr int o0 = kb2 * HALF + 12 * pi;  // ordinal of this pair's first MFMA
+          bf16x8 anext[6];
+          if constexpr (pi + 1 < PAIRS) read_a(std::integral_constant<int, pi + 1>{}, anext);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x16 g0 = g[ot0], g1;
+          if constexpr (two) g1 = g[ot1];
+          // (term, operand) in issue order: smallest products first
+          static_for<6>([&](auto tc) {
+            constexpr int term = decltype(tc)::value;
+            constexpr int ai = term == 0 ? 0 : (term <= 2 ? 1 : 2);                    // Pl | Pm Pm | Ph Ph Ph
+            const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
+            if constexpr (!(EBM_BIG_EXP & 1)) g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
+            else g0[term] += (float)acur[ai][0] * (float)bp[0];
+            slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
+            if constexpr (two) {
+              if constexpr (!(EBM_BIG_EXP & 1)) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
+              else g1[term] += (float)acur[3 + ai][0] * (float)bp[0];
+              slot(std::integral_constant<int, o0 + 2 * term + 1>{});
+            }
+          });
+          g[ot0] = g0;
+          if constexpr (two) g[ot1] = g1;
+          if constexpr (pi + 1 < PAIRS) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acur[i] = anext[i];
+          }
+        });
+      });
+      if constexpr (s + 1 < OT) b0 = jb0n.tri();
+      ++gstage;
+      if constexpr (!(EBM_BIG_EXP & 16)) __syncthreads();  // the next slab is written, this one is read by everyone
+    });
+
+    // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad; all in registers
+    uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+    asm volatile("" : "+v"(e_row));
+    const bool keep_now = a.traj && until_keep == 1;
+    static_for<OT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      static_for<4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const int k0 = 32 * t + 8 * q + 4 * h;
+        const bool ok = active && k0 < dim;
+        f32x4 eps;
+        if constexpr (EBM_BIG_EXP & 2) {
+          eps = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+        } else if (a.noise) {
+          eps = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)step * a.n_chains * dim + (active ? (int64_t)e_row : 0) + (ok ? k0 : 0));
+        } else {
+          const F4 n4 = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
+          eps = f32x4{n4.v[0], n4.v[1], n4.v[2], n4.v[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
+          const float dw = eps[i] * sqrt_eta;
+          float nv = x1 + noise_coef * dw;
+          if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+          x[t][4 * q + i] = ok ? nv : 0.0f;  // padding held at 0
+        }
+        if (keep_now && ok) {
+          const f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(a.traj + ((int64_t)e_row * a.n_kept + kept * (int64_t)dim) + k0) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
+      });
+      EBM_BLOCK_CUT();
+    });
+    if (--until_keep == 0) {
+      until_keep = a.thin;
+      ++kept;
+    }
+  }
+  static_for<OT * 4>([&](auto ic) {
+    constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
+    const int k0 = 32 * t + 8 * q + 4 * h;
+    if (active && k0 < dim) {
+      const f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(a.x + row + k0) = v;
+    }
+  });
+}
+
+template <int OT>
+int launch_res(const BigArgs& a, hipStream_t st) {
+  using C = ResCfg<OT>;
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)C::SMEM);
+  const int64_t blocks = ceil_div64(a.n_chains, 128);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL((gauss_res_langevin_kernel<OT>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+
 template <int OT, int NS>
 int launch_big(const BigArgs& a, hipStream_t st) {
   using C = BigCfg<OT, NS>;
@@ -334,7 +691,7 @@ int launch_big(const BigArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
   const int64_t blocks = ceil_div64(a.n_chains, C::CHAINS);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS>), dim3((unsigned)blocks), dim3(kBigBlock), C::SMEM, st, a);
+  hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
@@ -357,6 +714,16 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
   const int tiles = (dim + 31) / 32;  // 5 .. 16
+#ifndef EBM_BIG_TILED_ONLY
+  // up to seven tiles the register-resident kernel, eight tiles the tiled one (same box, 2^17 chains x 20 steps, ms:
+  // dims 132 / 160 / 192 / 224 / 256: 1.37 / 1.42 / 1.89 / 2.55 / 3.48 resident, 1.48 / 1.67 / 2.23 / 2.51 / 3.02 tiled)
+  switch (tiles) {
+    case 5: return launch_res<5>(a, st);
+    case 6: return launch_res<6>(a, st);
+    case 7: return launch_res<7>(a, st);
+    default: break;
+  }
+#endif
   if (tiles <= 8) {
     switch (tiles) {
       case 5: return launch_big<5, 1>(a, st);

@@ -41,6 +41,12 @@ def em_coefficients(eta: float, sigma: float) -> Tuple[float, float, float]:
     return eta, eta**0.5, (2.0 * sigma**2) ** 0.5
 
 
+def _gaussian_chain_on_matrix_cores(dim: int) -> bool:
+    """Widths at which ``ebm_langevin_chain_f32`` runs the dense Gaussian on the matrix cores (csrc/gauss_mfma.hip: up to 128,
+    packed rows included; csrc/gauss_big.hip: multiples of 4 up to 512)."""
+    return dim <= 128 or (dim % 4 == 0 and dim <= 512)
+
+
 def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
     """One iteration of the graph route: a replay once the graph exists; until then the step body runs eagerly (a real
     step), and behind the FIRST one of a call the graph is captured -- unless, by default, that step showed side effects
@@ -156,6 +162,11 @@ class LangevinDynamics(BaseSampler):
             )
             return "eager", None
         spec = self._fusable_spec(x, model_kwargs)
+        if spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and not _gaussian_chain_on_matrix_cores(spec.dim):
+            # The chain kernels for these widths (not a multiple of 4 above 128, or above 512) are the lane-group mat-vec:
+            # 2 TFLOP/s.  The step route -- one library GEMM for the gradient (GaussianModel._hip_gradient) and the fused
+            # update kernel on the same random field, replayed from a HIP graph -- is 10 - 40x faster there.
+            return "step", None
         return ("fused", spec) if spec is not None else ("step", None)
 
     def _fusable_spec(self, x: torch.Tensor, model_kwargs: Dict[str, Any]) -> Optional[FusedSpec]:
