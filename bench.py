@@ -391,6 +391,9 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                 "value": n * T / td, "ms_per_call": td * 1e3, "kernel_ms_per_call": kd,
                 "executed_fp32_TFLOPs": dense_flops / (kd * 1e-3 if kd else td) / 1e12,
                 "frac_of_fp32_vector_peak": dense_flops / (kd * 1e-3 if kd else td) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                "note": "VALU-bound, not latency-bound: 78 % of the SIMD cycles execute VALU instructions, 526 per leapfrog step of which "
+                        "256 are the packed FMAs of the two K x dim passes (profiles/r03_pmc_hmc_dense.txt); the 157 TF/s spec figure is "
+                        "not reachable by FMA streams at the clock the part holds (profiles/r03_probe_packed.jsonl: 116 - 123 TFLOP/s)",
             },
         }
 
@@ -511,6 +514,27 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
             }
         return out
 
+    def gaussian_widths():
+        # dense Gaussian Langevin over widths: packed rows (8 / 30 / 50), resident in registers + LDS (64 / 128), Ps streamed
+        # (160 / 256 / 512) -- csrc/gauss_mfma.hip, csrc/gauss_big.hip; VERDICT r2 item 5
+        out = {"name": "gaussian_langevin_widths", "workload": "LangevinDynamics.sample on GaussianModel, k = 20 steps per call, widths "
+               "8 / 30 / 50 (packed rows), 64 / 128 (register-resident, Ps in LDS), 160 / 256 / 512 (Ps streamed through LDS)",
+               "bound": "valu + bf16 mfma", "metric": "chain-steps/s; step-equivalent fraction of 8 TB/s = n k 8 dim / t / 8e12", "dims": {}}
+        k = 20
+        for dim, n in ((8, 1 << 18), (30, 1 << 18), (50, 1 << 18), (64, 1 << 18), (128, 1 << 18), (160, 1 << 17), (256, 1 << 17), (512, 1 << 16)):
+            gd = torch.Generator().manual_seed(dim)
+            a = torch.randn(dim, dim, generator=gd)
+            model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=device)
+            ld = ta.LangevinDynamics(model, step_size=0.01, device=device)
+            x0 = torch.randn(n, dim, device=device)
+            fn = lambda: ld.sample(x=x0, n_steps=k)  # noqa: E731
+            fn()
+            kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 3, device)
+            out["dims"][str(dim)] = {"n_chains": n, "kernel_ms": kms, "chain_steps_per_s": n * k / (kms * 1e-3),
+                                     "step_equivalent_frac_of_8TBps": n * k * 8 * dim / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "useful_TFLOPs": 2 * n * k * dim * dim / (kms * 1e-3) / 1e12}
+        return out
+
     def step_kernel():
         # the genuinely HBM-bound kernel of the path: one Euler-Maruyama step with an external gradient, 2^26 elements
         n = 1 << 26
@@ -581,6 +605,7 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
     guarded("mlp_benchmark_network_dim32", mlp_bench_net)
     guarded("langevin_step_kernel", step_kernel)
     guarded("matrix_pipe_energies", matrix_pipe)
+    guarded("gaussian_langevin_widths", gaussian_widths)
     return out
 
 

@@ -165,6 +165,8 @@ chain_case("chain_mlp_32_128", ta.MLPEnergy(32, 128, device=dev), 1 << 16, 32, 2
 chain_case("chain_mlp_32_256", ta.MLPEnergy(32, 256, device=dev), 1 << 16, 32, 20)
 hmc_case("hmc_mlp_32_128", ta.MLPEnergy(32, 128, device=dev), 1 << 16, 32, 10, 10, 0.05)
 hmc_case("hmc_gmm8_c3", ta.core.ring_mixture(8, 32, device=dev), 1 << 18, 32, 10, 20, 0.1)
+gd = torch.Generator().manual_seed(7)
+hmc_case("hmc_gmm8_dense", ta.GaussianMixtureModel(torch.randn(8, 32, generator=gd) * 2.0, sigma=1.0, device=dev), 1 << 18, 32, 10, 20, 0.1)
 hmc_case("hmc_dw_dim32", dw, 1 << 18, 32, 10, 20, 0.05)
 hmc_case("hmc_dw_dim128", dw, 1 << 16, 128, 10, 10, 0.03)
 hmc_case("hmc_gauss_dim64", gauss64, 1 << 16, 64, 10, 10, 0.1)

@@ -39,8 +39,8 @@ struct GaussArgs {
   uint64_t step0;
   const float* mean;  // [sub_dim]
   const float* prec;  // [sub_dim, sub_dim], symmetric
-  int32_t sub_dim;    // PACKED rows: dim = pack * sub_dim -- `pack` consecutive chains of a sub_dim-dimensional Gaussian are ONE
-  int32_t pack;       // row of the block-diagonal Gaussian kron(I_pack, Ps) (n_chains counts packed rows); else sub_dim = dim
+  int32_t sub_dim = 0;  // PACKED rows: dim = pack * sub_dim -- `pack` consecutive chains of a sub_dim-dimensional Gaussian are ONE
+  int32_t pack = 1;     // row of the block-diagonal Gaussian kron(I_pack, Ps) (n_chains counts packed rows); else sub_dim = dim
   gmm3::Params gm;    // the mixture kernels (GKR > 0 below)
   diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept steps (DIAG kernels)
   int diag_offset_floats;  // start of the diagnostics tile in dynamic LDS
@@ -508,6 +508,7 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj; a.noise = noise;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset; a.mean = nullptr; a.prec = nullptr;
+  a.sub_dim = dim; a.pack = 1;  // (mixtures do not pack)
   a.gm = gmm3::Params{e.dev0, e.dev1, e.n_comp, dim, e.s[0], e.s[1]};
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0}; a.diag_offset_floats = 0;
   switch ((dim + 31) / 32) {

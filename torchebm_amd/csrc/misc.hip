@@ -363,9 +363,12 @@ __global__ __launch_bounds__(kBlock) void probe_valu_kernel(float* __restrict__ 
   float a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 1e-3f + j;
+  float m = 1.0001f + threadIdx.x * 1e-9f, c = 0.5f;
+  asm volatile("" : "+v"(m), "+v"(c));
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(a[j], 1.0001f, 0.5f);
+    for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(m), "v"(c));  // (literal: left to the
+    // compiler, adjacent FMAs are SLP-packed into v_pk_fma_f32 -- the same issue time per FMA on this part, but not what the name says)
   }
   float s = 0.0f;
 #pragma unroll
