@@ -21,7 +21,7 @@
 //     waits in registers until the second slice has read the old state (in place, no second state buffer).
 //
 // Where the time goes (MI355X, 2^17 chains x 256 dims x 20 steps; scripts/ab_big.sh removes one phase at a time): the
-// MFMAs alone 1.46 ms (= the bf16 peak for 6 products), Philox + Box-Muller + update 0.85 - 1.0 ms, the slab path (loads of Ps,
+// MFMAs 1.46 ms (0.82 ms of pipe time at the bf16 peak for the 6 products), Philox + Box-Muller + update 0.85 - 1.0 ms, the slab path (loads of Ps,
 // split, LDS write) 0.7 - 1.5 ms, not overlapped.  3.0 ms as shipped (round 2's lane-group kernel: 17.9 ms; the same chain as
 // torch ops -- a GEMM and four element-wise kernels per step -- 8.3 ms).  Open: the slab loads take ~2 stages to land (every
 // workgroup asks L2 for the same lines of Ps at the same time) -- a deeper prefetch needs 32 more registers; the normals could
