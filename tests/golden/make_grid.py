@@ -119,5 +119,22 @@ def extra():
         langevin(f"ld_gauss_{dim}", en, dim, 0.02, 0.8, seed, 1.0)
 
 
+def extra_wide():
+    """Round 3: dense Gaussians above 128 dims (csrc/gauss_big.hip: Ps streamed through LDS -- register-resident state at 160,
+    tiled per step at 256) and HMC on a Gaussian at a width that is not a multiple of 4 / above 128 (lane-group kernels)."""
+    seed = 9100
+    for dim in (160, 256):
+        seed += 1
+        langevin(f"ld_gauss_{dim}", energies(dim)["gauss"], dim, 0.02, 0.8, seed, 1.0)
+    for dim in (30, 256):
+        seed += 1
+        hmc(f"hmc5_gauss_{dim}", energies(dim)["gauss"], dim, 5, 0.15 if dim == 30 else 0.08, seed + 100, 1.0)
+
+
 if __name__ == "__main__":
-    extra() if "--extra" in sys.argv else main()
+    if "--extra-wide" in sys.argv:
+        extra_wide()
+    elif "--extra" in sys.argv:
+        extra()
+    else:
+        main()

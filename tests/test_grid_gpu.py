@@ -45,6 +45,26 @@ def _finish(layout, rec, work, n, dim, n_kept, dev, with_accept):
     return {k: v.cpu() for k, v in out.items()}
 
 
+def _state_pass_diagnostics(desc, x, nz, table, rows, n, dim, k, thin, dev):
+    n_kept = k // thin
+    out = {"mean": torch.empty(n_kept, dim, device=dev), "var": torch.empty(n_kept, dim, device=dev), "energy": torch.empty(n_kept, device=dev)}
+    work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=dev)
+    energy = torch.empty(n, device=dev)
+    st = _lib.stream_handle(dev)
+    for keep in range(n_kept):
+        s0 = keep * thin
+        _lib.call("ebm_langevin_chain_f32", desc, x.data_ptr(), n, dim, thin, rows[s0][0], rows[s0][1], rows[s0][2], table[s0:].data_ptr(),
+                  0, 0.0, 0.0, thin, None, None, nz[s0:].data_ptr(), 0, 0, st)
+        _lib.call("ebm_chain_stats_f32", x.data_ptr(), n, dim, out["mean"][keep].data_ptr(), out["var"][keep].data_ptr(), work.data_ptr(), st)
+        _lib.call("ebm_energy_grad_f32", desc, x.data_ptr(), n, dim, energy.data_ptr(), None, st)
+        out["energy"][keep] = energy.mean()
+    if n_kept * thin < k:
+        s0 = n_kept * thin
+        _lib.call("ebm_langevin_chain_f32", desc, x.data_ptr(), n, dim, k - s0, rows[s0][0], rows[s0][1], rows[s0][2], table[s0:].data_ptr(),
+                  0, 0.0, 0.0, thin, None, None, nz[s0:].data_ptr(), 0, 0, st)
+    return {key: v.cpu() for key, v in out.items()}
+
+
 def _check_diag(got, want, keys):
     for key in keys:
         torch.testing.assert_close(got[key], want[key], rtol=1e-4, atol=1e-5, msg=lambda m, key=key: f"{key}: {m}")
@@ -59,11 +79,16 @@ def test_langevin_grid(cuda_device, name):
     desc = model.fused_spec().to_c()
     rows = [em_coefficients(e, s) for e, s in zip(fx["etas"], fx["sigmas"])]
     table = torch.tensor([(r[0], r[1], r[2], 0.0) for r in rows], dtype=torch.float32, device=cuda_device)
-    layout, rec, work = _records(desc, _lib.DIAG_LANGEVIN, n, dim, k // thin, cuda_device)
     x, nz = x0.to(cuda_device), noise.to(cuda_device)
-    _lib.call("ebm_langevin_chain_f32", desc, x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
-              0, 0.0, 0.0, thin, None, rec.data_ptr(), nz.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
-    diag = _finish(layout, rec, work, n, dim, k // thin, cuda_device, False)
+    if _lib.diag_layout(desc, _lib.DIAG_LANGEVIN, n, dim, True, False) is None:
+        # no in-kernel records (dense Gaussians above 128 dims, csrc/gauss_big.hip): `thin` steps per launch and the
+        # statistics from the state, as the sampler does (samplers/langevin.py, _fused_with_state_passes)
+        diag = _state_pass_diagnostics(desc, x, nz, table, rows, n, dim, k, thin, cuda_device)
+    else:
+        layout, rec, work = _records(desc, _lib.DIAG_LANGEVIN, n, dim, k // thin, cuda_device)
+        _lib.call("ebm_langevin_chain_f32", desc, x.data_ptr(), n, dim, k, rows[0][0], rows[0][1], rows[0][2], table.data_ptr(),
+                  0, 0.0, 0.0, thin, None, rec.data_ptr(), nz.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+        diag = _finish(layout, rec, work, n, dim, k // thin, cuda_device, False)
     got = x.cpu()
     if fx["energy"]["kind"] in ("double_well", "harmonic"):
         assert sha16(got) == fx["ref"]["sha_x"]  # all 1000 x dim values bit-identical to the reference
