@@ -493,6 +493,9 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   f32x4 ra[UPT][2];
   static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(0, j, ra[j][0], ra[j][1]); });
   static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, 0, j, ra[j][0], ra[j][1]); });
+  // (from here on `ra` holds the slab the NEXT stage splits: a unit's registers are reloaded -- for the slab after that --
+  //  as soon as its split has copied them, a full stage before they are needed again)
+  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(1 % OT, j, ra[j][0], ra[j][1]); });
   __syncthreads();
 
   for (int step = 0; step < a.k_steps; ++step) {
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       constexpr int s = decltype(sc)::value, sn = (s + 1) % OT;  // the stage after the last one is stage 0 of the next step
       constexpr int HALF = 6 * OT;                                // MFMAs per K-block
       const int buf = gstage & 1;
-      if constexpr (!(EBM_BIG_EXP & 4)) static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(sn, j, ra[j][0], ra[j][1]); });
+      constexpr int sn2 = (s + 2) % OT;  // the slab requested during this stage
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU + lane;
       SplitJob jb1, jb0n, ja;
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         if constexpr (st == 0) {
           if constexpr (EBM_BIG_EXP & 64) { ja.d = f32x8{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, (float)tid}; }
           else mask_a(sn, j, ra[j][0], ra[j][1], ja.d);
+          if constexpr (!(EBM_BIG_EXP & 4)) load_a(sn2, j, ra[j][0], ra[j][1]);  // the copy above freed them
         } else {
           ja.step(std::integral_constant<int, st - 1>{});
           if constexpr (st == 8 && !(EBM_BIG_EXP & 128)) write_a(buf ^ 1, j, ja.tri());
