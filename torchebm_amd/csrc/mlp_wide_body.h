@@ -185,10 +185,11 @@ __device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval b
   });
 }
 
-// FAST: the plain call only -- a real chain (k_steps > 0), in-kernel noise, no clamp, dim % 4 == 0 or dim == 2, no diagnostics records --
+// FAST = 1: the plain call only -- a real chain (k_steps > 0), in-kernel noise, no clamp, dim % 4 == 0 or dim == 2, no diagnostics records --
 // with everything else compiled out (the injected-noise and per-element Philox paths, the clamp, the record code and its
-// out-of-line call): the update loses its uniform branches, the kernel a third of its code.
-template <int HT, int DT, int MODE, bool FAST = false>
+// out-of-line call): the update loses its uniform branches, the kernel a third of its code.  FAST = 2: the same call WITH records
+// (return_diagnostics=True otherwise falls to the general kernel, 8 % slower: 512 registers and spills where this one has neither).
+template <int HT, int DT, int MODE, int FAST = 0>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 #include "mlp_wide_setup.inc"
 
@@ -217,31 +218,31 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   [[maybe_unused]] int diag_keep = 0;
   int diag_pending = -1;
-  const bool diag_tail = !FAST && a.diag_partials && a.k_steps > 0 && a.thin > 0 && a.k_steps % a.thin == 0;
-  const int n_evals = FAST ? a.k_steps : (a.k_steps > 0 ? a.k_steps + (diag_tail ? 1 : 0) : 1);
+  const bool diag_tail = FAST != 1 && a.diag_partials && a.k_steps > 0 && a.thin > 0 && a.k_steps % a.thin == 0;
+  const int n_evals = FAST == 1 ? a.k_steps : (a.k_steps > 0 ? a.k_steps + (diag_tail ? 1 : 0) : 1);
 
 #ifdef EBM_PHASE_TIMES
   int stamp_n_ = 0;
 #endif
   for (int step = 0; step < n_evals; ++step) {
     EBM_STAMP();
-    constexpr bool eval_block_cuts = FAST;
-    bool eval_energy_only = !FAST && a.k_steps > 0 && step >= a.k_steps;  // the extra evaluation of a kept last step
+    constexpr bool eval_block_cuts = FAST != 0;
+    bool eval_energy_only = FAST != 1 && a.k_steps > 0 && step >= a.k_steps;  // the extra evaluation of a kept last step
     // FAST: never -- but left as an opaque (always false) scalar: the branch it guards cuts the evaluation's one basic block in
     // two, and without that cut the scheduler stretches live ranges until 160 registers spill (19 with it)
-    if constexpr (FAST) {
+    if constexpr (FAST == 1) {
       int never = 0;
       asm volatile("" : "+s"(never));
       eval_energy_only = never != 0;
     }
 #include "mlp_wide_eval.inc"
-    if (!FAST && diag_pending >= 0) {
+    if (FAST != 1 && diag_pending >= 0) {
       wave_record_tail(a.diag_partials, a.diag_blocks, diag_pending, wave_id, dim, energy, active, false, lane);
       diag_pending = -1;
     }
-    if (!FAST && a.k_steps > 0 && step >= a.k_steps) break;  // the extra evaluation of a kept last step
+    if (FAST != 1 && a.k_steps > 0 && step >= a.k_steps) break;  // the extra evaluation of a kept last step
 
-    if (!FAST && a.k_steps == 0) {  // evaluation only
+    if (FAST == 0 && a.k_steps == 0) {  // evaluation only
       if (active) {
         if (a.energy_out && h == 0) a.energy_out[sample] = energy;
         if (a.grad_out) {
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 
     // ------------------------------------------------------------ Euler-Maruyama update (reference op order)
     int64_t smp = sample;  // STREAM / FAST: nothing derived from the chain index (counters, addresses) is hoisted out of the loop and spilled
-    if constexpr (STREAM || FAST) asm volatile("" : "+v"(smp));
+    if constexpr (STREAM || FAST != 0) asm volatile("" : "+v"(smp));
     if (a.table) {
       const float4 tb = a.table[step];
       eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
         const int c0 = 32 * td + 8 * q + 4 * h;
         float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (c0 < dim) {
-          if (!FAST && a.noise) {
+          if (FAST == 0 && a.noise) {
             if (active)
 #pragma unroll
               for (int i = 0; i < 4; ++i)
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
             const F4 nrm = normal4_at(a.key, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, a.step0 + (uint64_t)step);
 #pragma unroll
             for (int i = 0; i < 4; ++i) eps[i] = nrm.v[i];
-          } else if constexpr (FAST) {  // dim == 2 (config 5's shape): a chain's two elements are half a Philox counter
+          } else if constexpr (FAST != 0) {  // dim == 2 (config 5's shape): a chain's two elements are half a Philox counter
             if (td == 0 && q == 0) {
               const F4 nrm = normal4_at(a.key, (uint64_t)smp >> 1, a.step0 + (uint64_t)step);
               const bool odd = (smp & 1) != 0;
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
           const float x1 = xr[td][r] - eta * g[td][r];
           const float dw = eps[i] * sqrt_eta;
           float nv = x1 + noise_coef * dw;
-          if (!FAST && a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
+          if (FAST == 0 && a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
           xr[td][r] = (c0 + i < dim) ? nv : 0.0f;
         }
       }
-    if ((a.traj || (!FAST && a.diag_partials)) && --until_keep == 0) {
+    if ((a.traj || (FAST != 1 && a.diag_partials)) && --until_keep == 0) {
       until_keep = a.thin;
       if (a.traj && active) {
         float* dst = a.traj + smp * (int64_t)a.n_kept * dim + keep_off;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       }
       keep_off += dim;
 #ifndef EBM_MLP_NO_DIAG  // A/B builds only: what the records cost the general kernel
-      if (!FAST && a.diag_partials) {
+      if (FAST != 1 && a.diag_partials) {
         wave_record<DT>(a.diag_partials, a.diag_blocks, diag_keep, wave_id, dim, xr, active, lane);
         diag_pending = diag_keep++;
       }
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   }
 }
 
-template <int HT, int DT, int MODE, bool FAST>
+template <int HT, int DT, int MODE, int FAST>
 int launch_variant(const WideArgs& a, hipStream_t st, const char* who) {
   constexpr bool STREAM = MODE == 1;
   const size_t smem = wide_smem_bytes(HT, DT);
@@ -361,23 +362,31 @@ int launch_variant(const WideArgs& a, hipStream_t st, const char* who) {
   return check_launch(who);
 }
 
-// the FAST instantiations live in mlp_wide_fast.hip (their own translation unit: compiled in parallel)
+// the FAST instantiations live in mlp_wide_fast.hip / mlp_wide_fast_diag.hip (their own translation units: compiled in parallel)
 template <int HT, int DT>
 int launch_fast(const WideArgs& a, hipStream_t st, const char* who);
-#define EBM_FAST_DECL(HTV, DTV) template <> int launch_fast<HTV, DTV>(const WideArgs& a, hipStream_t st, const char* who);
+template <int HT, int DT>
+int launch_fast_diag(const WideArgs& a, hipStream_t st, const char* who);
+#define EBM_FAST_DECL(HTV, DTV)                                                                          \
+  template <> int launch_fast<HTV, DTV>(const WideArgs& a, hipStream_t st, const char* who);             \
+  template <> int launch_fast_diag<HTV, DTV>(const WideArgs& a, hipStream_t st, const char* who);
 EBM_FAST_DECL(2, 1) EBM_FAST_DECL(2, 2) EBM_FAST_DECL(2, 3) EBM_FAST_DECL(2, 4) EBM_FAST_DECL(4, 1) EBM_FAST_DECL(4, 2)
 #undef EBM_FAST_DECL
-inline bool wide_fast_shape(const WideArgs& a) {
-  return a.k_steps > 0 && !a.noise && !a.clamp_on && !a.diag_partials && ((a.dim & 3) == 0 || a.dim == 2);
+inline bool wide_fast_shape(const WideArgs& a) {  // (with or without records)
+  return a.k_steps > 0 && !a.noise && !a.clamp_on && ((a.dim & 3) == 0 || a.dim == 2);
 }
 
 template <int HT, int DT>
 int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
   constexpr int MODE = wide_mode(HT, DT);
   if constexpr (MODE == 2) {
-    if (wide_fast_shape(a)) return launch_fast<HT, DT>(a, st, who);
+#ifdef EBM_NO_FAST_DIAG  // A/B builds: records on the general kernel
+    if (wide_fast_shape(a) && !a.diag_partials) return launch_fast<HT, DT>(a, st, who);
+#else
+    if (wide_fast_shape(a)) return a.diag_partials ? launch_fast_diag<HT, DT>(a, st, who) : launch_fast<HT, DT>(a, st, who);
+#endif
   }
-  return launch_variant<HT, DT, MODE, false>(a, st, who);
+  return launch_variant<HT, DT, MODE, 0>(a, st, who);
 }
 
 }  // namespace widemlp
