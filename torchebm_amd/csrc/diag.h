@@ -202,9 +202,20 @@ __device__ __forceinline__ void emit_flat_fast(const DiagArgs d, int keep, float
 // geometry: E = 32 dim flat elements, S = dim slots, n_blocks = ceil(n / 32); diag_finish_kernel merges them like any other
 // layout.  Two passes (sum -> wave mean -> squared deviations), as in emit(): no cancellation.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_wave_sum(float v) {  // over the 32 lanes that share this lane's h
-#pragma unroll
-  for (int msk = 16; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
+// Sum over the 32 lanes that share this lane's h, in every lane.  Four DPP adds inside the row of 16 (quad swaps, half-row
+// mirror, row mirror: no LDS traffic, no wait) and ONE ds_swizzle for the other row (lane ^ 16).  As five __shfl_xor it was five
+// dependent ds_bpermute round trips per value -- 10 per record column, ~14 k cycles per record of a 32-wide state: 60 % of an
+// MLP Langevin step (scripts/bench_mlp_diag_kernel.py).
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_get<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_get<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_get<0x141>(v);  // row_half_mirror: the other quad of the eight
+  v += dpp_get<0x140>(v);  // row_mirror: the other eight of the sixteen
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // bit mode: and 0x1f, xor 0x10
   return v;
 }
 

@@ -27,7 +27,7 @@ from .. import _lib, _rng
 from ..core.energies import BaseModel, FusedSpec, fused_spec_for
 from ..core.integrator_base import BaseSymplecticIntegrator
 from ..core.module import graph_state_key, warn_once
-from .langevin import _replay_or_step
+from .langevin import _record_scratch, _record_scratch_done, _replay_or_step
 from ..core.sampler_base import BaseSampler
 from ..core.schedules import BaseScheduler
 from ..integrators.registry import resolve_integrator
@@ -432,8 +432,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         n_kept = n_steps // thin
         rec_floats = n_blocks * (2 * slots + 8)
         chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
-        records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
-        work = torch.zeros(chunk * (3 * dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        records, work = _record_scratch(self, state.device, stream, chunk * rec_floats, chunk * (3 * dim + 3))
         done_keep, done = 0, 0
         while done_keep < n_kept:
             kk = min(chunk, n_kept - done_keep)
@@ -454,6 +453,7 @@ class HamiltonianMonteCarlo(BaseSampler):
             )
             done_keep += kk
             done += n_mh
+        _record_scratch_done(self)
 
     def _fused_with_state_passes(self, spec_c, state, n, dim, eps_vals, n_steps, thin, traj, diag, seed, step0, stream):
         """Diagnostics for energies without in-kernel records (the MLP energy's matrix-layout kernel): one launch

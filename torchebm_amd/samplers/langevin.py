@@ -41,6 +41,25 @@ def em_coefficients(eta: float, sigma: float) -> Tuple[float, float, float]:
     return eta, eta**0.5, (2.0 * sigma**2) ** 0.5
 
 
+def _record_scratch(sampler, device: torch.device, stream: int, rec_floats: int, work_doubles: int):
+    """The record buffer and the merge's fp64 work row of a diagnostics call, kept on the sampler between calls of the same
+    size on the same stream: the merge leaves the work row zeroed (include/ebm_hip.h), so nothing has to be allocated or
+    filled per call -- on a 0.6 ms sampler call the two allocations and the fill kernel were a tenth of the records' cost.
+    Keyed by the stream: calls on different streams do not share (the zeroed-after-merge contract is per stream order)."""
+    key = (device, stream, rec_floats, work_doubles)
+    held = sampler.__dict__.get("_record_scratch_held")
+    if held is None or held[0] != key or sampler.__dict__.get("_record_scratch_open", False):
+        # (open: the previous call did not reach its last merge -- an exception in between -- so the work row may not be zero)
+        held = (key, torch.empty(rec_floats, dtype=torch.float32, device=device), torch.zeros(work_doubles, dtype=torch.float64, device=device))
+        sampler.__dict__["_record_scratch_held"] = held
+    sampler.__dict__["_record_scratch_open"] = True   # closed by the caller after its last merge (_record_scratch_done)
+    return held[1], held[2]
+
+
+def _record_scratch_done(sampler) -> None:
+    sampler.__dict__["_record_scratch_open"] = False
+
+
 def _gaussian_chain_on_matrix_cores(dim: int) -> bool:
     """Widths at which ``ebm_langevin_chain_f32`` runs the dense Gaussian on the matrix cores (csrc/gauss_mfma.hip: up to 128,
     packed rows included; csrc/gauss_big.hip: multiples of 4 up to 512)."""
@@ -477,8 +496,7 @@ class LangevinDynamics(BaseSampler):
         m_n, m_dim = n // pack, dim * pack
         rec_floats = n_blocks * (2 * slots + 8)
         chunk = max(1, min(n_kept, self.DIAG_RECORD_BYTES // (4 * rec_floats)))
-        records = torch.empty(chunk * rec_floats, dtype=torch.float32, device=state.device)
-        work = torch.zeros(chunk * (3 * m_dim + 3), dtype=torch.float64, device=state.device)  # the merge leaves it zeroed
+        records, work = _record_scratch(self, state.device, stream, chunk * rec_floats, chunk * (3 * m_dim + 3))
         if pack > 1:
             p_mean = torch.empty(chunk, m_dim, dtype=torch.float32, device=state.device)
             p_var = torch.empty_like(p_mean)
@@ -515,6 +533,7 @@ class LangevinDynamics(BaseSampler):
                 diag["energy"][sl] = p_energy[:kk] / pack  # a packed row's energy is the sum of its chains'
             done_keep += kk
             done_steps += steps
+        _record_scratch_done(self)
 
     def _fused_with_state_passes(self, spec_c, state, n, dim, rows, n_steps, thin, traj, diag, seed, step0, stream):
         """Diagnostics for the configurations without in-kernel records (the matrix-layout kernels of the MLP
