@@ -163,3 +163,31 @@ def test_widths_without_a_matrix_chain_kernel_take_the_gemm_step_route(cuda_devi
     xb = x0.clone()
     _call(model.fused_spec(), xb, k, [em_coefficients(0.01, 1.0)], seed=seed, step=first)
     torch.testing.assert_close(out, xb, rtol=5e-5, atol=5e-5)
+
+
+def test_wide_gaussian_hmc_takes_the_gemm_transition_route(cuda_device):
+    """Above 128 dims HamiltonianMonteCarlo runs the per-transition route for a GaussianModel -- gradient and energy as one
+    library GEMM each, kick / drift / accept kernels on the native field -- instead of the lane-group transition kernel;
+    same generator => same draws, so the chains agree with that kernel's (through the C ABI) except for borderline accepts."""
+    dim, n, T, L = 160, 512, 4, 5
+    model, _ = _model(dim, cuda_device, seed=9)
+    s = ta.HamiltonianMonteCarlo(model, step_size=0.08, n_leapfrog_steps=L, device=cuda_device)
+    x0 = torch.randn(n, dim, device=cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    out, diag = s.sample(x=x0, n_steps=T, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(21))
+    assert hip_calls("ebm_hmc_chain_f32") == c0
+    assert 0.5 < diag["acceptance_rate"].mean().item() <= 1.0
+    # the forward the route uses (one GEMM) against the reference's batched form
+    x = out
+    delta = x - model.mean
+    batched = 0.5 * torch.bmm(delta.unsqueeze(1), torch.bmm(model.cov_inv.unsqueeze(0).expand(n, -1, -1), delta.unsqueeze(-1))).squeeze()
+    torch.testing.assert_close(model(x), batched, rtol=2e-5, atol=2e-5)
+    # the transition kernel on the same seed
+    from torchebm_amd import _rng
+    seed, first = _rng.reserve(torch.Generator(device=cuda_device).manual_seed(21), cuda_device, 2 * T)
+    xb = x0.clone()
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    _lib.call("ebm_hmc_chain_f32", model.fused_spec().to_c(), xb.data_ptr(), n, dim, T, L, 0.08, None, 0, 1.0, None, 1, None, None,
+              mask.data_ptr(), None, None, None, seed, first, _lib.stream_handle(cuda_device))
+    rows_equal = ((out - xb).abs().max(dim=1).values < 2e-3).float().mean().item()
+    assert rows_equal > 0.97, rows_equal

@@ -241,10 +241,12 @@ class GaussianModel(BaseModel):
         x = x.to(dtype=self.dtype, device=self.device)
         prec = self.cov_inv.to(dtype=self.dtype, device=x.device)
         delta = x - self.mean
-        if delta.shape[0] > 1:
+        if delta.shape[0] > 1 and not (delta.is_cuda and d > self.CLOSED_FORM_GRADIENT_ABOVE):
             # batched form: P (d x d, broadcast) @ delta (d x 1), then delta^T @ that
             p_delta = torch.bmm(prec.unsqueeze(0).expand(delta.shape[0], -1, -1), delta.unsqueeze(-1))
             return 0.5 * torch.bmm(delta.unsqueeze(1), p_delta).squeeze(-1).squeeze(-1)
+        # one row, or a wide Gaussian on the GPU: the reference's single-row form (base_model.py:208) -- ONE GEMM instead of n
+        # mat-vecs against an expanded P (at dim 512 and 2^15 rows the batched form reads 34 GB); same value up to fp32 rounding
         return 0.5 * torch.sum(delta * torch.matmul(delta, prec), dim=-1)
 
     #: widths above which ``gradient()`` is the closed form ``(x - mu) @ sym(P)`` -- ONE library GEMM -- instead of autograd
