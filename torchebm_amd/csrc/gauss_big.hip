@@ -20,12 +20,15 @@
 //     MFMAs run), 256 chains per workgroup.  Beyond: two SLICES of <= 8 out tiles, four waves; the updated first slice
 //     waits in registers until the second slice has read the old state (in place, no second state buffer).
 //
-// Where the time goes (MI355X, 2^17 chains x 256 dims x 20 steps; scripts/ab_big.sh removes one phase at a time): the
-// MFMAs 1.46 ms (0.82 ms of pipe time at the bf16 peak for the 6 products), Philox + Box-Muller + update 0.85 - 1.0 ms, the slab path (loads of Ps,
-// split, LDS write) 0.7 - 1.5 ms, not overlapped.  3.0 ms as shipped (round 2's lane-group kernel: 17.9 ms; the same chain as
-// torch ops -- a GEMM and four element-wise kernels per step -- 8.3 ms).  Open: the slab loads take ~2 stages to land (every
-// workgroup asks L2 for the same lines of Ps at the same time) -- a deeper prefetch needs 32 more registers; the normals could
-// be drawn behind the MFMAs as in gauss_mfma.hip's FAST body if 16 OT more registers were free.
+// Where the time goes (MI355X, 2^17 chains x 256 dims x 20 steps; scripts/ab_big.sh removes one phase at a time,
+// profiles/r03_ab_gauss_big.txt): the MFMAs 1.46 ms (0.82 ms of pipe time at the bf16 peak for the 6 products), Philox +
+// Box-Muller + update 0.85 - 1.0 ms, the slab path 0.5 - 1.5 ms, not overlapped: one wave per SIMD overlaps only what is placed
+// between two MFMAs by hand.  3.0 ms as shipped (round 2's lane-group kernel: 17.9 ms; the same chain as torch ops -- a GEMM and
+// four element-wise kernels per step -- 8.3 ms).  Of the slab path the split and the LDS writes ARE hidden (slots); what is left is
+// the ISSUE of its global loads -- ~250 cycles per global_load_dwordx4 and wave, independent of footprint (all loads aliased to
+// 1 KB: same time), of the lead (half a stage or a whole one) and nearly of coalescing (-5 %).  Open: fewer, wider requests for Ps
+// (LDS-direct buffer loads of the fp32 slab would move the split to the readers: 4x the split work), and the normals behind the
+// MFMAs as in gauss_mfma.hip's FAST body (16 OT more registers).
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"
 #include "mlp_b16.h"  // EBM_BLOCK_CUT
@@ -45,7 +48,7 @@ using gauss3::static_for;
 #define EBM_BIG_TWO_WG 0  /* with 4 waves: 1 = one chain tile per wave, one K-block per stage, TWO workgroups per CU; 0 = two tiles per wave */
 #endif
 #ifndef EBM_BIG_EXP
-#define EBM_BIG_EXP 0  /* timing experiments (scripts/ab_big.sh): 1 no MFMA, 2 no Philox, 4 no loads in the K loop, 8 no slab writes */
+#define EBM_BIG_EXP 0  /* timing experiments (scripts/ab_big.sh): 1 no MFMA, 2 no Philox, 4 no Ps loads, 8 no slab work, 16 no stage barrier, 32 no B splits, 64 slab split fed from state registers, 256 / 512 loads aliased to 8 rows / one column block */
 #endif
 
 struct BigArgs {
@@ -80,6 +83,7 @@ __device__ __forceinline__ Tri split8(const f32x8 d) {
 }
 // (native vectors throughout: a conditional on HIP's float4 STRUCT is compiled through a stack slot)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t gauss3_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x8 join8(const f32x4 a, const f32x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 template <int OT, int NS>
 struct BigCfg {
@@ -410,8 +414,8 @@ template <int OT>
 struct ResCfg {
   static constexpr int THREADS = 256;
   static constexpr int UNITS = OT * 128;                  // [OT][2 K-blocks][64 lanes]
-  static constexpr int UPT = 4;                           // thread = row of Ps: the four lane-operand units of its 128 B per stage
-  static constexpr int SLABU = 8 * 128;                   // units allocated per image: every thread writes its four, no tail test
+  static constexpr int UPT = OT;                          // 16 B chunks of the slab per thread and stage: one per pass of 32 rows
+  static constexpr int SLABU = OT * 128;                  // units per image
   static constexpr size_t SLAB = (size_t)3 * SLABU * 16;
   static constexpr size_t SMEM = 2 * SLAB + 256 * sizeof(float);
 };
@@ -440,48 +444,57 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
     for (int i = 0; i < 4; ++i) x[t][4 * q + i] = ok ? v[i] : 0.0f;  // padding stays exactly 0: zero rows / columns of Ps, never stored
   });
 
-  // Slab units.  Thread t stages row t of Ps: per stage the 32 columns = ONE 128 B line, as the four lane-operand units
-  // (kb2, h') = (j >> 1, j & 1) -- unit (row, kb2, h') holds the eight columns that lane half h' pairs with its B registers in
-  // K-block 2 s + kb2: 32 s + 16 kb2 + 4 h' + {0..3} and + 8.  (Row-per-thread keeps a line's eight 16 B pieces in one
-  // thread, back to back: one L2 request per line.  Spread over waves -- unit u = tid + 256 j -- every piece was its own
-  // request, all 256 CUs asking for the same lines at the same time: the loads took ~2 stages to land, 40 % of the step.)
-  auto a_cols = [&](int s, int j, bool& ok0, bool& ok1, int& rowi, int& c0) {
-    rowi = tid;
-    c0 = 32 * s + 16 * (j >> 1) + 4 * (j & 1);
-    const bool ok = rowi < dim;
-    ok0 = ok && c0 < dim;
-    ok1 = ok && c0 + 8 < dim;
+  // The slab of a stage: rows 0 .. 32 OT - 1 of Ps at the stage's 32 columns -- one 128 B line per row, EIGHT lanes per line:
+  // lane (tid & 7) = chunk c loads the four columns 32 s + 4 c .. + 3 of row 32 j + (tid >> 3) in pass j (one fully
+  // coalesced instruction per pass: 8 rows x 128 B; as 16 B pieces strided by the row length every piece was its own request
+  // to the L1 -- 2 048 per stage and CU -- and the slab took more than a stage to arrive whatever the lead: 40 % of the step).
+  // A chunk is HALF a lane-operand unit: unit (row, kb2 = c >> 2, h' = c & 1) holds the columns 16 kb2 + 4 h' + {0..3} and
+  // + 8 that lane half h' pairs with its B registers in K-block 2 s + kb2; chunk c is its half (c >> 1) & 1.  The split is
+  // element-wise, so every lane splits its own four values and writes 8 B of the unit's slot in each of the three images.
+  // The slots of a (tile, kb2, h') group are ROTATED by 2 (2 kb2 + h'): the eight lanes of a row then write to eight
+  // different 8 B bank groups (unrotated, the four units of a row alias: 512 B apart); the b128 reads follow the rotation.
+  const int ch = tid & 7, rrow = tid >> 3;                       // chunk, row inside a pass
+  const int ch_kb2 = ch >> 2, ch_h = ch & 1, ch_half = (ch >> 1) & 1;
+  const int wr_unit = ch_kb2 * 64 + ch_h * 32 + ((rrow + 2 * (2 * ch_kb2 + ch_h)) & 31);
+  auto chunk_ok = [&](int s, int j) { return 32 * j + rrow < dim && 32 * s + 4 * ch < dim; };
+  auto load_a = [&](int s, int j, f32x4& v) {
+    const int rr = (EBM_BIG_EXP & 256) ? ((32 * j + rrow) & 7) : (32 * j + rrow);   // experiment 256: every pass reads the same 8 rows
+    const int ss = (EBM_BIG_EXP & 512) ? 0 : s;                                       // experiment 512: every stage reads the same columns
+    const float* p = a.prec + (int64_t)rr * dim + 32 * ss + 4 * ch;
+    v = *reinterpret_cast<const f32x4*>(chunk_ok(s, j) ? p : a.prec);
   };
-  auto unit_of = [&](int j) { return (tid >> 5) * 128 + (j >> 1) * 64 + (j & 1) * 32 + (tid & 31); };
-  auto load_a = [&](int s, int j, f32x4& v0, f32x4& v1) {
-    bool ok0, ok1;
-    int rowi, c0;
-    a_cols(s, j, ok0, ok1, rowi, c0);
-    const float* p = a.prec + (int64_t)rowi * dim + c0;
-    v0 = *reinterpret_cast<const f32x4*>(ok0 ? p : a.prec);
-    v1 = *reinterpret_cast<const f32x4*>(ok1 ? p + 8 : a.prec);
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  auto write_a = [&](int buf, int j, const mlpb16::Split8p& t) {  // pairs 0, 1 of t: this chunk's four values
+    unsigned char* dst = reinterpret_cast<unsigned char*>(slab + (size_t)buf * 3 * SLABU + j * 128 + wr_unit) + 8 * ch_half;
+    *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{t.h[0], t.h[1]};
+    *reinterpret_cast<u32x2_t*>(dst + (size_t)SLABU * 16) = u32x2_t{t.m[0], t.m[1]};
+    *reinterpret_cast<u32x2_t*>(dst + (size_t)2 * SLABU * 16) = u32x2_t{t.l[0], t.l[1]};
   };
-  auto store_a = [&](int buf, int s, int j, const f32x4& v0, const f32x4& v1) {
-    bool ok0, ok1;
-    int rowi, c0;
-    a_cols(s, j, ok0, ok1, rowi, c0);
-    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    const Tri t = split8(join8(ok0 ? v0 : z, ok1 ? v1 : z));
-    bf16x8* dst = slab + (size_t)buf * 3 * SLABU + unit_of(j);
-    dst[0] = t.h; dst[SLABU] = t.m; dst[2 * SLABU] = t.l;
+  // one chunk in five steps: mask | pair 0 hi | pair 0 mid, lo | pair 1 hi | pair 1 mid, lo + the three 8 B writes
+  struct ChunkJob {
+    f32x4 d;
+    mlpb16::f32x2 r;
+    mlpb16::Split8p t;
   };
-
-  auto mask_a = [&](int s, int j, const f32x4& v0, const f32x4& v1, f32x8& d) {
-    bool ok0, ok1;
-    int rowi, c0;
-    a_cols(s, j, ok0, ok1, rowi, c0);
-    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    d = join8(ok0 ? v0 : z, ok1 ? v1 : z);
+  auto chunk_step = [&](ChunkJob& cj, int buf, int s_of, auto jc, auto kc, const f32x4& v) {
+    constexpr int j = decltype(jc)::value, k = decltype(kc)::value;
+    if constexpr (k == 0) {
+      const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+      cj.d = chunk_ok(s_of, j) ? v : z;
+    } else if constexpr (k == 1) {
+      mlpb16::pair_split_a<0>(cj.t, cj.r, mlpb16::f32x2{cj.d[0], cj.d[1]});
+    } else if constexpr (k == 2) {
+      mlpb16::pair_split_b<0>(cj.t, cj.r);
+      mlpb16::pair_split_c<0>(cj.t, cj.r);
+    } else if constexpr (k == 3) {
+      mlpb16::pair_split_a<1>(cj.t, cj.r, mlpb16::f32x2{cj.d[2], cj.d[3]});
+    } else {
+      mlpb16::pair_split_b<1>(cj.t, cj.r);
+      mlpb16::pair_split_c<1>(cj.t, cj.r);
+      write_a(buf, j, cj.t);
+    }
   };
-  auto write_a = [&](int buf, int j, const Tri& t) {  // (unconditional: behind a branch the compiler gathers the whole unit's split there)
-    bf16x8* dst = slab + (size_t)buf * 3 * SLABU + unit_of(j);
-    dst[0] = t.h; dst[SLABU] = t.m; dst[2 * SLABU] = t.l;
-  };
+  const int rd_unit[2] = {h * 32 + ((m + 2 * h) & 31), 64 + h * 32 + ((m + 2 * (2 + h)) & 31)};  // this lane's operand slot per K-block
 
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
   int until_keep = a.thin;
@@ -490,12 +503,15 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   int gstage = 0;  // stages done so far: its parity is the LDS buffer (OT may be odd, the pipeline runs across steps)
 
   // the first slab
-  f32x4 ra[UPT][2];
-  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(0, j, ra[j][0], ra[j][1]); });
-  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, 0, j, ra[j][0], ra[j][1]); });
-  // (from here on `ra` holds the slab the NEXT stage splits: a unit's registers are reloaded -- for the slab after that --
+  f32x4 ra[UPT];
+  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(0, j, ra[j]); });
+  static_for<UPT>([&](auto jc) {
+    ChunkJob cj;
+    static_for<5>([&](auto kc) { chunk_step(cj, 0, 0, jc, kc, ra[decltype(jc)::value]); });
+  });
+  // (from here on `ra` holds the slab the NEXT stage splits: a chunk's registers are reloaded -- for the slab after that --
   //  as soon as its split has copied them, a full stage before they are needed again)
-  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(1 % OT, j, ra[j][0], ra[j][1]); });
+  static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(1 % OT, j, ra[j]); });
   __syncthreads();
 
   for (int step = 0; step < a.k_steps; ++step) {
@@ -532,30 +548,29 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       const int buf = gstage & 1;
       constexpr int sn2 = (s + 2) % OT;  // the slab requested during this stage
       __builtin_amdgcn_sched_barrier(0);
-      const bf16x8* sb = slab + (size_t)buf * 3 * SLABU + lane;
-      SplitJob jb1, jb0n, ja;
+      const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
+      SplitJob jb1, jb0n;
       // Slots: one behind every MFMA, each <= 6 .. 8 instructions (what fits a 32-cycle MFMA; more delays the next one).
       //   behind K-block 0 (HALF slots): the B operands of K-block 1 and of the next stage's K-block 0, alternating --
       //   2 init + 8 split steps each;   behind K-block 1: the next slab (its loads were issued at the top of the stage) --
       //   per unit 1 mask step, 8 split steps, the LDS write with the last one
-      constexpr int A_STEPS = 9 * UPT, B_STEPS = 10;
-      constexpr int A_PER = (A_STEPS + HALF - 1) / HALF;  // (five tiles: 36 steps behind 30 MFMAs -- two per slot until they are done)
-      static_assert(2 * B_STEPS <= HALF, "the split work of a stage fits behind its MFMAs");
+      constexpr int A_STEPS = 5 * UPT, B_STEPS = 10;
+      constexpr int A_PER = (A_STEPS + HALF - 1) / HALF;
+      static_assert(2 * B_STEPS <= HALF && A_PER == 1, "the split work of a stage fits behind its MFMAs");
       auto b_job = [&](SplitJob& jb, auto tc, auto kc, auto kk) {  // step kk of 10 of a B operand
         constexpr int k = decltype(kk)::value;
         if constexpr (k < 2) b_init(jb, tc, kc, std::integral_constant<int, k>{});
         else jb.step(std::integral_constant<int, k - 2>{});
       };
-      auto a_job = [&](auto kk) {  // step kk of 9 UPT of the next slab
-        constexpr int k = decltype(kk)::value, j = k / 9, st = k % 9;
-        if constexpr (st == 0) {
-          if constexpr (EBM_BIG_EXP & 64) { ja.d = f32x8{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, (float)tid}; }
-          else mask_a(sn, j, ra[j][0], ra[j][1], ja.d);
-          if constexpr (!(EBM_BIG_EXP & 4)) load_a(sn2, j, ra[j][0], ra[j][1]);  // the copy above freed them
+      ChunkJob cj;
+      auto a_job = [&](auto kk) {  // step kk of 5 UPT of the next slab
+        constexpr int k = decltype(kk)::value, j = k / 5, st = k % 5;
+        if constexpr ((EBM_BIG_EXP & 64) != 0 && st == 0) {  // timing experiment: the split's input from state registers
+          cj.d = f32x4{x[s][0], x[s][1], x[s][2], x[s][3]};
         } else {
-          ja.step(std::integral_constant<int, st - 1>{});
-          if constexpr (st == 8 && !(EBM_BIG_EXP & 128)) write_a(buf ^ 1, j, ja.tri());
+          chunk_step(cj, buf ^ 1, sn, std::integral_constant<int, j>{}, std::integral_constant<int, st>{}, ra[j]);
         }
+        if constexpr (st == 0 && !(EBM_BIG_EXP & 4)) load_a(sn2, j, ra[j]);  // the copy above freed them
       };
       auto slot = [&](auto oc) {
         constexpr int o = decltype(oc)::value;
@@ -580,9 +595,10 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         const Tri bb = kb2 == 0 ? b0 : jb1.tri();
         auto read_a = [&](auto pc, bf16x8 (&a6)[6]) {
           constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
-          a6[0] = sb[2 * SLABU + ot0 * 128 + kb2 * 64]; a6[1] = sb[SLABU + ot0 * 128 + kb2 * 64]; a6[2] = sb[ot0 * 128 + kb2 * 64];
+          const bf16x8* sr = sb + rd_unit[kb2];
+          a6[0] = sr[2 * SLABU + ot0 * 128]; a6[1] = sr[SLABU + ot0 * 128]; a6[2] = sr[ot0 * 128];
           if constexpr (ot1 != ot0) {
-            a6[3] = sb[2 * SLABU + ot1 * 128 + kb2 * 64]; a6[4] = sb[SLABU + ot1 * 128 + kb2 * 64]; a6[5] = sb[ot1 * 128 + kb2 * 64];
+            a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
           }
         };
         bf16x8 acur[6];
