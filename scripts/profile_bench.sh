@@ -7,7 +7,7 @@
 set -u
 TAG="${1:-r01}"
 ARGS="${2:---steps 20 --warmup 3 --no-cpu-baseline}"          # the kernel trace: the driver's own command line minus the CPU baseline
-PMC_ARGS="${3:---steps 5 --warmup 1 --no-cpu-baseline --no-extra}"  # counter passes: the headline kernel only
+PMC_ARGS="${3:---steps 5 --warmup 1 --no-cpu-baseline}"  # counter passes: headline kernel AND the extras (the HBM-bound step kernel is one of them)
 REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"

@@ -191,3 +191,30 @@ def test_wide_gaussian_hmc_takes_the_gemm_transition_route(cuda_device):
               mask.data_ptr(), None, None, None, seed, first, _lib.stream_handle(cuda_device))
     rows_equal = ((out - xb).abs().max(dim=1).values < 2e-3).float().mean().item()
     assert rows_equal > 0.97, rows_equal
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_schedules_thinning_and_clamp_against_the_oracle(cuda_device, seed):
+    """Random widths (multiples of 4 in 132 .. 512: all three kernel families, ragged last tiles), chain counts with ragged
+    last workgroups, scheduled coefficients, thinning with a trajectory, and a clamp that bites -- the oracle's chain on the
+    same injected noise."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    dim = 4 * int(torch.randint(33, 129, (1,), generator=g))
+    n = int(torch.randint(1, 400, (1,), generator=g))
+    k = int(torch.randint(3, 9, (1,), generator=g))
+    thin = int(torch.randint(1, 4, (1,), generator=g))
+    model, ref = _model(dim, cuda_device, seed=seed)
+    etas = [0.02 * (0.85 ** i) for i in range(k)]
+    sigmas = [1.0 - 0.07 * i for i in range(k)]
+    clamp = (-1.2, 1.4) if seed % 2 else None
+    x0 = torch.randn(n, dim, generator=g) * 1.5
+    noise = torch.randn(k, n, dim, generator=g)
+    want, wtraj, _ = oracle.langevin_chain(ref, x0, noise, etas, sigmas, clamp=clamp, thin=thin, want_traj=True)
+    x = x0.to(cuda_device)
+    n_kept = k // thin
+    traj = torch.full((n, n_kept, dim), float("nan"), device=cuda_device) if n_kept else None
+    rows = [em_coefficients(e, s) for e, s in zip(etas, sigmas)]
+    _call(model.fused_spec(), x, k, rows, clamp=clamp, thin=thin, traj=traj, noise=noise.to(cuda_device))
+    torch.testing.assert_close(x.cpu(), want, rtol=3e-5, atol=3e-5)
+    if n_kept:
+        torch.testing.assert_close(traj.cpu(), wtraj, rtol=3e-5, atol=3e-5)
