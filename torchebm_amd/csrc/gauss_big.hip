@@ -741,6 +741,9 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
     case 5: return launch_res<5>(a, st);
     case 6: return launch_res<6>(a, st);
     case 7: return launch_res<7>(a, st);
+#ifdef EBM_BIG_RES8
+    case 8: return launch_res<8>(a, st);
+#endif
     default: break;
   }
 #endif
