@@ -542,6 +542,10 @@ class LangevinDynamics(BaseSampler):
         n_kept = n_steps // thin
         work = torch.zeros(2 * dim + 1, dtype=torch.float64, device=state.device)  # the kernel leaves it zeroed
         energy = torch.empty(n, dtype=torch.float32, device=state.device)
+        # a dense Gaussian above 128 dims: ebm_energy_grad_f32 is the lane-group mat-vec there (2 TFLOP/s: at 2^17 x 256 one
+        # energy pass would cost more than the 20 chain steps before it)
+        from ..core.energies import GaussianModel
+        wide_gaussian = type(self.model) is GaussianModel and dim > GaussianModel.CLOSED_FORM_GRADIENT_ABOVE
         done = 0
         for keep in range(n_kept):
             self._launch_chain(spec_c, state, n, dim, rows, done, thin, thin, None, seed, step0 + done, stream)
@@ -557,7 +561,10 @@ class LangevinDynamics(BaseSampler):
             else:
                 diag["mean"][keep] = state[0]
                 diag["var"][keep].zero_()
-            _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
-            diag["energy"][keep] = energy.mean()
+            if wide_gaussian:
+                diag["energy"][keep] = self.model(state).mean()   # one library GEMM (GaussianModel.forward, wide CUDA batches)
+            else:
+                _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
+                diag["energy"][keep] = energy.mean()
         if done < n_steps:
             self._launch_chain(spec_c, state, n, dim, rows, done, n_steps - done, thin, None, seed, step0 + done, stream)
