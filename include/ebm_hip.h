@@ -301,8 +301,8 @@ EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, con
  *   chain call will pass a noise / trajectory pointer (they select the kernel family);
  *   outputs: n_blocks (records per kept step), slots S and block_elems E.  The caller allocates
  *   diag_partials = float[n_kept][n_blocks][2*S + 8] and work = double[n_kept][3*dim + 3] (zeroed once; the merge
- *   leaves it zeroed; 3*max(S, dim) + 3 doubles per kept step when S > dim, below).  Dense Gaussians above 128 dims run on
- *   kernels that keep no records (csrc/gauss_big.hip): EBM_EDIM there -- statistics from the state between launches.  S > dim means PACKED rows: a dense
+ *   leaves it zeroed; 3*max(S, dim) + 3 doubles per kept step when S > dim, below).  (Dense Gaussians above 128 dims: records from the
+ *   streamed-Ps kernels, csrc/gauss_big.hip, for multiples of 4 up to 512.)  S > dim means PACKED rows: a dense
  *   Gaussian whose width the matrix-layout kernel does not take as is (below 20, or not a multiple of 4) runs S / dim
  *   consecutive chains as one row of width S (block-diagonal precision; same element order, same random field), and
  *   the records are those of n_chains * dim / S rows: call ebm_diag_finish_f32 with (n_chains * dim / S, S) and fold

@@ -118,25 +118,31 @@ def test_dims_it_does_not_take_keep_the_lane_group_kernel(cuda_device):
         torch.testing.assert_close(x.cpu(), want, rtol=2e-5, atol=2e-5)
 
 
-def test_diagnostics_come_from_state_passes_between_launches(cuda_device):
-    """No in-kernel records on these kernels (ebm_diag_layout says so): the sampler launches `thin` steps at a time and takes
-    the column statistics / energies from the state -- same numbers as torch reductions of the stored trajectory."""
-    dim, n = 160, 1000
+@pytest.mark.parametrize("dim,n", [(160, 1000), (256, 515), (384, 130)])
+def test_diagnostics_come_from_in_kernel_records(cuda_device, dim, n):
+    """The streamed-Ps kernels keep records like the other matrix-layout kernels (one per wave-tile of 32 chains; the energy
+    share one step late, a kept last step one contraction more): return_diagnostics=True is ONE chain launch, the chains are
+    the same as without, and the numbers are those of torch reductions over the stored trajectory."""
     model, _ = _model(dim, cuda_device, seed=5)
-    assert _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim) is None
+    layout = _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim)
+    assert layout == ((n + 31) // 32, dim, 32 * dim)
     s = ta.LangevinDynamics(model, step_size=0.02, device=cuda_device)
     x0 = torch.randn(n, dim, device=cuda_device)
-    c0 = hip_calls("ebm_langevin_chain_f32")
-    traj, diag = s.sample(x=x0, n_steps=12, thin=4, return_trajectory=True, return_diagnostics=True,
-                          generator=torch.Generator(device=cuda_device).manual_seed(3))
-    assert hip_calls("ebm_langevin_chain_f32") == c0 + 3
-    plain = s.sample(x=x0, n_steps=12, generator=torch.Generator(device=cuda_device).manual_seed(3))
-    assert torch.equal(traj[:, -1], plain)
-    t64 = traj.double()
-    torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)
-    want_e = torch.stack([model(traj[:, j]).double().mean() for j in range(3)])
-    torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-4)
+    for n_steps, thin in ((12, 4), (13, 4), (6, 1)):
+        c0 = hip_calls("ebm_langevin_chain_f32")
+        traj, diag = s.sample(x=x0, n_steps=n_steps, thin=thin, return_trajectory=True, return_diagnostics=True,
+                              generator=torch.Generator(device=cuda_device).manual_seed(3))
+        assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+        plain = s.sample(x=x0, n_steps=n_steps, generator=torch.Generator(device=cuda_device).manual_seed(3))
+        kept_only = s.sample(x=x0, n_steps=(n_steps // thin) * thin, generator=torch.Generator(device=cuda_device).manual_seed(3))
+        assert torch.equal(traj[:, -1], kept_only)
+        _, diag2 = s.sample(x=x0, n_steps=n_steps, thin=thin, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(3))
+        assert plain.shape == x0.shape and torch.equal(diag2["mean"], diag["mean"])
+        t64 = traj.double()
+        torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)
+        want_e = torch.stack([model(traj[:, j]).double().mean() for j in range(n_steps // thin)])
+        torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("dim", [130, 1024])

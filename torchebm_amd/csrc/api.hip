@@ -64,7 +64,8 @@ int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 
 bool gauss_big_supported(int32_t dim);                      // gauss_big.hip: dims 132 .. 512 in steps of 4, tiled per step
 int launch_langevin_chain_gauss_big(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                     const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
-                                    hipStream_t);
+                                    float*, hipStream_t);
+bool gauss_big_diag_plan(int64_t, int32_t, diag::DiagArgs&);  // gauss_big.hip: one record per wave-tile of 32 chains
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
 bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -135,7 +136,7 @@ int reject_mlp(const ebm_energy_t* en, const char* who) {
 
 // Which kernel family serves a chain call that asks for diagnostics records, and with what record geometry.
 // One function for the layout query and for the dispatch, so the two cannot disagree.
-enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows, kDiagMatrix, kDiagMlp };
+enum DiagFamily { kDiagNone = 0, kDiagElemFlat, kDiagRows, kDiagHmcRows, kDiagMatrix, kDiagMlp, kDiagGaussBig };
 
 DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32_t dim, bool has_noise, bool has_traj,
                      diag::DiagArgs& d) {
@@ -150,9 +151,8 @@ DiagFamily plan_diag(const ebm_energy_t& e, int sampler, int64_t n_chains, int32
   static const bool gmm_rows = ab_switch("EBM_GMM_ROWS");
   const bool forced_rows = (e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows);
   if (!heun && !forced_rows && matrix_langevin_diag_plan(e, n_chains, dim, d)) return kDiagMatrix;
-  // dense Gaussians above 128 dims run on the streamed-Ps kernels (gauss_big.hip), which keep no records: statistics
-  // between launches (the lane-group kernel that has them is 5 - 40x slower than those kernels plus the state passes)
-  if (!heun && !forced_rows && e.kind == EBM_ENERGY_GAUSSIAN && gauss_big_supported(dim)) return kDiagNone;
+  // dense Gaussians above 128 dims: the streamed-Ps kernels (gauss_big.hip) and their records
+  if (!heun && !forced_rows && e.kind == EBM_ENERGY_GAUSSIAN && gauss_big_diag_plan(n_chains, dim, d)) return kDiagGaussBig;
   return rows_langevin_diag_plan(e, heun, n_chains, dim, d) ? kDiagRows : kDiagNone;
 }
 
@@ -245,6 +245,9 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (fam == kDiagMlp)
       return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
                                        thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
+    if (fam == kDiagGaussBig)
+      return launch_langevin_chain_gauss_big(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
+                                             cmax, thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
     if (fam == kDiagMatrix)
       return launch_langevin_chain_matrix_diag(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on,
                                                cmin, cmax, thin, traj, noise, seed, offset, diag_partials, (hipStream_t)stream);
@@ -269,7 +272,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)
       return launch_langevin_chain_gauss_big(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
-                                             clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+                                             clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
   }
   // mixtures of up to 32 components on the matrix layout (gauss_mfma.hip / gmm_bf16x3.h); dims 16 / 32 with K <= 8 keep
   // one lane per chain with the means as scalar operands

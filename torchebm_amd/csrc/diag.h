@@ -223,7 +223,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // The energy / accept shares follow through wave_record_tail() (the MLP Langevin kernel: one evaluation later).
 template <int NT, class At>
 __device__ __forceinline__ void wave_record(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, At at, bool active,
-                                            int lane) {
+                                            int lane, int tile0 = 0) {  // tile0: the first tile's index in the row (a slice of it)
   if (wave_id >= n_blocks) return;  // a wave past the last chain has no record (wave-uniform)
   const int h = lane >> 5;
   const int valid = __popcll(__ballot(active)) >> 1;  // both K-halves of a chain vote
@@ -237,7 +237,7 @@ __device__ __forceinline__ void wave_record(float* partials, int64_t n_blocks, i
       const float sum = half_wave_sum(v);
       const float dv = active ? v - sum * inv : 0.0f;
       const float m2 = half_wave_sum(dv * dv);
-      const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int c = 32 * (t + tile0) + (r & 3) + 8 * (r >> 2) + 4 * h;
       if ((lane & 31) == 0 && c < dim) {
         rec[c] = sum;
         rec[dim + c] = m2;

@@ -30,6 +30,7 @@
 // (LDS-direct buffer loads of the fp32 slab would move the split to the readers: 4x the split work), and the normals behind the
 // MFMAs as in gauss_mfma.hip's FAST body (16 OT more registers).
 #include "ebm_common.h"
+#include "diag.h"
 #include "gauss_bf16x3.h"
 #include "mlp_b16.h"  // EBM_BLOCK_CUT
 
@@ -67,6 +68,7 @@ struct BigArgs {
   const float* prec;
   RngKey key;
   uint64_t step0;
+  diag::DiagArgs diag;  // records of the kept steps (diag.h: one per wave-tile of 32 chains, E = 32 dim, S = dim); partials == nullptr: none
 };
 
 struct Tri {
@@ -102,7 +104,7 @@ struct BigCfg {
   static constexpr size_t SMEM = 2 * SLAB + 512 * sizeof(float);
 };
 
-template <int OT, int NS>
+template <int OT, int NS, bool DIAG = false>
 __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG ? 2 : 1)) void gauss_big_langevin_kernel(BigArgs a) {
   using C = BigCfg<OT, NS>;
   constexpr int kBigBlock = C::THREADS;
@@ -174,12 +176,23 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
     return join8((active[c] && kcol < dim) ? v0 : z, (active[c] && kcol + 4 < dim) ? v1 : z);
   };
 
-  for (int step = 0; step < a.k_steps; ++step) {
-    if (a.table) {
+  // Records (DIAG; as in the resident kernel below): column sums of a kept state from the epilogue's registers; its energy
+  // 0.5 d . P d one step late, from the next step's contraction and the old state the epilogue reads anyway; a kept LAST step
+  // costs one more trip (contraction and energy only: `upd` false).
+  [[maybe_unused]] int rec_keep = 0, rec_pending = -1;
+  const bool records = DIAG && a.diag.partials != nullptr;
+  const int n_trips = a.k_steps + ((records && a.k_steps > 0 && a.k_steps % a.thin == 0) ? 1 : 0);
+  for (int step = 0; step < n_trips; ++step) {
+    const bool upd = !DIAG || step < a.k_steps;
+    if (a.table && upd) {
       const float4 tb = a.table[step];
       eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
     }
-    const bool keep_now = a.traj && until_keep == 1;
+    const bool keep_now = a.traj && until_keep == 1 && upd;
+    const bool rec_now = records && until_keep == 1 && upd;
+    [[maybe_unused]] float e_acc[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) e_acc[c] = 0.0f;
     // (hidden from LICM: left visible, every quad's address of every step is formed before the step loop and spilled)
     int h4 = 4 * h;
     asm volatile("" : "+v"(h4));
@@ -319,8 +332,18 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
           const int d0 = row0 + 32 * ot + 8 * q + h4;
           const bool ok = active[c] && d0 < dim;
           const int off = ok ? d0 : 0;
-          f32x4 eps;
-          if constexpr (EBM_BIG_EXP & 2) {
+          const f32x4 xo = xold[t % (AHEAD + 1)][q];
+          if constexpr (DIAG) {
+            if (rec_pending >= 0) {  // the energy share of the state kept one step ago: (x - mu) . g, before g is overwritten
+              const f32x4 mq = *reinterpret_cast<const f32x4*>(mus + (ok ? d0 : 0));
+#pragma unroll
+              for (int i = 0; i < 4; ++i) e_acc[c] = __builtin_fmaf(ok ? xo[i] - mq[i] : 0.0f, res[sl][c][ot][4 * q + i], e_acc[c]);
+            }
+          }
+          f32x4 eps = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (!upd) {
+            // the extra trip of a kept last step: no draw, no update
+          } else if constexpr (EBM_BIG_EXP & 2) {
             eps = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
           } else if (a.noise) {
             eps = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)step * a.n_chains * dim + (active[c] ? (int64_t)e_row : 0) + off);
@@ -328,7 +351,6 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
             const F4 n4 = normal4_at(a.key, (e_row + (uint64_t)d0) >> 2, a.step0 + (uint64_t)step);
             eps = f32x4{n4.v[0], n4.v[1], n4.v[2], n4.v[3]};
           }
-          const f32x4 xo = xold[t % (AHEAD + 1)][q];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float x1 = xo[i] - eta * res[sl][c][ot][4 * q + i];
@@ -338,7 +360,7 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
             res[sl][c][ot][4 * q + i] = nv;
           }
           if constexpr (sl == NS - 1) {  // nobody reads the old state after the last slice's K loop: store at once
-            if (ok) {
+            if (ok && upd) {
               const f32x4 v = {res[sl][c][ot][4 * q], res[sl][c][ot][4 * q + 1], res[sl][c][ot][4 * q + 2], res[sl][c][ot][4 * q + 3]};
               *reinterpret_cast<f32x4*>(a.x + xoff[c] + d0) = v;
               if (keep_now) *reinterpret_cast<f32x4*>(a.traj + ((int64_t)e_row * a.n_kept + kept * (int64_t)dim) + d0) = v;
@@ -346,9 +368,28 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
           }
           __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
         });
+        if constexpr (DIAG) {
+          if (rec_now)  // this tile of the kept state (padding rows hold garbage only where `c < dim` fails: not stored)
+            diag::wave_record<1>(a.diag.partials, a.diag.n_blocks, rec_keep, (int64_t)blockIdx.x * (C::CHAINS / 32) + wave * CTW + c, dim,
+                                 [&](int, int r) { return res[sl][c][ot][r]; }, active[c], lane, sl * OT + ot);
+        }
         EBM_BLOCK_CUT();  // one tile per basic block: the scheduler does not stretch 64 Philox calls over each other
       });
     });
+    if constexpr (DIAG) {
+      if (rec_pending >= 0) {
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          float acc = e_acc[c];
+          acc += __shfl_xor(acc, 32);
+          diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, rec_pending, (int64_t)blockIdx.x * (C::CHAINS / 32) + wave * CTW + c, dim,
+                                 0.5f * acc, active[c], false, lane);
+        }
+        rec_pending = -1;
+      }
+      if (!upd) break;
+      if (rec_now) rec_pending = rec_keep++;
+    }
 
     // ---- the held slices: every slice has read the old state by now
     if constexpr (NS > 1) {
@@ -420,7 +461,7 @@ struct ResCfg {
   static constexpr size_t SMEM = 2 * SLAB + 256 * sizeof(float);
 };
 
-template <int OT>
+template <int OT, bool DIAG = false>
 __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   using C = ResCfg<OT>;
   constexpr int UPT = C::UPT, SLABU = C::SLABU;
@@ -514,8 +555,14 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(1 % OT, j, ra[j]); });
   __syncthreads();
 
-  for (int step = 0; step < a.k_steps; ++step) {
-    if (a.table) {
+  // Records (DIAG): the column sums of a kept state come from the registers right after its update; its energy 0.5 d . P d
+  // is what the NEXT step's contraction computes (g = P d), so the energy share of a record is written one step late and only
+  // a kept LAST step costs a contraction of its own (one more trip of the loop, without an update).
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+  [[maybe_unused]] int rec_keep = 0, rec_pending = -1;
+  const int n_trips = a.k_steps + ((DIAG && a.k_steps > 0 && a.k_steps % a.thin == 0) ? 1 : 0);
+  for (int step = 0; step < n_trips; ++step) {
+    if (a.table && step < a.k_steps) {
       const float4 tb = a.table[step];
       eta = tb.x; sqrt_eta = tb.y; noise_coef = tb.z;
     }
@@ -639,6 +686,21 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       if constexpr (!(EBM_BIG_EXP & 16)) __syncthreads();  // the next slab is written, this one is read by everyone
     });
 
+    if constexpr (DIAG) {
+      if (rec_pending >= 0) {  // the energy of the state kept one step ago
+        float acc = 0.0f;
+        static_for<OT * 4>([&](auto ic) {
+          constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
+          const f32x4 mq = *reinterpret_cast<const f32x4*>(mus + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x[t][4 * q + i] - mq[i], g[t][4 * q + i], acc);
+        });
+        acc += __shfl_xor(acc, 32);
+        diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, rec_pending, wave_id, dim, 0.5f * acc, active, false, lane);
+        rec_pending = -1;
+      }
+      if (step >= a.k_steps) break;  // the extra trip of a kept last step
+    }
     // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad; all in registers
     uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
     asm volatile("" : "+v"(e_row));
@@ -677,6 +739,10 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
     if (--until_keep == 0) {
       until_keep = a.thin;
       ++kept;
+      if constexpr (DIAG) {
+        diag::wave_record<OT>(a.diag.partials, a.diag.n_blocks, rec_keep, wave_id, dim, [&](int t, int r) { return x[t][r]; }, active, lane);
+        rec_pending = rec_keep++;
+      }
     }
   }
   static_for<OT * 4>([&](auto ic) {
@@ -693,12 +759,16 @@ template <int OT>
 int launch_res(const BigArgs& a, hipStream_t st) {
   using C = ResCfg<OT>;
   static DeviceOnce attr_once;
-  if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)C::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)C::SMEM);
+  }
   const int64_t blocks = ceil_div64(a.n_chains, 128);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL((gauss_res_langevin_kernel<OT>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  if (a.diag.partials) hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
@@ -706,23 +776,35 @@ template <int OT, int NS>
 int launch_big(const BigArgs& a, hipStream_t st) {
   using C = BigCfg<OT, NS>;
   static DeviceOnce attr_once;
-  if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS>),
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+  }
   const int64_t blocks = ceil_div64(a.n_chains, C::CHAINS);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
+  // Two slices of six or more tiles: the records instantiation ALSO for the plain call -- its uniform branches (`upd`, the
+  // record tests) cut the epilogue's basic blocks and it allocates 414 .. 512 registers without a spill where the plain
+  // instantiation spills 59 .. 242: dims 384 / 512 4.16 / 6.95 -> 4.07 / 6.07 ms (same box; dim 320, five tiles: 3.01 -> 3.16, kept plain)
+  constexpr bool kRecordsKernelAlways = NS == 2 && OT >= 6;
+  if (a.diag.partials || kRecordsKernelAlways) hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, true>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
+  else hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, false>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
 }  // namespace
 
 bool gauss_big_supported(int32_t dim) { return dim > 128 && dim <= 512 && (dim % 4) == 0; }
+// records: one per wave-tile of 32 chains and kept step, as on the other matrix-layout kernels
+bool gauss_big_diag_plan(int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  return gauss_big_supported(dim) && diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
+}
 
 int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                                     float eta, float sqrt_eta, float noise_coef, const float* coef_table,
                                     int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
-                                    const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
+                                    const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
   BigArgs a;
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
@@ -733,6 +815,11 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
   a.mean = e.dev0; a.prec = e.dev1;
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  if (diag_partials) {
+    if (!gauss_big_diag_plan(n_chains, dim, a.diag)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no records layout for dim %d", dim);
+    a.diag.partials = diag_partials;
+  }
   const int tiles = (dim + 31) / 32;  // 5 .. 16
 #ifndef EBM_BIG_TILED_ONLY
   // up to seven tiles the register-resident kernel, eight tiles the tiled one (same box, 2^17 chains x 20 steps, ms:
