@@ -224,3 +224,31 @@ def test_random_shapes_schedules_thinning_and_clamp_against_the_oracle(cuda_devi
     torch.testing.assert_close(x.cpu(), want, rtol=3e-5, atol=3e-5)
     if n_kept:
         torch.testing.assert_close(traj.cpu(), wtraj, rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("dim,n", [(132, 200), (160, 257), (256, 515), (320, 129), (500, 77), (512, 260)])
+def test_energy_and_gradient_entry_on_the_matrix_cores(cuda_device, dim, n):
+    """ebm_energy_grad_f32 above 128 dims: one contraction pass of the tiled kernel (nothing updated) -- against fp64 with the
+    fp32 torch forms as the yardstick."""
+    model, ref = _model(dim, cuda_device, seed=11)
+    x = torch.randn(n, dim, device=cuda_device) * 1.3
+    x_before = x.clone()
+    e = torch.full((n,), float("nan"), device=cuda_device)
+    g = torch.full((n, dim), float("nan"), device=cuda_device)
+    st = _lib.stream_handle(cuda_device)
+    _lib.call("ebm_energy_grad_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, e.data_ptr(), g.data_ptr(), st)
+    assert torch.equal(x, x_before)
+    d64 = x.double() - model.mean.double()
+    p64 = 0.5 * (model.cov_inv.double() + model.cov_inv.double().t())
+    g64 = d64 @ p64
+    e64 = 0.5 * (d64 * g64).sum(dim=1)
+    g32 = (x - model.mean) @ (0.5 * (model.cov_inv + model.cov_inv.t()))
+    err_ref = (g32.double() - g64).abs().max().item()
+    assert (g.double() - g64).abs().max().item() <= 4.0 * err_ref + 1e-6
+    torch.testing.assert_close(e.double(), e64, rtol=2e-5, atol=2e-4)
+    # either output alone
+    e2 = torch.empty_like(e)
+    _lib.call("ebm_energy_grad_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, e2.data_ptr(), None, st)
+    g2 = torch.empty_like(g)
+    _lib.call("ebm_energy_grad_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, None, g2.data_ptr(), st)
+    assert torch.equal(e2, e) and torch.equal(g2, g)

@@ -66,6 +66,7 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t&, float*, int64_t, int32_
                                     const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                     float*, hipStream_t);
 bool gauss_big_diag_plan(int64_t, int32_t, diag::DiagArgs&);  // gauss_big.hip: one record per wave-tile of 32 chains
+int launch_energy_grad_gauss_big(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 bool gmm_mfma_supported(int32_t dim, int32_t n_comp);
 bool matrix_langevin_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -457,6 +458,10 @@ int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_ch
   if (grad_out && !aligned16(grad_out)) return fail(EBM_EINVAL, "%s: grad_out must be 16-byte aligned", who);
   if (energy->kind == EBM_ENERGY_MLP)
     return launch_energy_grad_mlp(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
+  if (energy->kind == EBM_ENERGY_GAUSSIAN && gauss_big_supported(dim)) {  // above 128 dims: one contraction pass on the matrix cores
+    static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
+    if (!force_rows) return launch_energy_grad_gauss_big(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
+  }
   return launch_energy_grad(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
 }
 

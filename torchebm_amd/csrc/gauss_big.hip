@@ -68,6 +68,8 @@ struct BigArgs {
   const float* prec;
   RngKey key;
   uint64_t step0;
+  float* energy_out;    // k_steps == 0: evaluation only (ebm_energy_grad_f32) -- E [n] and / or the gradient [n, dim], either may be null;
+  float* grad_out;      // x is read, not written
   diag::DiagArgs diag;  // records of the kept steps (diag.h: one per wave-tile of 32 chains, E = 32 dim, S = dim); partials == nullptr: none
 };
 
@@ -181,7 +183,9 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
   // costs one more trip (contraction and energy only: `upd` false).
   [[maybe_unused]] int rec_keep = 0, rec_pending = -1;
   const bool records = DIAG && a.diag.partials != nullptr;
-  const int n_trips = a.k_steps + ((records && a.k_steps > 0 && a.k_steps % a.thin == 0) ? 1 : 0);
+  const bool eval_only = DIAG && a.k_steps == 0;  // one contraction: gradient and energy out, nothing updated
+  if (eval_only) rec_pending = 0;
+  const int n_trips = eval_only ? 1 : a.k_steps + ((records && a.k_steps > 0 && a.k_steps % a.thin == 0) ? 1 : 0);
   for (int step = 0; step < n_trips; ++step) {
     const bool upd = !DIAG || step < a.k_steps;
     if (a.table && upd) {
@@ -339,6 +343,10 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
 #pragma unroll
               for (int i = 0; i < 4; ++i) e_acc[c] = __builtin_fmaf(ok ? xo[i] - mq[i] : 0.0f, res[sl][c][ot][4 * q + i], e_acc[c]);
             }
+            if (eval_only && ok && a.grad_out) {
+              const f32x4 gv = {res[sl][c][ot][4 * q], res[sl][c][ot][4 * q + 1], res[sl][c][ot][4 * q + 2], res[sl][c][ot][4 * q + 3]};
+              *reinterpret_cast<f32x4*>(a.grad_out + xoff[c] + d0) = gv;
+            }
           }
           f32x4 eps = {0.0f, 0.0f, 0.0f, 0.0f};
           if (!upd) {
@@ -382,6 +390,9 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
         for (int c = 0; c < CTW; ++c) {
           float acc = e_acc[c];
           acc += __shfl_xor(acc, 32);
+          if (eval_only) {
+            if (a.energy_out && active[c] && h == 0) a.energy_out[chain[c]] = 0.5f * acc;
+          } else
           diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, rec_pending, (int64_t)blockIdx.x * (C::CHAINS / 32) + wave * CTW + c, dim,
                                  0.5f * acc, active[c], false, lane);
         }
@@ -789,40 +800,15 @@ int launch_big(const BigArgs& a, hipStream_t st) {
   // record tests) cut the epilogue's basic blocks and it allocates 414 .. 512 registers without a spill where the plain
   // instantiation spills 59 .. 242: dims 384 / 512 4.16 / 6.95 -> 4.07 / 6.07 ms (same box; dim 320, five tiles: 3.01 -> 3.16, kept plain)
   constexpr bool kRecordsKernelAlways = NS == 2 && OT >= 6;
-  if (a.diag.partials || kRecordsKernelAlways) hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, true>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
+  if (a.diag.partials || kRecordsKernelAlways || a.k_steps == 0) hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, true>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
   else hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, false>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
-}  // namespace
-
-bool gauss_big_supported(int32_t dim) { return dim > 128 && dim <= 512 && (dim % 4) == 0; }
-// records: one per wave-tile of 32 chains and kept step, as on the other matrix-layout kernels
-bool gauss_big_diag_plan(int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
-  return gauss_big_supported(dim) && diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
-}
-
-int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
-                                    float eta, float sqrt_eta, float noise_coef, const float* coef_table,
-                                    int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
-                                    const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
-  if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
-  BigArgs a;
-  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
-  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
-  a.table = reinterpret_cast<const float4*>(coef_table);
-  a.noise = noise; a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
-  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj;
-  a.mean = e.dev0; a.prec = e.dev1;
-  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  a.step0 = offset;
-  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
-  if (diag_partials) {
-    if (!gauss_big_diag_plan(n_chains, dim, a.diag)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no records layout for dim %d", dim);
-    a.diag.partials = diag_partials;
-  }
+int dispatch_big(const BigArgs& a, int32_t dim, hipStream_t st) {
   const int tiles = (dim + 31) / 32;  // 5 .. 16
 #ifndef EBM_BIG_TILED_ONLY
+  if (a.k_steps > 0)
   // up to seven tiles the register-resident kernel, eight tiles the tiled one (same box, 2^17 chains x 20 steps, ms:
   // dims 132 / 160 / 192 / 224 / 256: 1.37 / 1.42 / 1.89 / 2.55 / 3.48 resident, 1.48 / 1.67 / 2.23 / 2.51 / 3.02 tiled)
   switch (tiles) {
@@ -849,6 +835,51 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
     case 7: return launch_big<7, 2>(a, st);
     default: return launch_big<8, 2>(a, st);
   }
+}
+
+}  // namespace
+
+bool gauss_big_supported(int32_t dim) { return dim > 128 && dim <= 512 && (dim % 4) == 0; }
+// records: one per wave-tile of 32 chains and kept step, as on the other matrix-layout kernels
+bool gauss_big_diag_plan(int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
+  return gauss_big_supported(dim) && diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
+}
+
+int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                                    float eta, float sqrt_eta, float noise_coef, const float* coef_table,
+                                    int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
+                                    const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
+  if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
+  BigArgs a;
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
+  a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
+  a.table = reinterpret_cast<const float4*>(coef_table);
+  a.noise = noise; a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
+  a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj;
+  a.mean = e.dev0; a.prec = e.dev1;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
+  a.energy_out = nullptr; a.grad_out = nullptr;
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  if (diag_partials) {
+    if (!gauss_big_diag_plan(n_chains, dim, a.diag)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no records layout for dim %d", dim);
+    a.diag.partials = diag_partials;
+  }
+  return dispatch_big(a, dim, st);
+}
+
+// E(x) and / or its gradient for the same widths (ebm_energy_grad_f32): one contraction pass of the tiled kernel, nothing updated
+int launch_energy_grad_gauss_big(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* energy_out, float* grad_out,
+                                 hipStream_t st) {
+  if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_energy_grad_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
+  BigArgs a;
+  a.x = const_cast<float*>(x); a.n_chains = n_chains; a.dim = dim; a.k_steps = 0;
+  a.eta = 0.0f; a.sqrt_eta = 0.0f; a.noise_coef = 0.0f; a.table = nullptr; a.noise = nullptr;
+  a.clamp_on = 0; a.cmin = 0.0f; a.cmax = 0.0f; a.thin = 1; a.n_kept = 0; a.traj = nullptr;
+  a.mean = e.dev0; a.prec = e.dev1; a.key = RngKey{0u, 0u}; a.step0 = 0;
+  a.energy_out = energy_out; a.grad_out = grad_out;
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  return dispatch_big(a, dim, st);
 }
 
 }  // namespace ebm
