@@ -240,6 +240,16 @@ class GaussianModel(BaseModel):
             raise ValueError(f"Input x expected batch_shape (batch_size, {d}), but got {x.shape}")
         x = x.to(dtype=self.dtype, device=self.device)
         prec = self.cov_inv.to(dtype=self.dtype, device=x.device)
+        if (x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 1 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and self._on_matrix_cores(x) and self._is_exactly(GaussianModel) and prec.dtype == torch.float32):
+            # a sampler's energy call (no autograd graph wanted): the same contraction pass, energy only
+            spec = self.fused_spec()
+            if spec is not None:
+                state = x.contiguous()
+                energy = torch.empty(state.shape[0], dtype=torch.float32, device=state.device)
+                _lib.call("ebm_energy_grad_f32", spec.to_c(), state.data_ptr(), state.shape[0], d, energy.data_ptr(), None,
+                          _lib.stream_handle(state.device))
+                return energy
         delta = x - self.mean
         if delta.shape[0] > 1 and not (delta.is_cuda and d > self.CLOSED_FORM_GRADIENT_ABOVE):
             # batched form: P (d x d, broadcast) @ delta (d x 1), then delta^T @ that
@@ -262,7 +272,21 @@ class GaussianModel(BaseModel):
             spec = self.fused_spec()
         if spec is None:
             return None
+        if self._on_matrix_cores(x):  # one contraction pass of the tiled kernel: no (x - mu) temporary, a third of the GEMM route's time
+            state = x.detach().contiguous()
+            grad = torch.empty_like(state)
+            _lib.call("ebm_energy_grad_f32", spec.to_c(), state.data_ptr(), state.shape[0], state.shape[1], None, grad.data_ptr(),
+                      _lib.stream_handle(state.device))
+            return grad
         return torch.mm(x.detach() - spec.dev0, spec.dev1)  # dev1 = sym(P): symmetric, no transpose needed
+
+    @staticmethod
+    def _on_matrix_cores(x: torch.Tensor) -> bool:
+        """Widths at which ``ebm_energy_grad_f32`` (the streamed-Ps kernel, csrc/gauss_big.hip: multiples of 4 up to 512) beats the
+        library GEMM form: up to 256 (HMC route, 2^16 chains: dims 160 / 256 12.0 / 20.0 -> 9.5 / 18.4 ms per 5 transitions; at 512
+        the two-slice kernel loses to hipBLAS: 26.6 -> 30.3)."""
+        d = x.shape[1]
+        return 128 < d <= 256 and d % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0
 
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(GaussianModel) or self.cov_inv.dtype != torch.float32:
