@@ -6,12 +6,13 @@ MODE="$1"; shift
 cd "$(dirname "$0")/.."
 if [ "$MODE" = build ]; then
   mkdir -p build/ab
-  OBJS=$(ls build/csrc/*.o | grep -v gauss_big.o)
+  OBJS=$(ls build/csrc/*.o | grep -v "gauss_big.o\|gauss_res.o")
+  CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wno-pass-failed"
   for spec in "$@"; do
     v="${spec%%=*}"; flags="${spec#*=}"; [ "$flags" = "$spec" ] && flags=""
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wno-pass-failed $flags \
-        -c torchebm_amd/csrc/gauss_big.hip -o build/ab/gauss_big_$v.o && \
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/big_$v.so $OBJS build/ab/gauss_big_$v.o && echo "built $v" ) &
+    ( $CC $flags -c torchebm_amd/csrc/gauss_big.hip -o build/ab/gauss_big_$v.o && \
+      $CC $flags -c torchebm_amd/csrc/gauss_res.hip -o build/ab/gauss_res_$v.o && \
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/big_$v.so $OBJS build/ab/gauss_big_$v.o build/ab/gauss_res_$v.o && echo "built $v" ) &
   done
   wait
 else
