@@ -47,7 +47,7 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
                                     int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                     const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_langevin_chain_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
-  BigArgs a;
+  BigArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
   a.table = reinterpret_cast<const float4*>(coef_table);
@@ -69,7 +69,7 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
 int launch_energy_grad_gauss_big(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* energy_out, float* grad_out,
                                  hipStream_t st) {
   if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "ebm_energy_grad_f32: the tiled Gaussian kernel takes dims 132 .. 512 in steps of 4, not %d", dim);
-  BigArgs a;
+  BigArgs a{};
   a.x = const_cast<float*>(x); a.n_chains = n_chains; a.dim = dim; a.k_steps = 0;
   a.eta = 0.0f; a.sqrt_eta = 0.0f; a.noise_coef = 0.0f; a.table = nullptr; a.noise = nullptr;
   a.clamp_on = 0; a.cmin = 0.0f; a.cmax = 0.0f; a.thin = 1; a.n_kept = 0; a.traj = nullptr;

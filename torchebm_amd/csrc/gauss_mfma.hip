@@ -439,7 +439,7 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
                                      float eta, float sqrt_eta, float noise_coef, const float* coef_table,
                                      int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                      const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
-  GaussArgs a;
+  GaussArgs a{};
   const int32_t pack = gauss_pack_factor(dim, n_chains);
   if (pack < 1) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout form for a Gaussian of dim %d over %lld chains", dim, (long long)n_chains);
   a.sub_dim = dim; a.pack = pack;
@@ -500,7 +500,7 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
                                    float eta, float sqrt_eta, float noise_coef, const float* coef_table,
                                    int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                    const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
-  GaussArgs a;
+  GaussArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
   a.table = reinterpret_cast<const float4*>(coef_table);
@@ -562,7 +562,7 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
                                       float eta, float sqrt_eta, float noise_coef, const float* coef_table,
                                       int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                       const float* noise, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
-  GaussArgs a;
+  GaussArgs a{};
   if (!matrix_langevin_diag_plan(e, n_chains, dim, a.diag))
     return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout diagnostics records for this energy / dim %d", dim);
   const bool mixture = e.kind == EBM_ENERGY_GMM;

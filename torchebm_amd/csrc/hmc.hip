@@ -106,7 +106,7 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   }
   Geometry geo;
   if (!hmc_geometry(e, dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
-  HmcArgs a;
+  HmcArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
   a.mass_raw = (float)mass_scalar;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void langevin_step_diffusion_kernel(StepArg
 int launch_langevin_step_diffusion(const float* x, const float* grad, float* out, const float* noise, const float* diffusion,
                                    int64_t period, int64_t n_elem, float eta, float sqrt_eta, uint64_t seed, uint64_t offset,
                                    hipStream_t st) {
-  StepArgs a;
+  StepArgs a{};
   a.rng_dev = nullptr;
   a.x = x; a.grad = grad; a.out = out; a.noise = noise; a.n_elem = n_elem;
   a.c = StepCoef{eta, sqrt_eta, 0.0f};
@@ -252,7 +252,7 @@ int launch_langevin_step(const float* x, const float* grad, float* out, const fl
                          int64_t n_elem, float eta, float sqrt_eta, float noise_coef, int clamp_on,
                          float cmin, float cmax, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
                          hipStream_t st) {
-  StepArgs a;
+  StepArgs a{};
   a.rng_dev = rng_dev;
   a.x = x; a.grad = grad; a.out = out; a.noise = noise; a.n_elem = n_elem;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
@@ -279,7 +279,7 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
                                const float* coef_table, int clamp_on, float cmin, float cmax,
                                int32_t thin, float* traj, const float* noise, uint64_t seed,
                                uint64_t offset, int heun, hipStream_t st) {
-  ChainArgs a;
+  ChainArgs a{};
   a.x = x; a.n_elem = n_chains * (int64_t)dim; a.dim = dim; a.k_steps = k_steps;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
   a.table = reinterpret_cast<const float4*>(coef_table);

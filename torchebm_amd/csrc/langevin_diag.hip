@@ -20,7 +20,7 @@ int launch_langevin_chain_elem_diag(int kind, float s0, float s1, float* x, int6
                                     float* traj, uint64_t seed, uint64_t offset, int heun, float* diag_partials,
                                     hipStream_t st) {
   const char* who = heun ? "ebm_langevin_heun_chain_f32" : "ebm_langevin_chain_f32";
-  ChainArgs a;
+  ChainArgs a{};
   a.x = x; a.n_elem = n_chains * (int64_t)dim; a.dim = dim; a.k_steps = k_steps;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
   a.table = reinterpret_cast<const float4*>(coef_table);

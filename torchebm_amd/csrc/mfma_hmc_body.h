@@ -493,7 +493,7 @@ inline GaussHmcArgs matrix_hmc_args(const ebm_energy_t& e, float* x, int64_t n_c
                                     float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
                                     const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask,
                                     uint32_t* accept_count, const float* p_noise, const float* u, uint64_t seed, uint64_t offset) {
-  GaussHmcArgs a;
+  GaussHmcArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table;
   a.has_mass = mass_kind == EBM_MASS_SCALAR;

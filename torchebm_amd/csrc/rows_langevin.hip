@@ -410,7 +410,7 @@ int launch_langevin_chain_rows(const ebm_energy_t& e, float* x, int64_t n_chains
   bool lane_per_chain;
   if (!rows_langevin_geometry(e, dim, heun, geo, lane_per_chain))
     return fail(EBM_EDIM, "ebm_langevin_chain_f32: dim %d > 1024 is not supported for this energy", dim);
-  RowChainArgs a;
+  RowChainArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;
   a.table = reinterpret_cast<const float4*>(coef_table);
@@ -459,7 +459,7 @@ int launch_descent_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int3
   Geometry geo;
   if (!pick_geometry(dim, geo)) return fail(EBM_EDIM, "ebm_descent_chain_f32: dim %d > 1024 is not supported", dim);
   geo.full = false;  // deterministic optimiser, not a throughput path: one masked variant per geometry
-  DescentArgs a;
+  DescentArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps; a.eta = eta; a.eta_table = eta_table;
   a.nesterov = nesterov; a.mu = momentum; a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj;
   size_t smem = 0;
@@ -487,7 +487,7 @@ int launch_energy_grad(const ebm_energy_t& e, const float* x, int64_t n_chains, 
     return check_launch("ebm_energy_grad_f32");
   }
   geo.full = false;  // one evaluation per launch: the masked form is as fast, and halves the variants
-  EgArgs a;
+  EgArgs a{};
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.e_out = e_out; a.g_out = g_out;
   size_t smem = 0;
   plan_params(e, dim, geo, a.energy, a.param_floats, smem);
