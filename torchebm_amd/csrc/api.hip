@@ -60,6 +60,7 @@ int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, 
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 bool gauss_mfma_supported(int32_t dim);
+bool gauss_lds5_supported(int32_t dim);   // gauss_mfma.hip: 132 .. 160, Ps resident in LDS (plain Langevin call)
 int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 as is, > 1 packed rows, 0 no matrix-layout form
 bool gauss_big_supported(int32_t dim);                      // gauss_big.hip: dims 132 .. 512 in steps of 4, tiled per step
 int launch_langevin_chain_gauss_big(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -266,6 +267,12 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)
+      return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                              clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
+  }
+  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_lds5_supported(dim)) {
+    static const bool force_big = ab_switch("EBM_GAUSS_NO_LDS5");
+    if (!force_big)
       return launch_langevin_chain_gauss_mfma(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                               clamp_on, cmin, cmax, thin, traj, noise, seed, offset, (hipStream_t)stream);
   }

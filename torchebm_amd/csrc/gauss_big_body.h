@@ -11,7 +11,8 @@
 // products per (out tile, chain tile, K-block) as in gauss_bf16x3.h, smallest first, two independent accumulators
 // alternating; fp32 accumulation.  Two kernels:
 //
-//   gauss_res_langevin_kernel<OT>  (dims up to 224)   the state STAYS IN REGISTERS (C/D layout, 16 OT registers + 16 OT
+//   gauss_res_langevin_kernel<OT>  (dims 164 .. 224; 132 .. 160 only with records -- the plain call there keeps Ps resident in LDS:
+//     gauss_mfma.hip, five tiles)   the state STAYS IN REGISTERS (C/D layout, 16 OT registers + 16 OT
 //     accumulators, one wave per SIMD, 128 chains per workgroup): no HBM traffic in the step loop; the B operand of a
 //     K-block is eight state registers; the split work (B operands, next slab) sits in slots behind the MFMAs.
 //   gauss_big_langevin_kernel<OT, NS>  (dims 228 .. 512)   a step is one pass of a tiled GEMM over the state, the

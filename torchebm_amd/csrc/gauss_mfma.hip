@@ -418,6 +418,8 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
 // dims that are multiples of 4 run on zero-padded 32-wide tiles; below 20 the padding waste outweighs the
 // matrix cores (measured: scripts/bench_gauss_dims.py), those stay on the lane-group kernel
 bool gauss_mfma_supported(int32_t dim) { return dim >= 20 && dim <= 128 && (dim % 4) == 0; }
+// the plain Langevin call only (no records, no HMC): five tiles, 150 KB of split operands + mu in the CU's 160 KB
+bool gauss_lds5_supported(int32_t dim) { return dim > 128 && dim <= 160 && (dim % 4) == 0; }
 
 // Other widths (below 20, or not a multiple of 4) PACKED: `pack` consecutive chains of the row-major state are one row of
 // width pack * dim, whose Gaussian is block diagonal -- kron(I, Ps), the mean repeated.  The flat element order, hence the
@@ -440,7 +442,8 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
                                      int clamp_on, float cmin, float cmax, int32_t thin, float* traj,
                                      const float* noise, uint64_t seed, uint64_t offset, hipStream_t st) {
   GaussArgs a{};
-  const int32_t pack = gauss_pack_factor(dim, n_chains);
+  // (dims 132 .. 160: FIVE tiles -- the three splits of Ps are 150 KB, the last width whose precision matrix stays resident in LDS)
+  const int32_t pack = gauss_lds5_supported(dim) ? 1 : gauss_pack_factor(dim, n_chains);
   if (pack < 1) return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout form for a Gaussian of dim %d over %lld chains", dim, (long long)n_chains);
   a.sub_dim = dim; a.pack = pack;
   n_chains /= pack; dim *= pack;  // the packed geometry from here on
@@ -457,7 +460,8 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
     case 1: return launch_nt<1>(a, st);
     case 2: return launch_nt<2>(a, st);
     case 3: return launch_nt<3>(a, st);
-    default: return launch_nt<4>(a, st);
+    case 4: return launch_nt<4>(a, st);
+    default: return launch_nt<5>(a, st);
   }
 }
 
