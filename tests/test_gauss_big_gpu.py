@@ -175,7 +175,7 @@ def test_wide_gaussian_hmc_takes_the_gemm_transition_route(cuda_device):
     """Above 128 dims HamiltonianMonteCarlo runs the per-transition route for a GaussianModel -- gradient and energy as one
     library GEMM each, kick / drift / accept kernels on the native field -- instead of the lane-group transition kernel;
     same generator => same draws, so the chains agree with that kernel's (through the C ABI) except for borderline accepts."""
-    dim, n, T, L = 160, 512, 4, 5
+    dim, n, T, L = 192, 512, 4, 5
     model, _ = _model(dim, cuda_device, seed=9)
     s = ta.HamiltonianMonteCarlo(model, step_size=0.08, n_leapfrog_steps=L, device=cuda_device)
     x0 = torch.randn(n, dim, device=cuda_device)
@@ -252,3 +252,45 @@ def test_energy_and_gradient_entry_on_the_matrix_cores(cuda_device, dim, n):
     g2 = torch.empty_like(g)
     _lib.call("ebm_energy_grad_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, None, g2.data_ptr(), st)
     assert torch.equal(e2, e) and torch.equal(g2, g)
+
+
+@pytest.mark.parametrize("dim,mass", [(132, None), (160, None), (160, 1.7), (148, "diag")])
+def test_hmc_five_tile_transition_kernel_against_the_oracle(cuda_device, dim, mass):
+    """HMC at dims 132 .. 160: five tiles -- the three split images of Ps (150 KB) still fit the CU's LDS -- on the matrix-core
+    transition kernel; injected momenta / uniforms, accept decisions identical to the oracle's wherever its margin is not
+    borderline, states to the Gaussian tolerance; with and without records."""
+    from torchebm_amd.integrators.symplectic import _mass_args
+    n, T, L, eps = 300, 4, 5, 0.06
+    model, ref = _model(dim, cuda_device, seed=13)
+    g = torch.Generator().manual_seed(dim)
+    x0 = torch.randn(n, dim, generator=g)
+    p = torch.randn(T, n, dim, generator=g)
+    u = torch.rand(T, n, generator=g)
+    m = None
+    if mass == "diag":
+        m = torch.rand(dim, generator=g) + 0.5
+    elif mass is not None:
+        m = mass
+    o = oracle.hmc_chain(ref, x0, p, u, [eps] * T, L, mass=m, thin=2, want_diag=True, want_margins=True)
+    m_dev = m.to(cuda_device) if torch.is_tensor(m) else m
+    p_dev, u_dev = p.to(cuda_device), u.to(cuda_device)  # (kept referenced until the launches that read them are enqueued)
+    for with_records in (False, True):
+        x = x0.to(cuda_device)
+        mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+        kind, ms, md = _mass_args(m_dev, x)
+        desc = model.fused_spec().to_c()
+        rec = None
+        if with_records:
+            nb, S, E = _lib.diag_layout(desc, _lib.DIAG_HMC, n, dim, True, False)
+            rec = torch.empty((T // 2) * nb * (2 * S + 8), device=cuda_device)
+        _lib.call("ebm_hmc_chain_f32", desc, x.data_ptr(), n, dim, T, L, eps, None, kind, ms, _lib.ptr(md), 2, None, _lib.ptr(rec),
+                  mask.data_ptr(), None, p_dev.data_ptr(), u_dev.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+        safe = o["margins"].abs() > 1e-4
+        assert torch.equal(mask.cpu().bool()[safe], o["accepted"][safe])
+        rows_ok = (mask.cpu().bool() == o["accepted"]).all(dim=0)
+        torch.testing.assert_close(x.cpu()[rows_ok], o["x"][rows_ok], rtol=5e-4, atol=5e-4)
+    # and the sampler takes it (one launch)
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, mass=m_dev, device=cuda_device)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    s.sample(x=x0.to(cuda_device), n_steps=T)
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1

@@ -26,7 +26,8 @@ bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind) {
   // measured against the lane-group kernel (profiles/r02_bench_gauss_hmc_{mfma,rows}.jsonl, ms per 10 transitions, L = 10,
   // 2^16 chains): dim 32: 0.20 vs 0.41, dim 64: 0.45 vs 1.32, dim 96: 1.19 vs 3.50, dim 100: 2.27 vs 3.89, dim 128: 2.26 vs 11.5
   (void)mass_kind;
-  return dim >= 20 && dim <= 128 && (dim % 4) == 0;
+  // round 3: five tiles (dims 132 .. 160) -- 150 KB of split operands still fit the CU's LDS; beyond, the sampler's GEMM route
+  return dim >= 20 && dim <= 160 && (dim % 4) == 0;
 }
 
 int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
@@ -41,14 +42,16 @@ int launch_hmc_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_chain
       case 1: return launch_nt<1, true>(a, st);
       case 2: return launch_nt<2, true>(a, st);
       case 3: return launch_nt<3, true>(a, st);
-      default: return launch_nt<4, true>(a, st);
+      case 4: return launch_nt<4, true>(a, st);
+      default: return launch_nt<5, true>(a, st);
     }
   }
   switch ((dim + 31) / 32) {
     case 1: return launch_nt<1, false>(a, st);
     case 2: return launch_nt<2, false>(a, st);
     case 3: return launch_nt<3, false>(a, st);
-    default: return launch_nt<4, false>(a, st);
+    case 4: return launch_nt<4, false>(a, st);
+    default: return launch_nt<5, false>(a, st);
   }
 }
 

@@ -34,7 +34,8 @@ int launch_diag(const GaussHmcArgs& a, bool mixture, hipStream_t st) {
   if (nt == 1) return launch_gauss_diag<1, DIAGM>(a, st);
   if (nt == 2) return launch_gauss_diag<2, DIAGM>(a, st);
   if (nt == 3) return launch_gauss_diag<3, DIAGM>(a, st);
-  return launch_gauss_diag<4, DIAGM>(a, st);
+  if (nt == 4) return launch_gauss_diag<4, DIAGM>(a, st);
+  return launch_gauss_diag<5, DIAGM>(a, st);
 }
 }  // namespace
 

@@ -117,7 +117,7 @@ struct GaussE {
   static constexpr int kMatFloats = B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM;
   static constexpr int kLdsFloats = kMatFloats + DIM;
   static constexpr bool kEvalGivesEnergy = true;
-  static constexpr bool kCarry = !(B3 && NT == 4);
+  static constexpr bool kCarry = !(B3 && NT >= 4);  // (four / five tiles: the split operands leave no LDS for the parked force)
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
     const int dim = a.dim;
     if constexpr (B3) {

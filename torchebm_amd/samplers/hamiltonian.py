@@ -130,8 +130,9 @@ class HamiltonianMonteCarlo(BaseSampler):
             spec = fused_spec_for(self.model, x, model_kwargs)
             if spec is not None and not spec.hmc:
                 spec = None  # (a wide MLP energy: fused for Langevin only)
-            if spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None and spec.dim > 128:
-                # Above 128 dims the transition kernel is the lane-group mat-vec (2 TFLOP/s); the per-transition route -- the
+            if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None and spec.dim > 128
+                    and not (spec.dim <= 160 and spec.dim % 4 == 0)):  # (132 .. 160: five tiles, the split operands still fit LDS)
+                # Above 160 dims (and off multiples of 4 above 128) the transition kernel is the lane-group mat-vec (2 TFLOP/s); the per-transition route -- the
                 # gradient and the energy as one library GEMM each (GaussianModel), kick / drift / accept kernels on the same
                 # random field, replayed from a HIP graph -- is 1.5 - 30x faster there (scripts/bench_gauss_hmc_big.py).
                 spec = None
