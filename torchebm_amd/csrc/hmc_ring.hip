@@ -10,22 +10,25 @@
 // 256 VGPRs = two waves per SIMD with 27 spilled registers; two waves issue plain VALU work at 75 % of the chip's
 // rate (profiles/r02_valu_occupancy.txt).  This kernel is built around a 128-register budget:
 //   * the state x and the momentum p are the only full rows in registers (64 VGPRs);
-//   * the 28 shared columns are held as y = x - mu_0 (exact when mu_0 is zero there, as on the ring; one rounding at
-//     load and one at store otherwise -- the HMC state is a tolerance tier), so their force is ONE packed multiply,
-//     f = -y / sigma^2, never stored: the kick consumes it on the spot.  Only the four active-slot forces are carried
-//     from step to step (and from transition to transition: an accepted proposal's end-of-trajectory force starts
-//     the next trajectory);
+//   * ACTIVE columns are those of slot 0 on which the component means differ: all four, or -- the ring, whose means
+//     sit in a plane -- columns 0 and 1 only (the kernel looks at the means itself: a wave-uniform branch between two
+//     instantiations of the body).  Every other column is SHARED: all components agree on its mean, it drops out of
+//     the responsibilities and its energy is that of one Gaussian;
+//   * shared columns are held as y = x - mu_0 (exact when mu_0 is zero there, as on the ring; one rounding at load and
+//     one at store otherwise -- the HMC state is a tolerance tier), so their force -y / sigma^2 is never formed: the
+//     kick is ONE packed FMA, p += (-kick / sigma^2) y, and a leapfrog step costs a shared pair of columns two packed
+//     FMAs -- the floor for a leapfrog step.  Only the active forces are carried from step to step (and from
+//     transition to transition: an accepted proposal's end-of-trajectory force starts the next trajectory);
 //   * the accepted state is parked in a lane-private LDS slot during the proposal (32 KiB per workgroup, four
 //     workgroups per CU), the carried active force next to it;
-//   * every constant of the step loop is a scalar register: the 8 x 4 active means pre-scaled by log2(e) / sigma^2
-//     (the logits come out in base 2: v_exp_f32 directly) and the logit offsets;
-//   * safe mode costs ONE running NaN-propagating maximum: m = maximum3(m, |f_a|, |f_b|) per packed pair.  The
-//     reference clamps the force to +-1e6 and scrubs non-finite x / p after every step; both are the identity while
-//     every |f| <= 1e6 and p starts below 1e30 (the force is clamped, so p cannot leave the finite range within a
-//     trajectory), and a non-finite coordinate or logit makes a force NaN / inf.  A chain whose trajectory ends with
-//     !(m <= 1e6) is REDONE from the parked state by the literal sequence (NaN-propagating clamps, half kicks,
-//     scrub after every step, force re-evaluated on the scrubbed state) -- cold code behind a wave-level branch.
-// Per leapfrog step and chain: ~140 VALU instructions (~200 issue units) where the shared body took ~220 (~300).
+//   * every constant of the step loop is a scalar register: the active means pre-scaled by log2(e) / sigma^2 (the
+//     logits come out in base 2: v_exp_f32 directly), in the two pairings the two passes use, and the logit offsets;
+//   * safe mode costs running NaN-propagating maxima (v_maximum3_f32, one per packed pair).  The reference clamps
+//     the force to +-1e6 and scrubs non-finite x / p after every step; both are the identity while every |f| <= 1e6
+//     and p starts below 1e30 (the force is clamped, so p cannot leave the finite range within a trajectory), and a
+//     non-finite coordinate or logit makes a force NaN / inf.  A chain whose trajectory ends outside those bounds is
+//     REDONE from the parked state by the literal sequence (NaN-propagating clamps, half kicks, scrub after every
+//     step, force re-evaluated on the scrubbed state) -- cold code behind a wave-level branch.
 #include "hmc_kernel.h"
 
 namespace ebm {
@@ -47,66 +50,59 @@ __device__ __forceinline__ v2f splat(float v) { return v2f{v, v}; }
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
-constexpr int kTabFloats = 32 + 8 + 32;  // raw active means [8][4], log-weights [8], row 0 of the means [32]
+constexpr int kTabFloats = 32 + 8 + 32;  // raw slot-0 means [8][4], log-weights [8], row 0 of the means [32]
+constexpr int kLdsHead = kTabFloats + 8; // ... and the eight logit offsets behind the table
+constexpr int NV = 8, D = 32, NP = 16;   // float4 vectors, columns, packed pairs of a row
 
-}  // namespace
-
-template <int NV>
-__global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
-  if (!gmm_is_slot1(a.energy)) return;  // any other mask: the dense kernel, launched behind this one, does the work
-  static_assert(NV == 8, "dim 32");
-  constexpr int D = 4 * NV, NP = 2 * NV;  // columns, packed pairs; pairs 0 and 1 are the active slot
-  using LaneT = Lane<1, NV, true>;
-  LaneT L;
-  L.init(a.n_chains, a.dim);
-
-  // ---- LDS: [table | parked state, [v][thread] float4 | parked active force, [thread] float4]
-  float* const tab = hmc_smem;
-  const int K = a.energy.n_comp;
-  for (int i = threadIdx.x; i < kTabFloats; i += kBlock) {
-    float v;
-    if (i < 32) {
-      const int k = i >> 2, kk = k < K ? k : K - 1;
-      v = a.energy.dev0[kk * D + (i & 3)];
-    } else if (i < 40) {
-      v = (i - 32) < K ? a.energy.dev1[i - 32] : -__builtin_inff();
-    } else {
-      v = a.energy.dev0[i - 40];
-    }
-    tab[i] = v;
-  }
-  const int park0 = kTabFloats + 4 * (int)threadIdx.x;
-  const int fpark = kTabFloats + NV * 4 * kBlock + 4 * (int)threadIdx.x;
-  __syncthreads();
+// ACT: active columns (2 or 4), pairs 0 .. ACT/2 - 1 of the row.
+template <int ACT>
+__device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
+  constexpr int AP = ACT / 2;  // active pairs
+  // The lane's chain index is the ONLY per-lane address register that lives through the kernel: every global address
+  // is formed from it where it is used (chain_now() hides it from the optimiser, which otherwise hoists row offsets,
+  // Philox counters and pointers out of the transition loop -- a dozen 64-bit registers, spilled and reloaded).
+  const uint32_t chain32 = blockIdx.x * (uint32_t)kBlock + threadIdx.x;  // n_chains < 2^31 (hmc_slot1_applies)
+  const bool active = (int64_t)chain32 < a.n_chains;
+  auto chain_now = [&]() -> uint64_t {
+    uint32_t c = chain32;
+    asm volatile("" : "+v"(c));
+    return active ? (uint64_t)c : 0ull;
+  };
+  const int park0 = kLdsHead + 4 * (int)threadIdx.x;
+  const int fpark = kLdsHead + NV * 4 * kBlock + 4 * (int)threadIdx.x;
 
   // ---- constants of the step loop (wave-uniform: scalar registers)
   const float invs2 = a.energy.s1, inv2s2 = a.energy.s0;
-  float m2[8][4];  // mu_k[i] * log2(e) / sigma^2
-  float c2v[8];    // (logw_k - |mu_k[0:4]|^2 / (2 sigma^2)) * log2(e): the x-independent part of the base-2 logit
+  float m2[8][ACT];  // mu_k[i] * log2(e) / sigma^2
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int i = 0; i < ACT; ++i) m2[k][i] = to_sgpr(tab[4 * k + i] * (invs2 * kLog2e));
+  // (logw_k - |mu_k[active]|^2 / (2 sigma^2)) * log2(e), the x-independent part of the base-2 logit: in the LDS table,
+  // read into vector-register pairs at the top of every trajectory (a broadcast read; no register lives across the
+  // momentum draw for them)
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x;
     float nrm = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float mu = tab[4 * k + i];
-      nrm = __builtin_fmaf(mu, mu, nrm);
-      m2[k][i] = to_sgpr(mu * (invs2 * kLog2e));
-    }
-    c2v[k] = __builtin_fmaf(-nrm, inv2s2, tab[32 + k]) * kLog2e;
+    for (int i = 0; i < ACT; ++i) nrm = __builtin_fmaf(tab[4 * k + i], tab[4 * k + i], nrm);
+    tab[kTabFloats + k] = __builtin_fmaf(-nrm, inv2s2, tab[32 + k]) * kLog2e;
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) c2v[k] = to_sgpr(c2v[k]);
-  const v2f NI = splat(-invs2);
+  __syncthreads();
 
-  // active-slot force -dE/dx[0:4] at (xa, xb):  f = (sum_k r_k mu_k - x) / sigma^2,  r = softmax of the logits
-  auto active_force = [&](v2f xa, v2f xb, const v2f (&C2)[4], float (&fa)[4]) {
+  // active force -dE/dx at the active columns:  f = (sum_k r_k mu_k - x) / sigma^2,  r = softmax of the logits
+  //   l_k = c2_k + sum_i x_i m2_ki   (components in packed pairs (2q, 2q+1); x_i broadcast by op_sel)
+  auto active_force = [&](const v2f (&XA)[AP], const v2f (&C2)[4], v2f (&FA)[AP]) {
     v2f lp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      v2f t = pk_fma(splat(xa.x), v2f{m2[2 * q][0], m2[2 * q + 1][0]}, C2[q]);
-      t = pk_fma(splat(xa.y), v2f{m2[2 * q][1], m2[2 * q + 1][1]}, t);
-      t = pk_fma(splat(xb.x), v2f{m2[2 * q][2], m2[2 * q + 1][2]}, t);
-      lp[q] = pk_fma(splat(xb.y), v2f{m2[2 * q][3], m2[2 * q + 1][3]}, t);
+      v2f t = C2[q];
+#pragma unroll
+      for (int i = 0; i < ACT; ++i) {
+        const float xi = (i & 1) ? XA[i >> 1].y : XA[i >> 1].x;
+        t = pk_fma(splat(xi), v2f{m2[2 * q][i], m2[2 * q + 1][i]}, t);
+      }
+      lp[q] = t;
     }
     float top = __builtin_fmaxf(__builtin_fmaxf(lp[0].x, lp[0].y), lp[1].x);  // a NaN logit resurfaces in the sum
     top = __builtin_fmaxf(__builtin_fmaxf(top, lp[1].y), lp[2].x);
@@ -122,26 +118,32 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
     const float sum = s2.x + s2.y;  // in [1, 8] for finite logits
     // 1 / (sigma^2 log2 e) is folded into m2: sum_k w_k m2_k = (log2 e / sigma^2) sum_k w_k mu_k
     const float s = __builtin_amdgcn_rcpf(sum) * kLn2;
-    const v2f ta = xa * NI, tb = xb * NI;
-    const float tx[4] = {ta.x, ta.y, tb.x, tb.y};
+    // weighted means, columns in packed pairs (i, i+1), w_k broadcast by op_sel
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v2f acc = w[0] * v2f{m2[0][i], m2[1][i]};
+    for (int h = 0; h < AP; ++h) {
+      v2f acc = splat(w[0].x) * v2f{m2[0][2 * h], m2[0][2 * h + 1]};
 #pragma unroll
-      for (int q = 1; q < 4; ++q) acc = pk_fma(w[q], v2f{m2[2 * q][i], m2[2 * q + 1][i]}, acc);
-      fa[i] = __builtin_fmaf(acc.x + acc.y, s, tx[i]);
+      for (int k = 1; k < 8; ++k) {
+        const float wk = (k & 1) ? w[k >> 1].y : w[k >> 1].x;
+        acc = pk_fma(splat(wk), v2f{m2[k][2 * h], m2[k][2 * h + 1]}, acc);
+      }
+      FA[h] = pk_fma(acc, splat(s), XA[h] * splat(-invs2));
     }
   };
 
   // E(x) in the reference's difference form (the form the shared body evaluates H0 / H1 in):
-  //   sum_{d >= 4} (x_d - mu_0d)^2 / (2 sigma^2) - logsumexp_k(logw_k - |x[0:4] - mu_k[0:4]|^2 / (2 sigma^2))
+  //   sum_{shared d} (x_d - mu_0d)^2 / (2 sigma^2) - logsumexp_k(logw_k - |x_act - mu_k,act|^2 / (2 sigma^2))
   auto energy_exact = [&](const v2f (&X)[NP]) -> float {
     float logit[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float4 m = *reinterpret_cast<const float4*>(&tab[4 * k]);
-      const v2f da = X[0] - v2f{m.x, m.y}, db = X[1] - v2f{m.z, m.w};
-      const v2f d2 = pk_fma(db, db, da * da);
+      const v2f da = X[0] - v2f{m.x, m.y};
+      v2f d2 = da * da;
+      if constexpr (ACT == 4) {
+        const v2f db = X[1] - v2f{m.z, m.w};
+        d2 = pk_fma(db, db, d2);
+      }
       logit[k] = __builtin_fmaf(-(d2.x + d2.y), inv2s2, tab[32 + k]);
     }
     float top = logit[0];
@@ -152,9 +154,9 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
     for (int k = 0; k < 8; ++k) sum += __expf(logit[k] - top);
     v2f sq = {0.0f, 0.0f}, sq_b = {0.0f, 0.0f};
 #pragma unroll
-    for (int v = 1; v < NV; ++v) {  // the shared columns are held as x - mu_0
-      sq = pk_fma(X[2 * v], X[2 * v], sq);
-      sq_b = pk_fma(X[2 * v + 1], X[2 * v + 1], sq_b);
+    for (int j = AP; j < NP; ++j) {  // the shared columns are held as x - mu_0
+      if ((j - AP) & 1) sq_b = pk_fma(X[j], X[j], sq_b);
+      else sq = pk_fma(X[j], X[j], sq);
     }
     sq += sq_b;
     return __builtin_fmaf(sq.x + sq.y, inv2s2, -(top + logf(sum)));
@@ -172,13 +174,12 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
     return clamp_nanprop(0.5f * (acc.x + acc.y), 0.0f, 1e10f);
   };
 
-  const int64_t row = L.active ? L.chain * (int64_t)D : 0;
-  // full rows, 16-byte aligned: whole float4 accesses, lanes past the last chain hold zeros and never store
+  // full rows, 16-byte aligned: whole float4 accesses; lanes past the last chain hold zeros and never store
   auto load_row = [&](const float* __restrict__ src, v2f (&R)[NP]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (L.active) q = *reinterpret_cast<const float4*>(src + 4 * v);
+      if (active) q = *reinterpret_cast<const float4*>(src + 4 * v);
       R[2 * v] = v2f{q.x, q.y};
       R[2 * v + 1] = v2f{q.z, q.w};
     }
@@ -186,10 +187,9 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
   // shared columns <-> y = x - mu_0 (row 0 of the means, from the LDS table)
   auto shift = [&](v2f (&R)[NP], float sign) {
 #pragma unroll
-    for (int v = 1; v < NV; ++v) {
-      const float4 mu = *reinterpret_cast<const float4*>(&tab[40 + 4 * v]);
-      R[2 * v] = pk_fma(splat(sign), v2f{mu.x, mu.y}, R[2 * v]);      // sign = +-1: the product is exact
-      R[2 * v + 1] = pk_fma(splat(sign), v2f{mu.z, mu.w}, R[2 * v + 1]);
+    for (int j = AP; j < NP; ++j) {
+      const float2 mu = *reinterpret_cast<const float2*>(&tab[40 + 2 * j]);
+      R[j] = pk_fma(splat(sign), v2f{mu.x, mu.y}, R[j]);  // sign = +-1: the product is exact
     }
   };
   auto store_row = [&](float* __restrict__ dst, const v2f (&R)[NP]) {
@@ -197,35 +197,51 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) O[j] = R[j];
     shift(O, 1.0f);
-    if (L.active) {
+    if (active) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
         *reinterpret_cast<float4*>(dst + 4 * v) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
     }
   };
+  auto unpark = [&](v2f (&R)[NP]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float4 q = *reinterpret_cast<const float4*>(&hmc_smem[park0 + v * (4 * kBlock)]);
+      R[2 * v] = v2f{q.x, q.y};
+      R[2 * v + 1] = v2f{q.z, q.w};
+    }
+  };
   v2f X[NP];
-  load_row(a.x + row, X);
+  load_row(a.x + chain_now() * D, X);
   shift(X, -1.0f);
   auto draw_momentum = [&](int t, v2f (&P)[NP]) {
     if (a.p_noise) {
-      load_row(a.p_noise + ((int64_t)t * a.n_chains) * D + row, P);
+      load_row(a.p_noise + ((uint64_t)t * (uint64_t)a.n_chains + chain_now()) * D, P);
     } else {
-      Slice<NV> s;
-      normal_slice(L, a.key, a.step0 + 2ull * (uint64_t)t, s);
+      const uint64_t step = a.step0 + 2ull * (uint64_t)t;
+      // (the chain index hidden from the optimiser: the counter words and the first Philox multiply of all eight calls
+      //  are invariant across transitions -- hoisted out of the loop they are 16 registers, spilled and reloaded)
+      uint32_t c = chain32;
+      asm volatile("" : "+v"(c));
+      const uint64_t g0 = (uint64_t)c * (uint64_t)(D / 4);  // Philox counter of the row's first float4
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        P[2 * v] = v2f{s.a[v][0], s.a[v][1]};
-        P[2 * v + 1] = v2f{s.a[v][2], s.a[v][3]};
+        const F4 n = normal4_at(a.key, g0 + (uint64_t)v, step);
+        P[2 * v] = v2f{n.v[0], n.v[1]};
+        P[2 * v + 1] = v2f{n.v[2], n.v[3]};
+        // two counters at a time: eight interleaved Philox chains cost more registers than the budget has
+        if (v & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
 
-  const int64_t traj_row = L.active ? L.chain * (int64_t)a.n_kept * D : 0;
   int until_keep = a.thin;
-  int64_t keep_off = 0;
+  int keep = 0;
   float eps = a.eps;
-  float e_cur = 0.0f;
-  float fa[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // active-slot force at the state the chain holds
+  float e_cur = 0.0f, e_keep = 0.0f;
+  v2f FA[AP];  // active force at the state the chain holds
+#pragma unroll
+  for (int h = 0; h < AP; ++h) FA[h] = v2f{0.0f, 0.0f};
 
   // t = -1 is a pseudo-transition (zero momentum, zero step size, one leapfrog step, always "accepted", nothing
   // written): x + 0 * p is x bit for bit, so it leaves the energy and the carried force of the initial state.
@@ -245,84 +261,95 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
     }
     float uu;
     if (init) uu = -1.0f;
-    else if (a.u) uu = L.active ? a.u[(int64_t)t * a.n_chains + L.chain] : 2.0f;
-    else uu = u01_half_open(pick(philox_at(a.key, (uint64_t)L.chain >> 2, a.step0 + 2ull * (uint64_t)t + 1ull),
-                                 (int)(L.chain & 3)));
+    else if (a.u) uu = active ? a.u[(uint64_t)t * (uint64_t)a.n_chains + chain_now()] : 2.0f;
+    else {
+      uint32_t c = chain32;
+      asm volatile("" : "+v"(c));
+      uu = u01_half_open(pick(philox_at(a.key, (uint64_t)(c >> 2), a.step0 + 2ull * (uint64_t)t + 1ull), (int)(c & 3)));
+    }
     const float h0 = clamp_nanprop(e_cur, -1e10f, 1e10f) + kinetic(P);
 
     // park the accepted state and its active force
 #pragma unroll
     for (int v = 0; v < NV; ++v)
       *reinterpret_cast<float4*>(&hmc_smem[park0 + v * (4 * kBlock)]) = make_float4(X[2 * v].x, X[2 * v].y, X[2 * v + 1].x, X[2 * v + 1].y);
-    *reinterpret_cast<float4*>(&hmc_smem[fpark]) = make_float4(fa[0], fa[1], fa[2], fa[3]);
+    // ... and the scalars that are only needed again behind the trajectory: the chain's active force and energy,
+    // H0 and the accept uniform (four active columns: the force is re-evaluated on a rejection instead -- the slot
+    // holds four floats, and a CU's LDS holds four workgroups only at nine float4 per lane)
+    if constexpr (AP == 1) *reinterpret_cast<float4*>(&hmc_smem[fpark]) = make_float4(FA[0].x, FA[0].y, h0, uu);
+    else *reinterpret_cast<float4*>(&hmc_smem[fpark]) = make_float4(e_cur, 0.0f, h0, uu);
 
-    // the logit offsets as vector-register pairs for the trajectory (the packed FMA that adds them already takes the
-    // means from scalar registers); made here so that they are not live across the momentum draw
+    // the logit offsets as vector-register pairs (the packed FMA that adds them already takes the means from scalar
+    // registers)
     v2f C2[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      C2[q] = v2f{c2v[2 * q], c2v[2 * q + 1]};
-      asm volatile("" : "+v"(C2[q]));
+      const float2 c = *reinterpret_cast<const float2*>(&tab[kTabFloats + 2 * q]);
+      C2[q] = v2f{c.x, c.y};
     }
 
-    // ---- the trajectory, common path.  m: running NaN-propagating maximum of |force| and of the entry momentum / 1e24
-    float m = 0.0f;
+    // ---- the trajectory, common path.  Running NaN-propagating maxima: m_p of the entry momentum, m_y of the shared
+    //      coordinates a force is taken at, m_f of the active forces
+    float m_p = 0.0f, m_y = 0.0f, m_f = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) m = max3np(m, __builtin_fabsf(P[j].x) * 1e-24f, __builtin_fabsf(P[j].y) * 1e-24f);  // |p| >= 1e30 <=> > 1e6
+    for (int j = 0; j < NP; ++j) m_p = max3np(m_p, __builtin_fabsf(P[j].x), __builtin_fabsf(P[j].y));
+    asm volatile("" : "+v"(m_p));  // here, not sunk to its use behind the trajectory (see h0)
     {
-      const v2f H2 = splat(half_eps);
-      m = max3np(m, __builtin_fabsf(fa[0]), __builtin_fabsf(fa[1]));
-      m = max3np(m, __builtin_fabsf(fa[2]), __builtin_fabsf(fa[3]));
-      P[0] = pk_fma(H2, v2f{fa[0], fa[1]}, P[0]);
-      P[1] = pk_fma(H2, v2f{fa[2], fa[3]}, P[1]);
+      const v2f H2 = splat(half_eps), HN = splat(half_eps * -invs2);
 #pragma unroll
-      for (int j = 2; j < NP; ++j) {
-        const v2f F = X[j] * NI;
-        m = max3np(m, __builtin_fabsf(F.x), __builtin_fabsf(F.y));
-        P[j] = pk_fma(H2, F, P[j]);
+      for (int h = 0; h < AP; ++h) {
+        m_f = max3np(m_f, __builtin_fabsf(FA[h].x), __builtin_fabsf(FA[h].y));
+        P[h] = pk_fma(H2, FA[h], P[h]);
+      }
+#pragma unroll
+      for (int j = AP; j < NP; ++j) {
+        m_y = max3np(m_y, __builtin_fabsf(X[j].x), __builtin_fabsf(X[j].y));
+        P[j] = pk_fma(HN, X[j], P[j]);
       }
     }
     const v2f E2 = splat(eps_t);
     for (int l = 0; l < n_lf; ++l) {
-      const v2f K2 = splat(l + 1 >= n_lf ? half_eps : eps_t);  // the next step's first half kick rides along
+      const float kick = l + 1 >= n_lf ? half_eps : eps_t;  // the next step's first half kick rides along
+      const v2f K2 = splat(kick), KN = splat(kick * -invs2);
 #pragma unroll
       for (int j = 0; j < NP; ++j) X[j] = pk_fma(E2, P[j], X[j]);
-      active_force(X[0], X[1], C2, fa);
-      m = max3np(m, __builtin_fabsf(fa[0]), __builtin_fabsf(fa[1]));
-      m = max3np(m, __builtin_fabsf(fa[2]), __builtin_fabsf(fa[3]));
-      P[0] = pk_fma(K2, v2f{fa[0], fa[1]}, P[0]);
-      P[1] = pk_fma(K2, v2f{fa[2], fa[3]}, P[1]);
+      v2f XA[AP];
 #pragma unroll
-      for (int j = 2; j < NP; ++j) {
-        const v2f F = X[j] * NI;
-        m = max3np(m, __builtin_fabsf(F.x), __builtin_fabsf(F.y));
-        P[j] = pk_fma(K2, F, P[j]);
+      for (int h = 0; h < AP; ++h) XA[h] = X[h];
+      active_force(XA, C2, FA);
+#pragma unroll
+      for (int h = 0; h < AP; ++h) {
+        m_f = max3np(m_f, __builtin_fabsf(FA[h].x), __builtin_fabsf(FA[h].y));
+        P[h] = pk_fma(K2, FA[h], P[h]);
+      }
+#pragma unroll
+      for (int j = AP; j < NP; ++j) {
+        m_y = max3np(m_y, __builtin_fabsf(X[j].x), __builtin_fabsf(X[j].y));
+        P[j] = pk_fma(KN, X[j], P[j]);
       }
     }
     float e1 = energy_exact(X);
     // Anything the reference's safe mode would have touched?  (a clamped force, a non-finite coordinate / logit /
     // momentum, a non-finite energy at the end: leapfrog.py:165-185 clamps and scrubs.)
-    const bool bad = !init && (!(m <= 1e6f) || !(__builtin_fabsf(e1) < __builtin_inff()));
+    const bool bad = !init && (!(m_y * invs2 <= 1e6f) || !(m_f <= 1e6f) || !(m_p < 1e30f) || !(__builtin_fabsf(e1) < __builtin_inff()));
     if (__builtin_expect(bad, 0)) {
       // ---- the literal sequence from the parked state:  per step  f = clamp(-dE/dx(x)); p += eps/2 f; x += eps p;
       //      f' = clamp(-dE/dx(x)); p += eps/2 f'; scrub x, p
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const float4 q = *reinterpret_cast<const float4*>(&hmc_smem[park0 + v * (4 * kBlock)]);
-        X[2 * v] = v2f{q.x, q.y};
-        X[2 * v + 1] = v2f{q.z, q.w};
-      }
+      unpark(X);
       draw_momentum(t, P);
       auto half_kick = [&]() {
-        float g[4];
-        active_force(X[0], X[1], C2, g);
-        P[0].x = __builtin_fmaf(half_eps, clamp_nanprop(g[0], -1e6f, 1e6f), P[0].x);
-        P[0].y = __builtin_fmaf(half_eps, clamp_nanprop(g[1], -1e6f, 1e6f), P[0].y);
-        P[1].x = __builtin_fmaf(half_eps, clamp_nanprop(g[2], -1e6f, 1e6f), P[1].x);
-        P[1].y = __builtin_fmaf(half_eps, clamp_nanprop(g[3], -1e6f, 1e6f), P[1].y);
+        v2f XA[AP], G[AP];
 #pragma unroll
-        for (int j = 2; j < NP; ++j) {
-          const v2f F = X[j] * NI;
+        for (int h = 0; h < AP; ++h) XA[h] = X[h];
+        active_force(XA, C2, G);
+#pragma unroll
+        for (int h = 0; h < AP; ++h) {
+          P[h].x = __builtin_fmaf(half_eps, clamp_nanprop(G[h].x, -1e6f, 1e6f), P[h].x);
+          P[h].y = __builtin_fmaf(half_eps, clamp_nanprop(G[h].y, -1e6f, 1e6f), P[h].y);
+        }
+#pragma unroll
+        for (int j = AP; j < NP; ++j) {
+          const v2f F = X[j] * splat(-invs2);
           P[j].x = __builtin_fmaf(half_eps, clamp_nanprop(F.x, -1e6f, 1e6f), P[j].x);
           P[j].y = __builtin_fmaf(half_eps, clamp_nanprop(F.y, -1e6f, 1e6f), P[j].y);
         }
@@ -342,56 +369,96 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
         }
       }
       // the force the next trajectory starts from (the reference re-evaluates it on the scrubbed state)
-      active_force(X[0], X[1], C2, fa);
+      v2f XA[AP];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = clamp_nanprop(fa[i], -1e6f, 1e6f);
+      for (int h = 0; h < AP; ++h) XA[h] = X[h];
+      active_force(XA, C2, FA);
+#pragma unroll
+      for (int h = 0; h < AP; ++h) FA[h] = v2f{clamp_nanprop(FA[h].x, -1e6f, 1e6f), clamp_nanprop(FA[h].y, -1e6f, 1e6f)};
       e1 = energy_exact(X);
     }
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(P);
+    const float4 parked = *reinterpret_cast<const float4*>(&hmc_smem[fpark]);
+    const float h0_ = parked.z, uu_ = parked.w;
+    if constexpr (AP == 1) e_keep = e_cur; else e_keep = parked.x;
 
     // ---- Metropolis accept (samplers/hmc.py:277-292)
-    const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
+    const float dlt = clamp_nanprop(h0_ - h1, -50.0f, 50.0f);
     float acc_p = expf(dlt);
     acc_p = (acc_p > 1.0f) ? 1.0f : acc_p;  // clamp_(max=1); NaN stays NaN and rejects
-    const bool accept = init || (L.active && (uu < acc_p));
+    const bool accept = init || (active && (uu_ < acc_p));
     if (accept) {
       e_cur = e1;
     } else {  // rejected: bring the parked state and its force back
+      e_cur = e_keep;
+      unpark(X);
+      if constexpr (AP == 1) {
+        FA[0] = v2f{parked.x, parked.y};
+      } else {
+        v2f XA[AP];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const float4 q = *reinterpret_cast<const float4*>(&hmc_smem[park0 + v * (4 * kBlock)]);
-        X[2 * v] = v2f{q.x, q.y};
-        X[2 * v + 1] = v2f{q.z, q.w};
+        for (int h = 0; h < AP; ++h) XA[h] = X[h];
+        active_force(XA, C2, FA);  // finite state of a finished trajectory's start: inside the clamp
       }
-      const float4 q = *reinterpret_cast<const float4*>(&hmc_smem[fpark]);
-      fa[0] = q.x; fa[1] = q.y; fa[2] = q.z; fa[3] = q.w;
     }
     if (init) continue;
 
-    if (a.accept_mask && L.active) a.accept_mask[(int64_t)t * a.n_chains + L.chain] = accept ? 1 : 0;
+    if (a.accept_mask && active) a.accept_mask[(uint64_t)t * (uint64_t)a.n_chains + chain_now()] = accept ? 1 : 0;
     if (a.accept_count) {  // wavefront-level count, one atomic per wave
-      const unsigned long long b = __ballot(accept && L.active);
+      const unsigned long long b = __ballot(accept && active);
       if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.accept_count + t, (uint32_t)__popcll(b));
     }
     if (a.traj && --until_keep == 0) {
       until_keep = a.thin;
-      store_row(a.traj + traj_row + keep_off, X);
-      keep_off += D;
+      store_row(a.traj + (chain_now() * (uint64_t)a.n_kept + (uint64_t)keep) * D, X);
+      ++keep;
     }
   }
-  store_row(a.x + row, X);
+  store_row(a.x + chain_now() * D, X);
+}
+
+}  // namespace
+
+// ACT = 2: the means differ in columns 0 and 1 only (the ring); ACT = 4: anywhere in columns 0..3.  Both instantiations
+// are launched, each returns at once unless the mixture is its own (one kernel per body: each gets the whole
+// register budget -- with both bodies in one kernel the allocator spilled).
+template <int ACT>
+__global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
+  if (!gmm_is_slot1(a.energy)) return;  // any other mask: the dense kernel, launched behind this one, does the work
+  // ---- LDS: [table | parked state, [v][thread] float4 | parked active force, [thread] float4]
+  float* const tab = hmc_smem;
+  const int K = a.energy.n_comp;
+  for (int i = threadIdx.x; i < kTabFloats; i += kBlock) {
+    float v;
+    if (i < 32) {
+      const int k = i >> 2, kk = k < K ? k : K - 1;  // padding components repeat the last row, their log-weight is -inf
+      v = a.energy.dev0[kk * D + (i & 3)];
+    } else if (i < 40) {
+      v = (i - 32) < K ? a.energy.dev1[i - 32] : -__builtin_inff();
+    } else {
+      v = a.energy.dev0[i - 40];
+    }
+    tab[i] = v;
+  }
+  __syncthreads();
+  // columns 2 and 3 shared by all components (the ring: a mixture of a plane)?  wave-uniform
+  bool plane = true;
+  for (int k = 1; k < 8; ++k) plane = plane && tab[4 * k + 2] == tab[2] && tab[4 * k + 3] == tab[3];
+  if ((__builtin_amdgcn_readfirstlane((int)plane) != 0) != (ACT == 2)) return;
+  slot1_body<ACT>(a, tab);
 }
 
 // Launched IN FRONT of the dense kernel when the energy carries an active-column mask: the kernel whose body does not
 // match the mask returns at once (a wave-uniform read of the mask: no host read of device memory).
 bool hmc_slot1_applies(const ebm_energy_t& e, const rows::Geometry& geo, int32_t mass_kind, bool diag) {
   return e.kind == EBM_ENERGY_GMM && e.aux != nullptr && e.n_comp >= 1 && e.n_comp <= 8 && geo.G == 1 && geo.NV == 8 &&
-         geo.full && mass_kind == EBM_MASS_NONE && !diag;
+         geo.full && mass_kind == EBM_MASS_NONE && !diag;  // (one lane per chain: the launcher caps the grid below 2^31 chains)
 }
 
 void launch_slot1(dim3 grid, hipStream_t st, HmcArgs a) {
-  const size_t smem = ((size_t)kTabFloats + (size_t)(8 + 1) * 4 * kBlock) * sizeof(float);
-  hipLaunchKernelGGL((hmc_slot1_kernel<8>), grid, dim3(kBlock), smem, st, a);
+  const size_t smem = ((size_t)kLdsHead + (size_t)(NV + 1) * 4 * kBlock) * sizeof(float);
+  hipLaunchKernelGGL(hmc_slot1_kernel<2>, grid, dim3(kBlock), smem, st, a);
+  hipLaunchKernelGGL(hmc_slot1_kernel<4>, grid, dim3(kBlock), smem, st, a);
 }
 
 }  // namespace hmc
