@@ -21,7 +21,7 @@ void launch_harmonic_diag(const rows::Geometry&, dim3, size_t, hipStream_t, cons
 void launch_gaussian_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 void launch_gmm_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 // hmc_ring.hip: the mixture whose means differ in columns 0..3 only, at four waves per SIMD
-bool hmc_slot1_applies(const ebm_energy_t&, const rows::Geometry&, int32_t mass_kind, bool diag);
+bool hmc_slot1_applies(const ebm_energy_t&, const rows::Geometry&, int32_t mass_kind);
 void launch_slot1(dim3, hipStream_t, HmcArgs);
 }  // namespace hmc
 using hmc::HmcArgs;
@@ -137,6 +137,9 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks);
+  // A mixture that carries an active-column mask: the kernels specialised for mask == 1 go first and return at once
+  // for any other mask; the general kernel behind them returns at once for mask == 1 (each reads the mask itself).
+  if (hmc::hmc_slot1_applies(e, geo, mass_kind)) hmc::launch_slot1(grid, st, a);
   if (diag_kernel) {
     switch (e.kind) {
       case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well_diag(geo, grid, smem, st, a); break;
@@ -146,9 +149,6 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     }
     return check_launch("ebm_hmc_chain_f32");
   }
-  // A mixture that carries an active-column mask: the kernel specialised for mask == 1 goes first and returns at once
-  // for any other mask; the general kernel behind it returns at once for mask == 1 (each reads the mask itself).
-  if (hmc::hmc_slot1_applies(e, geo, mass_kind, false)) hmc::launch_slot1(grid, st, a);
   switch (e.kind) {
     case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well(geo, grid, smem, st, a); break;
     case EBM_ENERGY_HARMONIC:    hmc::launch_harmonic(geo, grid, smem, st, a); break;

@@ -444,8 +444,8 @@ template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
   if constexpr (KIND == EBM_ENERGY_GMM && G == 1 && FULL && NV >= 4) {
     if (gmm_is_slot1(a.energy)) {
-      // identity mass, no records: hmc_slot1_kernel (hmc_ring.hip), launched in front of this one, has done the work
-      if constexpr (MASS == 0 && !DIAG && NV == 8) return;
+      // identity mass: hmc_slot1_kernel (hmc_ring.hip), launched in front of this one, has done the work
+      if constexpr (MASS == 0 && NV == 8) return;
       hmc_chain_body<kGmmSlot1, G, NV, FULL, MASS, DIAG, true>(a);
       return;
     }

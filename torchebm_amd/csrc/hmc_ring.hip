@@ -55,7 +55,9 @@ constexpr int kLdsHead = kTabFloats + 8; // ... and the eight logit offsets behi
 constexpr int NV = 8, D = 32, NP = 16;   // float4 vectors, columns, packed pairs of a row
 
 // ACT: active columns (2 or 4), pairs 0 .. ACT/2 - 1 of the row.
-template <int ACT>
+// DIAG: per-block diagnostics records at the kept transitions (diag.h), a compile-time switch: the call into diag::emit
+// costs registers around it.
+template <int ACT, bool DIAG>
 __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
   constexpr int AP = ACT / 2;  // active pairs
   // The lane's chain index is the ONLY per-lane address register that lives through the kernel: every global address
@@ -135,16 +137,20 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
   //   sum_{shared d} (x_d - mu_0d)^2 / (2 sigma^2) - logsumexp_k(logw_k - |x_act - mu_k,act|^2 / (2 sigma^2))
   auto energy_exact = [&](const v2f (&X)[NP]) -> float {
     float logit[8];
+    // Two table rows in flight at a time: left alone the scheduler issues all ten LDS reads first (40 registers).  The
+    // read offset of the next pair is tied to the logits of this one (an empty asm: no instruction).
+    int toff = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float4 m = *reinterpret_cast<const float4*>(&tab[4 * k]);
+      const float4 m = *reinterpret_cast<const float4*>(&tab[4 * k + toff]);
       const v2f da = X[0] - v2f{m.x, m.y};
       v2f d2 = da * da;
       if constexpr (ACT == 4) {
         const v2f db = X[1] - v2f{m.z, m.w};
         d2 = pk_fma(db, db, d2);
       }
-      logit[k] = __builtin_fmaf(-(d2.x + d2.y), inv2s2, tab[32 + k]);
+      logit[k] = __builtin_fmaf(-(d2.x + d2.y), inv2s2, tab[32 + k + toff]);
+      if (k & 1) asm volatile("" : "+v"(toff) : "v"(logit[k]), "v"(logit[k - 1]));
     }
     float top = logit[0];
 #pragma unroll
@@ -408,9 +414,30 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
       const unsigned long long b = __ballot(accept && active);
       if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.accept_count + t, (uint32_t)__popcll(b));
     }
-    if (a.traj && --until_keep == 0) {
+    if ((a.traj != nullptr || DIAG) && --until_keep == 0) {
       until_keep = a.thin;
-      store_row(a.traj + (chain_now() * (uint64_t)a.n_kept + (uint64_t)keep) * D, X);
+      if (a.traj) store_row(a.traj + (chain_now() * (uint64_t)a.n_kept + (uint64_t)keep) * D, X);
+      if constexpr (DIAG) {
+        // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain holds now,
+        // acceptance rate.  The tile is the parking area of the state -- dead until the next transition parks again and
+        // exactly one block of rows wide; the barrier: a slower wave may still have to bring its parked state back.
+        float* const tile = hmc_smem + kLdsHead;
+        float* const scratch = tile + (NV + 1) * 4 * kBlock;
+        __syncthreads();
+        {
+          v2f O[NP];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) O[j] = X[j];
+          shift(O, 1.0f);
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            *reinterpret_cast<float4*>(tile + (int)threadIdx.x * D + 4 * v) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
+        }
+        const int64_t left = a.n_chains - (int64_t)blockIdx.x * kBlock;
+        const int valid = (left >= kBlock ? kBlock : (left > 0 ? (int)left : 0)) * D;
+        diag::emit(a.diag, keep, tile, scratch, valid, D, active ? clamp_nanprop(e_cur, -1e10f, 1e10f) : 0.0f,
+                   (accept && active) ? 1.0f : 0.0f);
+      }
       ++keep;
     }
   }
@@ -422,7 +449,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
 // ACT = 2: the means differ in columns 0 and 1 only (the ring); ACT = 4: anywhere in columns 0..3.  Both instantiations
 // are launched, each returns at once unless the mixture is its own (one kernel per body: each gets the whole
 // register budget -- with both bodies in one kernel the allocator spilled).
-template <int ACT>
+template <int ACT, bool DIAG>
 __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
   if (!gmm_is_slot1(a.energy)) return;  // any other mask: the dense kernel, launched behind this one, does the work
   // ---- LDS: [table | parked state, [v][thread] float4 | parked active force, [thread] float4]
@@ -445,20 +472,27 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
   bool plane = true;
   for (int k = 1; k < 8; ++k) plane = plane && tab[4 * k + 2] == tab[2] && tab[4 * k + 3] == tab[3];
   if ((__builtin_amdgcn_readfirstlane((int)plane) != 0) != (ACT == 2)) return;
-  slot1_body<ACT>(a, tab);
+  slot1_body<ACT, DIAG>(a, tab);
 }
 
 // Launched IN FRONT of the dense kernel when the energy carries an active-column mask: the kernel whose body does not
 // match the mask returns at once (a wave-uniform read of the mask: no host read of device memory).
-bool hmc_slot1_applies(const ebm_energy_t& e, const rows::Geometry& geo, int32_t mass_kind, bool diag) {
+bool hmc_slot1_applies(const ebm_energy_t& e, const rows::Geometry& geo, int32_t mass_kind) {
   return e.kind == EBM_ENERGY_GMM && e.aux != nullptr && e.n_comp >= 1 && e.n_comp <= 8 && geo.G == 1 && geo.NV == 8 &&
-         geo.full && mass_kind == EBM_MASS_NONE && !diag;  // (one lane per chain: the launcher caps the grid below 2^31 chains)
+         geo.full && mass_kind == EBM_MASS_NONE;  // (one lane per chain: the launcher caps the grid below 2^31 chains)
 }
 
+// a.diag.partials != nullptr: the records of the lane-group layout (diag::plan over kBlock rows per workgroup)
 void launch_slot1(dim3 grid, hipStream_t st, HmcArgs a) {
-  const size_t smem = ((size_t)kLdsHead + (size_t)(NV + 1) * 4 * kBlock) * sizeof(float);
-  hipLaunchKernelGGL(hmc_slot1_kernel<2>, grid, dim3(kBlock), smem, st, a);
-  hipLaunchKernelGGL(hmc_slot1_kernel<4>, grid, dim3(kBlock), smem, st, a);
+  size_t smem = ((size_t)kLdsHead + (size_t)(NV + 1) * 4 * kBlock) * sizeof(float);
+  if (a.diag.partials) {
+    smem += (size_t)diag::scratch_floats(a.diag.S) * sizeof(float);
+    hipLaunchKernelGGL((hmc_slot1_kernel<2, true>), grid, dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((hmc_slot1_kernel<4, true>), grid, dim3(kBlock), smem, st, a);
+  } else {
+    hipLaunchKernelGGL((hmc_slot1_kernel<2, false>), grid, dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((hmc_slot1_kernel<4, false>), grid, dim3(kBlock), smem, st, a);
+  }
 }
 
 }  // namespace hmc
