@@ -155,6 +155,9 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
     float top = logit[0];
 #pragma unroll
     for (int k = 1; k < 8; ++k) top = __builtin_fmaxf(top, logit[k]);
+    // torch.logsumexp shifts by the maximum unless that is infinite (then by 0): every distance overflowing gives
+    // logsumexp = -inf, E = +inf -- not NaN (the energy the reference clamps to 1e10 in H)
+    top = __builtin_fabsf(top) == __builtin_inff() ? 0.0f : top;
     float sum = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sum += __expf(logit[k] - top);
@@ -343,21 +346,30 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
       //      f' = clamp(-dE/dx(x)); p += eps/2 f'; scrub x, p
       unpark(X);
       draw_momentum(t, P);
-      auto half_kick = [&]() {
-        v2f XA[AP], G[AP];
+      // -dE/dx as autograd returns it for E = -logsumexp_k(logw_k - |x - mu_k|^2 / (2 sigma^2)): when every squared
+      // distance overflows all logits are -inf and the softmax -- the whole gradient row -- is NaN.  E(x) = +inf (or NaN)
+      // says so; the active-column form above would not notice an overflow in the shared columns.
+      auto literal_force = [&](v2f (&G)[AP]) -> bool {
+        v2f XA[AP];
 #pragma unroll
         for (int h = 0; h < AP; ++h) XA[h] = X[h];
         active_force(XA, C2, G);
+        return !(energy_exact(X) < __builtin_inff());
+      };
+      auto half_kick = [&]() {
+        v2f G[AP];
+        const bool blown = literal_force(G);
+        const float nan = __builtin_nanf("");
 #pragma unroll
         for (int h = 0; h < AP; ++h) {
-          P[h].x = __builtin_fmaf(half_eps, clamp_nanprop(G[h].x, -1e6f, 1e6f), P[h].x);
-          P[h].y = __builtin_fmaf(half_eps, clamp_nanprop(G[h].y, -1e6f, 1e6f), P[h].y);
+          P[h].x = __builtin_fmaf(half_eps, blown ? nan : clamp_nanprop(G[h].x, -1e6f, 1e6f), P[h].x);
+          P[h].y = __builtin_fmaf(half_eps, blown ? nan : clamp_nanprop(G[h].y, -1e6f, 1e6f), P[h].y);
         }
 #pragma unroll
         for (int j = AP; j < NP; ++j) {
           const v2f F = X[j] * splat(-invs2);
-          P[j].x = __builtin_fmaf(half_eps, clamp_nanprop(F.x, -1e6f, 1e6f), P[j].x);
-          P[j].y = __builtin_fmaf(half_eps, clamp_nanprop(F.y, -1e6f, 1e6f), P[j].y);
+          P[j].x = __builtin_fmaf(half_eps, blown ? nan : clamp_nanprop(F.x, -1e6f, 1e6f), P[j].x);
+          P[j].y = __builtin_fmaf(half_eps, blown ? nan : clamp_nanprop(F.y, -1e6f, 1e6f), P[j].y);
         }
       };
       for (int l = 0; l < n_lf; ++l) {
@@ -368,19 +380,25 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
             for (int j = 0; j < NP; ++j) X[j] = pk_fma(E2, P[j], X[j]);
           }
         }
+        // nan_to_num_ on x and p; the shared columns are scrubbed as x = y + mu_0 (a NaN becomes x = 0, not x = mu_0)
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-          X[j] = v2f{nan_to_num0(X[j].x), nan_to_num0(X[j].y)};
+          v2f xs = X[j], mu = v2f{0.0f, 0.0f};
+          if (j >= AP) {
+            const float2 m0 = *reinterpret_cast<const float2*>(&tab[40 + 2 * j]);
+            mu = v2f{m0.x, m0.y};
+            xs = xs + mu;
+          }
+          xs = v2f{nan_to_num0(xs.x), nan_to_num0(xs.y)};
+          X[j] = (j >= AP) ? xs - mu : xs;
           P[j] = v2f{nan_to_num0(P[j].x), nan_to_num0(P[j].y)};
         }
       }
       // the force the next trajectory starts from (the reference re-evaluates it on the scrubbed state)
-      v2f XA[AP];
+      const bool blown = literal_force(FA);
 #pragma unroll
-      for (int h = 0; h < AP; ++h) XA[h] = X[h];
-      active_force(XA, C2, FA);
-#pragma unroll
-      for (int h = 0; h < AP; ++h) FA[h] = v2f{clamp_nanprop(FA[h].x, -1e6f, 1e6f), clamp_nanprop(FA[h].y, -1e6f, 1e6f)};
+      for (int h = 0; h < AP; ++h)
+        FA[h] = blown ? splat(__builtin_nanf("")) : v2f{clamp_nanprop(FA[h].x, -1e6f, 1e6f), clamp_nanprop(FA[h].y, -1e6f, 1e6f)};
       e1 = energy_exact(X);
     }
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(P);
