@@ -23,6 +23,9 @@ void launch_gmm_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const Hmc
 // hmc_ring.hip: the mixture whose means differ in columns 0..3 only, at four waves per SIMD
 bool hmc_slot1_applies(const ebm_energy_t&, const rows::Geometry&, int32_t mass_kind);
 void launch_slot1(dim3, hipStream_t, HmcArgs);
+// hmc_gmm32.hip: any other mixture of up to eight components at dim 32, identity mass, at four waves per SIMD
+bool hmc_gmm32_applies(const ebm_energy_t&, const rows::Geometry&, int32_t mass_kind);
+void launch_gmm32(dim3, hipStream_t, HmcArgs);
 }  // namespace hmc
 using hmc::HmcArgs;
 
@@ -140,6 +143,10 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   // A mixture that carries an active-column mask: the kernels specialised for mask == 1 go first and return at once
   // for any other mask; the general kernel behind them returns at once for mask == 1 (each reads the mask itself).
   if (hmc::hmc_slot1_applies(e, geo, mass_kind)) hmc::launch_slot1(grid, st, a);
+  if (hmc::hmc_gmm32_applies(e, geo, mass_kind)) {  // (returns at once for mask == 1)
+    hmc::launch_gmm32(grid, st, a);
+    return check_launch("ebm_hmc_chain_f32");
+  }
   if (diag_kernel) {
     switch (e.kind) {
       case EBM_ENERGY_DOUBLE_WELL: hmc::launch_double_well_diag(geo, grid, smem, st, a); break;

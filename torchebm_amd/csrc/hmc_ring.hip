@@ -29,30 +29,17 @@
 //     non-finite coordinate or logit makes a force NaN / inf.  A chain whose trajectory ends outside those bounds is
 //     REDONE from the parked state by the literal sequence (NaN-propagating clamps, half kicks, scrub after every
 //     step, force re-evaluated on the scrubbed state) -- cold code behind a wave-level branch.
-#include "hmc_kernel.h"
+#include "hmc_lane.h"
 
 namespace ebm {
 namespace hmc {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
+using namespace lane;
 
 namespace {
 
-__device__ __forceinline__ float to_sgpr(float v) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
-// NaN-propagating maximum of three (v_maximum3_f32)
-__device__ __forceinline__ float max3np(float a, float b, float c) {
-  return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
-}
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat(float v) { return v2f{v, v}; }
-
-constexpr float kLog2e = 1.44269504088896340736f;
-constexpr float kLn2 = 0.69314718055994530942f;
 constexpr int kTabFloats = 32 + 8 + 32;  // raw slot-0 means [8][4], log-weights [8], row 0 of the means [32]
 constexpr int kLdsHead = kTabFloats + 8; // ... and the eight logit offsets behind the table
-constexpr int NV = 8, D = 32, NP = 16;   // float4 vectors, columns, packed pairs of a row
 
 // ACT: active columns (2 or 4), pairs 0 .. ACT/2 - 1 of the row.
 // DIAG: per-block diagnostics records at the kept transitions (diag.h), a compile-time switch: the call into diag::emit
@@ -256,7 +243,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
   // written): x + 0 * p is x bit for bit, so it leaves the energy and the carried force of the initial state.
   for (int t = -1; t < a.n_mh; ++t) {
     const bool init = t < 0;
-    if (a.eps_table && !init) eps = a.eps_table[t];
+    if (a.eps_table && !init) eps = to_sgpr(a.eps_table[t]);  // wave-uniform: a scalar register
     const float eps_t = init ? 0.0f : eps;
     const float half_eps = 0.5f * eps_t;
     const int n_lf = init ? 1 : a.n_leapfrog;
