@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--n-chains", type=int, default=1 << 20, help="chains PER GPU")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="4 = BASELINE configs[3]'s per-GPU shard as the timed step (2^20 chains, dim 128, k 500: at 8 ranks "
+                         "the timed run IS configs[3]); default 2 = configs[1]")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = plumbing dry-run (gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (the `extra` array)")
@@ -644,6 +647,8 @@ def main():
               file=sys.stderr)
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
 
+    if args.config == 4:
+        args.n_chains, args.dim, args.k = 1 << 20, 128, 500
     n, dim, k = args.n_chains, args.dim, args.k
     model = ta.DoubleWellModel(barrier_height=2.0, b=1.0, device=device)
     sampler = ta.LangevinDynamics(model, step_size=ETA, noise_scale=SIGMA, device=device)
@@ -699,6 +704,8 @@ def main():
     last_step_with_readback()  # step K
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
+    timed_pairs = _lib.timed_events.pop("ebm_langevin_chain_f32") if on_gpu else []  # the K timed steps' launches only
 
     if world > 1:
         import torch.distributed as dist
@@ -707,9 +714,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1, behind the timed region: WHY the N-rank number is what it is.  The same step three ways, each fenced
+    #      (barrier + device sync) on both sides, median of 3, maximum over ranks: plain (no collective), with the
+    #      pipelined read-back (what the timed run's last step does), and the all-gather alone (not overlapped).
+    multi = None
+    if world > 1:
+        import torch.distributed as dist
+
+        from torchebm_amd.utils import all_gather_cat
+
+        def fenced_ms(fn, reps=3):
+            ts = []
+            for _ in range(reps):
+                fence()
+                a = time.perf_counter()
+                fn()
+                fence()
+                ts.append((time.perf_counter() - a) * 1e3)
+            v = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=device)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            return float(v.item())
+
+        plain_ms = fenced_ms(one_step)
+        pipelined_ms = None if readback.startswith("disabled") else fenced_ms(last_step_with_readback)
+        gather_ms, gather_err = None, None
+        try:
+            gather_ms = fenced_ms(lambda: all_gather_cat(state))
+        except Exception as exc:
+            gather_err = f"{type(exc).__name__}: {exc}"[:200]
+        shard_bytes = n * dim * 4
+        # per-rank time of the timed run (wall per step; on the GPU also the chain kernel's event time): min / max over ranks
+        mine = [elapsed_local / args.steps * 1e3, -1.0]
+        if timed_pairs:
+            mine[1] = sum(a.elapsed_time(b) for a, b in timed_pairs) / args.steps
+        every = torch.zeros(world, 2, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every.view(-1), torch.tensor(mine, dtype=torch.float64, device=device))
+        every = every.cpu()
+        multi = {
+            "bytes_per_rank": shard_bytes,
+            "gathered_bytes_per_rank": world * shard_bytes,
+            "plain_step_ms": plain_ms,
+            "step_with_pipelined_readback_ms": pipelined_ms,
+            "exposed_ms": None if pipelined_ms is None else max(0.0, pipelined_ms - plain_ms),
+            "allgather_alone_ms": gather_ms,
+            # bytes a rank RECEIVES over the links / time of the collective alone; bus bandwidth in nccl-tests' sense is the same
+            # figure for an all-gather ((N-1)/N of the gathered size per rank)
+            "algbw_GBps": None if not gather_ms else (world - 1) * shard_bytes / (gather_ms * 1e-3) / 1e9,
+            "allgather_error": gather_err,
+            "per_rank_ms_per_step": {"min": float(every[:, 0].min()), "max": float(every[:, 0].max()),
+                                     "all": [round(float(v), 4) for v in every[:, 0]]},
+            "per_rank_kernel_ms": None if float(every[:, 1].min()) < 0 else
+                {"min": float(every[:, 1].min()), "max": float(every[:, 1].max()), "all": [round(float(v), 4) for v in every[:, 1]]},
+            "how": "behind the timed region; each figure = median of 3 fenced runs, maximum over ranks",
+        }
+
     kernel_ms, kernel_dist = None, None
     if on_gpu:
-        pairs = _lib.timed_events.pop("ebm_langevin_chain_f32")
+        pairs = timed_pairs
         if pairs:  # GPU time of the chain kernel per step (the pipelined last step of N > 1 is several launches)
             each = [a.elapsed_time(b) for a, b in pairs]
             kernel_ms = sum(each) / args.steps
@@ -778,7 +839,9 @@ def main():
             "config": {
                 "workload": f"LangevinDynamics.sample on DoubleWell(h=2,b=1): n_chains={n} per GPU, dim={dim}, "
                             f"k={k} steps per call, eta={ETA}, sigma={SIGMA} "
-                            + ("(BASELINE configs[1])" if (n, dim, k) == (1 << 20, 64, 200) else "(shape overridden on the command line)"),
+                            + ("(BASELINE configs[1])" if (n, dim, k) == (1 << 20, 64, 200) else
+                               (f"(BASELINE configs[3]'s per-GPU shard; {world} of its 8 shards run here)" if (n, dim, k) == (1 << 20, 128, 500)
+                                else "(shape overridden on the command line)")),
                 "n_chains_per_gpu": n,
                 "dim": dim,
                 "k_steps": k,
@@ -790,6 +853,7 @@ def main():
                 "readback": readback,
                 "device": args.device,
             },
+            "readback": multi,
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dim, k),
         }

@@ -135,6 +135,32 @@ def test_bench_contract_two_processes_cpu():
     assert rec["metric"] == "MCMC chain-steps/sec" and rec["unit"] == "chain-steps/s" and rec["higher_is_better"] is True
     assert rec["value"] == pytest.approx(2 * 256 * 3 * 2 / (rec["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert rec["cpu_baseline"] is None  # rank 0 at N = 1 only
+    # the N > 1 line says why it is what it is: the read-back's exposed time, the collective alone, per-rank spread
+    rb = rec["readback"]
+    assert rb["bytes_per_rank"] == 256 * 8 * 4 and rb["gathered_bytes_per_rank"] == 2 * 256 * 8 * 4
+    assert rb["plain_step_ms"] > 0 and rb["step_with_pipelined_readback_ms"] > 0 and rb["exposed_ms"] >= 0
+    assert rb["allgather_alone_ms"] > 0 and rb["allgather_error"] is None
+    assert rb["algbw_GBps"] == pytest.approx(256 * 8 * 4 / (rb["allgather_alone_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert len(rb["per_rank_ms_per_step"]["all"]) == 2 and rb["per_rank_ms_per_step"]["min"] <= rb["per_rank_ms_per_step"]["max"]
+    assert rb["per_rank_kernel_ms"] is None  # event times exist on the GPU only
+
+
+def test_bench_config4_preset_is_baseline_config_4s_shard():
+    """--config 4 times BASELINE configs[3]'s per-GPU shard (2^20 x 128, k = 500); checked on the argument level only
+    (the shape is far beyond a CPU test)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["bench.py", "--config", "4"]
+    try:
+        a = mod.parse()
+    finally:
+        sys.argv = argv
+    assert a.config == 4
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.n_chains, args.dim, args.k = 1 << 20, 128, 500" in src
 
 
 def test_bench_contract_single_process_cpu():
