@@ -53,12 +53,12 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
 ETA, SIGMA = 0.01, 1.0
 # Issue cost of one Euler-Maruyama step of one float4 group in the lean DoubleWell loop, in units of one plain
-# full-rate VALU op: 18 v_mad_u64_u32 x 2.6 + 20 v_bitop3_b32 + 8 transcendentals x 3.2 + 11 plain + 20 packed-f32 x 1.8
+# full-rate VALU op: 18 v_mad_u64_u32 x 2.6 + 20 v_bitop3_b32 + 8 transcendentals x 3.2 + 10 plain + 20 packed-f32 x 1.8
 # (static ISA count of langevin_chain_lean_kernel<DoubleWell>; per-class costs measured by scripts/ubench/valu_rates.hip,
 # profiles/r01_valu_rates.txt)
 LEAN_LOOP_ISSUE_UNITS = 140.0  # round-1 constant, kept as the fallback and printed next to the value measured in the run
 # static instruction mix of the lean loop per float4 group and step (scripts/isa_mix.py on langevin.hip)
-LEAN_LOOP_MIX = {"mad_u64_u32": 18, "bitop3": 20, "transcendental": 8, "packed_f32": 20, "plain": 11}
+LEAN_LOOP_MIX = {"mad_u64_u32": 18, "bitop3": 20, "transcendental": 8, "packed_f32": 20, "plain": 10}  # 76: SQ_INSTS_VALU says 76.1
 
 
 def parse():
@@ -129,16 +129,23 @@ def cpu_baseline(dim: int, k_full: int):
 
     ncpu = os.cpu_count() or 1
     best_threads, best_t = 1, float("inf")
+    probed = {}
     for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
         torch.set_num_threads(th)
         run(1)
         t0 = time.perf_counter()
         run(2)
         dt = time.perf_counter() - t0
+        probed[th] = n * 2 / dt
         if dt < best_t:
             best_threads, best_t = th, dt
         if dt > 5.0:
             break
+    if ncpu not in probed:  # the whole machine is always reported (BASELINE.md section 4 names os.cpu_count() threads)
+        torch.set_num_threads(ncpu)
+        t0 = time.perf_counter()
+        run(1)
+        probed[ncpu] = n / (time.perf_counter() - t0)
     torch.set_num_threads(best_threads)
     run(1)
     # size the timed sample to ~6 s per run (3 runs) from the probe's rate
@@ -156,6 +163,9 @@ def cpu_baseline(dim: int, k_full: int):
         "unit": "chain-steps/s",
         "cores": best_threads,
         "kind": "port",
+        "all_cores": {"cores": ncpu, "value": probed[ncpu], "unit": "chain-steps/s",
+                      "note": "torch.set_num_threads(os.cpu_count()), 2-step probe of the same loop"},
+        "thread_probe": {str(th): round(v) for th, v in sorted(probed.items())},
         "sample": f"oracle (torch CPU restatement of the reference loop: randn + autograd gradient + eager update), "
                   f"DoubleWell n=2^16 dim={dim} k={k}, median of {len(times)} runs ({t:.2f} s each) at the fastest of the "
                   f"probed torch thread counts ({best_threads} of {ncpu} cores); rate is per chain-step.  BASELINE.md section 4 "
@@ -226,8 +236,28 @@ def issue_costs(device, blocks=256 * 8, iters=2048, reps=3):
         "plain": 1.0,
     }
     loop = sum(LEAN_LOOP_MIX[k] * units[k] for k in LEAN_LOOP_MIX)
+    # kind 7: the loop's own static mix (77 instructions per trip), dependency-free at eight waves per SIMD: seconds per
+    # wave-trip, whole chip -- the ceiling of a kernel made of exactly this mix
+    # eight rounds of workgroups per launch (the kernel's launch is 32 rounds deep: a single round pays the ramp and the tail in
+    # full), the fastest of three: a ceiling, not an average
+    mix_blocks = blocks * 8
+    mix_out = torch.empty(mix_blocks * 256, dtype=torch.float32, device=device)
+
+    def t_mix_once():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call("ebm_probe_issue_f32", mix_out.data_ptr(), mix_blocks, iters, 7, st)
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b)
+
+    t_mix_once()
+    t_mix = min(t_mix_once() for _ in range(3)) / 8.0  # per round of `blocks` workgroups
+    mixed_s_per_wave_trip = t_mix * 1e-3 / (blocks * 4 * iters)
     return {"units_per_class": {k: round(v, 3) for k, v in units.items()}, "static_mix_per_group_step": LEAN_LOOP_MIX,
-            "issue_units_per_float4_group_step": loop, "round1_constant": LEAN_LOOP_ISSUE_UNITS}
+            "issue_units_per_float4_group_step": loop, "round1_constant": LEAN_LOOP_ISSUE_UNITS,
+            "mixed_stream_s_per_wave_trip": mixed_s_per_wave_trip,
+            "mixed_stream_units_per_trip": t_mix / per if per > 0 else None}
 
 
 def pick_threads(run_once, candidates=(8, 16, 32, 64)):
@@ -345,7 +375,7 @@ def kernel_ms_of(entry, fn, reps, device):
 # ---------------------------------------------------------------------------------------
 # the other BASELINE configs, measured in the same run (N = 1, rank 0): `extra`
 # ---------------------------------------------------------------------------------------
-def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=True):
+def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=True, mixed_s_per_wave_trip=None):
     out = []
 
     def guarded(name, fn):
@@ -367,11 +397,12 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         t = timed(fn, reps=5, warm=2, device=device)
         kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 3, device)
         _, d = s.sample(x=x0, n_steps=T, thin=T, return_diagnostics=True, generator=gen)
-        # Work actually executed.  The ring's modes differ in columns 0..1 only; the kernel (rows.h: kGmmSlot1) runs the
-        # two K x 4 passes over the one float4 slot that holds them and treats the other 28 columns as the shared
-        # quadratic, and it carries energy / force across transitions: L evaluations per transition, not L + 1.
+        # Work actually executed.  The ring's modes differ in columns 0..1 only; the kernel (csrc/hmc_ring.hip:
+        # hmc_slot1_kernel<2>) runs the two K x 2 passes over those columns and treats the other 30 as the shared quadratic
+        # (kick and drift: two FMAs per column and step), and it carries energy / active force across transitions: L
+        # evaluations per transition, not L + 1.
         evals = n * T * L
-        flops = evals * (2 * 2 * 8 * 4 + 2 * (dim - 4)) + n * T * L * 6 * dim
+        flops = evals * (2 * 2 * 8 * 2) + n * T * L * 4 * dim
         # the same call on a mixture whose means differ in EVERY column (the general body: two K x dim passes)
         gd = torch.Generator().manual_seed(7)
         dense = ta.GaussianMixtureModel(torch.randn(8, dim, generator=gd) * 2.0, sigma=1.0, device=device)
@@ -379,13 +410,14 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         fd = lambda: sd.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
         td = timed(fd, reps=3, warm=1, device=device)
         kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 3, device)
-        dense_flops = evals * (2 * 2 * 8 * dim) + n * T * L * 6 * dim
+        dense_flops = n * T * (L + 1) * (2 * 2 * 8 * dim + 4 * dim) + n * T * L * 4 * dim  # L + 1 evaluations (csrc/hmc_gmm32.hip)
         return {
             "name": "config3_hmc_gmm8", "workload": "HamiltonianMonteCarlo.sample, L=20, 8-mode GaussianMixture, n_chains=2^18, dim=32, "
             "eps=0.1, 50 MH steps per call (BASELINE configs[2])", "metric": "MH-steps/s", "value": n * T / t,
             "ms_per_call": t * 1e3, "kernel_ms_per_call": kms, "leapfrog_steps_per_s": n * T * L / t,
             "grad_evals_per_s": evals / t, "executed_fp32_TFLOPs": flops / (kms * 1e-3 if kms else t) / 1e12,
-            "bound": "valu", "body": "active-column (the ring's means differ in columns 0..1 only)",
+            "bound": "valu", "body": "hmc_slot1_kernel<2> (csrc/hmc_ring.hip): two active columns (the ring's means differ in columns 0..1 only), "
+                                     "four waves per SIMD, 0 scratch; profiles/r04_pmc_hmc_c3.txt: VALU busy 92.7 %, counter traffic 1.006 x algorithmic",
             "step_equivalent_GBps": n * T * 8 * dim / t / 1e9,
             "acceptance_rate": float(d["acceptance_rate"][-1]),
             "cpu_baseline": cpu_config3() if cpu else None,
@@ -394,9 +426,10 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                 "value": n * T / td, "ms_per_call": td * 1e3, "kernel_ms_per_call": kd,
                 "executed_fp32_TFLOPs": dense_flops / (kd * 1e-3 if kd else td) / 1e12,
                 "frac_of_fp32_vector_peak": dense_flops / (kd * 1e-3 if kd else td) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                "note": "VALU-bound, not latency-bound: 78 % of the SIMD cycles execute VALU instructions, 526 per leapfrog step of which "
-                        "256 are the packed FMAs of the two K x dim passes (profiles/r03_pmc_hmc_dense.txt); the 157 TF/s spec figure is "
-                        "not reachable by FMA streams at the clock the part holds (profiles/r03_probe_packed.jsonl: 116 - 123 TFLOP/s)",
+                "note": "hmc_gmm32_kernel (csrc/hmc_gmm32.hip), four waves per SIMD: 84 % of the SIMD cycles execute VALU instructions, 398 per "
+                        "evaluation of which 256 are the packed FMAs of the two K x dim passes, the rest of the time waits on the scalar loads "
+                        "that stream the means (profiles/r04_pmc_hmc_c3.txt); the 157 TF/s spec figure is not reachable by FMA streams at the "
+                        "clock the part holds (profiles/r03_probe_packed.jsonl: 116 - 123 TFLOP/s)",
             },
         }
 
@@ -409,12 +442,12 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         fn = lambda: s.sample(x=x0, n_steps=k, generator=gen)  # noqa: E731
         t = timed(fn, reps=3, warm=1, device=device)
         kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 2, device)
-        limit_ms = (n * dim / 4 / 64) * k * loop_units / valu_rate * 1e3
+        ceiling_ms = (n * dim / 4 / 64) * k * mixed_s_per_wave_trip * 1e3 if mixed_s_per_wave_trip else None
         return {
             "name": "config4_shard", "workload": "LangevinDynamics.sample on DoubleWell, one GPU's shard of BASELINE configs[3]: "
             "n_chains=2^20 (of 2^23 over 8 GPUs), dim=128, k=500", "metric": "chain-steps/s per GPU", "value": n * k / t,
             "ms_per_call": t * 1e3, "kernel_ms_per_call": kms, "bound": "valu",
-            "frac_of_valu_issue_limit": (limit_ms / kms) if kms else None,
+            "frac_of_mixed_ceiling": (ceiling_ms / kms) if (kms and ceiling_ms) else None,  # see roofline.valu.mixed_ceiling_definition
             "step_equivalent_GBps": n * k * 8 * dim / t / 1e9, "step_equivalent_frac_of_8TBps": n * k * 8 * dim / t / 8e12,
             "allgather_bytes_per_rank": n * dim * 4,
         }
@@ -792,6 +825,8 @@ def main():
             loop_units = costs["issue_units_per_float4_group_step"]
             physical = 2 * n * dim * 4  # what the k-fused launch has to move: the state in, the state out
             issue_limit_ms = (n * dim / 4 / 64) * k * loop_units / valu_rate * 1e3
+            # the bound: the same number of wave-trips of the loop's exact static instruction mix, issued dependency-free
+            mixed_ceiling_ms = (n * dim / 4 / 64) * k * costs["mixed_stream_s_per_wave_trip"] * 1e3
             roof = {
                 # The kernel keeps the state in registers for all k steps, so it is NOT memory-shaped: the physical
                 # limiter is VALU issue (Philox-10 + Box-Muller).  `achieved`/`peak`/`frac` keep BASELINE.json's
@@ -807,8 +842,14 @@ def main():
                     "issue_units_per_float4_group_step": loop_units,
                     "issue_costs_measured_in_run": costs,
                     "plain_valu_wave_instr_per_s": valu_rate,
-                    "issue_limit_ms": issue_limit_ms,
-                    "frac_of_issue_limit": issue_limit_ms / kernel_ms,
+                    "mixed_ceiling_ms": mixed_ceiling_ms,
+                    "frac_of_mixed_ceiling": mixed_ceiling_ms / kernel_ms,
+                    "mixed_ceiling_definition": "ebm_probe_issue_f32 kind 7: the lean loop's static mix (18 v_mad_u64_u32, 20 v_bitop3, "
+                                                "8 transcendentals, 20 packed-f32, 10 plain per float4 group and step = 76; SQ_INSTS_VALU: 76.1), dependency-free, "
+                                                "eight waves per SIMD, timed in this run; x the launch's wave-trips / kernel time: <= 1 by construction",
+                    "per_class_sum_ms": issue_limit_ms,
+                    "per_class_sum_note": "sum of per-class costs x static counts: a calibration that over-prices a mixed stream "
+                                          "(classes overlap), NOT a ceiling -- kept for continuity with rounds 1-3",
                 },
                 "hbm_physical": {
                     "bytes_per_launch": physical,
@@ -860,7 +901,8 @@ def main():
         if on_gpu and world == 1 and not args.no_extra:
             line["extra"] = extra_measurements(device, valu_rate or plain_valu_rate(device),
                                                (roof or {}).get("valu", {}).get("issue_units_per_float4_group_step") or LEAN_LOOP_ISSUE_UNITS,
-                                               cpu=not args.no_cpu_baseline)
+                                               cpu=not args.no_cpu_baseline,
+                                               mixed_s_per_wave_trip=((roof or {}).get("valu", {}).get("issue_costs_measured_in_run") or {}).get("mixed_stream_s_per_wave_trip"))
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -334,6 +334,8 @@ EBM_API int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* 
  *   kind 2: 8 x (v_log_f32 + v_add_f32)                 kind 3: 8 v_pk_fma_f32 (16 fused multiply-adds; SGPR-pair multiplicand)
  *   kind 4: 8 v_bitop3_b32                              kind 5: 8 v_pk_fma_f32, every operand a VGPR pair
  *   kind 6: 8 v_pk_mul_f32
+ *   kind 7: the lean Langevin loop's static mix per float4 group and step -- 18 v_mad_u64_u32, 20 v_bitop3_b32, 8 transcendentals,
+ *           20 packed-f32 (14 v_pk_mul_f32 + 6 v_pk_add_f32), 10 plain (76 instructions per iteration; `iters` even), dependency-free: the ceiling of a kernel made of that mix
  * independent across the eight slots (`iters` a multiple of 4 for kinds 3 / 5 / 6).  Since ABI version 3. */
 EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream);
 

@@ -543,7 +543,7 @@ int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* stream) 
 int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream) {
   const char* who = "ebm_probe_issue_f32";
   if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
-  if (kind < 0 || kind > 6) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3 | 5 pk_fma, VGPR operands | 6 pk_mul)", who, kind);
+  if (kind < 0 || kind > 7) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3 | 5 pk_fma, VGPR operands | 6 pk_mul | 7 the lean loop's mix)", who, kind);
   return launch_probe_issue(out, blocks, iters, kind, (hipStream_t)stream);
 }
 

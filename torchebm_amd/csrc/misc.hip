@@ -628,6 +628,67 @@ __global__ __launch_bounds__(kBlock) void probe_issue_kernel(float* __restrict__
   }
 }
 
+// kind 7: the lean Langevin loop's own static instruction mix per float4 group and step (langevin_elem.h; scripts/isa_mix.py:
+// 18 v_mad_u64_u32, 20 v_bitop3_b32, 8 transcendentals, 20 packed-f32 (14 v_pk_mul + 6 v_pk_add), 10 plain = 76 instructions;
+// SQ_INSTS_VALU of the kernel: 76.1 per group-step), dependency-free: every
+// register chain is touched at most twice per trip, ~40 instructions apart.  At eight waves per SIMD its duration per trip
+// is the ceiling a kernel made of exactly this mix can reach on this box at this clock -- bench.py reports the lean kernel's
+// time per group-step against it (roofline.valu.frac_of_mixed_ceiling, <= 1 by construction).
+__global__ __launch_bounds__(kBlock, 8) void probe_mix_kernel(float* __restrict__ out, int iters) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  uint32_t u[10];
+  float f[8], g[3];
+  f32x2 v[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    u[j] = threadIdx.x * 2654435761u + j;
+    v[j] = (f32x2){threadIdx.x * 1e-3f + j, threadIdx.x * 2e-3f + j};
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = 0.3f + threadIdx.x * 1e-4f + j * 0.01f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) g[j] = threadIdx.x * 1e-3f + j;
+  uint32_t k1 = 0x9E3779B9u + blockIdx.x, k2 = 0xBB67AE85u + threadIdx.x;
+  f32x2 mv = {1.0001f + threadIdx.x * 1e-9f, 0.9999f}, cv = {0.5f, 0.25f + threadIdx.x * 1e-9f};
+  float m = 1.0001f + threadIdx.x * 1e-9f, c = 0.5f;
+  asm volatile("" : "+v"(mv), "+v"(cv), "+v"(m), "+v"(c), "+v"(k1), "+v"(k2));
+  for (int it = 0; it < iters; it += 2) {  // two trips per pass of the loop, like the kernel's two steps per trip
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {       // half trips: 9 multiplies + 10 three-input xors + 4 transcendentals + 10 packed each
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        if (j < 9) {
+          const uint64_t p = (uint64_t)0xD2511F53u * u[j];                                   // v_mad_u64_u32 (v_mul_hi + v_mul_lo)
+          u[j] = __builtin_amdgcn_bitop3_b32((uint32_t)(p >> 32), (uint32_t)p, k1, 0x96);  // v_bitop3_b32
+        } else {
+          u[j] = __builtin_amdgcn_bitop3_b32(u[j], k1, k2, 0x96);
+        }
+        asm volatile("" : "+v"(u[j]));
+        if (j < 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[j]) : "v"(mv));  // 14 v_pk_mul_f32 + 6 v_pk_add_f32 per trip, as in the loop
+        else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(cv));
+        if (j < 4) {
+          f[4 * (h & 1) + j] = __builtin_amdgcn_logf(f[4 * (h & 1) + j]) + 2.0f;             // transcendental + one plain op
+          asm volatile("" : "+v"(f[4 * (h & 1) + j]));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(g[j % 3]) : "v"(m), "v"(c));  // 8 + 2 = 10 plain per trip
+  }
+  uint32_t su = 0;
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    su += u[j];
+    s += v[j].x + v[j].y;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += f[j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s += g[j];
+  out[(int64_t)blockIdx.x * kBlock + threadIdx.x] = s + __builtin_bit_cast(float, su & 0x007fffffu);
+}
+
 int launch_probe_issue(float* out, int32_t blocks, int32_t iters, int32_t kind, hipStream_t st) {
   const dim3 g((unsigned)blocks), b(kBlock);
   switch (kind) {
@@ -638,6 +699,7 @@ int launch_probe_issue(float* out, int32_t blocks, int32_t iters, int32_t kind, 
     case 4: hipLaunchKernelGGL(probe_issue_kernel<4>, g, b, 0, st, out, iters); break;
     case 5: hipLaunchKernelGGL(probe_issue_kernel<5>, g, b, 0, st, out, iters); break;
     case 6: hipLaunchKernelGGL(probe_issue_kernel<6>, g, b, 0, st, out, iters); break;
+    case 7: hipLaunchKernelGGL(probe_mix_kernel, g, b, 0, st, out, iters); break;
     default: return fail(EBM_EKIND, "ebm_probe_issue_f32: kind %d", kind);
   }
   return check_launch("ebm_probe_issue_f32");
