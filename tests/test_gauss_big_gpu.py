@@ -149,11 +149,19 @@ def test_diagnostics_come_from_in_kernel_records(cuda_device, dim, n):
 def test_widths_without_a_matrix_chain_kernel_take_the_gemm_step_route(cuda_device, dim):
     """dim 130 (not a multiple of 4) / 1024 (above 512): the sampler runs the per-step route -- the gradient as one library
     GEMM (GaussianModel's closed form above 128 dims), the update kernel on the native field -- not the lane-group chain
-    kernel; same chains as that kernel on the same seed (shared (seed, step, element) field), to fp32 round-off."""
-    n, k = 512, 5
+    kernel; same chains as that kernel on the same seed (shared (seed, step, element) field), to fp32 round-off.  The reroute
+    is for batches that fill the GEMM and calls that can be replayed from a graph: few chains, or
+    capture_graph = False, keep the ONE fused launch."""
+    n, k = 16384, 5
     model, _ = _model(dim, cuda_device, seed=7)
     s = ta.LangevinDynamics(model, step_size=0.01, device=cuda_device)
     x0 = torch.randn(n, dim, device=cuda_device)
+    c_chain = hip_calls("ebm_langevin_chain_f32")
+    s.sample(x=x0[:512], n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(11))
+    s.capture_graph = False
+    s.sample(x=x0, n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(11))
+    s.capture_graph = None
+    assert hip_calls("ebm_langevin_chain_f32") == c_chain + 2
     c_chain, c_step = hip_calls("ebm_langevin_chain_f32"), hip_calls("ebm_langevin_step_f32") + hip_calls("ebm_langevin_step_dev_f32")
     out = s.sample(x=x0, n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(11))
     assert hip_calls("ebm_langevin_chain_f32") == c_chain
@@ -175,11 +183,14 @@ def test_wide_gaussian_hmc_takes_the_gemm_transition_route(cuda_device):
     """Above 128 dims HamiltonianMonteCarlo runs the per-transition route for a GaussianModel -- gradient and energy as one
     library GEMM each, kick / drift / accept kernels on the native field -- instead of the lane-group transition kernel;
     same generator => same draws, so the chains agree with that kernel's (through the C ABI) except for borderline accepts."""
-    dim, n, T, L = 192, 512, 4, 5
+    dim, n, T, L = 192, 16384, 4, 5
     model, _ = _model(dim, cuda_device, seed=9)
     s = ta.HamiltonianMonteCarlo(model, step_size=0.08, n_leapfrog_steps=L, device=cuda_device)
     x0 = torch.randn(n, dim, device=cuda_device)
     c0 = hip_calls("ebm_hmc_chain_f32")
+    s.sample(x=x0[:512], n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(21))  # few chains: the fused launch
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    c0 += 1
     out, diag = s.sample(x=x0, n_steps=T, return_diagnostics=True, generator=torch.Generator(device=cuda_device).manual_seed(21))
     assert hip_calls("ebm_hmc_chain_f32") == c0
     assert 0.5 < diag["acceptance_rate"].mean().item() <= 1.0

@@ -10,7 +10,14 @@ from helpers import grid_inputs, grid_names, load_grid, oracle_energy, sha16
 
 # the fixtures were recorded with one intra-op thread (tests/golden/make_golden.py): above 128 dims the CPU BLAS blocks the
 # Gaussian's bmm differently per thread count, and the bit-for-bit bar below is against THAT run (7e-7 apart at 8 threads)
-torch.set_num_threads(1)
+@pytest.fixture(autouse=True, scope="module")
+def _one_intra_op_thread():
+    """One thread for THIS module only; the previous count comes back on teardown (a module-level set_num_threads would
+    make every later CPU test single-threaded and the outcome depend on collection order)."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(before)
 
 
 def test_the_grid_is_complete():

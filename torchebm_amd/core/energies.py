@@ -239,17 +239,7 @@ class GaussianModel(BaseModel):
         if x.ndim != 2 or x.shape[1] != d:
             raise ValueError(f"Input x expected batch_shape (batch_size, {d}), but got {x.shape}")
         x = x.to(dtype=self.dtype, device=self.device)
-        prec = self.cov_inv.to(dtype=self.dtype, device=x.device)
-        if (x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 1 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
-                and self._on_matrix_cores(x) and self._is_exactly(GaussianModel) and prec.dtype == torch.float32):
-            # a sampler's energy call (no autograd graph wanted): the same contraction pass, energy only
-            spec = self.fused_spec()
-            if spec is not None:
-                state = x.contiguous()
-                energy = torch.empty(state.shape[0], dtype=torch.float32, device=state.device)
-                _lib.call("ebm_energy_grad_f32", spec.to_c(), state.data_ptr(), state.shape[0], d, energy.data_ptr(), None,
-                          _lib.stream_handle(state.device))
-                return energy
+        prec = self.cov_inv.to(dtype=self.dtype, device=x.device)  # read LIVE: forward() never goes through the spec cache
         delta = x - self.mean
         if delta.shape[0] > 1 and not (delta.is_cuda and d > self.CLOSED_FORM_GRADIENT_ABOVE):
             # batched form: P (d x d, broadcast) @ delta (d x 1), then delta^T @ that
@@ -258,6 +248,25 @@ class GaussianModel(BaseModel):
         # one row, or a wide Gaussian on the GPU: the reference's single-row form (base_model.py:208) -- ONE GEMM instead of n
         # mat-vecs against an expanded P (at dim 512 and 2^15 rows the batched form reads 34 GB); same value up to fp32 rounding
         return 0.5 * torch.sum(delta * torch.matmul(delta, prec), dim=-1)
+
+    def _sampler_energy(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """The energy for a SAMPLER's own use (the accept step of the per-transition HMC route, diagnostics): one contraction pass
+        of the tiled kernel at the widths it covers, ``None`` elsewhere (the caller then calls ``forward``).  Not reachable
+        through ``model(x)``: the public forward reads ``cov_inv`` live and rounds the same way with and without autograd --
+        this path reads sym(P) from the spec cache, which the sampler refreshes at the top of every ``sample()`` call."""
+        d = self.mean.shape[0]
+        if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] > 1 and x.shape[1] == d
+                and not torch.is_autocast_enabled() and self._on_matrix_cores(x) and self._is_exactly(GaussianModel)
+                and self.cov_inv.dtype == torch.float32):
+            return None
+        spec = self.fused_spec()
+        if spec is None:
+            return None
+        state = x.contiguous()
+        energy = torch.empty(state.shape[0], dtype=torch.float32, device=state.device)
+        _lib.call("ebm_energy_grad_f32", spec.to_c(), state.data_ptr(), state.shape[0], d, energy.data_ptr(), None,
+                  _lib.stream_handle(state.device))
+        return energy
 
     #: widths above which ``gradient()`` is the closed form ``(x - mu) @ sym(P)`` -- ONE library GEMM -- instead of autograd
     #: through ``forward``'s batched form (base_model.py:199-206 expands P to n matrices: at dim 1024 that is n mat-vecs of

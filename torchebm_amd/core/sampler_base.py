@@ -56,6 +56,11 @@ class BaseSampler(Schedulable, TorchEBMModule, ABC):
     def _model_energy(self, x: torch.Tensor, model_kwargs: Dict[str, object]) -> torch.Tensor:
         if model_kwargs:
             return self.model(x, **model_kwargs)
+        fast = getattr(self.model, "_sampler_energy", None)  # (a kernel pass for the sampler's own energy calls: GaussianModel)
+        if fast is not None and not torch.is_grad_enabled():
+            e = fast(x)
+            if e is not None:
+                return e
         return self.model(x)
 
     @abstractmethod

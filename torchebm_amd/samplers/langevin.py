@@ -41,11 +41,22 @@ def em_coefficients(eta: float, sigma: float) -> Tuple[float, float, float]:
     return eta, eta**0.5, (2.0 * sigma**2) ** 0.5
 
 
+_RECORD_SCRATCH_KEEP_BYTES = 16 << 20
+WIDE_GAUSSIAN_STEP_ROUTE_MIN_CHAINS = 16384  # below: k x (GEMM + update) launches lose to the one fused launch
+_CAPTURE_LOCK = __import__("threading").Lock()  # serialises graph capture: it toggles the process-wide cyclic GC
+
+
 def _record_scratch(sampler, device: torch.device, stream: int, rec_floats: int, work_doubles: int):
     """The record buffer and the merge's fp64 work row of a diagnostics call, kept on the sampler between calls of the same
     size on the same stream: the merge leaves the work row zeroed (include/ebm_hip.h), so nothing has to be allocated or
     filled per call -- on a 0.6 ms sampler call the two allocations and the fill kernel were a tenth of the records' cost.
-    Keyed by the stream: calls on different streams do not share (the zeroed-after-merge contract is per stream order)."""
+    Keyed by the stream: calls on different streams do not share (the zeroed-after-merge contract is per stream order).
+    Only SMALL buffers are kept (<= 16 MiB: the sub-millisecond calls this was built for); a large run's records (up to
+    1 GiB) are per-call temporaries that go back to the caching allocator, as they did before."""
+    if rec_floats * 4 > _RECORD_SCRATCH_KEEP_BYTES:
+        sampler.__dict__.pop("_record_scratch_held", None)
+        return (torch.empty(rec_floats, dtype=torch.float32, device=device),
+                torch.zeros(work_doubles, dtype=torch.float64, device=device))
     key = (device, stream, rec_floats, work_doubles)
     held = sampler.__dict__.get("_record_scratch_held")
     if held is None or held[0] != key or sampler.__dict__.get("_record_scratch_open", False):
@@ -93,25 +104,28 @@ def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
         # The cyclic collector must not run inside the capture: finalising a dead sampler's CUDAGraph (or any tensor whose
         # storage goes back to the driver) while this stream records aborts the process.  torch.cuda.graph() collects
         # once on entry; what becomes garbage during the body waits until the capture has ended.
+        # The GC switch is process-wide: the lock keeps a second sampler capturing on another thread from re-enabling it in
+        # the middle of this capture (and the prior state is read inside the lock).
         import gc
 
-        gc_was_on = gc.isenabled()
-        try:
-            graph = torch.cuda.CUDAGraph()
-            gc.disable()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                g["body"]()
-            g["graph"] = graph
-            return
-        except RuntimeError as exc:  # the forward cannot be captured (host sync, data-dependent control flow ...)
-            if "ebm_" in str(exc):
-                raise
-            warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
-                      "continuing with eager launches.", UserWarning)
-            probe, why = None, [f"capture failed: {exc}"]
-        finally:
-            if gc_was_on:
-                gc.enable()
+        with _CAPTURE_LOCK:
+            gc_was_on = gc.isenabled()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                gc.disable()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    g["body"]()
+                g["graph"] = graph
+                return
+            except RuntimeError as exc:  # the forward cannot be captured (host sync, data-dependent control flow ...)
+                if "ebm_" in str(exc):
+                    raise
+                warn_once("capture-graph-failed", f"torchebm_amd: HIP-graph capture of the step route failed ({exc}); "
+                          "continuing with eager launches.", UserWarning)
+                probe, why = None, [f"capture failed: {exc}"]
+            finally:
+                if gc_was_on:
+                    gc.enable()
     refused.pop(g["key"], None)
     if len(refused) >= 8:
         refused.pop(next(iter(refused)))
@@ -181,10 +195,14 @@ class LangevinDynamics(BaseSampler):
             )
             return "eager", None
         spec = self._fusable_spec(x, model_kwargs)
-        if spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and not _gaussian_chain_on_matrix_cores(spec.dim):
+        if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and not _gaussian_chain_on_matrix_cores(spec.dim)
+                and x.shape[0] >= WIDE_GAUSSIAN_STEP_ROUTE_MIN_CHAINS and self.capture_graph is not False
+                and self._graph_eligible(model_kwargs)):
             # The chain kernels for these widths (not a multiple of 4 above 128, or above 512) are the lane-group mat-vec:
             # 2 TFLOP/s.  The step route -- one library GEMM for the gradient (GaussianModel._hip_gradient) and the fused
-            # update kernel on the same random field, replayed from a HIP graph -- is 10 - 40x faster there.
+            # update kernel on the same random field, replayed from a HIP graph -- is 10 - 40x faster there, for batches
+            # that fill the GEMM and calls that can be replayed.  Few chains, capture_graph = False, a scheduled step size
+            # or conditioning keep the ONE fused launch (with its in-kernel records and donate_input).
             return "step", None
         return ("fused", spec) if spec is not None else ("step", None)
 
@@ -562,7 +580,7 @@ class LangevinDynamics(BaseSampler):
                 diag["mean"][keep] = state[0]
                 diag["var"][keep].zero_()
             if wide_gaussian:
-                diag["energy"][keep] = self.model(state).mean()   # one library GEMM (GaussianModel.forward, wide CUDA batches)
+                diag["energy"][keep] = self._model_energy(state, {}).mean()   # one library GEMM (GaussianModel.forward, wide CUDA batches)
             else:
                 _lib.call("ebm_energy_grad_f32", spec_c, _lib.ptr(state), n, dim, _lib.ptr(energy), None, stream)
                 diag["energy"][keep] = energy.mean()
