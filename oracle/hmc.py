@@ -61,6 +61,7 @@ def hmc_chain(
     want_traj: bool = False,
     want_diag: bool = False,
     want_margins: bool = False,
+    forced_accept: Optional[torch.Tensor] = None,
 ):
     """T = len(eps_values) transitions; ``p_noise[t]`` are the standard normals of transition
     t (scaled by sqrt(mass) here, hmc.py:118-133), ``u[t]`` the accept uniforms.
@@ -68,6 +69,8 @@ def hmc_chain(
     Returns a dict: ``x`` final state, ``accepted`` bool [T, n], ``margin`` = min |u - a| over
     all decisions (how far the closest accept/reject call was from flipping; ``margins`` [T, n]: per decision), optional
     ``trajectory`` [n, T // thin, dim] and ``diagnostics`` (mean, var, energy, acceptance_rate).
+    ``forced_accept`` (bool [T, n]): take these decisions instead of ``u < a`` -- the fp64 referee run follows the
+    fp32 run's accept path (tests/golden/make_referee.py).
     """
     x = x0.clone()
     n, dim = x.shape
@@ -99,6 +102,8 @@ def hmc_chain(
         delta = (h0 - h1).clamp_(min=-50.0, max=50.0)
         a = torch.exp(delta).clamp_(max=1.0)
         acc = u[t] < a
+        if forced_accept is not None:
+            acc = forced_accept[t].clone()
         finite = torch.isfinite(a)
         if bool(finite.any()):
             margin = min(margin, float((u[t][finite] - a[finite]).abs().min()))
