@@ -278,7 +278,11 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       until_keep = a.thin;
       if (a.traj && active) {
         if (a.pack > 1) {  // packed rows: element j of the row is coordinate j % sub_dim of chain pack * row + j / sub_dim
-          const int sd = a.sub_dim;
+          // (sub_dim laundered INSIDE the branch: visible, the 64 per-element divisions and addresses of this path are
+          //  loop-invariant, get hoisted into the step loop and spilled there -- 53 scratch stores per lane and step of
+          //  every call, packed or not: the dim-128 / 160 kernels wrote 2.7 - 4x their state size per step)
+          int sd = a.sub_dim;
+          asm volatile("" : "+s"(sd));
           const int64_t kept = keep_off / dim;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -354,7 +358,9 @@ __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_kernel(GaussArgs
 }
 template <int NT>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(GaussArgs a) {
-  gauss_langevin_mfma_body<NT, true, true>(a);
+  // five tiles: the normals of four are drawn behind the MFMAs, the fifth tile's after the contraction -- all five (80
+  // registers across the contraction) left the 512-register wave with 76 spilled values
+  gauss_langevin_mfma_body<NT, true, true, kBlock, (NT >= 5 ? 4 : NT)>(a);
 }
 template <int NT, int GKR>
 __global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_kernel(GaussArgs a) {
