@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _plane_means(k, dim, cols, seed=0, shared_zero=False):
-    """k means that differ in `cols` (a subset of 0..3) only; the shared columns random (or zero)."""
+    """k means that differ in `cols` (inside ONE aligned block of four columns) only; the shared columns random (or zero)."""
     g = torch.Generator().manual_seed(seed)
     m = torch.zeros(k, dim)
     if not shared_zero:
@@ -42,13 +42,14 @@ def _run(desc, x0, T, L, eps, dev, p=None, u=None, seed=0, offset=0, thin=1, wan
     return x.cpu(), mask.cpu().bool(), cnt.cpu(), (traj.cpu() if want_traj else None)
 
 
-@pytest.mark.parametrize("cols,k", [((0, 1), 8), ((0, 1, 2, 3), 8), ((0, 3), 5), ((1,), 3)])
+@pytest.mark.parametrize("cols,k", [((0, 1), 8), ((0, 1, 2, 3), 8), ((0, 3), 5), ((1,), 3),
+                                    ((8, 9), 8), ((20, 21, 22, 23), 6), ((28, 31), 4)])  # ... and in another slot (round 4)
 @pytest.mark.parametrize("n", [1, 255, 700])
 def test_bodies_match_oracle_and_general_kernel(cuda_device, cols, k, n):
     dim, T, L, eps = 32, 6, 7, 0.09
     means = _plane_means(k, dim, cols, seed=len(cols) + k)
     model = ta.GaussianMixtureModel(means, sigma=0.9, device=cuda_device)
-    assert int(model.fused_spec().aux.item()) == 1
+    assert int(model.fused_spec().aux.item()) == 1 << (cols[0] // 4)
     en = oracle.GaussianMixture(means, 0.9)
     g = torch.Generator().manual_seed(n)
     x0 = torch.randn(n, dim, generator=g) * 1.5

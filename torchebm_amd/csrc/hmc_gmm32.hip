@@ -384,7 +384,7 @@ __device__ __forceinline__ void dense_body(const HmcArgs& a) {
 template <bool DIAG>
 __global__ __launch_bounds__(kBlock, 4) void hmc_gmm32_kernel(HmcArgs a) {
   // the mixtures whose means differ in columns 0..3 only have their own kernels (hmc_ring.hip), launched in front
-  if (gmm_is_slot1(a.energy)) return;
+  if (gmm_single_slot(a.energy) >= 0) return;
   dense_body<DIAG>(a);
 }
 

@@ -1,5 +1,5 @@
-// HMC transition kernel for mixtures whose component means differ in columns 0..3 only (the `aux` mask of
-// EBM_ENERGY_GMM equal to 1: a K-mode mixture of a plane embedded in a wider state -- BASELINE config 3's
+// HMC transition kernel for mixtures whose component means differ in ONE aligned block of four columns only (the `aux` mask of
+// EBM_ENERGY_GMM a single bit; bit 0: a K-mode mixture of a plane embedded in a wider state -- BASELINE config 3's
 // eight-mode ring), one lane per chain, dim 32, identity mass.  Round 4: its own kernel at FOUR waves per SIMD.
 //
 // Reference: torchebm/samplers/hmc.py:243-312 (transition loop, Metropolis accept),
@@ -44,9 +44,13 @@ constexpr int kLdsHead = kTabFloats + 8; // ... and the eight logit offsets behi
 // ACT: active columns (2 or 4), pairs 0 .. ACT/2 - 1 of the row.
 // DIAG: per-block diagnostics records at the kept transitions (diag.h), a compile-time switch: the call into diag::emit
 // costs registers around it.
+// slot: the 4-column block the means differ in.  The row is held with that block FIRST: register block i holds column block
+// blk(i) (0 <-> slot swapped) -- every per-column operation is symmetric in the columns, so only the addresses know
+// (loads, stores, the Philox counters of the momentum draw, the staged tables).
 template <int ACT, bool DIAG>
-__device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
+__device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab, const int slot) {
   constexpr int AP = ACT / 2;  // active pairs
+  const auto blk = [slot](int i) { return i == 0 ? slot : (i == slot ? 0 : i); };
   // The lane's chain index is the ONLY per-lane address register that lives through the kernel: every global address
   // is formed from it where it is used (chain_now() hides it from the optimiser, which otherwise hoists row offsets,
   // Philox counters and pointers out of the transition loop -- a dozen 64-bit registers, spilled and reloaded).
@@ -175,7 +179,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (active) q = *reinterpret_cast<const float4*>(src + 4 * v);
+      if (active) q = *reinterpret_cast<const float4*>(src + 4 * blk(v));
       R[2 * v] = v2f{q.x, q.y};
       R[2 * v + 1] = v2f{q.z, q.w};
     }
@@ -196,7 +200,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
     if (active) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        *reinterpret_cast<float4*>(dst + 4 * v) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
+        *reinterpret_cast<float4*>(dst + 4 * blk(v)) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
     }
   };
   auto unpark = [&](v2f (&R)[NP]) {
@@ -222,7 +226,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
       const uint64_t g0 = (uint64_t)c * (uint64_t)(D / 4);  // Philox counter of the row's first float4
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const F4 n = normal4_at(a.key, g0 + (uint64_t)v, step);
+        const F4 n = normal4_at(a.key, g0 + (uint64_t)blk(v), step);
         P[2 * v] = v2f{n.v[0], n.v[1]};
         P[2 * v + 1] = v2f{n.v[2], n.v[3]};
         // two counters at a time: eight interleaved Philox chains cost more registers than the budget has
@@ -436,7 +440,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
           shift(O, 1.0f);
 #pragma unroll
           for (int v = 0; v < NV; ++v)
-            *reinterpret_cast<float4*>(tile + (int)threadIdx.x * D + 4 * v) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
+            *reinterpret_cast<float4*>(tile + (int)threadIdx.x * D + 4 * blk(v)) = make_float4(O[2 * v].x, O[2 * v].y, O[2 * v + 1].x, O[2 * v + 1].y);
         }
         const int64_t left = a.n_chains - (int64_t)blockIdx.x * kBlock;
         const int valid = (left >= kBlock ? kBlock : (left > 0 ? (int)left : 0)) * D;
@@ -456,7 +460,8 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab) {
 // register budget -- with both bodies in one kernel the allocator spilled).
 template <int ACT, bool DIAG>
 __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
-  if (!gmm_is_slot1(a.energy)) return;  // any other mask: the dense kernel, launched behind this one, does the work
+  const int slot = gmm_single_slot(a.energy);
+  if (slot < 0) return;  // no or several slots: the dense kernel, launched behind this one, does the work
   // ---- LDS: [table | parked state, [v][thread] float4 | parked active force, [thread] float4]
   float* const tab = hmc_smem;
   const int K = a.energy.n_comp;
@@ -464,11 +469,12 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
     float v;
     if (i < 32) {
       const int k = i >> 2, kk = k < K ? k : K - 1;  // padding components repeat the last row, their log-weight is -inf
-      v = a.energy.dev0[kk * D + (i & 3)];
+      v = a.energy.dev0[kk * D + 4 * slot + (i & 3)];
     } else if (i < 40) {
       v = (i - 32) < K ? a.energy.dev1[i - 32] : -__builtin_inff();
-    } else {
-      v = a.energy.dev0[i - 40];
+    } else {  // row 0 of the means in REGISTER order: position p holds column 4 blk(p / 4) + p % 4
+      const int pos = i - 40, b = pos >> 2;
+      v = a.energy.dev0[4 * (b == 0 ? slot : (b == slot ? 0 : b)) + (pos & 3)];
     }
     tab[i] = v;
   }
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
   bool plane = true;
   for (int k = 1; k < 8; ++k) plane = plane && tab[4 * k + 2] == tab[2] && tab[4 * k + 3] == tab[3];
   if ((__builtin_amdgcn_readfirstlane((int)plane) != 0) != (ACT == 2)) return;
-  slot1_body<ACT, DIAG>(a, tab);
+  slot1_body<ACT, DIAG>(a, tab, slot);
 }
 
 // Launched IN FRONT of the dense kernel when the energy carries an active-column mask: the kernel whose body does not

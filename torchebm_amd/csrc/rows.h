@@ -231,6 +231,14 @@ __device__ __forceinline__ bool gmm_is_slot1(const EnergyParams& P) {
   if (P.aux == nullptr || P.n_comp > 8 || P.n_comp < 1) return false;
   return __builtin_amdgcn_readfirstlane(P.aux[0]) == 1;
 }
+// The one 4-column slot (0 .. 7) the component means differ in, or -1 (no hint, no or several slots): hmc_ring.hip runs the
+// active-column kernels for ANY single slot (round 4; the shared body above only for slot 0).
+__device__ __forceinline__ int gmm_single_slot(const EnergyParams& P) {
+  if (P.aux == nullptr || P.n_comp > 8 || P.n_comp < 1) return -1;
+  const int mask = __builtin_amdgcn_readfirstlane(P.aux[0]);
+  if (mask <= 0 || mask > 0x80 || (mask & (mask - 1)) != 0) return -1;
+  return __builtin_ctz((unsigned)mask);
+}
 
 // LDS carve-up (dynamic shared memory, 16-byte aligned):
 //   [0, param_floats)                      shared parameters (P rows / mixture means + log-weights)
