@@ -32,13 +32,14 @@
 #ifndef EBM_HIP_H
 #define EBM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 3
+#define EBM_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -71,7 +72,13 @@ enum {
                                  dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
                                  Supported by ebm_langevin_chain_f32, ebm_energy_grad_f32 and ebm_hmc_chain_f32 (EBM_EDIM for
                                  other widths).  H = 256 reads
-                                 the weights from dev0 throughout the launch: dev0 must then be 16-byte aligned.           */
+                                 the weights from dev0 throughout the launch: dev0 must then be 16-byte aligned.
+                                 aux = NULL, or (H = 128, 64 < dim <= 128, since ABI version 4) the device image that
+                                 ebm_mlp_w1_image_f32 built from THIS dev0 (cast to const int32_t*): with it the Langevin
+                                 and energy / gradient entries run their contractions on the bf16 matrix pipe with
+                                 three-way split operands (fp32 accuracy) as the narrower shapes always do; without it on
+                                 the exact-f32 matrix instruction (1.6x slower).  A stale image gives the old network's
+                                 samples; NULL is always safe.                                                            */
 };
 
 typedef struct ebm_energy {
@@ -338,6 +345,15 @@ EBM_API int ebm_probe_valu_f32(float* out, int32_t blocks, int32_t iters, void* 
  *           20 packed-f32 (14 v_pk_mul_f32 + 6 v_pk_add_f32), 10 plain (76 instructions per iteration; `iters` even), dependency-free: the ceiling of a kernel made of that mix
  * independent across the eight slots (`iters` a multiple of 4 for kinds 3 / 5 / 6).  Since ABI version 3. */
 EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind, void* stream);
+
+/* The pre-split first-layer image of an EBM_ENERGY_MLP network (see the enum: ebm_energy_t.aux).  Both weight matrices as
+ * bf16 triples are 192 KB at H = 128 and dim > 64 -- more than a CU's LDS -- so the W1 triple is laid out once in global
+ * memory (the caller's buffer, 16-byte aligned, ebm_mlp_w1_image_bytes() long; 0 = this shape has no image) in the order the
+ * chain kernel streams it through LDS.  Rebuild it whenever the parameters change (one small kernel; stream-ordered like every
+ * entry).  No counterpart in the reference: there the network is nn.Linear modules evaluated by autograd every step
+ * (samplers/langevin_dynamics.py:168-172).  Since ABI version 4. */
+EBM_API size_t ebm_mlp_w1_image_bytes(int32_t hidden, int32_t dim);
+EBM_API int ebm_mlp_w1_image_f32(const float* params, int32_t hidden, int32_t dim, void* image, void* stream);
 
 #ifdef __cplusplus
 }

@@ -459,7 +459,15 @@ class MLPEnergy(BaseModel):
             packed = torch.cat([p.detach().reshape(-1) for p in (
                 self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
                 self.net[4].weight, self.net[4].bias)])
-        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, langevin_only=True, dim=int(self.in_dim),
+            # H = 128 beyond dim 64: the pre-split W1 image the chain kernel streams through LDS (include/ebm_hip.h,
+            # ebm_mlp_w1_image_f32) -- rebuilt with the parameters, i.e. on every call, like `packed` itself
+            image = None
+            n_img = int(_lib.lib().ebm_mlp_w1_image_bytes(int(self.hidden), int(self.in_dim)))
+            if n_img:
+                image = torch.empty(n_img // 4, dtype=torch.int32, device=w.device)
+                _lib.call("ebm_mlp_w1_image_f32", packed.data_ptr(), int(self.hidden), int(self.in_dim), image.data_ptr(),
+                          _lib.stream_handle(w.device))
+        return FusedSpec(_lib.ENERGY_MLP, n_comp=self.hidden, dev0=packed, aux=image, langevin_only=True, dim=int(self.in_dim),
                          hmc=self.in_dim <= self.HMC_MAX_DIM.get(self.hidden, 0))
 
 

@@ -59,6 +59,8 @@ int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
+size_t mlp_w1_image_bytes(int32_t hidden, int32_t dim);  // mlp_wide_slab.hip
+int launch_mlp_w1_image(const float* params, int32_t hidden, int32_t dim, void* image, hipStream_t st, const char* who);
 bool gauss_mfma_supported(int32_t dim);
 bool gauss_lds5_supported(int32_t dim);   // gauss_mfma.hip: 132 .. 160, Ps resident in LDS (plain Langevin call)
 int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 as is, > 1 packed rows, 0 no matrix-layout form
@@ -545,6 +547,12 @@ int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind,
   if (!out || blocks < 1 || iters < 1) return fail(EBM_EINVAL, "%s: out is NULL or blocks/iters < 1", who);
   if (kind < 0 || kind > 7) return fail(EBM_EINVAL, "%s: kind %d (0 fma | 1 mad_u64_u32 | 2 transcendental | 3 pk_fma | 4 bitop3 | 5 pk_fma, VGPR operands | 6 pk_mul | 7 the lean loop's mix)", who, kind);
   return launch_probe_issue(out, blocks, iters, kind, (hipStream_t)stream);
+}
+
+size_t ebm_mlp_w1_image_bytes(int32_t hidden, int32_t dim) { return mlp_w1_image_bytes(hidden, dim); }
+
+int ebm_mlp_w1_image_f32(const float* params, int32_t hidden, int32_t dim, void* image, void* stream) {
+  return launch_mlp_w1_image(params, hidden, dim, image, (hipStream_t)stream, "ebm_mlp_w1_image_f32");
 }
 
 }  // extern "C"

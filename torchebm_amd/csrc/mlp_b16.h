@@ -55,6 +55,37 @@ struct Img {
 
 __host__ __device__ constexpr size_t image_bytes(int rows, int cols) { return (size_t)3 * rows * cols * 2; }
 
+// ---- MODE 3 (round 4): W1 at H = 128 and dim > 64.  Both images are 96 KB -- 192 KB against the CU's 160.  W2 stays
+// resident; W1 is kept in GLOBAL memory as a PRE-SPLIT image (ebm_mlp_w1_image_f32 builds it: the caller's buffer, handed
+// over in ebm_energy_t.aux) made of four SLABS of 32 hidden rows: slab s = the three split images [32][128] of rows
+// 32 s .. 32 s + 31, each exactly what stage_image<32, 128> would write (24 KB).  A slab is what ONE output tile of the
+// forward walk (W1 x: all eight K-blocks of rows 32 s ..) and ONE pair of K-blocks of the transposed walk (W1^T d1) read, so
+// both walks run slab by slab out of two 24 KB LDS buffers, filled by LDS-direct loads (global_load_lds_dwordx4: no
+// registers, no ds_write pass) one slab ahead of the MFMAs -- 48 of them per slab and wave to land in.
+constexpr int kSlabRows = 32, kSlabCols = 128;
+constexpr uint32_t kSlabBytes = 3u * kSlabRows * kSlabCols * 2u;  // 24 576
+// All threads: request slab `s` of the global image into the LDS buffer at byte address `dst`.  One wave-instruction moves
+// 1 KiB -- lane l's 16 bytes land at M0 + 16 l, so the copy is linear -- 24 pieces, six per wave of a 256-thread workgroup.
+// Written as assembly ON PURPOSE: after the builtin the compiler assumes every later LDS read may alias the transfer and
+// puts s_waitcnt vmcnt(0) in front of it, which serialises exactly the overlap this is for; slab_wait() is the one wait.
+// (The buffers sit below 64 KiB -- mlp_wide_setup.inc -- so M0 holds a plain 16-bit LDS address.)
+__device__ __forceinline__ void slab_request(const char* image, int s, uint32_t dst, int n_threads) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, waves = n_threads >> 6;
+  const char* src = image + (size_t)s * kSlabBytes;
+  for (int piece = wave; piece < (int)(kSlabBytes / 1024u); piece += waves) {
+    const uint32_t voff = (uint32_t)(piece * 1024 + lane * 16), base = dst + (uint32_t)piece * 1024u;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
+  }
+}
+// Before a slab is read: this wave's pieces have landed, and so have everybody else's (the barrier); every wave has also
+// finished with the buffer used before, which the next request overwrites.
+__device__ __forceinline__ void slab_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // All threads of the workgroup: W[rows_real][cols_real] (fp32, row-major, global) -> three split images of [R][C] in LDS
 // (split s at img + s R 2 C), zero beyond the real extent.
 template <int R, int C>

@@ -15,7 +15,9 @@ constexpr int kBlock = 256;
 
 // How a shape keeps its weights (MODE of the kernels): 0 = fp32 in LDS, exact-f32 MFMA; 1 = STREAM (H = 256: fp32 read from
 // L2, exact-f32 MFMA); 2 = B16 (three bf16 split images in LDS, bf16 MFMA at fp32 accuracy: mlp_b16.h) wherever the images fit
-// the 160 KiB: H = 64 at every input width, H = 128 up to dim 64.  -DEBM_MLP_F32LDS (scripts only): the round-2 kernels.
+// the 160 KiB: H = 64 at every input width, H = 128 up to dim 64; 3 = SLAB (round 4: H = 128, dim 65 .. 128 -- the W2 image in
+// LDS, the W1 image PRE-SPLIT in global memory and walked slab by slab through two 24 KB LDS buffers: mlp_b16.h "MODE 3"),
+// chosen at run time when the caller hands over the image (WideArgs::w1_image).  -DEBM_MLP_F32LDS (scripts only): round 2.
 __host__ __device__ constexpr int b16_cols(int dt) { return dt == 1 ? 32 : (dt == 2 ? 64 : 128); }  // width of the W1 image
 __host__ __device__ constexpr int wide_mode(int ht, int dt) {
 #ifdef EBM_MLP_F32LDS
@@ -24,9 +26,10 @@ __host__ __device__ constexpr int wide_mode(int ht, int dt) {
   return ht > 4 ? 1 : ((ht == 2 || dt <= 2) ? 2 : 0);
 #endif
 }
-__host__ __device__ constexpr size_t wide_smem_bytes(int ht, int dt) {
-  const int H = 32 * ht, DP = 32 * dt, mode = wide_mode(ht, dt);
-  return mode == 1 ? (size_t)(16 * ht * kBlock + 3 * H) * sizeof(float)
+__host__ __device__ constexpr size_t wide_smem_bytes(int ht, int dt, int mode) {
+  const int H = 32 * ht, DP = 32 * dt;
+  return mode == 3 ? (size_t)3 * H * sizeof(float) + 2 * mlpb16::kSlabBytes + mlpb16::image_bytes(H, H)
+         : mode == 1 ? (size_t)(16 * ht * kBlock + 3 * H) * sizeof(float)
          : mode == 2 ? (size_t)3 * H * sizeof(float) + mlpb16::image_bytes(H, H) + mlpb16::image_bytes(H, b16_cols(dt))
                      : (size_t)(H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
 }
@@ -53,6 +56,7 @@ struct WideArgs {
   float* grad_out;       // k_steps == 0: dE/dx[n, dim]
   float* diag_partials;  // in-kernel diagnostics records (one per WAVE: 32 chains), or null
   int64_t diag_blocks;   // records per kept step = ceil(n_chains / 32)
+  const char* w1_image;  // MODE 3: the pre-split W1 image (ebm_mlp_w1_image_f32), or null
 };
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       asm volatile("" : "+s"(never));
       eval_energy_only = never != 0;
     }
+    [[maybe_unused]] const bool slab_more = step + 1 < n_evals;
 #include "mlp_wide_eval.inc"
     if (FAST != 1 && diag_pending >= 0) {
       wave_record_tail(a.diag_partials, a.diag_blocks, diag_pending, wave_id, dim, energy, active, false, lane);
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
             }
         }
       }
+      if constexpr (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no slab transfer outlives its workgroup)
       return;
     }
 
@@ -343,12 +349,13 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
         if (c < dim) a.x[sample * dim + c] = xr[td][r];
       }
   }
+  if constexpr (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slab a kept last step's energy pass left in flight
 }
 
 template <int HT, int DT, int MODE, int FAST>
 int launch_variant(const WideArgs& a, hipStream_t st, const char* who) {
   constexpr bool STREAM = MODE == 1;
-  const size_t smem = wide_smem_bytes(HT, DT);
+  const size_t smem = wide_smem_bytes(HT, DT, MODE);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
@@ -372,6 +379,11 @@ int launch_fast_diag(const WideArgs& a, hipStream_t st, const char* who);
   template <> int launch_fast_diag<HTV, DTV>(const WideArgs& a, hipStream_t st, const char* who);
 EBM_FAST_DECL(2, 1) EBM_FAST_DECL(2, 2) EBM_FAST_DECL(2, 3) EBM_FAST_DECL(2, 4) EBM_FAST_DECL(4, 1) EBM_FAST_DECL(4, 2)
 #undef EBM_FAST_DECL
+// MODE 3 (mlp_wide_slab.hip): H = 128, dim 65 .. 128 with the W1 image at hand; fast = 0 general, 1 plain call, 2 records
+template <int DT>
+int launch_slab(const WideArgs& a, int fast, hipStream_t st, const char* who);
+template <> int launch_slab<3>(const WideArgs& a, int fast, hipStream_t st, const char* who);
+template <> int launch_slab<4>(const WideArgs& a, int fast, hipStream_t st, const char* who);
 inline bool wide_fast_shape(const WideArgs& a) {  // (with or without records)
   return a.k_steps > 0 && !a.noise && !a.clamp_on && ((a.dim & 3) == 0 || a.dim == 2);
 }
@@ -379,6 +391,12 @@ inline bool wide_fast_shape(const WideArgs& a) {  // (with or without records)
 template <int HT, int DT>
 int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
   constexpr int MODE = wide_mode(HT, DT);
+#ifndef EBM_MLP_F32LDS
+  if constexpr (HT == 4 && DT >= 3) {
+    if (a.w1_image && (reinterpret_cast<uintptr_t>(a.w1_image) & 15) == 0)
+      return launch_slab<DT>(a, wide_fast_shape(a) ? (a.diag_partials ? 2 : 1) : 0, st, who);
+  }
+#endif
   if constexpr (MODE == 2) {
 #ifdef EBM_NO_FAST_DIAG  // A/B builds: records on the general kernel
     if (wide_fast_shape(a) && !a.diag_partials) return launch_fast<HT, DT>(a, st, who);

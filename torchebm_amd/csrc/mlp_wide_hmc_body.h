@@ -27,6 +27,7 @@ struct WideHmcArgs {
   const float* params;
   float* diag_partials;  // in-kernel diagnostics records (mlp_wide_body.h: one per wave), or null
   int64_t diag_blocks;
+  const char* w1_image;  // MODE 3 (mlp_wide_body.h), or null
 };
 
 // FAST: the plain call only -- in-kernel momenta and uniforms, no diagnostics records, dim % 4 == 0 or dim == 2 -- with the
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
           }
       }
       constexpr bool eval_energy_only = false, eval_block_cuts = false;
+      [[maybe_unused]] constexpr bool slab_more = false;  // (MODE 3 is a chain-kernel mode)
 #include "mlp_wide_eval.inc"
       if (mode == 0) {  // H0 and the first (clamped) force
         h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
@@ -279,7 +281,7 @@ template <int HT, int DT, bool DIAGM, bool FAST>
 int launch_hmc_variant(const WideHmcArgs& a, hipStream_t st, const char* who) {
   constexpr int MODE = wide_mode(HT, DT);
   constexpr bool STREAM = MODE == 1;
-  const size_t smem = wide_smem_bytes(HT, DT);
+  const size_t smem = wide_smem_bytes(HT, DT, MODE);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
     return fail(EBM_EINVAL, "%s: the MLP parameter block must be 16-byte aligned", who);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
