@@ -277,7 +277,8 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * td + 8 * q + 4 * h;
         float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (c0 < dim) {
+        // (FAST: dim % 4 == 0 or dim == 2, and dim > 32 (DT - 1) -- only the last tile has quads past dim)
+        if ((FAST != 0 && td + 1 < DT) || c0 < dim) {
           if (FAST == 0 && a.noise) {
             if (active)
 #pragma unroll
@@ -316,7 +317,10 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
           const float dw = eps[i] * sqrt_eta;
           float nv = x1 + noise_coef * dw;
           if (FAST == 0 && a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
-          xr[td][r] = (c0 + i < dim) ? nv : 0.0f;
+          // FAST: no select -- a padding column has x = 0, g = 0 exactly (the image columns past dim are zero) and no draw,
+          // so the update leaves it 0 by itself; 16 DT selects and as many loop-invariant masks (spilled to lanes) fewer.
+          // (A chain whose d1 is not finite gets NaN there one step before its real columns would hand it on anyway.)
+          xr[td][r] = (FAST != 0 || c0 + i < dim) ? nv : 0.0f;
         }
       }
     if ((a.traj || (FAST != 1 && a.diag_partials)) && --until_keep == 0) {

@@ -58,3 +58,10 @@ int launch_mlp_w1_image(const float* params, int32_t hidden, int32_t dim, void* 
 }
 
 }  // namespace ebm
+
+#ifdef EBM_PHASE_TIMES
+// scripts/mlp_phase_times.py on a MODE 3 shape: build THIS file alone with -DEBM_PHASE_TIMES (the log is per translation unit)
+extern "C" __attribute__((visibility("default"))) int ebm_debug_phase_log(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ebm::widemlp::ebm_phase_log), (size_t)n * sizeof(unsigned long long));
+}
+#endif
