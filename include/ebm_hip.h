@@ -56,7 +56,11 @@ extern "C" {
 enum {
   EBM_ENERGY_DOUBLE_WELL = 0, /* E = h * sum_j (x_j^2 - b^2)^2   base_model.py:130-148  s[0]=h  s[1]=(float)(b*b)           */
   EBM_ENERGY_HARMONIC    = 1, /* E = (0.5*k) * sum_j x_j^2       base_model.py:213-229  s[0]=(float)(0.5*k)                 */
-  EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1) */
+  EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1)
+                                 aux = NULL, or (dims 132 .. 512, since ABI version 4) the device image that
+                                 ebm_gauss_prec_image_f32 built from THIS dev1: the tiled kernels (dims 228 .. 512) then move
+                                 their slabs of P by LDS-direct loads instead of loading, splitting and storing fp32 rows
+                                 every stage.  A stale image gives the old matrix's samples; NULL is always safe.          */
   EBM_ENERGY_GMM         = 3, /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
                                  s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]
                                  aux = NULL, or device int32[1]: bit v set <=> the component means differ somewhere in
@@ -352,6 +356,12 @@ EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32
  * chain kernel streams it through LDS.  Rebuild it whenever the parameters change (one small kernel; stream-ordered like every
  * entry).  No counterpart in the reference: there the network is nn.Linear modules evaluated by autograd every step
  * (samplers/langevin_dynamics.py:168-172).  Since ABI version 4. */
+/* The same for an EBM_ENERGY_GAUSSIAN precision matrix at dims 132 .. 512 (multiples of 4): the three bf16 pieces of P
+ * (hi + mid + lo = the fp32 value) in the order the stages of the tiled Langevin kernel consume them, 1.5 x the size of P.
+ * `prec` is the SYMMETRIC matrix handed over as dev1.  0 bytes = this width has no image.  Since ABI version 4. */
+EBM_API size_t ebm_gauss_prec_image_bytes(int32_t dim);
+EBM_API int ebm_gauss_prec_image_f32(const float* prec, int32_t dim, void* image, void* stream);
+
 EBM_API size_t ebm_mlp_w1_image_bytes(int32_t hidden, int32_t dim);
 EBM_API int ebm_mlp_w1_image_f32(const float* params, int32_t hidden, int32_t dim, void* image, void* stream);
 

@@ -1,5 +1,5 @@
 """Dense Gaussian Langevin at dims above 128 (csrc/gauss_big.hip): ms per call, step-equivalent fraction of 8 TB/s, useful TFLOP/s,
-and the same chain as plain torch ops (a GEMM + element-wise ops per step) beside it.  BIG_DIMS=160,256 restricts the dims."""
+and the same chain as plain torch ops (a GEMM + element-wise ops per step) beside it.  BIG_DIMS=160,256 restricts the dims; BIG_NO_IMAGE=1 runs without the pre-split precision image."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,10 @@ for dim, n in cases:
     model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=dev)
     k = 20
     x = torch.randn(n, dim, device=dev)
-    spec = model.fused_spec().to_c()
+    fs = model.fused_spec()
+    spec = fs.to_c()
+    if os.environ.get("BIG_NO_IMAGE"):  # A/B: the fp32 slab path (load, split, store every stage)
+        spec.aux = None
     aa, sq, coef = em_coefficients(0.01, 1.0)
     st = _lib.stream_handle(dev)
     ms = timeit(lambda: _lib.call("ebm_langevin_chain_f32", spec, x.data_ptr(), n, dim, k, aa, sq, coef, None, 0, 0.0, 0.0, 1, None, None, None, 1, 0, st))

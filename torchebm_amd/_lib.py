@@ -55,6 +55,8 @@ EXPORTS = (
     "ebm_probe_issue_f32",
     "ebm_mlp_w1_image_bytes",
     "ebm_mlp_w1_image_f32",
+    "ebm_gauss_prec_image_bytes",
+    "ebm_gauss_prec_image_f32",
 )
 
 #: number of calls made through each entry point in this process (tests use it to
@@ -116,6 +118,8 @@ _PROTOTYPES = {
     "ebm_probe_issue_f32": (C.c_int, [_p, _i32, _i32, _i32, _p]),
     "ebm_mlp_w1_image_bytes": (C.c_size_t, [_i32, _i32]),
     "ebm_mlp_w1_image_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ebm_gauss_prec_image_bytes": (C.c_size_t, [_i32]),
+    "ebm_gauss_prec_image_f32": (C.c_int, [_p, _i32, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -304,8 +304,17 @@ class GaussianModel(BaseModel):
         key = (self.cov_inv.data_ptr(), self.cov_inv._version, self.cov_inv.device)
         if self._sym_cache is None or self._sym_cache[0] != key:
             sym = (0.5 * (self.cov_inv + self.cov_inv.t())).contiguous()
-            self._sym_cache = (key, sym)
-        return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1], dim=int(self.mean.shape[0]))
+            # dims 132 .. 512: the matrix pre-split into bf16 triples in the order the tiled kernel's stages consume it
+            # (include/ebm_hip.h, ebm_gauss_prec_image_f32) -- built with the symmetrised matrix, i.e. when cov_inv changes
+            image = None
+            if sym.is_cuda and _lib.is_built():
+                n_img = int(_lib.lib().ebm_gauss_prec_image_bytes(int(sym.shape[0])))
+                if n_img:
+                    image = torch.empty(n_img // 4, dtype=torch.int32, device=sym.device)
+                    _lib.call("ebm_gauss_prec_image_f32", sym.data_ptr(), int(sym.shape[0]), image.data_ptr(), _lib.stream_handle(sym.device))
+            self._sym_cache = (key, sym, image)
+        return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1], aux=self._sym_cache[2],
+                         dim=int(self.mean.shape[0]))
 
 
 class GaussianMixtureModel(BaseModel):

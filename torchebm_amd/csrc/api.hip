@@ -61,6 +61,8 @@ int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 size_t mlp_w1_image_bytes(int32_t hidden, int32_t dim);  // mlp_wide_slab.hip
 int launch_mlp_w1_image(const float* params, int32_t hidden, int32_t dim, void* image, hipStream_t st, const char* who);
+size_t gauss_prec_image_bytes(int32_t dim);  // gauss_big_img.hip
+int launch_gauss_prec_image(const float* prec, int32_t dim, void* image, hipStream_t st, const char* who);
 bool gauss_mfma_supported(int32_t dim);
 bool gauss_lds5_supported(int32_t dim);   // gauss_mfma.hip: 132 .. 160, Ps resident in LDS (plain Langevin call)
 int32_t gauss_pack_factor(int32_t dim, int64_t n_chains);  // gauss_mfma.hip: 1 as is, > 1 packed rows, 0 no matrix-layout form
@@ -550,6 +552,12 @@ int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32_t kind,
 }
 
 size_t ebm_mlp_w1_image_bytes(int32_t hidden, int32_t dim) { return mlp_w1_image_bytes(hidden, dim); }
+
+size_t ebm_gauss_prec_image_bytes(int32_t dim) { return gauss_prec_image_bytes(dim); }
+
+int ebm_gauss_prec_image_f32(const float* prec, int32_t dim, void* image, void* stream) {
+  return launch_gauss_prec_image(prec, dim, image, (hipStream_t)stream, "ebm_gauss_prec_image_f32");
+}
 
 int ebm_mlp_w1_image_f32(const float* params, int32_t hidden, int32_t dim, void* image, void* stream) {
   return launch_mlp_w1_image(params, hidden, dim, image, (hipStream_t)stream, "ebm_mlp_w1_image_f32");

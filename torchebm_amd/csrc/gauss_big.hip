@@ -54,6 +54,7 @@ int launch_langevin_chain_gauss_big(const ebm_energy_t& e, float* x, int64_t n_c
   a.noise = noise; a.clamp_on = clamp_on; a.cmin = cmin; a.cmax = cmax;
   a.thin = thin; a.n_kept = k_steps / thin; a.traj = traj;
   a.mean = e.dev0; a.prec = e.dev1;
+  a.prec_image = reinterpret_cast<const char*>(e.aux);  // (the resident kernels up to seven tiles do not read it)
   a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
   a.step0 = offset;
   a.energy_out = nullptr; a.grad_out = nullptr;
@@ -74,6 +75,7 @@ int launch_energy_grad_gauss_big(const ebm_energy_t& e, const float* x, int64_t 
   a.eta = 0.0f; a.sqrt_eta = 0.0f; a.noise_coef = 0.0f; a.table = nullptr; a.noise = nullptr;
   a.clamp_on = 0; a.cmin = 0.0f; a.cmax = 0.0f; a.thin = 1; a.n_kept = 0; a.traj = nullptr;
   a.mean = e.dev0; a.prec = e.dev1; a.key = RngKey{0u, 0u}; a.step0 = 0;
+  a.prec_image = reinterpret_cast<const char*>(e.aux);
   a.energy_out = energy_out; a.grad_out = grad_out;
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
   return dispatch_big(a, dim, st);

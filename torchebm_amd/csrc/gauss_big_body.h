@@ -73,6 +73,7 @@ struct BigArgs {
   uint64_t step0;
   float* energy_out;    // k_steps == 0: evaluation only (ebm_energy_grad_f32) -- E [n] and / or the gradient [n, dim], either may be null;
   float* grad_out;      // x is read, not written
+  const char* prec_image;  // IMG kernels: Ps pre-split in slab order (ebm_gauss_prec_image_f32; ebm_energy_t.aux), else null
   diag::DiagArgs diag;  // records of the kept steps (diag.h: one per wave-tile of 32 chains, E = 32 dim, S = dim); partials == nullptr: none
 };
 
@@ -109,7 +110,12 @@ struct BigCfg {
   static constexpr size_t SMEM = 2 * SLAB + 512 * sizeof(float);
 };
 
-template <int OT, int NS, bool DIAG = false>
+// IMG (round 4): the slabs come READY-MADE.  ebm_gauss_prec_image_f32 lays the three bf16 pieces of Ps out once, in global
+// memory, in the order the stages consume them -- [slice][stage][piece][unit], each stage's 3 UNITS 16 bytes exactly the LDS
+// image store_a() would have written -- and a stage's slab is moved by LDS-direct loads (global_load_lds_dwordx4: 1 KiB per
+// wave-instruction, no registers, no split, no ds_write): six to twelve instructions per wave and stage where the fp32 path
+// spends ~100 per thread on loads, masks, splits and stores.  The image is 1.5 x the fp32 matrix (0.4 - 1.5 MB: L2-resident).
+template <int OT, int NS, bool DIAG = false, bool IMG = false>
 __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG ? 2 : 1)) void gauss_big_langevin_kernel(BigArgs a) {
   using C = BigCfg<OT, NS>;
   constexpr int kBigBlock = C::THREADS;
@@ -169,6 +175,22 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
       dst[0] = t.h; dst[UNITS] = t.m; dst[2 * UNITS] = t.l;
     }
   };
+  // IMG: request the slab of (slice sl, stage s) into buffer `buf` -- the pieces of 1 KiB dealt round-robin to the waves.
+  // Assembly on purpose: behind the builtin the compiler puts s_waitcnt vmcnt(0) in front of every later LDS read (it
+  // assumes they alias the transfer); the one wait that is needed stands in front of the stage barrier.
+  [[maybe_unused]] const uint32_t slab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)big_smem;
+  [[maybe_unused]] auto dma_stage = [&](int buf, int sl, int s) {
+    constexpr uint32_t STAGE_BYTES = 3u * UNITS * 16u;
+    const char* src = a.prec_image + (size_t)(sl * n_stage + s) * STAGE_BYTES;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t dst = slab_lds + (uint32_t)buf * STAGE_BYTES;
+    for (int piece = wv; piece < (int)(STAGE_BYTES / 1024u); piece += C::WAVES) {
+      const uint32_t voff = (uint32_t)(piece * 1024 + lane * 16), base = dst + (uint32_t)piece * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
+    }
+  };
   auto load_b = [&](int c, int s, int kb2, f32x4& v0, f32x4& v1) {
     const int kcol = KW * s + 16 * kb2 + 8 * h;
     const float* p = a.x + xoff[c] + kcol;
@@ -222,13 +244,16 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
       });
 
       // ---- stage 0 of the slice: its slab and this wave's B operands
-      f32x4 ra[UPT][2], rb[CTW][KBS][2];
-      static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, 0, j, ra[j][0], ra[j][1]); });
+      [[maybe_unused]] f32x4 ra[IMG ? 1 : UPT][2];
+      f32x4 rb[CTW][KBS][2];
+      if constexpr (IMG) dma_stage(0, sl, 0);
+      else static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, 0, j, ra[j][0], ra[j][1]); });
       static_for<CTW * KBS>([&](auto ic) {
         constexpr int c = decltype(ic)::value / KBS, kb2 = decltype(ic)::value % KBS;
         load_b(c, 0, kb2, rb[c][kb2][0], rb[c][kb2][1]);
       });
-      static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, row0, 0, j, ra[j][0], ra[j][1]); });
+      if constexpr (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(0, row0, 0, j, ra[j][0], ra[j][1]); });
       __syncthreads();
 
       for (int s = 0; s < n_stage; ++s) {
@@ -244,7 +269,8 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
           ball[kb2][c] = split8(masked_b(c, s, kb2, rb[c][kb2][0], rb[c][kb2][1]) - join8(m0, m1));
         });
         if (more && !(EBM_BIG_EXP & 4)) {  // a whole stage of matrix work for them to land
-          static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, s + 1, j, ra[j][0], ra[j][1]); });
+          if constexpr (IMG) dma_stage(buf ^ 1, sl, s + 1);
+          else static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(row0, s + 1, j, ra[j][0], ra[j][1]); });
           static_for<CTW * KBS>([&](auto ic) {
             constexpr int c = decltype(ic)::value / KBS, kb2 = decltype(ic)::value % KBS;
             load_b(c, s + 1, kb2, rb[c][kb2][0], rb[c][kb2][1]);
@@ -309,7 +335,9 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
             }
           });
         });
-        if (more && !(EBM_BIG_EXP & 8)) {
+        if constexpr (IMG) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next slab (and its next B operands) have landed
+        } else if (more && !(EBM_BIG_EXP & 8)) {
           static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; store_a(buf ^ 1, row0, s + 1, j, ra[j][0], ra[j][1]); });
         }
         __syncthreads();  // the next slab is written, this one is read by everyone
@@ -787,14 +815,31 @@ int launch_res(const BigArgs& a, hipStream_t st) {
   return check_launch("ebm_langevin_chain_f32");
 }
 
+// the IMG instantiations live in gauss_big_img.hip (their own translation unit: compiled in parallel)
 template <int OT, int NS>
+int launch_big_img(const BigArgs& a, hipStream_t st);
+#define EBM_BIG_IMG_DECL(OTV, NSV) template <> int launch_big_img<OTV, NSV>(const BigArgs& a, hipStream_t st);
+EBM_BIG_IMG_DECL(5, 1) EBM_BIG_IMG_DECL(6, 1) EBM_BIG_IMG_DECL(7, 1) EBM_BIG_IMG_DECL(8, 1)
+EBM_BIG_IMG_DECL(5, 2) EBM_BIG_IMG_DECL(6, 2) EBM_BIG_IMG_DECL(7, 2) EBM_BIG_IMG_DECL(8, 2)
+#undef EBM_BIG_IMG_DECL
+// bytes of the image of a [dim x dim] matrix for the (OT, NS) kernel: [NS][n_stage][3][UNITS][16]
+template <int OT, int NS>
+constexpr size_t big_image_bytes(int dim) {
+  using C = BigCfg<OT, NS>;
+  return (size_t)NS * (size_t)(((dim + 31) & ~31) / (16 * C::KBS)) * 3u * C::UNITS * 16u;
+}
+
+template <int OT, int NS, bool IMG = false>
 int launch_big(const BigArgs& a, hipStream_t st) {
   using C = BigCfg<OT, NS>;
+  if constexpr (!IMG) {
+    if (a.prec_image && (reinterpret_cast<uintptr_t>(a.prec_image) & 15) == 0) return launch_big_img<OT, NS>(a, st);
+  }
   static DeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, false, IMG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_big_langevin_kernel<OT, NS, true, IMG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
   }
   const int64_t blocks = ceil_div64(a.n_chains, C::CHAINS);
@@ -803,8 +848,8 @@ int launch_big(const BigArgs& a, hipStream_t st) {
   // record tests) cut the epilogue's basic blocks and it allocates 414 .. 512 registers without a spill where the plain
   // instantiation spills 59 .. 242: dims 384 / 512 4.16 / 6.95 -> 4.07 / 6.07 ms (same box; dim 320, five tiles: 3.01 -> 3.16, kept plain)
   constexpr bool kRecordsKernelAlways = NS == 2 && OT >= 6;
-  if (a.diag.partials || kRecordsKernelAlways || a.k_steps == 0) hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, true>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
-  else hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, false>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
+  if (a.diag.partials || kRecordsKernelAlways || a.k_steps == 0) hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, true, IMG>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
+  else hipLaunchKernelGGL((gauss_big_langevin_kernel<OT, NS, false, IMG>), dim3((unsigned)blocks), dim3(C::THREADS), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 

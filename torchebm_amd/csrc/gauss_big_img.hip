@@ -1,0 +1,78 @@
+// The IMG instantiations of the tiled dense-Gaussian Langevin kernel (gauss_big_body.h: slabs of Ps arrive ready-made by
+// LDS-direct loads) and the builder of the image they read.  Reference: torchebm/core/base_model.py:181-210 (GaussianModel:
+// the gradient cov_inv (x - mean) is what every step contracts), samplers/langevin_dynamics.py:150-185 (the step loop).
+#include "gauss_big_body.h"
+
+namespace ebm {
+namespace gbig {
+
+// One thread per lane-operand unit: eight consecutive fp32 of a row of Ps -> three bf16x8 pieces at
+// [slice][stage][piece][unit] (unit = [out tile][K-block of the stage][lane (row in tile, K-half)]), zero beyond dim.
+__global__ __launch_bounds__(256) void gauss_prec_image_kernel(const float* __restrict__ prec, int dim, int ot_n, int kbs, int ns, int n_stage,
+                                                               char* __restrict__ out) {
+  const int units = ot_n * 64 * kbs;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)ns * n_stage * units) return;
+  const int u = (int)(g % units), s = (int)((g / units) % n_stage), sl = (int)(g / ((int64_t)units * n_stage));
+  const int it = u / (64 * kbs), kb2 = (u >> 6) % kbs, ul = u & 63;
+  const int row = sl * 32 * ot_n + 32 * it + (ul & 31);
+  const int kcol = 16 * kbs * s + 16 * kb2 + 8 * (ul >> 5);
+  f32x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (row < dim && kcol + i < dim) ? prec[(int64_t)row * dim + kcol + i] : 0.0f;
+  const Tri t = split8(v);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out) + ((int64_t)sl * n_stage + s) * 3 * units + u;
+  dst[0] = t.h; dst[units] = t.m; dst[2 * units] = t.l;
+}
+
+#define EBM_BIG_IMG(OTV, NSV) \
+  template <> int launch_big_img<OTV, NSV>(const BigArgs& a, hipStream_t st) { return launch_big<OTV, NSV, true>(a, st); }
+EBM_BIG_IMG(5, 1) EBM_BIG_IMG(6, 1) EBM_BIG_IMG(7, 1) EBM_BIG_IMG(8, 1)
+EBM_BIG_IMG(5, 2) EBM_BIG_IMG(6, 2) EBM_BIG_IMG(7, 2) EBM_BIG_IMG(8, 2)
+#undef EBM_BIG_IMG
+
+namespace {
+struct ImgShape {
+  int ot, ns, kbs;
+  size_t bytes;
+};
+// the (OT, NS) the dispatch of gauss_big.hip picks for this width
+template <int OT, int NS>
+ImgShape shape_of(int dim) { return ImgShape{OT, NS, BigCfg<OT, NS>::KBS, big_image_bytes<OT, NS>(dim)}; }
+ImgShape image_shape(int32_t dim) {
+  const int tiles = (dim + 31) / 32;
+  if (tiles <= 8) {
+    switch (tiles) {
+      case 5: return shape_of<5, 1>(dim);
+      case 6: return shape_of<6, 1>(dim);
+      case 7: return shape_of<7, 1>(dim);
+      default: return shape_of<8, 1>(dim);
+    }
+  }
+  switch ((tiles + 1) / 2) {
+    case 5: return shape_of<5, 2>(dim);
+    case 6: return shape_of<6, 2>(dim);
+    case 7: return shape_of<7, 2>(dim);
+    default: return shape_of<8, 2>(dim);
+  }
+}
+}  // namespace
+}  // namespace gbig
+
+bool gauss_big_supported(int32_t dim);  // gauss_big.hip
+
+// ebm_gauss_prec_image_bytes / ebm_gauss_prec_image_f32 (api.hip)
+size_t gauss_prec_image_bytes(int32_t dim) { return gauss_big_supported(dim) ? gbig::image_shape(dim).bytes : 0; }
+int launch_gauss_prec_image(const float* prec, int32_t dim, void* image, hipStream_t st, const char* who) {
+  if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "%s: no precision image at dim %d (132 .. 512 in steps of 4 only)", who, dim);
+  if (!prec || !image) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  if (reinterpret_cast<uintptr_t>(image) & 15) return fail(EBM_EINVAL, "%s: the image must be 16-byte aligned", who);
+  const gbig::ImgShape sh = gbig::image_shape(dim);
+  const int n_stage = ((dim + 31) & ~31) / (16 * sh.kbs);
+  const int64_t work = (int64_t)sh.ns * n_stage * sh.ot * 64 * sh.kbs;
+  hipLaunchKernelGGL(gbig::gauss_prec_image_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, prec, dim, sh.ot, sh.kbs, sh.ns, n_stage,
+                     static_cast<char*>(image));
+  return check_launch(who);
+}
+
+}  // namespace ebm
