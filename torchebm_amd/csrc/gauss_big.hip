@@ -10,13 +10,15 @@ namespace {
 int dispatch_big(const BigArgs& a, int32_t dim, hipStream_t st) {
   const int tiles = (dim + 31) / 32;  // 5 .. 16
 #ifndef EBM_BIG_TILED_ONLY
-  if (a.k_steps > 0)
-  // up to seven tiles the register-resident kernel, eight tiles the tiled one (same box, 2^17 chains x 20 steps, ms:
-  // dims 132 / 160 / 192 / 224 / 256: 1.37 / 1.42 / 1.89 / 2.55 / 3.48 resident, 1.48 / 1.67 / 2.23 / 2.51 / 3.02 tiled)
-  if (tiles <= 7) return launch_gauss_res(tiles, a, st);  // gauss_res.hip
-#ifdef EBM_BIG_RES8
-  if (tiles == 8) return launch_gauss_res(tiles, a, st);
-#endif
+  if (a.k_steps > 0) {
+    // up to seven tiles the register-resident kernel, eight tiles the tiled one (same box, 2^17 chains x 20 steps, ms:
+    // dims 132 / 160 / 192 / 224 / 256: 1.37 / 1.42 / 1.89 / 2.55 / 3.48 resident, 1.48 / 1.67 / 2.23 / 2.51 / 3.02 tiled) --
+    // unless the pre-split image is there (round 4): the resident kernel then has no slab work, and eight tiles (dim 256) stay in
+    // registers too: 2.84 (tiled, image) -> 2.37 ms, no state traffic in the step loop (with or without records: the same chains)
+    if (tiles <= 7) return launch_gauss_res(tiles, a, st);  // gauss_res.hip
+    if (tiles == 8 && a.prec_image && (reinterpret_cast<uintptr_t>(a.prec_image) & 15) == 0)
+      return launch_gauss_res(tiles, a, st);
+  }
 #endif
   if (tiles <= 8) {
     switch (tiles) {

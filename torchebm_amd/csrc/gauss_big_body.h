@@ -110,6 +110,12 @@ struct BigCfg {
   static constexpr size_t SMEM = 2 * SLAB + 512 * sizeof(float);
 };
 
+// bytes of the image of a [dim x dim] matrix for the (OT, NS) kernel: [NS][n_stage][3][UNITS][16]
+template <int OT, int NS>
+constexpr size_t big_image_bytes(int dim) {
+  using C = BigCfg<OT, NS>;
+  return (size_t)NS * (size_t)(((dim + 31) & ~31) / (16 * C::KBS)) * 3u * C::UNITS * 16u;
+}
 // IMG (round 4): the slabs come READY-MADE.  ebm_gauss_prec_image_f32 lays the three bf16 pieces of Ps out once, in global
 // memory, in the order the stages consume them -- [slice][stage][piece][unit], each stage's 3 UNITS 16 bytes exactly the LDS
 // image store_a() would have written -- and a stage's slab is moved by LDS-direct loads (global_load_lds_dwordx4: 1 KiB per
@@ -503,8 +509,57 @@ struct ResCfg {
   static constexpr size_t SMEM = 2 * SLAB + 256 * sizeof(float);
 };
 
-template <int OT, bool DIAG = false>
+// IMG (round 4): as in the tiled kernel, the three images of a stage arrive ready-made from the pre-split copy of Ps
+// (ebm_gauss_prec_image_f32 appends this kernel's layout -- [stage][piece][unit], the rotated slots included -- behind the
+// tiled kernel's, see res_image_offset) by LDS-direct loads: the 5 UPT chunk steps per thread and stage (mask, split, three
+// 8-byte writes: ~50 instructions per chunk, the larger half of a stage's non-matrix work) and the UPT load registers go.
+template <int OT>
+constexpr size_t res_image_bytes() { return (size_t)OT * 3u * ResCfg<OT>::SLABU * 16u; }
+
+// FOLD (round 4, with IMG, plain call: no records, in-kernel draws): the step's normals are drawn BEHIND THE MFMAs as well, in
+// the slots the slab split left empty, and folded into the state in place -- x[t] += noise_coef (eps sqrt_eta) as soon as tile
+// t has served as a B operand for the last time (from the second half of stage t on) -- so the epilogue is x - eta g and no
+// register holds a normal.  One wave per SIMD issues ~one instruction per five cycles whatever runs beside it: the 32 Philox
+// calls of a 256-wide step in the epilogue cost more than the step's 768 MFMAs (scripts/ab_big.sh); behind them they cost
+// nothing while a slot holds <= 8 instructions.  The sum is associated (x + noise) - eta g instead of the reference's
+// (x - eta g) + noise (core/base_integrator.py:711-731): same three terms, each product rounded as there, one rounding in a
+// different place -- inside the tolerance these kernels are held to (bf16 x 3 contraction), not bit-identical to the
+// records / injected-noise instantiations, which keep the reference's order.
+// The plan: per quad 13 stages (counter | ten Philox rounds | two Box-Muller pairs with their fold), 52 per tile; stage k of the
+// step's 52 OT goes to the k-th take of the free slots in issue order, a slot taking ceil(left / free slots left) stages
+// (1, rarely 2) but never one of a tile that is still a B operand.
+template <int OT>
+struct FoldPlan {
+  static constexpr int HALF = 6 * OT, SLOTS = 2 * HALF * OT, PER_TILE = 52, B_STEPS = 10;
+  int pos[SLOTS + 1];  // stages taken before slot i (slot = stage * 2 HALF + ordinal)
+  static constexpr bool is_free(int s, int o) {
+    if (o >= HALF) return true;
+    if (o / 2 >= B_STEPS) return true;
+    return (o % 2 == 1) && !(s + 1 < OT);
+  }
+  constexpr FoldPlan() : pos{} {
+    int free_left = 0;
+    for (int i = 0; i < SLOTS; ++i) free_left += is_free(i / (2 * HALF), i % (2 * HALF)) ? 1 : 0;
+    int p = 0;
+    for (int i = 0; i < SLOTS; ++i) {
+      pos[i] = p;
+      const int s = i / (2 * HALF), o = i % (2 * HALF);
+      if (!is_free(s, o)) continue;
+      const int allowed = PER_TILE * (o >= HALF ? s + 1 : s);  // tiles that are no longer B operands
+      const int left = PER_TILE * OT - p;
+      int want = (left + free_left - 1) / free_left;
+      if (want > allowed - p) want = allowed - p;
+      if (want < 0) want = 0;
+      p += want;
+      --free_left;
+    }
+    pos[SLOTS] = p;
+  }
+};
+
+template <int OT, bool DIAG = false, bool IMG = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
+  static_assert(!FOLD || (IMG && !DIAG), "FOLD is the plain call on the image");
   using C = ResCfg<OT>;
   constexpr int UPT = C::UPT, SLABU = C::SLABU;
   extern __shared__ __align__(16) unsigned char big_smem[];
@@ -585,8 +640,27 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   Tri b0;  // the B operand of the next K-block 0
   int gstage = 0;  // stages done so far: its parity is the LDS buffer (OT may be odd, the pipeline runs across steps)
 
+  // IMG: request stage s of the image into buffer `buf` (6 OT pieces of 1 KiB dealt round-robin to the four waves; assembly so
+  // that the compiler does not serialise every later LDS read behind the transfer -- see the tiled kernel)
+  [[maybe_unused]] const uint32_t slab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)big_smem;
+  [[maybe_unused]] auto dma_stage = [&](int buf, int s) {
+    constexpr uint32_t STAGE_BYTES = 3u * SLABU * 16u;
+    const char* src = a.prec_image + big_image_bytes<OT, 1>(32 * OT) + (size_t)s * STAGE_BYTES;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t dst = slab_lds + (uint32_t)buf * STAGE_BYTES;
+    for (int piece = wv; piece < (int)(STAGE_BYTES / 1024u); piece += 4) {
+      const uint32_t voff = (uint32_t)(piece * 1024 + lane * 16), base = dst + (uint32_t)piece * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
+    }
+  };
   // the first slab
-  f32x4 ra[UPT];
+  [[maybe_unused]] f32x4 ra[IMG ? 1 : UPT];
+  if constexpr (IMG) {
+    dma_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
   static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(0, j, ra[j]); });
   static_for<UPT>([&](auto jc) {
     ChunkJob cj;
@@ -595,6 +669,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   // (from here on `ra` holds the slab the NEXT stage splits: a chunk's registers are reloaded -- for the slab after that --
   //  as soon as its split has copied them, a full stage before they are needed again)
   static_for<UPT>([&](auto jc) { constexpr int j = decltype(jc)::value; load_a(1 % OT, j, ra[j]); });
+  }
   __syncthreads();
 
   // Records (DIAG): the column sums of a kept state come from the registers right after its update; its energy 0.5 d . P d
@@ -631,11 +706,39 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       static_for<8>([&](auto kc) { j0.step(kc); });
       b0 = j0.tri();
     }
+    // FOLD: the noise stages of this step (see FoldPlan)
+    [[maybe_unused]] uint32_t nc0 = 0, nc1 = 0, nc2 = 0, nc3 = 0, nk0 = 0, nk1 = 0;
+    [[maybe_unused]] uint64_t n_row = (uint64_t)chain * (uint64_t)dim;
+    if constexpr (FOLD) asm volatile("" : "+v"(n_row));
+    [[maybe_unused]] auto noise_stage = [&](auto kc) {
+      constexpr int K = decltype(kc)::value, t = K / 52, q = (K % 52) / 13, sub = K % 13;
+      if constexpr (sub == 0) {
+        const uint64_t grp = (n_row + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2;
+        const uint64_t stp = a.step0 + (uint64_t)step;
+        nc0 = (uint32_t)grp; nc1 = (uint32_t)(grp >> 32); nc2 = (uint32_t)stp; nc3 = (uint32_t)(stp >> 32);
+        nk0 = a.key.k0; nk1 = a.key.k1;
+      } else if constexpr (sub <= 10) {  // one round of philox4x32_10 (ebm_common.h)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * nc0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * nc2;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), nc1, nk0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), nc3, nk1);
+        nc1 = (uint32_t)p1; nc3 = (uint32_t)p0; nc0 = n0; nc2 = n2;
+        nk0 += 0x9E3779B9u; nk1 += 0xBB67AE85u;
+      } else {
+        constexpr int e0 = 4 * q + 2 * (sub - 11);
+        float n0, n1;
+        if constexpr (sub == 11) box_muller(nc0, nc1, n0, n1);
+        else box_muller(nc2, nc3, n0, n1);
+        x[t][e0] = x[t][e0] + noise_coef * (n0 * sqrt_eta);
+        x[t][e0 + 1] = x[t][e0 + 1] + noise_coef * (n1 * sqrt_eta);
+      }
+    };
     static_for<OT>([&](auto sc) {
       constexpr int s = decltype(sc)::value, sn = (s + 1) % OT;  // the stage after the last one is stage 0 of the next step
       constexpr int HALF = 6 * OT;                                // MFMAs per K-block
       const int buf = gstage & 1;
       constexpr int sn2 = (s + 2) % OT;  // the slab requested during this stage
+      if constexpr (IMG) dma_stage(buf ^ 1, sn);  // (the barrier that ended the stage before freed that buffer)
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
       SplitJob jb1, jb0n;
@@ -663,6 +766,11 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       };
       auto slot = [&](auto oc) {
         constexpr int o = decltype(oc)::value;
+        if constexpr (FOLD) {
+          constexpr FoldPlan<OT> plan{};
+          constexpr int i = s * 2 * HALF + o, k0 = plan.pos[i], k1 = plan.pos[i + 1];
+          static_for<k1 - k0>([&](auto kk) { noise_stage(std::integral_constant<int, k0 + decltype(kk)::value>{}); });
+        }
         if constexpr (o < HALF) {
           if constexpr (EBM_BIG_EXP & 32) {
           } else if constexpr (o % 2 == 0 && o / 2 < B_STEPS) {
@@ -670,7 +778,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
           } else if constexpr (o % 2 == 1 && o / 2 < B_STEPS && s + 1 < OT) {
             b_job(jb0n, std::integral_constant<int, (s + 1 < OT ? s + 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, o / 2>{});
           }
-        } else {
+        } else if constexpr (!IMG) {
           constexpr int ak = (o - HALF) * A_PER;
           static_for<A_PER>([&](auto ic) {
             if constexpr (ak + decltype(ic)::value < A_STEPS && !(EBM_BIG_EXP & 8)) a_job(std::integral_constant<int, ak + decltype(ic)::value>{});
@@ -725,6 +833,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       });
       if constexpr (s + 1 < OT) b0 = jb0n.tri();
       ++gstage;
+      if constexpr (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next slab have landed
       if constexpr (!(EBM_BIG_EXP & 16)) __syncthreads();  // the next slab is written, this one is read by everyone
       // (a block cut here -- the OT unrolled stages are ONE basic block -- was tried: more spills in the plain kernels, dim 224 2.31 -> 2.84 ms)
     });
@@ -755,7 +864,9 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         const int k0 = 32 * t + 8 * q + 4 * h;
         const bool ok = active && k0 < dim;
         f32x4 eps;
-        if constexpr (EBM_BIG_EXP & 2) {
+        if constexpr (FOLD) {
+          eps = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // (already in x)
+        } else if constexpr (EBM_BIG_EXP & 2) {
           eps = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
         } else if (a.noise) {
           eps = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)step * a.n_chains * dim + (active ? (int64_t)e_row : 0) + (ok ? k0 : 0));
@@ -766,8 +877,11 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
-          const float dw = eps[i] * sqrt_eta;
-          float nv = x1 + noise_coef * dw;
+          float nv = x1;
+          if constexpr (!FOLD) {
+            const float dw = eps[i] * sqrt_eta;
+            nv = x1 + noise_coef * dw;
+          }
           if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
           x[t][4 * q + i] = ok ? nv : 0.0f;  // padding held at 0
         }
@@ -798,21 +912,51 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   });
 }
 
-template <int OT>
-int launch_res(const BigArgs& a, hipStream_t st) {
+template <int OT, bool IMG>
+int launch_res_as(const BigArgs& a, hipStream_t st) {
   using C = ResCfg<OT>;
   static DeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false, IMG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)C::SMEM);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, true, IMG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)C::SMEM);
   }
   const int64_t blocks = ceil_div64(a.n_chains, 128);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
-  if (a.diag.partials) hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
-  else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  if (a.diag.partials) hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, true, IMG>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, IMG>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
+}
+// -DEBM_BIG_FOLD (scripts only): the plain call on the image draws its normals behind the MFMAs (FoldPlan).  Measured on the same
+// box, 2^17 chains x 20 steps, dims 192 / 224 / 256: 1.59 / 1.99 / 2.37 -> 1.51 / 1.93 / 2.34 ms -- one wave per SIMD is bound by
+// the instructions it issues, not by where they stand, and the matrix pipe's shadow was full already -- for which the native draws
+// stop being bit-identical to the materialised field (the fold re-associates the update).  Off.
+#ifdef EBM_BIG_FOLD
+constexpr bool kResFold = true;
+#else
+constexpr bool kResFold = false;
+#endif
+template <int OT>
+int launch_res_plain_img(const BigArgs& a, hipStream_t st) {  // the plain call on the image (no records instantiation beside it)
+  using C = ResCfg<OT>;
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false, true, kResFold>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)C::SMEM);
+  if (kResFold && a.noise) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: the EBM_BIG_FOLD build draws its own normals at this width");
+  const int64_t blocks = ceil_div64(a.n_chains, 128);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, true, kResFold>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  return check_launch("ebm_langevin_chain_f32");
+}
+template <int OT>
+int launch_res(const BigArgs& a, hipStream_t st) {
+  if (a.prec_image && (reinterpret_cast<uintptr_t>(a.prec_image) & 15) == 0) {
+    if (kResFold && !a.diag.partials && !a.noise) return launch_res_plain_img<OT>(a, st);
+    return launch_res_as<OT, true>(a, st);
+  }
+  return launch_res_as<OT, false>(a, st);
 }
 
 // the IMG instantiations live in gauss_big_img.hip (their own translation unit: compiled in parallel)
@@ -822,12 +966,6 @@ int launch_big_img(const BigArgs& a, hipStream_t st);
 EBM_BIG_IMG_DECL(5, 1) EBM_BIG_IMG_DECL(6, 1) EBM_BIG_IMG_DECL(7, 1) EBM_BIG_IMG_DECL(8, 1)
 EBM_BIG_IMG_DECL(5, 2) EBM_BIG_IMG_DECL(6, 2) EBM_BIG_IMG_DECL(7, 2) EBM_BIG_IMG_DECL(8, 2)
 #undef EBM_BIG_IMG_DECL
-// bytes of the image of a [dim x dim] matrix for the (OT, NS) kernel: [NS][n_stage][3][UNITS][16]
-template <int OT, int NS>
-constexpr size_t big_image_bytes(int dim) {
-  using C = BigCfg<OT, NS>;
-  return (size_t)NS * (size_t)(((dim + 31) & ~31) / (16 * C::KBS)) * 3u * C::UNITS * 16u;
-}
 
 template <int OT, int NS, bool IMG = false>
 int launch_big(const BigArgs& a, hipStream_t st) {

@@ -25,6 +25,27 @@ __global__ __launch_bounds__(256) void gauss_prec_image_kernel(const float* __re
   dst[0] = t.h; dst[units] = t.m; dst[2 * units] = t.l;
 }
 
+// The resident kernel's layout (gauss_res_langevin_kernel: units of a (tile, K-block, K-half) group rotated by 2 (2 kb2 + h')):
+// one thread per unit of [stage][piece][tile j][kb2][h'][slot]; the unit of row r holds Ps[32 j + r][32 s + 16 kb2 + 4 h' + {0..3, 8..11}].
+__global__ __launch_bounds__(256) void gauss_prec_image_res_kernel(const float* __restrict__ prec, int dim, int ot_n, char* __restrict__ out) {
+  const int slabu = ot_n * 128;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ot_n * slabu) return;
+  const int u = g % slabu, s = g / slabu;
+  const int j = u >> 7, kb2 = (u >> 6) & 1, hh = (u >> 5) & 1, slot = u & 31;
+  const int r = (slot - 2 * (2 * kb2 + hh)) & 31;
+  const int row = 32 * j + r, k0 = 32 * s + 16 * kb2 + 4 * hh;
+  f32x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int col = k0 + (i & 3) + 8 * (i >> 2);
+    v[i] = (row < dim && col < dim) ? prec[(int64_t)row * dim + col] : 0.0f;
+  }
+  const Tri t = split8(v);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out) + (int64_t)s * 3 * slabu + u;
+  dst[0] = t.h; dst[slabu] = t.m; dst[2 * slabu] = t.l;
+}
+
 #define EBM_BIG_IMG(OTV, NSV) \
   template <> int launch_big_img<OTV, NSV>(const BigArgs& a, hipStream_t st) { return launch_big<OTV, NSV, true>(a, st); }
 EBM_BIG_IMG(5, 1) EBM_BIG_IMG(6, 1) EBM_BIG_IMG(7, 1) EBM_BIG_IMG(8, 1)
@@ -34,11 +55,15 @@ EBM_BIG_IMG(5, 2) EBM_BIG_IMG(6, 2) EBM_BIG_IMG(7, 2) EBM_BIG_IMG(8, 2)
 namespace {
 struct ImgShape {
   int ot, ns, kbs;
-  size_t bytes;
+  size_t bytes;      // the tiled kernel's image ...
+  size_t res_bytes;  // ... and behind it the resident kernel's (widths it takes: up to eight tiles), or 0
 };
 // the (OT, NS) the dispatch of gauss_big.hip picks for this width
 template <int OT, int NS>
-ImgShape shape_of(int dim) { return ImgShape{OT, NS, BigCfg<OT, NS>::KBS, big_image_bytes<OT, NS>(dim)}; }
+ImgShape shape_of(int dim) {
+  constexpr bool kRes = NS == 1;
+  return ImgShape{OT, NS, BigCfg<OT, NS>::KBS, big_image_bytes<OT, NS>(dim), kRes ? res_image_bytes<OT>() : 0};
+}
 ImgShape image_shape(int32_t dim) {
   const int tiles = (dim + 31) / 32;
   if (tiles <= 8) {
@@ -62,7 +87,11 @@ ImgShape image_shape(int32_t dim) {
 bool gauss_big_supported(int32_t dim);  // gauss_big.hip
 
 // ebm_gauss_prec_image_bytes / ebm_gauss_prec_image_f32 (api.hip)
-size_t gauss_prec_image_bytes(int32_t dim) { return gauss_big_supported(dim) ? gbig::image_shape(dim).bytes : 0; }
+size_t gauss_prec_image_bytes(int32_t dim) {
+  if (!gauss_big_supported(dim)) return 0;
+  const gbig::ImgShape sh = gbig::image_shape(dim);
+  return sh.bytes + sh.res_bytes;
+}
 int launch_gauss_prec_image(const float* prec, int32_t dim, void* image, hipStream_t st, const char* who) {
   if (!gauss_big_supported(dim)) return fail(EBM_EDIM, "%s: no precision image at dim %d (132 .. 512 in steps of 4 only)", who, dim);
   if (!prec || !image) return fail(EBM_EINVAL, "%s: NULL pointer", who);
@@ -72,6 +101,11 @@ int launch_gauss_prec_image(const float* prec, int32_t dim, void* image, hipStre
   const int64_t work = (int64_t)sh.ns * n_stage * sh.ot * 64 * sh.kbs;
   hipLaunchKernelGGL(gbig::gauss_prec_image_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, prec, dim, sh.ot, sh.kbs, sh.ns, n_stage,
                      static_cast<char*>(image));
+  if (sh.res_bytes) {
+    const int res_work = sh.ot * sh.ot * 128;
+    hipLaunchKernelGGL(gbig::gauss_prec_image_res_kernel, dim3((unsigned)((res_work + 255) / 256)), dim3(256), 0, st, prec, dim, sh.ot,
+                       static_cast<char*>(image) + sh.bytes);
+  }
   return check_launch(who);
 }
 

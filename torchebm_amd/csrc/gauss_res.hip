@@ -8,10 +8,8 @@ int launch_gauss_res(int tiles, const gbig::BigArgs& a, hipStream_t st) {
     case 5: return gbig::launch_res<5>(a, st);
     case 6: return gbig::launch_res<6>(a, st);
     case 7: return gbig::launch_res<7>(a, st);
-#ifdef EBM_BIG_RES8
-    case 8: return gbig::launch_res<8>(a, st);
-#endif
-    default: return fail(EBM_EDIM, "ebm_langevin_chain_f32: the register-resident Gaussian kernel takes 5 .. 7 tiles, not %d", tiles);
+    case 8: return gbig::launch_res<8>(a, st);  // (the caller checked: the image is there -- without it eight tiles run tiled)
+    default: return fail(EBM_EDIM, "ebm_langevin_chain_f32: the register-resident Gaussian kernel takes 5 .. 8 tiles, not %d", tiles);
   }
 }
 
