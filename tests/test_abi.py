@@ -75,3 +75,14 @@ def test_plain_hip_program_drives_the_library_without_python(cuda_device, tmp_pa
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "c_abi_demo: OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+def test_image_sizes_are_host_arithmetic():
+    """ebm_*_image_bytes (ABI version 4) need no GPU: 0 = this shape has no image."""
+    lib = _lib.lib()
+    assert lib.ebm_mlp_w1_image_bytes(128, 128) == lib.ebm_mlp_w1_image_bytes(128, 65) == 4 * 3 * 32 * 128 * 2
+    assert lib.ebm_mlp_w1_image_bytes(128, 64) == 0 and lib.ebm_mlp_w1_image_bytes(64, 128) == 0 and lib.ebm_mlp_w1_image_bytes(256, 128) == 0
+    assert lib.ebm_gauss_prec_image_bytes(128) == 0 and lib.ebm_gauss_prec_image_bytes(130) == 0 and lib.ebm_gauss_prec_image_bytes(516) == 0
+    assert lib.ebm_gauss_prec_image_bytes(256) == 2 * 8 * 3 * 1024 * 16          # tiled kernel's copy + resident kernel's copy
+    assert lib.ebm_gauss_prec_image_bytes(512) == 2 * 16 * 3 * 1024 * 16         # two slices x 16 stages
+    assert lib.ebm_gauss_prec_image_bytes(132) == 5 * 3 * 640 * 16 + 5 * 3 * 640 * 16
