@@ -30,6 +30,9 @@ void launch_gmm32(dim3, hipStream_t, HmcArgs);
 using hmc::HmcArgs;
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
+bool gauss_hmc_stream_supported(const ebm_energy_t& e, int32_t dim);  // gauss_hmc_stream.hip: dims 164 .. 256 with the pre-split image
+int launch_hmc_chain_gauss_stream(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
+                                  const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
 bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);
 bool matrix_hmc_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_hmc_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
@@ -97,6 +100,9 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
       return launch_hmc_chain_gauss_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
                                          mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
   }
+  if (!diag_partials && gauss_hmc_stream_supported(e, dim))
+    return launch_hmc_chain_gauss_stream(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag, thin,
+                                         traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
   // Mixtures of up to 32 components, dims 20 .. 96: the two K x dim passes of the gradient on the bf16 matrix pipe
   // (gauss_hmc_mfma.hip: GmmE).  One shape stays on the lane-group kernel: dim 32 with K <= 8, where one lane per chain
   // with the means as scalar operands (and the active-column body) is faster -- dense means, ms per 10 transitions at

@@ -1,15 +1,17 @@
 // The matrix-layout HMC kernels with in-kernel diagnostics records (mfma_hmc_body.h: DIAG; one record per wave of 32
-// chains, diag::wave_record).  Dense Gaussians at every dim the kernels take (20 .. 128) and mixtures at dims 20 .. 96 -- the
+// chains, diag::wave_record).  Dense Gaussians at every dim the kernels take (20 .. 160; 164 .. 256 with the pre-split image) and mixtures at dims 20 .. 96 -- the
 // shapes that run here under EVERY mass form, which the layout query (ebm_diag_layout) is not told; a mixture beyond 96
 // takes a run with records on the lane-group kernels.
 #include "mfma_hmc_body.h"
+#include "gauss_stream_e.h"
 
 namespace ebm {
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
+bool gauss_hmc_stream_supported(const ebm_energy_t& e, int32_t dim);  // gauss_hmc_stream.hip
 
 bool matrix_hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
-  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, EBM_MASS_NONE);
+  const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && (gauss_hmc_mfma_supported(dim, EBM_MASS_NONE) || gauss_hmc_stream_supported(e, dim));
   const bool mix = e.kind == EBM_ENERGY_GMM && dim >= 20 && dim <= 96 && dim % 4 == 0 && e.n_comp >= 1 && e.n_comp <= 32 &&
                    !(dim == 32 && e.n_comp <= 8);
   if (!gauss && !mix) return false;
@@ -35,7 +37,11 @@ int launch_diag(const GaussHmcArgs& a, bool mixture, hipStream_t st) {
   if (nt == 2) return launch_gauss_diag<2, DIAGM>(a, st);
   if (nt == 3) return launch_gauss_diag<3, DIAGM>(a, st);
   if (nt == 4) return launch_gauss_diag<4, DIAGM>(a, st);
-  return launch_gauss_diag<5, DIAGM>(a, st);
+  if (nt == 5) return launch_gauss_diag<5, DIAGM>(a, st);
+  // 164 .. 256: the streamed evaluation (the plan admitted these widths only with the image at hand)
+  if (nt == 6) return launch_policy<6, DIAGM, GaussStreamE<6>, 0, true>(a, st);
+  if (nt == 7) return launch_policy<7, DIAGM, GaussStreamE<7>, 0, true>(a, st);
+  return launch_policy<8, DIAGM, GaussStreamE<8>, 0, true>(a, st);
 }
 }  // namespace
 

@@ -12,6 +12,7 @@
 // of hmc_kernel.h; the accepted state is "parked" in the x array itself (written on accept, re-read on
 // reject), which costs 256 B per chain and transition and no registers.
 #pragma once
+#include <type_traits>
 #include "diag.h"
 #include "ebm_common.h"
 #include "gauss_bf16x3.h"
@@ -43,6 +44,7 @@ struct GaussHmcArgs {
   const float* mean;  // [dim]
   const float* prec;  // [dim, dim], symmetric
   const float* mass_diag;  // [dim] diagonal mass (null: none / scalar)
+  const char* prec_image;  // dense Gaussian beyond 160 dims (gauss_hmc_stream.hip): the pre-split precision image, else null
   // Gaussian mixture (GmmE below): means [n_comp, dim], log-weights [n_comp], 1 / (2 sigma^2), 1 / sigma^2
   const float* gm_means;
   const float* gm_logw;
@@ -163,9 +165,23 @@ struct GmmE {
 // registers) at the kept transitions; the energy is the carried one, the accept share the decision just taken.
 // CARRY off (E::kCarry: the four-tile Gaussian on the split contraction, whose 96 KB of operands leave no LDS for the parked
 // force): energy and force are evaluated at the top of every transition, as the reference does.
+// An energy whose evaluation has workgroup barriers inside (GaussStreamE: the slabs of Ps stream through LDS) says so with
+// kBlockVote: the fast / literal decision of a leapfrog step is then taken per WORKGROUP -- every wave makes the same number
+// of evaluations.  (For chains that are fine the literal path computes exactly what the fast path does.)
+template <class E, class = void>
+struct BlockVote { static constexpr bool value = false; };
+template <class E>
+struct BlockVote<E, std::enable_if_t<E::kBlockVote>> { static constexpr bool value = true; };
+template <class E>
+__device__ __forceinline__ bool vote_all(bool pred) {
+  if constexpr (BlockVote<E>::value) return __syncthreads_and(pred ? 1 : 0) != 0;
+  else return __all(pred);
+}
+
 template <int NT, bool DIAGM, class E, bool DIAG = false>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr bool CARRY = E::kCarry;
+  E en{};  // (state of the evaluation across calls, if it has any: GaussStreamE's buffer parity)
   constexpr int DIM = 32 * NT;
   float* elds = gauss_hmc_smem;  // the energy's own area
   // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
@@ -255,7 +271,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   Tile<NT> f;
   float e_cur = 0.0f;
   if constexpr (CARRY) {
-    e_cur = E::eval(a, elds, x, f, m, h);
+    e_cur = en.eval(a, elds, x, f, m, h);
     if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -314,7 +330,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 
     // ---- H0 and the first (clamped) force: the carried pair
     if constexpr (!CARRY) {
-      e_cur = E::eval(a, elds, x, f, m, h);
+      e_cur = en.eval(a, elds, x, f, m, h);
       if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
     }
     const float e0 = e_cur;
@@ -358,7 +374,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
       // a second inlined copy of the 64 NT^2 MFMAs costs registers in the hot loop)
       bool scrubbed = false;
       for (;;) {
-        e1 = E::eval(a, elds, x, f, m, h);  // f holds +g here (e1: the energy, or a finiteness witness)
+        e1 = en.eval(a, elds, x, f, m, h);  // f holds +g here (e1: the energy, or a finiteness witness)
         if (scrubbed) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -370,7 +386,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
         // MFMA evaluation, and an MFMA writes its result for every lane whatever EXEC says -- it must not
         // run while other chains of the wave sit in the fast path.  (For a chain that is fine the literal
         // path computes exactly what the fast path does.)
-        if (__all(__builtin_fabsf(e1) < __builtin_inff())) {
+        if (vote_all<E>(__builtin_fabsf(e1) < __builtin_inff())) {
           float pz = 0.0f;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -507,6 +523,7 @@ inline GaussHmcArgs matrix_hmc_args(const ebm_energy_t& e, float* x, int64_t n_c
   a.mass_diag = mass_kind == EBM_MASS_DIAG ? mass_diag : nullptr;
   const bool mixture = e.kind == EBM_ENERGY_GMM;
   a.mean = mixture ? nullptr : e.dev0; a.prec = mixture ? nullptr : e.dev1;
+  a.prec_image = (!mixture && e.kind == EBM_ENERGY_GAUSSIAN) ? reinterpret_cast<const char*>(e.aux) : nullptr;
   a.gm_means = mixture ? e.dev0 : nullptr; a.gm_logw = mixture ? e.dev1 : nullptr;
   a.n_comp = mixture ? e.n_comp : 0; a.inv2s2 = mixture ? e.s[0] : 0.0f; a.invs2 = mixture ? e.s[1] : 0.0f;
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0};

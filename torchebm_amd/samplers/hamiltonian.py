@@ -132,6 +132,7 @@ class HamiltonianMonteCarlo(BaseSampler):
                 spec = None  # (a wide MLP energy: fused for Langevin only)
             if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None and spec.dim > 128
                     and not (spec.dim <= 160 and spec.dim % 4 == 0)  # (132 .. 160: five tiles, the split operands still fit LDS)
+                    and not (spec.dim <= 256 and spec.dim % 4 == 0 and spec.aux is not None)  # (164 .. 256: the slabs stream from the pre-split image)
                     and x.shape[0] >= 16384 and self.capture_graph is not False and self._graph_eligible(model_kwargs)):
                 # Above 160 dims (and off multiples of 4 above 128) the transition kernel is the lane-group mat-vec (2 TFLOP/s); the per-transition route -- the
                 # gradient and the energy as one library GEMM each (GaussianModel), kick / drift / accept kernels on the same
