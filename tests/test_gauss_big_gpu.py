@@ -180,10 +180,11 @@ def test_widths_without_a_matrix_chain_kernel_take_the_gemm_step_route(cuda_devi
 
 
 def test_wide_gaussian_hmc_takes_the_gemm_transition_route(cuda_device):
-    """Above 128 dims HamiltonianMonteCarlo runs the per-transition route for a GaussianModel -- gradient and energy as one
+    """Above 256 dims (round 4: 164 .. 256 run the streamed transition kernel, tests/test_gauss_hmc_stream_gpu.py)
+    HamiltonianMonteCarlo runs the per-transition route for a GaussianModel -- gradient and energy as one
     library GEMM each, kick / drift / accept kernels on the native field -- instead of the lane-group transition kernel;
     same generator => same draws, so the chains agree with that kernel's (through the C ABI) except for borderline accepts."""
-    dim, n, T, L = 192, 16384, 4, 5
+    dim, n, T, L = 320, 16384, 4, 5
     model, _ = _model(dim, cuda_device, seed=9)
     s = ta.HamiltonianMonteCarlo(model, step_size=0.08, n_leapfrog_steps=L, device=cuda_device)
     x0 = torch.randn(n, dim, device=cuda_device)
