@@ -404,3 +404,41 @@ def test_gaussian_bf16x3_contraction_is_fp32_accurate(cuda_device, dim):
     natural = eta * (d.abs() @ ps.abs().t()) + x0.double().abs()
     err = (x.cpu().double() - want).abs() / natural
     assert err.max().item() < 16 * 2.0 ** -24, err.max().item()
+
+
+@pytest.mark.parametrize("dim", [8, 32, 64, 130, 192, 300])
+@pytest.mark.parametrize("kind", ["gauss", "dw", "har"])
+def test_chains_that_start_non_finite_keep_their_state_until_they_accept(cuda_device, kind, dim):
+    """reference samplers/hmc.py:243-292: model(x) at the top of the first transition is evaluated on the state as handed over
+    -- a NaN coordinate makes H0 NaN and every proposal is rejected, the chain KEEPS its NaN; an infinite one gives an infinite
+    (clamped) H0 and the state stays until a proposal is accepted.  Round 4: the lane-group kernels' pseudo-transition (the
+    carried energy / force of the initial state, hmc_kernel.h) used to scrub such a state and carry the scrubbed state's
+    energy -- NaN chains could accept, infinite ones came back as 3.4e38.  Every kernel family against the oracle."""
+    g = torch.Generator().manual_seed(dim)
+    a = torch.randn(dim, dim, generator=g)
+    mean, cov = torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim)
+    model, en = {"gauss": (ta.GaussianModel(mean, cov, device=cuda_device), oracle.Gaussian(mean, cov)),
+                 "dw": (ta.DoubleWellModel(2.0, 1.0, device=cuda_device), oracle.DoubleWell(2.0, 1.0)),
+                 "har": (ta.HarmonicModel(k=1.3, device=cuda_device), oracle.Harmonic(1.3))}[kind]
+    n, T, L, eps = 70, 3, 4, 0.05
+    x0 = torch.randn(n, dim, generator=g)
+    x0[3, dim - 1] = float("nan")
+    x0[5, 0] = float("inf")
+    x0[7, 2] = float("-inf")
+    p, u = torch.randn(T, n, dim, generator=g), torch.rand(T, n, generator=g)
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, want_margins=True)
+    spec = model.fused_spec()
+    x = x0.to(cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    pd, ud = p.to(cuda_device), u.to(cuda_device)
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, dim, T, L, eps, None, 0, 0.0, None, 1, None, None, mask.data_ptr(), None,
+              pd.data_ptr(), ud.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    x, mask = x.cpu(), mask.cpu().bool()
+    for c in (3, 5, 7):
+        assert mask[:, c].tolist() == want["accepted"][:, c].tolist(), c
+        assert torch.equal(torch.isnan(x[c]), torch.isnan(want["x"][c])), c
+        keep = ~torch.isnan(x[c])
+        if not want["accepted"][:, c].any():
+            assert torch.equal(x[c][keep], x0[c][keep]), c      # rejected throughout: the state as handed over, bit for bit
+    clear = want["margins"] > 2e-4
+    assert torch.equal(mask[clear], want["accepted"][clear])

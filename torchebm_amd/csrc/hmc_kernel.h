@@ -60,7 +60,7 @@ template <bool HAS_MASS, class En, class LaneT>
 __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Slice<LaneT::NV>& x,
                                                 Slice<LaneT::NV>& p, Slice<LaneT::NV>& f,
                                                 const Slice<LaneT::NV>& m_safe, float eps, float half_eps,
-                                                int n_steps, float e_in) {
+                                                int n_steps, float e_in, bool init = false) {
   constexpr int NV = LaneT::NV;
   typedef float v2f __attribute__((ext_vector_type(2)));
   float e = e_in;
@@ -146,6 +146,16 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
           p = pn;
         }
       }
+    } else if (init) {
+      // The pseudo-transition on a state that is not finite (or whose energy is not): NOTHING is scrubbed -- the reference
+      // evaluates model(x) at the top of the first transition on the state as it was handed over (samplers/hmc.py:243-256), so
+      // the carried energy is the raw one (NaN rejects every proposal, an infinite one is clamped in H0) and the chain keeps
+      // its state until a proposal is accepted; the force takes the NaN-propagating clamp of the first half kick.
+      if (!have_e) e = en.template eval<true>(L, x, g);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[v][i] = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
     } else {  // rare: literal semantics
       if (!have_e) e = en.template eval<true>(L, x, g);
 #pragma unroll
@@ -349,9 +359,9 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
       for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) drift_scale.a[v][i] = eps_t / m_safe.a[v][i];
-      e1 = leapfrog_steps<true>(en, L, x, p, f, drift_scale, eps_t, half_eps, n_lf, e0);
+      e1 = leapfrog_steps<true>(en, L, x, p, f, drift_scale, eps_t, half_eps, n_lf, e0, init);
     }
-    else e1 = leapfrog_steps<false>(en, L, x, p, f, x, eps_t, half_eps, n_lf, e0);
+    else e1 = leapfrog_steps<false>(en, L, x, p, f, x, eps_t, half_eps, n_lf, e0, init);
     if constexpr (F_TWO) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) park_put(NV * (2 - fcur) + v, f.a[v]);
