@@ -554,10 +554,12 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         # dense Gaussian Langevin over widths: packed rows (8 / 30 / 50), resident in registers + LDS (64 / 128), Ps streamed
         # (160 / 256 / 512) -- csrc/gauss_mfma.hip, csrc/gauss_big.hip; VERDICT r2 item 5
         out = {"name": "gaussian_langevin_widths", "workload": "LangevinDynamics.sample on GaussianModel, k = 20 steps per call, widths "
-               "8 / 30 / 50 (packed rows), 64 / 128 (register-resident, Ps in LDS), 160 / 256 / 512 (Ps streamed through LDS)",
+               "8 / 30 / 50 (packed rows), 64 / 128 / 160 (register-resident, Ps in LDS), 192 / 224 / 256 (register-resident, Ps streamed from its "
+               "pre-split image by LDS-direct loads), 384 / 512 (tiled, same image)",
                "bound": "valu + bf16 mfma", "metric": "chain-steps/s; step-equivalent fraction of 8 TB/s = n k 8 dim / t / 8e12", "dims": {}}
         k = 20
-        for dim, n in ((8, 1 << 18), (30, 1 << 18), (50, 1 << 18), (64, 1 << 18), (128, 1 << 18), (160, 1 << 17), (256, 1 << 17), (512, 1 << 16)):
+        for dim, n in ((8, 1 << 18), (30, 1 << 18), (50, 1 << 18), (64, 1 << 18), (128, 1 << 18), (160, 1 << 17), (192, 1 << 17), (224, 1 << 17),
+                       (256, 1 << 17), (384, 1 << 16), (512, 1 << 16)):
             gd = torch.Generator().manual_seed(dim)
             a = torch.randn(dim, dim, generator=gd)
             model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=device)
@@ -633,7 +635,9 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                 "vs_fp32_matrix_peak": flops / (kms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
                 "issued_bf16_TFLOPs": 6 * flops / (kms * 1e-3) / 1e12, "peak": BF16_MATRIX_PEAK_TFLOPS,
                 "frac": 6 * flops / (kms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, "chain_steps_per_s": n * k / (kms * 1e-3),
-                "hidden_256": wide(256, "langevin"), "hmc_hidden_128": wide(128, "hmc"), "hmc_hidden_256": wide(256, "hmc")}
+                "hidden_256": wide(256, "langevin"), "hmc_hidden_128": wide(128, "hmc"), "hmc_hidden_256": wide(256, "hmc"),
+                # the same network at the reference's widest benchmark input (dim 128): W1's split image streamed through LDS (round 4)
+                "dim_128": wide(128, "langevin", dim=128)}
 
     guarded("config3_hmc_gmm8", c3)
     guarded("config4_shard", c4)
@@ -642,6 +646,29 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
     guarded("langevin_step_kernel", step_kernel)
     guarded("matrix_pipe_energies", matrix_pipe)
     guarded("gaussian_langevin_widths", gaussian_widths)
+
+    def gaussian_hmc_widths():
+        # HMC on dense Gaussians beyond the LDS-resident widths: one ebm_hmc_chain_f32 launch (csrc/gauss_hmc_stream.hip) -- VERDICT r3 item 7
+        out = {"name": "gaussian_hmc_widths", "workload": "HamiltonianMonteCarlo.sample on GaussianModel, 5 transitions of 10 leapfrog steps, "
+               "n_chains = 2^17: dims 160 (precision images resident in LDS), 192 / 256 (streamed from the pre-split image)",
+               "bound": "instruction issue at one wave per SIMD; bf16 mfma", "metric": "ms per call; useful fp32-equivalent TFLOP/s", "dims": {}}
+        n, T, L = 1 << 17, 5, 10
+        for dim in (160, 192, 256):
+            gd = torch.Generator().manual_seed(dim)
+            a = torch.randn(dim, dim, generator=gd)
+            model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=device)
+            hm = ta.HamiltonianMonteCarlo(model, step_size=0.05, n_leapfrog_steps=L, device=device)
+            x0 = torch.randn(n, dim, device=device)
+            fn = lambda: hm.sample(x=x0, n_steps=T)  # noqa: E731
+            fn()
+            before = _lib.call_counts["ebm_hmc_chain_f32"]
+            kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 3, device)
+            launches = (_lib.call_counts["ebm_hmc_chain_f32"] - before) / 3
+            out["dims"][str(dim)] = {"kernel_ms": kms, "launches_per_call": launches, "mh_steps_per_s": n * T / (kms * 1e-3),
+                                     "useful_TFLOPs": 2 * n * dim * dim * T * (L + 1) / (kms * 1e-3) / 1e12}
+        return out
+
+    guarded("gaussian_hmc_widths", gaussian_hmc_widths)
     return out
 
 
