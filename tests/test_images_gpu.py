@@ -192,3 +192,31 @@ def test_mlp_with_and_without_the_image(cuda_device, dim, n):
     plain = s.sample(x=x0, n_steps=6, generator=torch.Generator(device=cuda_device).manual_seed(5))
     assert torch.equal(traj[:, -1], plain)
     torch.testing.assert_close(d["energy"][-1], model(traj[:, -1]).mean(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dim,mass_kind", [(96, 0), (128, 0), (100, 2)])
+def test_mlp_hmc_with_and_without_the_image(cuda_device, dim, mass_kind):
+    """The transition kernel at H = 128 beyond dim 64: MODE 3 (image) and MODE 0 (aux = NULL: exact-f32 MFMA) on the same draws --
+    the same accept decisions but for chains within rounding of a tie, the same positions to the tolerance of the two contractions."""
+    torch.manual_seed(dim)
+    model = ta.MLPEnergy(dim, 128, device=cuda_device)
+    spec = model.fused_spec()
+    n, T, L, eps = 300, 4, 5, 0.05
+    x0 = torch.randn(n, dim, device=cuda_device)
+    mass = (torch.rand(dim, device=cuda_device) + 0.5) if mass_kind == 2 else None
+    outs = []
+    for with_image in (True, False):
+        d = spec.to_c()
+        if not with_image:
+            d.aux = None
+        x = x0.clone()
+        mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+        _lib.call("ebm_hmc_chain_f32", d, x.data_ptr(), n, dim, T, L, eps, None, mass_kind, 0.0, _lib.ptr(mass), 1, None, None, mask.data_ptr(),
+                  None, None, None, 11, 4, _lib.stream_handle(cuda_device))
+        outs.append((x.cpu(), mask.cpu().bool()))
+    (xa, ma), (xb, mb) = outs
+    same = (ma == mb).all(dim=0)
+    assert same.float().mean().item() >= 0.98
+    assert 0.3 < ma.float().mean().item() <= 1.0
+    torch.testing.assert_close(xa[same], xb[same], rtol=2e-4, atol=2e-4)
+    assert torch.isfinite(xa).all()

@@ -18,7 +18,7 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
                               int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
                               const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
                               const float* p_noise, const float* u, uint64_t seed, uint64_t offset, float* diag_partials,
-                              hipStream_t st, const char* who);
+                              const void* w1_image, hipStream_t st, const char* who);
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
@@ -59,7 +59,7 @@ int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int3
   const char* who = "ebm_hmc_chain_f32";
   if (int r = mlp_check(e, dim, who, true)) return r;
   return launch_hmc_chain_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
-                                   mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st, who);
+                                   mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, e.aux, st, who);
 }
 
 int launch_energy_grad_mlp(const ebm_energy_t& e, const float* x, int64_t n_chains, int32_t dim, float* e_out,

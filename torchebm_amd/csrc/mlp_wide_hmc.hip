@@ -27,8 +27,9 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
                               int32_t n_leapfrog, float eps, const float* eps_table, int32_t mass_kind, double mass_scalar,
                               const float* mass_diag, int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count,
                               const float* p_noise, const float* u, uint64_t seed, uint64_t offset, float* diag_partials,
-                              hipStream_t st, const char* who) {
+                              const void* w1_image, hipStream_t st, const char* who) {
   widemlp::WideHmcArgs a{};
+  a.w1_image = static_cast<const char*>(w1_image);
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
   a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
   a.mass_raw = (float)mass_scalar;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
           }
       }
       constexpr bool eval_energy_only = false, eval_block_cuts = false;
-      [[maybe_unused]] constexpr bool slab_more = false;  // (MODE 3 is a chain-kernel mode)
+      [[maybe_unused]] constexpr bool slab_more = true;  // MODE 3: every evaluation asks for the next one's first slab (drained at the end)
 #include "mlp_wide_eval.inc"
       if (mode == 0) {  // H0 and the first (clamped) force
         h0 = clamp_nanprop(energy, -1e10f, 1e10f) + kinetic(p);
@@ -186,7 +186,11 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
       } else if (mode == 1) {
         // E finite => x finite and the gradient free of NaN (hmc_kernel.h); decided per WAVE because the literal path
         // re-runs the MFMA evaluation
-        if (__all(__builtin_fabsf(energy) < __builtin_inff())) {
+        // (MODE 3: per WORKGROUP -- its evaluation has barriers inside, every wave must make the same number of them; for
+        //  chains that are fine the literal path computes exactly what the fast path does)
+        const bool all_fine = SLAB ? (__syncthreads_and(__builtin_fabsf(energy) < __builtin_inff() ? 1 : 0) != 0)
+                                   : (bool)__all(__builtin_fabsf(energy) < __builtin_inff());
+        if (all_fine) {
           float pz = 0.0f;
 #pragma unroll
           for (int td = 0; td < DT; ++td)
@@ -275,11 +279,12 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
       keep_off += dim;
     }
   }
+  if constexpr (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the slab the last evaluation asked for)
 }
 
-template <int HT, int DT, bool DIAGM, bool FAST>
+template <int HT, int DT, bool DIAGM, bool FAST, int MODE_ = -1>
 int launch_hmc_variant(const WideHmcArgs& a, hipStream_t st, const char* who) {
-  constexpr int MODE = wide_mode(HT, DT);
+  constexpr int MODE = MODE_ >= 0 ? MODE_ : wide_mode(HT, DT);
   constexpr bool STREAM = MODE == 1;
   const size_t smem = wide_smem_bytes(HT, DT, MODE);
   if (STREAM && (reinterpret_cast<uintptr_t>(a.params) & 15) != 0)
@@ -302,8 +307,20 @@ int launch_hmc_fast(const WideHmcArgs& a, hipStream_t st, const char* who);
 EBM_HMC_FAST_DECL(2, 1) EBM_HMC_FAST_DECL(2, 2) EBM_HMC_FAST_DECL(2, 3) EBM_HMC_FAST_DECL(2, 4) EBM_HMC_FAST_DECL(4, 1) EBM_HMC_FAST_DECL(4, 2)
 #undef EBM_HMC_FAST_DECL
 
+// MODE 3 (mlp_wide_hmc_slab.hip): H = 128, dim 65 .. 128 with the W1 image at hand
+template <int DT, bool DIAGM>
+int launch_hmc_slab(const WideHmcArgs& a, hipStream_t st, const char* who);
+#define EBM_HMC_SLAB_DECL(DTV, DM) template <> int launch_hmc_slab<DTV, DM>(const WideHmcArgs& a, hipStream_t st, const char* who);
+EBM_HMC_SLAB_DECL(3, false) EBM_HMC_SLAB_DECL(3, true) EBM_HMC_SLAB_DECL(4, false) EBM_HMC_SLAB_DECL(4, true)
+#undef EBM_HMC_SLAB_DECL
+
 template <int HT, int DT, bool DIAGM>
 int launch_hmc_one(const WideHmcArgs& a, hipStream_t st, const char* who) {
+#ifndef EBM_MLP_F32LDS
+  if constexpr (HT == 4 && DT >= 3) {
+    if (a.w1_image && (reinterpret_cast<uintptr_t>(a.w1_image) & 15) == 0) return launch_hmc_slab<DT, DIAGM>(a, st, who);
+  }
+#endif
   if constexpr (wide_mode(HT, DT) == 2 && !DIAGM) {
     if (!a.p_noise && !a.u && !a.diag_partials && ((a.dim & 3) == 0 || a.dim == 2)) return launch_hmc_fast<HT, DT>(a, st, who);
   }
