@@ -653,3 +653,25 @@ print("datasets-ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         assert "datasets-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_descriptor_keeps_its_tensors_alive():
+    """``model.fused_spec().to_c()``: the C descriptor holds raw pointers, the FusedSpec is a temporary -- the descriptor itself
+    must own the tensors (a mixture's ``aux`` hint is allocated per call; freed, the caching allocator gives its block to
+    the next allocation before the launch reads it)."""
+    import gc
+    import weakref
+
+    from torchebm_amd.core.energies import FusedSpec
+
+    aux = torch.zeros(1, dtype=torch.int32)
+    dev0 = torch.zeros(8, 4)
+    refs = [weakref.ref(aux), weakref.ref(dev0)]
+    desc = FusedSpec(_lib.ENERGY_GMM, aux=aux, dev0=dev0, n_comp=8, dim=4).to_c()
+    del aux, dev0
+    gc.collect()
+    assert all(r() is not None for r in refs)
+    assert desc.aux == refs[0]().data_ptr() and desc.dev0 == refs[1]().data_ptr()
+    del desc
+    gc.collect()
+    assert all(r() is None for r in refs)

@@ -51,6 +51,10 @@ class FusedSpec:
         d.dev0 = _lib.ptr(self.dev0)
         d.dev1 = _lib.ptr(self.dev1)
         d.aux = _lib.ptr(self.aux)
+        # the descriptor holds raw device pointers: it keeps their tensors alive itself (``aux`` of a mixture is a fresh
+        # temporary of every fused_spec() call -- with ``model.fused_spec().to_c()`` the spec is gone before the launch, the
+        # allocator hands the block to the next allocation and the kernel reads whatever was written there)
+        d._keepalive = (self.dev0, self.dev1, self.aux)
         return d
 
 

@@ -88,7 +88,9 @@ struct NoFill {
 };
 // MTL / IT0: the staged matrix has MTL row tiles and this call produces tiles IT0 .. IT0 + MT - 1 of them (MT < MTL:
 // the output in pieces, for bodies that have no registers for all accumulators and operands at once).
-template <int MT, int KB, bool SUB, class Fill = NoFill, int MTL = MT, int IT0 = 0>
+// KBU: the K-blocks actually contracted (the staged layout keeps KB): trailing K-blocks that hold nothing but zero padding
+// -- 16 KBU >= dim -- add exactly 0 to every accumulator and are left out (their MFMAs, their split of the operand).
+template <int MT, int KB, bool SUB, class Fill = NoFill, int MTL = MT, int IT0 = 0, int KBU = KB>
 __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop, const float* __restrict__ mus,
                                                  const f32x16 (&x)[(KB + 1) / 2], f32x16 (&g)[MT], int lane,
                                                  Fill&& fill = NoFill{}) {
@@ -105,7 +107,8 @@ __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][it][r] = 0.0f;
   const bf16x8* ap = reinterpret_cast<const bf16x8*>(aop) + lane;
-  static_for<KB>([&](auto kbc) {
+  static_assert(KBU >= 1 && KBU <= KB, "K-blocks used");
+  static_for<KBU>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value;
     constexpr int t = kb >> 1, b = kb & 1;
     float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
@@ -174,10 +177,10 @@ __device__ __forceinline__ void contract_pieces(const __bf16* __restrict__ aop, 
 }
 
 // the Gaussian form: g = Ps (x - mu) on (32 NT)^2
-template <int NT, class Fill = NoFill>
+template <int NT, int KBU = 2 * NT, class Fill = NoFill>
 __device__ __forceinline__ void contract(const __bf16* __restrict__ aop, const float* __restrict__ mus, const f32x16 (&x)[NT],
                                          f32x16 (&g)[NT], int lane, Fill&& fill = NoFill{}) {
-  contract_general<NT, 2 * NT, true>(aop, mus, x, g, lane, static_cast<Fill&&>(fill));
+  contract_general<NT, 2 * NT, true, Fill, NT, 0, KBU>(aop, mus, x, g, lane, static_cast<Fill&&>(fill));
 }
 
 }  // namespace gauss3

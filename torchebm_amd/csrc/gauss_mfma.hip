@@ -65,9 +65,12 @@ extern __shared__ __attribute__((aligned(16))) float gauss_smem[];
 // DIAG: the in-kernel diagnostics records (diag.h) at the kept steps -- the workgroup's 128 chains go to an LDS tile
 // in flat order, the energy of a kept state is one more evaluation (Gaussian: contraction + dot; mixture: the
 // difference-form logsumexp).
-template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, int GKR = 0, bool DIAG = false>
+// KT: trailing K-blocks of 16 coordinates that are padding only (dim <= 32 NT - 16 KT) and left out of the contraction
+// (dims 36..48, 68..80, 100..112, 132..144: a quarter .. a tenth of the MFMAs and of the operand split).
+template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, int GKR = 0, bool DIAG = false, int KT = 0>
 __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
-  constexpr int DIM = 32 * NT;
+  constexpr int DIM = 32 * NT, KBU = 2 * NT - KT;
+  static_assert(KT == 0 || (B3 && GKR == 0), "trimmed K-blocks: the dense Gaussian on the bf16 pipe");
   using Mix = gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>;
   // LDS: the precision matrix -- fp32 [DIM][DIM], or its three operand-ready bf16 splits (1.5x the bytes) -- then mu
   float* Ps = gauss_smem;
@@ -137,7 +140,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       asm volatile("" : "+v"(e_row));
       f32x16 eps[NT];
       constexpr int QUADS = 4 * HIDE, PER_QUAD = 13, STAGES = QUADS * PER_QUAD;
-      constexpr int N_MFMA = GKR > 0 ? Mix::kMfmas : 6 * NT * (2 * NT);
+      constexpr int N_MFMA = GKR > 0 ? Mix::kMfmas : 6 * NT * KBU;
       constexpr int PER_MFMA = (STAGES + N_MFMA - 1) / N_MFMA;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, k0 = 0, k1 = 0;
       auto stage = [&](auto sc) {
@@ -172,7 +175,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
       };
       if constexpr (GKR > 0) Mix::grad(a.gm, gauss_smem, x, g, lane, behind_mfma);
-      else gauss3::contract<NT>(aop, mus, x, g, lane, behind_mfma);
+      else gauss3::contract<NT, KBU>(aop, mus, x, g, lane, behind_mfma);
       // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
       static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
       if constexpr (HIDE < NT) {  // the remaining tiles: drawn now, one quad at a time
@@ -207,7 +210,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
     if constexpr (GKR > 0) {
       Mix::grad(a.gm, gauss_smem, x, g, lane);
     } else if constexpr (B3) {
-      gauss3::contract<NT>(aop, mus, x, g, lane);  // (contract_pieces costs this body registers: it has no spill to cure)
+      gauss3::contract<NT, KBU>(aop, mus, x, g, lane);  // (contract_pieces costs this body registers: it has no spill to cure)
     } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -315,7 +318,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           e_now = Mix::energy(a.gm, gauss_smem, x, lane);
         } else {
           f32x16 g2[NT];
-          gauss3::contract<NT>(aop, mus, x, g2, lane);
+          gauss3::contract<NT, KBU>(aop, mus, x, g2, lane);
           float acc = 0.0f;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -352,15 +355,15 @@ template <int NT>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_mfma_kernel(GaussArgs a) {
   gauss_langevin_mfma_body<NT, false>(a);
 }
-template <int NT>
+template <int NT, int KT = 0>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_kernel(GaussArgs a) {
-  gauss_langevin_mfma_body<NT, true>(a);
+  gauss_langevin_mfma_body<NT, true, false, kBlock, NT, 0, false, KT>(a);
 }
-template <int NT>
+template <int NT, int KT = 0>
 __global__ __launch_bounds__(kBlock) void gauss_langevin_bf16x3_fast_kernel(GaussArgs a) {
   // five tiles: the normals of four are drawn behind the MFMAs, the fifth tile's after the contraction -- all five (80
   // registers across the contraction) left the 512-register wave with 76 spilled values
-  gauss_langevin_mfma_body<NT, true, true, kBlock, (NT >= 5 ? 4 : NT)>(a);
+  gauss_langevin_mfma_body<NT, true, true, kBlock, (NT >= 5 ? 4 : NT), 0, false, KT>(a);
 }
 template <int NT, int GKR>
 __global__ __launch_bounds__(kBlock) void gmm_langevin_bf16x3_kernel(GaussArgs a) {
@@ -376,12 +379,12 @@ __global__ __launch_bounds__(kBlock) void matrix_langevin_diag_kernel(GaussArgs 
   gauss_langevin_mfma_body<NT, true, false, kBlock, NT, GKR, true>(a);
 }
 constexpr int kWideBlock = 512;
-template <int NT, int HIDE>
+template <int NT, int HIDE, int KT = 0>
 __global__ __launch_bounds__(kWideBlock) void gauss_langevin_bf16x3_fast_wide_kernel(GaussArgs a) {
-  gauss_langevin_mfma_body<NT, true, true, kWideBlock, HIDE>(a);
+  gauss_langevin_mfma_body<NT, true, true, kWideBlock, HIDE, 0, false, KT>(a);
 }
 
-template <int NT>
+template <int NT, int KT = 0>
 int launch_nt(const GaussArgs& a, hipStream_t st) {
   // A/B switch for tests and profiling: EBM_GAUSS_F32MFMA=1 keeps the exact-f32 MFMA contraction
   static const bool f32_mfma = ab_switch("EBM_GAUSS_F32MFMA");
@@ -390,9 +393,9 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
   if (attr_once.first() && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_mfma_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_kernel<NT, KT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_kernel<NT, KT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
@@ -404,18 +407,18 @@ int launch_nt(const GaussArgs& a, hipStream_t st) {
       constexpr int HIDE = 2;
       static bool wide_attr = false;
       if (!wide_attr && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE, KT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         wide_attr = true;
       }
       const int64_t wblocks = ceil_div64(a.n_chains, 32 * (kWideBlock / 64));
-      hipLaunchKernelGGL((gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE>), dim3((unsigned)wblocks), dim3(kWideBlock), smem, st, a);
+      hipLaunchKernelGGL((gauss_langevin_bf16x3_fast_wide_kernel<NT, HIDE, KT>), dim3((unsigned)wblocks), dim3(kWideBlock), smem, st, a);
       return check_launch("ebm_langevin_chain_f32");
     }
   }
   if (f32_mfma) hipLaunchKernelGGL(gauss_langevin_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else if (!a.noise && !a.clamp_on) hipLaunchKernelGGL(gauss_langevin_bf16x3_fast_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
-  else hipLaunchKernelGGL(gauss_langevin_bf16x3_kernel<NT>, dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else if (!a.noise && !a.clamp_on) hipLaunchKernelGGL((gauss_langevin_bf16x3_fast_kernel<NT, KT>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+  else hipLaunchKernelGGL((gauss_langevin_bf16x3_kernel<NT, KT>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
@@ -462,12 +465,16 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
   a.step0 = offset; a.mean = e.dev0; a.prec = e.dev1;
   a.gm = gmm3::Params{nullptr, nullptr, 0, dim, 0.0f, 0.0f};
   a.diag = diag::DiagArgs{nullptr, 0, 0, 0}; a.diag_offset_floats = 0;
-  switch ((dim + 31) / 32) {
+  // the last 16 coordinates of the last tile all padding: that K-block is left out (EBM_GAUSS_NOTRIM=1: the A/B switch)
+  static const bool no_trim = ab_switch("EBM_GAUSS_NOTRIM");
+  const int nt = (dim + 31) / 32;
+  const bool trim = 32 * nt - dim >= 16 && !no_trim;
+  switch (nt) {
     case 1: return launch_nt<1>(a, st);
-    case 2: return launch_nt<2>(a, st);
-    case 3: return launch_nt<3>(a, st);
-    case 4: return launch_nt<4>(a, st);
-    default: return launch_nt<5>(a, st);
+    case 2: return trim ? launch_nt<2, 1>(a, st) : launch_nt<2>(a, st);
+    case 3: return trim ? launch_nt<3, 1>(a, st) : launch_nt<3>(a, st);
+    case 4: return trim ? launch_nt<4, 1>(a, st) : launch_nt<4>(a, st);
+    default: return trim ? launch_nt<5, 1>(a, st) : launch_nt<5>(a, st);
   }
 }
 
