@@ -154,8 +154,8 @@ __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop,
 // transients do not fit beside an HMC body's resident state (x, p, force) at once; the split of x is formed once per piece
 // instead, every time after the first from an OPAQUE copy of x -- left visible, the compiler merges the identical splits and
 // keeps the 12 split registers of every K-block live across the pieces (1 - 2 KB of scratch at three / four tiles).
-// `fill` ordinals run over all pieces: 0 .. 6 NT (2 NT) - 1, as in the one-piece form.
-template <int NT, int P, class Fill = NoFill>
+// `fill` ordinals run over all pieces: 0 .. 6 NT KBU - 1, as in the one-piece form.
+template <int NT, int P, int KBU = 2 * NT, class Fill = NoFill>
 __device__ __forceinline__ void contract_pieces(const __bf16* __restrict__ aop, const float* __restrict__ mus, const f32x16 (&x)[NT],
                                                 f32x16 (&g)[NT], int lane, Fill&& fill = NoFill{}) {
   static_assert(P >= 1 && P < NT, "more than one piece");
@@ -169,8 +169,8 @@ __device__ __forceinline__ void contract_pieces(const __bf16* __restrict__ aop, 
       if constexpr (pi > 0) asm volatile("" : "+v"(xb[t]));
     }
     f32x16 out[mt];
-    auto shifted = [&](auto ord) { fill(std::integral_constant<int, 6 * it0 * KB + decltype(ord)::value>{}); };
-    contract_general<mt, KB, true, decltype(shifted)&, NT, it0>(aop, mus, xb, out, lane, shifted);
+    auto shifted = [&](auto ord) { fill(std::integral_constant<int, 6 * it0 * KBU + decltype(ord)::value>{}); };
+    contract_general<mt, KB, true, decltype(shifted)&, NT, it0, KBU>(aop, mus, xb, out, lane, shifted);
 #pragma unroll
     for (int t = 0; t < mt; ++t) g[it0 + t] = out[t];
   });

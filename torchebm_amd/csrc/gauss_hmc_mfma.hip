@@ -10,6 +10,9 @@ namespace {
 // ignores a template-dependent __launch_bounds__ argument.)
 template <int NT, bool DIAGM, bool B3>
 int launch_nt_b(const GaussHmcArgs& a, hipStream_t st) {
+  // the last 16 coordinates of the last tile all padding: that K-block is left out of every contraction (bf16 form)
+  if constexpr (B3 && NT >= 2)
+    if (32 * NT - a.dim >= 16) return launch_policy<NT, DIAGM, GaussE<NT, true, 1>, 0>(a, st);
   return launch_policy<NT, DIAGM, GaussE<NT, B3>, (NT == 1 || (NT == 2 && !B3)) ? 2 : 0>(a, st);
 }
 

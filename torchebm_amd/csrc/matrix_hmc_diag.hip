@@ -21,6 +21,8 @@ bool matrix_hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, 
 namespace {
 template <int NT, bool DIAGM>
 int launch_gauss_diag(const GaussHmcArgs& a, hipStream_t st) {
+  if constexpr (NT >= 2)
+    if (32 * NT - a.dim >= 16) return launch_policy<NT, DIAGM, GaussE<NT, true, 1>, 0, true>(a, st);
   return launch_policy<NT, DIAGM, GaussE<NT, true>, 0, true>(a, st);
 }
 template <int NT, bool DIAGM>

@@ -63,7 +63,8 @@ struct Tile {
 // g^T = Ps (x - mu)^T and E = 0.5 (x - mu)^T Ps (x - mu) per chain (both halves of the wave hold E).
 // B3: the contraction on the bf16 matrix pipe with three-way split operands (gauss_bf16x3.h; `Ps` then points at the
 // operand-ready splits) -- 6/16 of the exact-f32 MFMA's matrix time; B3 = false: v_mfma_f32_32x32x2_f32 on fp32 Ps.
-template <int NT, bool B3>
+// KT: trailing all-padding K-blocks left out of the bf16 contraction (gauss_bf16x3.h KBU)
+template <int NT, bool B3, int KT = 0>
 __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
   constexpr int DIM = 32 * NT;
   auto k_of = [&](int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; };
@@ -72,9 +73,9 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
     // the output in two pieces of at most two tiles: gauss_bf16x3.h says why.  (Two tiles in single-tile pieces fit 256
     // VGPRs / two waves per SIMD without spills, but run 0.54 - 0.58 ms per 10 transitions at dims 48 / 64 where the one-piece
     // form, unconstrained, runs 0.46 - 0.50.)
-    gauss3::contract_pieces<NT, 2>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
+    gauss3::contract_pieces<NT, 2, 2 * NT - KT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else if constexpr (B3) {
-    gauss3::contract<NT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
+    gauss3::contract<NT, 2 * NT - KT>(reinterpret_cast<const __bf16*>(Ps), mus, x.t, g.t, m + 32 * h);
   } else {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -113,8 +114,9 @@ __device__ __forceinline__ float gauss_eval(const float* Ps, const float* mus, c
 // Energies of the matrix-layout transition body: what sits in LDS and how E / dE/dx come out of the state tiles.
 // ---------------------------------------------------------------------------------
 // Dense Gaussian.  LDS: Ps (fp32 [DIM][DIM], or its three operand-ready bf16 splits), mu [DIM].
-template <int NT, bool B3>
+template <int NT, bool B3, int KT = 0>
 struct GaussE {
+  static_assert(KT == 0 || B3, "trimmed K-blocks: the bf16 contraction");
   static constexpr int DIM = 32 * NT;
   static constexpr int kMatFloats = B3 ? (int)(gauss3::aop_bytes(NT) / sizeof(float)) : DIM * DIM;
   static constexpr int kLdsFloats = kMatFloats + DIM;
@@ -133,7 +135,7 @@ struct GaussE {
     for (int i = threadIdx.x; i < DIM; i += kBlock) lds[kMatFloats + i] = i < dim ? a.mean[i] : 0.0f;
   }
   __device__ static __forceinline__ float eval(const GaussHmcArgs&, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-    return gauss_eval<NT, B3>(lds, lds + kMatFloats, x, g, m, h);
+    return gauss_eval<NT, B3, KT>(lds, lds + kMatFloats, x, g, m, h);
   }
   __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
 };
