@@ -80,6 +80,9 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int3
 int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                    hipStream_t);
+bool gauss_shift_supported(int32_t dim);  // gauss_shift.hip: widths off multiples of 4, 21 .. 157, on shifted rows
+int launch_langevin_chain_gauss_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                      const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 int launch_langevin_chain_gauss_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                      const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                      hipStream_t);
@@ -267,6 +270,13 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
                                       cmax, thin, traj, noise, seed, offset, heun, (hipStream_t)stream);
+  if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_shift_supported(dim)) {
+    // A/B switch: EBM_GAUSS_NOSHIFT=1 keeps the packed rows / the lane-group kernel for widths off multiples of 4
+    static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+    if (!no_shift)
+      return launch_langevin_chain_gauss_shift(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                               clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
+  }
   if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_pack_factor(dim, n_chains) >= 1) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
@@ -530,6 +540,14 @@ int ebm_diag_finish_f32(const float* diag_partials, int32_t n_kept, int64_t n_bl
   if (n_kept < 0) return fail(EBM_EINVAL, "%s: n_kept < 0", who);
   if (n_kept == 0) return 0;
   if (!diag_partials || !mean_out || !var_out || !work) return fail(EBM_EINVAL, "%s: NULL records / outputs / workspace", who);
+  if (block_elems < 0) {  // records of interleaved classes (shifted rows): -32 dim, 4 / gcd(dim, 4) classes
+    const int K = diag::diag_classes(dim);
+    if (n_chains < 1 || dim < 1 || K < 2 || block_elems != -32 * dim || slots != dim || n_blocks != ceil_div64(n_chains, 32 * (int64_t)K) * K)
+      return fail(EBM_EINVAL, "%s: inconsistent interleaved layout (n_blocks %lld, slots %d, block_elems %d for [%lld, %d])", who,
+                  (long long)n_blocks, slots, block_elems, (long long)n_chains, dim);
+    return launch_diag_finish(diag_partials, n_kept, n_blocks, slots, block_elems, n_chains, dim, mean_out, var_out, energy_out,
+                              accept_out, work, (hipStream_t)stream);
+  }
   if (n_chains < 1 || dim < 1 || n_blocks < 1 || slots < 1 || block_elems < 1 || slots != (dim < block_elems ? dim : block_elems) ||
       (block_elems % dim != 0 && dim % block_elems != 0) || n_blocks != ceil_div64(n_chains * (int64_t)dim, block_elems))
     return fail(EBM_EINVAL, "%s: inconsistent layout (n_blocks %lld, slots %d, block_elems %d for [%lld, %d])", who,

@@ -223,7 +223,8 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // The energy / accept shares follow through wave_record_tail() (the MLP Langevin kernel: one evaluation later).
 template <int NT, class At>
 __device__ __forceinline__ void wave_record(float* partials, int64_t n_blocks, int keep, int64_t wave_id, int dim, At at, bool active,
-                                            int lane, int tile0 = 0) {  // tile0: the first tile's index in the row (a slice of it)
+                                            int lane, int tile0 = 0, int col0 = 0) {  // tile0: the first tile's index in the row (a slice of it)
+  // col0: tile coordinate of the row's column 0 (shifted rows, gauss_mfma_body.h SH; tile coordinates outside the row: no column)
   if (wave_id >= n_blocks) return;  // a wave past the last chain has no record (wave-uniform)
   const int h = lane >> 5;
   const int valid = __popcll(__ballot(active)) >> 1;  // both K-halves of a chain vote
@@ -237,8 +238,8 @@ __device__ __forceinline__ void wave_record(float* partials, int64_t n_blocks, i
       const float sum = half_wave_sum(v);
       const float dv = active ? v - sum * inv : 0.0f;
       const float m2 = half_wave_sum(dv * dv);
-      const int c = 32 * (t + tile0) + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if ((lane & 31) == 0 && c < dim) {
+      const int c = 32 * (t + tile0) + (r & 3) + 8 * (r >> 2) + 4 * h - col0;
+      if ((lane & 31) == 0 && c >= 0 && c < dim) {
         rec[c] = sum;
         rec[dim + c] = m2;
       }
@@ -263,6 +264,18 @@ inline bool plan(int64_t n_chains, int32_t dim, int64_t block_elems, DiagArgs& d
   d.E = (int32_t)block_elems;
   d.S = dim < block_elems ? dim : (int32_t)block_elems;
   d.n_blocks = ceil_div64(n_chains * (int64_t)dim, block_elems);
+  return true;
+}
+
+// Records of INTERLEAVED CLASSES (shifted rows): record b = (group b / K, class b % K) holds chains 32 K g + K m + s,
+// m = 0 .. 31 -- K waves of different workgroups share a run of 32 K consecutive chains.  Signalled to the caller and to
+// ebm_diag_finish_f32 by a NEGATIVE block_elems (-32 dim); K = 4 / gcd(dim, 4).
+inline int diag_classes(int32_t dim) { return (dim & 1) ? 4 : ((dim & 2) ? 2 : 1); }
+inline bool plan_classes(int64_t n_chains, int32_t dim, DiagArgs& d) {
+  const int K = diag_classes(dim);
+  d.E = -32 * dim;
+  d.S = dim;
+  d.n_blocks = ceil_div64(n_chains, 32 * (int64_t)K) * K;
   return true;
 }
 

@@ -391,7 +391,13 @@ __global__ __launch_bounds__(kBlock) void probe_valu_kernel(float* __restrict__ 
 // The last workgroup of a kept step (ticket) turns the sums into the outputs and leaves the work row zeroed.
 // work: double[n_kept][3 * dim + 3] = {A[dim], B[dim], C[dim], energy sum, accept sum, ticket}, zeroed by the caller.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t diag_block_len(int64_t b, int E, int64_t n_elem) {
+// K > 1: records of K interleaved classes (diag.h plan_classes): record b holds the chains 32 K (b / K) + K m + (b % K)
+__device__ __forceinline__ int64_t diag_block_len(int64_t b, int E, int64_t n_elem, int K = 1, int dim = 1) {
+  if (K > 1) {
+    const int64_t n = n_elem / dim, first = 32 * (int64_t)K * (b / K) + (b % K);
+    const int64_t rows = first < n ? (n - first + K - 1) / K : 0;
+    return (rows > 32 ? 32 : rows) * dim;
+  }
   const int64_t left = n_elem - b * (int64_t)E;
   return left >= E ? E : (left > 0 ? left : 0);
 }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
                                                              int32_t S, int32_t E, int64_t n_chains, int32_t dim,
                                                              float* __restrict__ mean_out, float* __restrict__ var_out,
                                                              float* __restrict__ energy_out, float* __restrict__ accept_out,
-                                                             double* __restrict__ work) {
+                                                             double* __restrict__ work, int K) {
   const int j = blockIdx.x;
   const int W = gridDim.y, w = blockIdx.y, Q = gridDim.z, q = blockIdx.z;
   const int R = diag::record_floats(S);
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
   const int64_t n_win = (n_blocks - w + W - 1) / W;
   const int64_t per = (n_win + Q - 1) / Q;
   const int64_t i0 = (int64_t)q * per, i1 = (i0 + per < n_win) ? i0 + per : n_win;
-  const int64_t len_first = diag_block_len(w, E, n_elem);
+  const int64_t len_first = diag_block_len(w, E, n_elem, K, dim);
   // lanes: slot s = t % SP, record lane p = t / SP of P (small S: several lanes walk the same slot over
   // interleaved records); their partial sums meet in LDS before the atomics
   __shared__ double red[3][kBlock];
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
       shift = cnt0 > 0 ? (double)base[(int64_t)w * R + s] / (double)cnt0 : 0.0;
       // full blocks first, four records in flight per lane (one record per trip leaves the loop waiting on a single
       // pair of loads); the ragged tail of the state goes through the general trip below
-      const int64_t n_full = n_elem / E;
+      const int64_t n_full = K > 1 ? (n_chains / (32 * (int64_t)K)) * K : n_elem / E;
       const double cnt_full = (double)((E + dim - 1) / dim);
       double Cf = 0.0;
       int64_t i = i0 + p;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
       C = cnt_full * Cf;
       for (; i < i1; i += P) {
         const int64_t b = w + i * W;
-        const int64_t len = diag_block_len(b, E, n_elem);
+        const int64_t len = diag_block_len(b, E, n_elem, K, dim);
         if (s >= len) continue;
         const float* rec = base + b * R;
         const double sx = (double)rec[s];
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
     const double B = atomicExch(&wrow[dim + c], 0.0);
     const double C = atomicExch(&wrow[2 * dim + c], 0.0);
     const int wc = c / E, sc = c - wc * E;       // the shift this column's sums were taken about
-    const int64_t lf = diag_block_len(wc, E, n_elem);
+    const int64_t lf = diag_block_len(wc, E, n_elem, K, dim);
     const int cnt0 = sc < lf ? (int)((lf - sc + dim - 1) / dim) : 0;
     const double shift = cnt0 > 0 ? (double)base[(int64_t)wc * R + sc] / (double)cnt0 : 0.0;
     const double mean = A / n;
@@ -548,6 +554,11 @@ __global__ __launch_bounds__(kBlock) void diag_finish_kernel(const float* __rest
 int launch_diag_finish(const float* partials, int32_t n_kept, int64_t n_blocks, int32_t S, int32_t E, int64_t n_chains,
                        int32_t dim, float* mean_out, float* var_out, float* energy_out, float* accept_out, double* work,
                        hipStream_t st) {
+  int K = 1;
+  if (E < 0) {  // records of interleaved classes (diag.h plan_classes)
+    E = -E;
+    K = diag::diag_classes(dim);
+  }
   const int W = E % dim == 0 ? 1 : dim / E;
   const int64_t n_win = ceil_div64(n_blocks, W);
   int64_t Q = ceil_div64(n_win, 64);  // >= 64 records per workgroup and slot
@@ -556,7 +567,7 @@ int launch_diag_finish(const float* partials, int32_t n_kept, int64_t n_blocks, 
   if (Q < 1) Q = 1;
   if (Q > 65535) Q = 65535;
   hipLaunchKernelGGL(diag_finish_kernel, dim3((unsigned)n_kept, (unsigned)W, (unsigned)Q), dim3(kBlock), 0, st, partials,
-                     n_blocks, S, E, n_chains, dim, mean_out, var_out, energy_out, accept_out, work);
+                     n_blocks, S, E, n_chains, dim, mean_out, var_out, energy_out, accept_out, work, K);
   return check_launch("ebm_diag_finish_f32");
 }
 
