@@ -30,6 +30,13 @@ void launch_gmm32(dim3, hipStream_t, HmcArgs);
 using hmc::HmcArgs;
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
+bool gauss_hmc_shift_supported(int32_t dim);  // gauss_hmc_shift.hip: widths off multiples of 4, 21 .. 157, on shifted rows
+int launch_hmc_chain_gauss_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
+                                 const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t,
+                                 float*, hipStream_t);
+int launch_hmc_chain_gauss_shift_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
+                                      double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t,
+                                      uint64_t, float*, hipStream_t);
 bool gauss_hmc_stream_supported(const ebm_energy_t& e, int32_t dim);  // gauss_hmc_stream.hip: dims 164 .. 256 with the pre-split image
 int launch_hmc_chain_gauss_stream(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
                                   const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
@@ -71,6 +78,9 @@ static bool hmc_matrix_records(const ebm_energy_t& e, int64_t n_chains, int32_t 
   static const bool gauss_rows = ab_switch("EBM_GAUSS_ROWS");
   static const bool gmm_rows = ab_switch("EBM_GMM_ROWS");
   if ((e.kind == EBM_ENERGY_GAUSSIAN && gauss_rows) || (e.kind == EBM_ENERGY_GMM && gmm_rows)) return false;
+  // widths off multiples of 4 from 21: shifted rows, the records of their alignment classes interleaved (diag.h)
+  static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+  if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_shift_supported(dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   return matrix_hmc_diag_plan(e, n_chains, dim, d);
 }
 
@@ -88,11 +98,21 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
                      const float* u, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   if (diag_partials) {
     diag::DiagArgs dm;
+    if (hmc_matrix_records(e, n_chains, dim, dm) && dm.E < 0)
+      return launch_hmc_chain_gauss_shift_diag(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
+                                               thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st);
     if (hmc_matrix_records(e, n_chains, dim, dm))
       return launch_hmc_chain_matrix_diag(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
                                           thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st);
   }
   // (records beyond those shapes: the lane-group kernels)
+  if (!diag_partials && e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_shift_supported(dim)) {
+    // A/B switch: EBM_GAUSS_NOSHIFT=1 keeps the lane-group kernel for widths off multiples of 4
+    static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+    if (!no_shift)
+      return launch_hmc_chain_gauss_shift(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
+                                          thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, nullptr, st);
+  }
   if (!diag_partials && e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_mfma_supported(dim, mass_kind)) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");

@@ -51,6 +51,7 @@ struct GaussHmcArgs {
   int32_t n_comp;
   float inv2s2, invs2;
   diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept transitions (DIAG kernels)
+  int32_t sh_classes = 1;  // SHIFTED rows (SH kernels): 4 / gcd(dim, 4) alignment classes of chains, one per workgroup
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -122,6 +123,16 @@ struct GaussE {
   static constexpr int kLdsFloats = kMatFloats + DIM;
   static constexpr bool kEvalGivesEnergy = true;
   static constexpr bool kCarry = !(B3 && NT >= 4);  // (four / five tiles: the split operands leave no LDS for the parked force)
+  // lo: SHIFTED rows -- the row's column 0 sits at tile coordinate lo (gauss_mfma_body.h SH)
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds, int lo) {
+    static_assert(B3, "shifted rows: the bf16 contraction");
+    const int dim = a.dim;
+    gauss3::stage_split_matrix<NT, 2 * NT>([&](int r, int c) {
+      r -= lo; c -= lo;
+      return (r >= 0 && c >= 0 && r < dim && c < dim) ? a.prec[r * dim + c] : 0.0f;
+    }, reinterpret_cast<__bf16*>(lds), kBlock);
+    for (int i = threadIdx.x; i < DIM; i += kBlock) lds[kMatFloats + i] = (i >= lo && i - lo < dim) ? a.mean[i - lo] : 0.0f;
+  }
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
     const int dim = a.dim;
     if constexpr (B3) {
@@ -180,16 +191,23 @@ __device__ __forceinline__ bool vote_all(bool pred) {
   else return __all(pred);
 }
 
-template <int NT, bool DIAGM, class E, bool DIAG = false>
+// SH: SHIFTED rows (widths off multiples of 4; gauss_mfma_body.h says how): a workgroup takes the chains of one alignment
+// class, tile coordinate j = coordinate j - lo of the chain; the tile coordinates outside [lo, lo + dim) are padding like
+// the ones beyond dim -- x = p = f = 0 throughout (loaded as 0, their momentum draw discarded, zero rows of the staged matrix).
+template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   constexpr bool CARRY = E::kCarry;
+  const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a.sh_classes) : 0;
+  const int lo = SH ? ((a.dim * sh_s) & 3) : 0;
   E en{};  // (state of the evaluation across calls, if it has any: GaussStreamE's buffer parity)
   constexpr int DIM = 32 * NT;
   float* elds = gauss_hmc_smem;  // the energy's own area
   // dim <= DIM, dim % 4 == 0: zero-padded tiles -- padded coordinates have x = p = f = 0 throughout (their
   // rows / columns of the parameters are zero, their momentum draw is discarded) and are never loaded or stored
   const int dim = a.dim;
-  E::stage(a, elds);
+  const int hi = lo + dim;
+  if constexpr (SH) E::stage(a, elds, lo);
+  else E::stage(a, elds);
   // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
   // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
   // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
@@ -198,29 +216,61 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
   float* dsw = dsw_base + (threadIdx.x >> 6) * DIM;          // [DIM], this wave's
   constexpr bool diag_mass = DIAGM;
   if constexpr (diag_mass)
-    for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = i < dim ? a.mass_diag[i] : 1.0f;
+    for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = (i >= lo && i < hi) ? a.mass_diag[i - lo] : 1.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int64_t chain = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
+  const int64_t chain = SH ? (((int64_t)(blockIdx.x / (unsigned)a.sh_classes) * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m) * a.sh_classes + sh_s
+                           : ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32 + m;
   const bool active = chain < a.n_chains;
-  const int64_t row = active ? chain * (int64_t)dim : 0;
+  const int64_t row = active ? chain * (int64_t)dim - lo : 0;  // flat element of tile coordinate 0 (SH: a multiple of 4 all the same)
   auto quad_of = [&](const float* arr, int t, int q) { return *reinterpret_cast<const float4*>(arr + 32 * t + 8 * q + 4 * h); };
 
   // quad q of tile t = coordinates 32t + 8q + 4h .. +3  (one float4, one Philox counter)
-  auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst) {
+  // (SH: `off` addresses tile coordinate 0; quads_aligned: base + off is on the float4 grid -- the state itself; an injected
+  //  field or a trajectory row starts anywhere, and a quad shared with a neighbouring chain is element-wise in any case)
+  auto load_rows = [&](const float* base, int64_t off, Tile<NT>& dst, bool quads_aligned = true) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k0 = 32 * t + 8 * q + 4 * h;
+        if constexpr (SH) {
+          const float* src = base + off + k0;
+          if (active && quads_aligned && k0 >= lo && k0 + 3 < hi) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else if (active && k0 + 3 >= lo && k0 < hi) {
+            if (k0 + 0 >= lo && k0 + 0 < hi) v.x = src[0];
+            if (k0 + 1 >= lo && k0 + 1 < hi) v.y = src[1];
+            if (k0 + 2 >= lo && k0 + 2 < hi) v.z = src[2];
+            if (k0 + 3 >= lo && k0 + 3 < hi) v.w = src[3];
+          }
+        } else
         if (active && 32 * t + 8 * q + 4 * h < dim) v = *reinterpret_cast<const float4*>(base + off + 32 * t + 8 * q + 4 * h);
         dst.t[t][4 * q] = v.x; dst.t[t][4 * q + 1] = v.y; dst.t[t][4 * q + 2] = v.z; dst.t[t][4 * q + 3] = v.w;
       }
   };
-  auto store_rows = [&](float* base, int64_t off, const Tile<NT>& src) {
+  auto store_rows = [&](float* base, int64_t off, const Tile<NT>& src, bool quads_aligned = true) {
     if (!active) return;
+    if constexpr (SH) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k0 = 32 * t + 8 * q + 4 * h;
+          float* dst = base + off + k0;
+          if (quads_aligned && k0 >= lo && k0 + 3 < hi) {
+            *reinterpret_cast<float4*>(dst) = make_float4(src.t[t][4 * q], src.t[t][4 * q + 1], src.t[t][4 * q + 2], src.t[t][4 * q + 3]);
+          } else if (k0 + 3 >= lo && k0 < hi) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (k0 + i >= lo && k0 + i < hi) dst[i] = src.t[t][4 * q + i];
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -257,7 +307,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 
   Tile<NT> x;
   load_rows(a.x, row, x);
-  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim : 0;
+  const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim - lo : 0;
   int until_keep = a.thin;
   int64_t keep_off = 0;
   float eps = a.eps;
@@ -289,11 +339,11 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     // ---- momentum draw p ~ N(0, M)
     Tile<NT> p;
     if (a.p_noise) {
-      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * dim + row, p);
+      load_rows(a.p_noise, ((int64_t)tr * a.n_chains) * dim + row, p, !SH);
     } else {
       // (the per-quad Philox counters are formed here at every transition: hoisted out of the transition loop they
       //  are 2 registers per quad held across the whole trajectory)
-      uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+      uint64_t e_row = (uint64_t)chain * (uint64_t)dim - (uint64_t)lo;
       asm volatile("" : "+v"(e_row));
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -302,7 +352,10 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
           const int k0 = 32 * t + 8 * q + 4 * h;
           const F4 n = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + 2ull * (uint64_t)tr);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) p.t[t][4 * q + i] = k0 < dim ? n.v[i] : 0.0f;  // (straight-line: see gauss_mfma.hip)
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (SH) p.t[t][4 * q + i] = (k0 + i >= lo && k0 + i < hi) ? n.v[i] : 0.0f;
+            else p.t[t][4 * q + i] = k0 < dim ? n.v[i] : 0.0f;  // (straight-line: see gauss_mfma.hip)
+          }
         }
     }
     if (a.has_mass) {
@@ -453,13 +506,15 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
     }
     if ((a.traj || DIAG) && --until_keep == 0) {
       until_keep = a.thin;
-      if (a.traj) store_rows(a.traj, traj_row + keep_off, x);
+      if (a.traj) store_rows(a.traj, traj_row + keep_off, x, !SH);
       keep_off += dim;
       if constexpr (DIAG) {
         // samplers/hmc.py:294-310: population mean / var, mean of the clamped energy of the state the chain holds now,
         // acceptance rate of this transition
-        const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-        diag::wave_record<NT>(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, [&](int t, int r) { return x.t[t][r]; }, active, lane);
+        // (SH: the records of the K classes interleave -- record (group, class), diag.h plan_classes)
+        const int64_t wave_id = SH ? ((int64_t)(blockIdx.x / (unsigned)a.sh_classes) * (kBlock / 64) + (threadIdx.x >> 6)) * a.sh_classes + sh_s
+                                   : (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        diag::wave_record<NT>(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, [&](int t, int r) { return x.t[t][r]; }, active, lane, 0, lo);
         diag::wave_record_tail(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, clamp_nanprop(e_cur, -1e10f, 1e10f), active,
                                accept && leader, lane);
         ++keep;
@@ -471,37 +526,39 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
-template <int NT, bool DIAGM, class E, bool DIAG = false>
+template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
 }
-template <int NT, bool DIAGM, class E, bool DIAG = false>
+template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
 }
-template <int NT, bool DIAGM, class E, bool DIAG = false>
+template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
 }
 
 // WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
-template <int NT, bool DIAGM, class E, int WAVES, bool DIAG = false>
+template <int NT, bool DIAGM, class E, int WAVES, bool DIAG = false, bool SH = false>
 int launch_policy(const GaussHmcArgs& a, hipStream_t st) {
   // the energy's area, raw masses, one row of drift factors per wave, the parked force (one slot per lane and register)
   const size_t smem = (size_t)(E::kLdsFloats + (1 + kBlock / 64) * 32 * NT + (E::kCarry ? 16 * NT * kBlock : 0)) * sizeof(float);
   static DeviceOnce attr_once;  // the LDS opt-in is a per-device function attribute
   if (attr_once.first() && smem > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG, SH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  // (SH: every class gets the workgroups of the largest one, class-major inside blockIdx: b % K)
+  const int64_t blocks = SH ? ceil_div64(ceil_div64(a.n_chains, a.sh_classes), 32 * (kBlock / 64)) * a.sh_classes
+                            : ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   if constexpr (WAVES == 3)
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w3<NT, DIAGM, E, DIAG>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w3<NT, DIAGM, E, DIAG, SH>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else if constexpr (WAVES == 2)
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E, DIAG>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel_w2<NT, DIAGM, E, DIAG, SH>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   else
-    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL((gauss_hmc_mfma_kernel<NT, DIAGM, E, DIAG, SH>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch("ebm_hmc_chain_f32");
 }
 
