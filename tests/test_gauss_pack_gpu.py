@@ -1,4 +1,4 @@
-"""Dense Gaussians at widths below 20 (from 21 on, widths off multiples of 4 run on SHIFTED rows: tests/test_gauss_shift_gpu.py): `pack`
+"""Dense Gaussians at widths below 17 (from 17 on, widths off multiples of 4 run on SHIFTED rows: tests/test_gauss_shift_gpu.py): `pack`
 consecutive chains of the row-major state run as ONE row of the block-diagonal Gaussian kron(I, Ps) (csrc/gauss_mfma.hip,
 gauss_pack_factor) -- same flat element order, hence the same Philox field and the same update of every element.  The
 reference's recorded runs at dims 5 / 8 / 12 / 30 / 50 are in tests/test_grid_gpu.py (ld_gauss_*); here: the sampler's
@@ -20,7 +20,7 @@ def _model(dim, device, seed=0):
     return ta.GaussianModel(torch.randn(dim, generator=g) * 0.5, a @ a.t() / dim + 0.5 * torch.eye(dim), device=device)
 
 
-@pytest.mark.parametrize("dim,n,pack", [(8, 4096, 4), (16, 1000, 2), (5, 1024, 4), (18, 1000, 2), (10, 514, 2), (3, 4096, 8), (12, 1002, 2)])
+@pytest.mark.parametrize("dim,n,pack", [(8, 4096, 4), (16, 1000, 2), (5, 1024, 4), (14, 1000, 2), (10, 514, 2), (3, 4096, 8), (12, 1002, 2)])
 def test_layout_query_says_packed_and_the_sampler_pools_the_records(cuda_device, dim, n, pack):
     model = _model(dim, cuda_device)
     layout = _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim)
@@ -40,7 +40,7 @@ def test_layout_query_says_packed_and_the_sampler_pools_the_records(cuda_device,
     torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("dim", [8, 18])
+@pytest.mark.parametrize("dim", [8, 14])
 def test_packed_rows_and_the_lane_group_kernel_share_the_field(cuda_device, dim):
     """n divisible by the pack factor: packed rows on the matrix cores; one chain more: the lane-group kernel.  Same seed ->
     same (seed, step, element) field -> the common chains agree to fp32 round-off of the two contractions."""

@@ -1,0 +1,93 @@
+"""Gaussian mixtures at widths that are not a multiple of 4 on SHIFTED rows (csrc/gmm_shift.hip, gmm_hmc_shift.hip; the
+layout: tests/test_gauss_shift_gpu.py): Langevin and HMC through the samplers -- native Philox draws -- against the oracle
+fed the same field (ebm_noise_fill_f32), over the component-count classes, tile counts, mass forms; records against the
+trajectory; one launch per call."""
+
+import pytest
+import torch
+
+import oracle
+import torchebm_amd as ta
+from helpers import hip_calls
+from torchebm_amd import _lib, _rng
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(shape, seed, steps, device, kind=None):
+    kind = _lib.NOISE_NORMAL if kind is None else kind
+    rows = []
+    for st in steps:
+        buf = torch.empty(shape, device=device)
+        _lib.call("ebm_noise_fill_f32", buf.data_ptr(), buf.numel(), kind, seed, st, _lib.stream_handle(device))
+        rows.append(buf)
+    return torch.stack(rows)
+
+
+def _mixture(K, dim, device, seed=0):
+    g = torch.Generator().manual_seed(100 * K + dim + seed)
+    means = torch.randn(K, dim, generator=g) * 1.2
+    weights = torch.rand(K, generator=g) + 0.2
+    model = ta.GaussianMixtureModel(means, sigma=1.1, weights=weights, device=device)
+    return model, oracle.GaussianMixture(means, 1.1, log_weights=model.log_weights.detach().cpu()), g
+
+
+@pytest.mark.parametrize("K", [3, 8, 9, 16, 32])
+@pytest.mark.parametrize("dim", [21, 30, 33, 50, 65, 99, 125])
+def test_langevin_against_the_oracle(cuda_device, K, dim):
+    model, en, g = _mixture(K, dim, cuda_device)
+    n, k, thin = 203, 8, 2
+    s = ta.LangevinDynamics(model, step_size=0.05, noise_scale=0.9, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    seed = 900 + K + dim
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    traj, diag = s.sample(x=x0.to(cuda_device), n_steps=k, thin=thin, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    plain = s.sample(x=x0.to(cuda_device), n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    if dim + 3 > 32 or K > 8:  # (one tile with K <= 8: the lane-group kernel, records from its own family)
+        assert torch.equal(traj[:, -1], plain)
+    noise = _field((n, dim), _rng.kernel_seed(seed), range(k), cuda_device).cpu()
+    want, want_traj, _ = oracle.langevin_chain(en, x0, noise, [0.05] * k, [0.9] * k, thin=thin, want_traj=True)
+    err = ((traj.cpu() - want_traj).abs() / want_traj.abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()
+    assert err.median().item() <= 2e-5
+    t64 = traj.double()
+    torch.testing.assert_close(diag["mean"].double(), t64.mean(dim=0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["var"].double(), t64.var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)
+    want_e = torch.stack([model(traj[:, j]).double().mean() for j in range(k // thin)])
+    torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K", [3, 9, 16, 32])
+@pytest.mark.parametrize("dim,mass", [(21, None), (30, 1.7), (33, "diag"), (50, None), (65, "diag"), (93, 0.6), (99, None), (125, 1.3)])
+def test_hmc_against_the_oracle(cuda_device, K, dim, mass):
+    model, en, g = _mixture(K, dim, cuda_device, seed=1)
+    if mass == "diag":
+        mass = torch.rand(dim, generator=g) + 0.5
+    n, T, L, thin, eps = 97, 4, 6, 2, 0.12
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L,
+                                 mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    seed = 7000 + K + dim
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    traj = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True,
+                    generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    p = _field((n, dim), _rng.kernel_seed(seed), range(0, 2 * T, 2), cuda_device).cpu()
+    u = _field((n,), _rng.kernel_seed(seed), range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, mass=mass, thin=thin, want_traj=True, want_diag=True)
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    if want["margin"] > 1e-4:
+        assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()
+        assert err.median().item() <= 2e-5
+    else:
+        assert (err <= 5e-4).float().mean().item() >= 0.9
+    # with records (three tiles at most): same chains, the diagnostics of the oracle
+    if dim + 3 <= 96 and want["margin"] > 1e-4:
+        traj2, diag = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True, return_diagnostics=True,
+                               generator=torch.Generator(device=cuda_device).manual_seed(seed))
+        if dim + 3 > 32 or K > 8:
+            assert torch.equal(traj2, traj)
+        torch.testing.assert_close(diag["acceptance_rate"].cpu(), want["diagnostics"]["acceptance_rate"], rtol=0, atol=1e-6)
+        torch.testing.assert_close(diag["mean"].cpu(), want["diagnostics"]["mean"], rtol=1e-3, atol=1e-3)

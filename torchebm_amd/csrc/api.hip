@@ -80,6 +80,9 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int3
 int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                    hipStream_t);
+bool gmm_shift_supported(int32_t dim, int32_t n_comp);  // gmm_shift.hip: mixtures at widths off multiples of 4, 21 .. 125
+int launch_langevin_chain_gmm_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 bool gauss_shift_supported(int32_t dim);  // gauss_shift.hip: widths off multiples of 4, 21 .. 157, on shifted rows
 int launch_langevin_chain_gauss_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                       const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
@@ -294,6 +297,12 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     static const bool force_rows = ab_switch("EBM_GAUSS_ROWS");
     if (!force_rows)
       return launch_langevin_chain_gauss_big(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                             clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
+  }
+  if (!heun && energy->kind == EBM_ENERGY_GMM && gmm_shift_supported(dim, energy->n_comp)) {
+    static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+    if (!no_shift)
+      return launch_langevin_chain_gmm_shift(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                              clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
   }
   // mixtures of up to 32 components on the matrix layout (gauss_mfma.hip / gmm_bf16x3.h); dims 16 / 32 with K <= 8 keep

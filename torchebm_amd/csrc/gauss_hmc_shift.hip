@@ -10,7 +10,7 @@
 namespace ebm {
 
 #ifndef EBM_SHIFT_DIAG
-bool gauss_hmc_shift_supported(int32_t dim) { return dim >= 21 && (dim % 4) != 0 && dim + ((dim & 1) ? 3 : 2) <= 160; }
+bool gauss_hmc_shift_supported(int32_t dim) { return dim >= 17 && (dim % 4) != 0 && dim + ((dim & 1) ? 3 : 2) <= 160; }
 #else
 bool gauss_hmc_shift_supported(int32_t dim);
 #endif

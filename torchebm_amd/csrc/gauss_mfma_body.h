@@ -70,7 +70,7 @@ template <int NT, bool B3, bool FAST = false, int BLOCK = 256, int HIDE = NT, in
 __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   constexpr int DIM = 32 * NT, KBU = 2 * NT - KT;
   static_assert(KT == 0 || (B3 && GKR == 0), "trimmed K-blocks: the dense Gaussian on the bf16 pipe");
-  static_assert(!SH || (B3 && GKR == 0), "shifted rows: the dense Gaussian on the bf16 pipe");
+  static_assert(!SH || B3, "shifted rows: the contraction on the bf16 pipe");
   const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a.sh_classes) : 0;
   const int lo = SH ? ((a.dim * sh_s) & 3) : 0;  // first tile coordinate of the row (0 unless SH)
   using Mix = gmm3::Mixture<NT, GKR == 0 ? 4 : GKR>;
@@ -81,8 +81,10 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
   // dim <= DIM, dim % 4 == 0: the tiles are zero-padded -- padded coordinates stay exactly 0 (d = 0, g = 0,
   // no noise) and whole register quads beyond dim are never loaded, drawn or stored
   const int dim = a.dim;
+  gmm3::Params gm = a.gm;  // (the mixture kernels: with this workgroup's row offset)
+  gm.lo = lo;
   if constexpr (GKR > 0) {
-    Mix::stage(a.gm, gauss_smem, BLOCK);
+    Mix::stage(gm, gauss_smem, BLOCK);
   } else {
     // the precision of the (possibly packed) row: block-diagonal copies of the sub_dim x sub_dim matrix
     const int sd = a.sub_dim;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
         gauss3::static_for<PER_MFMA>([&](auto u) { stage(std::integral_constant<int, decltype(ord)::value * PER_MFMA + decltype(u)::value>{}); });
         __builtin_amdgcn_sched_barrier(0);
       };
-      if constexpr (GKR > 0) Mix::grad(a.gm, gauss_smem, x, g, lane, behind_mfma);
+      if constexpr (GKR > 0) Mix::grad(gm, gauss_smem, x, g, lane, behind_mfma);
       else gauss3::contract<NT, KBU>(aop, mus, x, g, lane, behind_mfma);
       // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
       static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
@@ -219,12 +221,15 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           const float x1 = x[t][r] - eta * g[t][r];
           const float dw = eps[t][r] * sqrt_eta;
           float nv = x1 + noise_coef * dw;
-          if constexpr (GKR > 0) nv = 32 * t + 8 * (r >> 2) + 4 * h < dim ? nv : 0.0f;  // mixture: padding held at 0
+          if constexpr (GKR > 0 && SH) {
+            const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            nv = (j >= lo && j < hi) ? nv : 0.0f;
+          } else if constexpr (GKR > 0) nv = 32 * t + 8 * (r >> 2) + 4 * h < dim ? nv : 0.0f;  // mixture: padding held at 0
           x[t][r] = nv;
         }
     } else {
     if constexpr (GKR > 0) {
-      Mix::grad(a.gm, gauss_smem, x, g, lane);
+      Mix::grad(gm, gauss_smem, x, g, lane);
     } else if constexpr (B3) {
       gauss3::contract<NT, KBU>(aop, mus, x, g, lane);  // (contract_pieces costs this body registers: it has no spill to cure)
     } else {
@@ -294,7 +299,8 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
           if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
           // (mixture: padding coordinates are held at 0 -- their "gradient" is x / sigma^2, and a select is free where the
           //  Gaussian's zero rows of Ps make it unnecessary)
-          if constexpr (GKR > 0) nv = k0 < dim ? nv : 0.0f;
+          if constexpr (GKR > 0 && SH) nv = (k0 + i >= lo && k0 + i < hi) ? nv : 0.0f;
+          else if constexpr (GKR > 0) nv = k0 < dim ? nv : 0.0f;
           x[t][4 * q + i] = nv;
         }
         if constexpr (NT >= 3) __builtin_amdgcn_sched_barrier(0);  // one Philox call's temporaries at a time
@@ -348,7 +354,7 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
         diag::wave_record<NT>(a.diag.partials, a.diag.n_blocks, keep, wave_id, dim, [&](int t, int r) { return x[t][r]; }, active, lane, 0, lo);
         float e_now;
         if constexpr (GKR > 0) {
-          e_now = Mix::energy(a.gm, gauss_smem, x, lane);
+          e_now = Mix::energy(gm, gauss_smem, x, lane);
         } else {
           f32x16 g2[NT];
           gauss3::contract<NT, KBU>(aop, mus, x, g2, lane);

@@ -61,7 +61,7 @@ inline int32_t shift_extent(int32_t dim) { return dim + ((dim & 1) ? 3 : 2); }
 }  // namespace
 
 // below 21 the packed rows stay (gauss_pack_factor: the padding of a 32-wide tile outweighs the block-diagonal waste there)
-bool gauss_shift_supported(int32_t dim) { return dim >= 21 && (dim % 4) != 0 && shift_extent(dim) <= 160; }
+bool gauss_shift_supported(int32_t dim) { return dim >= 17 && (dim % 4) != 0 && shift_extent(dim) <= 160; }
 
 int launch_langevin_chain_gauss_shift(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                                       float eta, float sqrt_eta, float noise_coef, const float* coef_table,

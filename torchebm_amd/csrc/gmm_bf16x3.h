@@ -12,6 +12,7 @@ struct Params {
   const float* logw;   // [n_comp], global
   int32_t n_comp, dim;
   float inv2s2, invs2;  // 1 / (2 sigma^2), 1 / sigma^2
+  int32_t lo = 0;       // SHIFTED rows (gauss_mfma_body.h SH): the row's column 0 sits at tile coordinate lo
 };
 
 // Isotropic Gaussian mixture, up to 32 components (core/energies.py: GaussianMixtureModel):
@@ -33,12 +34,12 @@ struct Mixture {
   static constexpr int kA2Floats = (int)(gauss3::aop_bytes_general(NT, KBC) / sizeof(float));
   static constexpr int kLdsFloats = kA1Floats + kA2Floats + 64 + KP * DIM;
   __device__ static __forceinline__ void stage(const Params& a, float* lds, int n_threads) {
-    const int dim = a.dim, K = a.n_comp;
+    const int dim = a.dim, K = a.n_comp, lo = a.lo;
     const float* mu = a.means;
-    gauss3::stage_split_matrix<1, 2 * NT>([&](int comp, int d) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
-                                           reinterpret_cast<__bf16*>(lds), n_threads);
-    gauss3::stage_split_matrix<NT, KBC>([&](int d, int comp) { return (comp < K && d < dim) ? mu[comp * dim + d] : 0.0f; },
-                                         reinterpret_cast<__bf16*>(lds + kA1Floats), n_threads);
+    // (tile coordinate d = column d - lo; outside the row: zero, like the columns beyond dim)
+    const auto mu_at = [&](int comp, int d) { return (comp < K && d >= lo && d - lo < dim) ? mu[comp * dim + (d - lo)] : 0.0f; };
+    gauss3::stage_split_matrix<1, 2 * NT>([&](int comp, int d) { return mu_at(comp, d); }, reinterpret_cast<__bf16*>(lds), n_threads);
+    gauss3::stage_split_matrix<NT, KBC>([&](int d, int comp) { return mu_at(comp, d); }, reinterpret_cast<__bf16*>(lds + kA1Floats), n_threads);
     float* cvec = lds + kA1Floats + kA2Floats;
     float* lw = cvec + 32;
     float* mf = lw + 32;
@@ -52,7 +53,7 @@ struct Mixture {
     }
     for (int i = threadIdx.x; i < KP * DIM; i += n_threads) {
       const int k = i / DIM, d = i - k * DIM;
-      mf[i] = (k < K && d < dim) ? mu[k * dim + d] : 0.0f;
+      mf[i] = mu_at(k, d);
     }
   }
   // MFMAs of one gradient: 12 NT for the logits, 6 NT KBC for the weighted mean
@@ -113,7 +114,8 @@ struct Mixture {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // (padding quads beyond dim hold no state: the Langevin body lets them drift with the noise)
-          const bool real = 32 * t + 8 * q + 4 * h < a.dim;
+          const int k0 = 32 * t + 8 * q + 4 * h;
+          const bool real = k0 + 3 >= a.lo && k0 < a.lo + a.dim;  // (a.lo > 0: the row's own padding is held at 0 by the bodies)
           const float4 mq = *reinterpret_cast<const float4*>(mf + k * DIM + 32 * t + 8 * q + 4 * h);
           const float e0 = real ? x[t][4 * q] - mq.x : 0.0f, e1 = real ? x[t][4 * q + 1] - mq.y : 0.0f;
           const float e2 = real ? x[t][4 * q + 2] - mq.z : 0.0f, e3 = real ? x[t][4 * q + 3] - mq.w : 0.0f;

@@ -52,6 +52,7 @@ struct GaussHmcArgs {
   float inv2s2, invs2;
   diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept transitions (DIAG kernels)
   int32_t sh_classes = 1;  // SHIFTED rows (SH kernels): 4 / gcd(dim, 4) alignment classes of chains, one per workgroup
+  int32_t sh_lo = 0;       // ... and, set by the body in its own copy, this workgroup's row offset (what the energies see)
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -160,9 +161,14 @@ struct GmmE {
   static constexpr bool kEvalGivesEnergy = false;
   static constexpr bool kCarry = true;
   __device__ static __forceinline__ gmm3::Params params(const GaussHmcArgs& a) {
-    return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2};
+    return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2, a.sh_lo};
   }
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) { M::stage(params(a), lds, kBlock); }
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds, int lo) {  // shifted rows
+    gmm3::Params pr = params(a);
+    pr.lo = lo;
+    M::stage(pr, lds, kBlock);
+  }
   // gradient into g; returns the softmax sum (in [1, K] for a finite state, NaN as soon as a coordinate is not)
   __device__ static __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
     return M::grad(params(a), lds, x.t, g.t, m + 32 * h);
@@ -195,10 +201,13 @@ __device__ __forceinline__ bool vote_all(bool pred) {
 // class, tile coordinate j = coordinate j - lo of the chain; the tile coordinates outside [lo, lo + dim) are padding like
 // the ones beyond dim -- x = p = f = 0 throughout (loaded as 0, their momentum draw discarded, zero rows of the staged matrix).
 template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
-__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a) {
+__device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   constexpr bool CARRY = E::kCarry;
-  const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a.sh_classes) : 0;
-  const int lo = SH ? ((a.dim * sh_s) & 3) : 0;
+  const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a_in.sh_classes) : 0;
+  const int lo = SH ? ((a_in.dim * sh_s) & 3) : 0;
+  GaussHmcArgs a_sh = a_in;  // (SH: the energies see this workgroup's row offset)
+  a_sh.sh_lo = lo;
+  const GaussHmcArgs& a = SH ? a_sh : a_in;
   E en{};  // (state of the evaluation across calls, if it has any: GaussStreamE's buffer parity)
   constexpr int DIM = 32 * NT;
   float* elds = gauss_hmc_smem;  // the energy's own area
