@@ -32,8 +32,9 @@ def _mixture(K, dim, device, seed=0):
     return model, oracle.GaussianMixture(means, 1.1, log_weights=model.log_weights.detach().cpu()), g
 
 
-@pytest.mark.parametrize("K", [3, 8, 9, 16, 32])
-@pytest.mark.parametrize("dim", [21, 30, 33, 50, 65, 99, 125])
+@pytest.mark.parametrize("K,dim", [(K, d) for K in (3, 8, 9, 16, 32) for d in (21, 30, 33, 50, 65, 99, 125)] +
+                         # 129 .. 256 dims: five to eight tiles (csrc/gmm_wide.hip), multiples of 4 and shifted rows
+                         [(K, d) for K in (8, 16, 32) for d in (126, 129, 132, 158, 160, 190, 200, 253, 254, 256)])
 def test_langevin_against_the_oracle(cuda_device, K, dim):
     model, en, g = _mixture(K, dim, cuda_device)
     n, k, thin = 203, 8, 2

@@ -80,6 +80,12 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int3
 int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                    hipStream_t);
+bool gmm_wide_supported(int32_t dim, int32_t n_comp);        // gmm_wide.hip: mixtures at 132 .. 256 dims (five to eight tiles)
+bool gmm_wide_shift_supported(int32_t dim, int32_t n_comp);  // gmm_wide_shift.hip: ... and the widths off multiples of 4 between 126 and 254
+int launch_langevin_chain_gmm_wide(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                   const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
+int launch_langevin_chain_gmm_wide_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                         const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 bool gmm_shift_supported(int32_t dim, int32_t n_comp);  // gmm_shift.hip: mixtures at widths off multiples of 4, 21 .. 125
 int launch_langevin_chain_gmm_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                     const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
@@ -298,6 +304,13 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (!force_rows)
       return launch_langevin_chain_gauss_big(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                              clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
+  }
+  if (!heun && energy->kind == EBM_ENERGY_GMM && (gmm_wide_supported(dim, energy->n_comp) || gmm_wide_shift_supported(dim, energy->n_comp))) {
+    static const bool no_wide = ab_switch("EBM_GMM_NOWIDE");  // A/B switch: the lane-group kernels above 128 dims
+    if (!no_wide)
+      return (gmm_wide_supported(dim, energy->n_comp) ? launch_langevin_chain_gmm_wide : launch_langevin_chain_gmm_wide_shift)(
+          *energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
+          nullptr, (hipStream_t)stream);
   }
   if (!heun && energy->kind == EBM_ENERGY_GMM && gmm_shift_supported(dim, energy->n_comp)) {
     static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");

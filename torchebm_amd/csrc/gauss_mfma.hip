@@ -210,6 +210,12 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
 // wave of 32 chains from the C/D registers (round 3; rounds 1-2 went through an LDS tile of the workgroup's chains, which did
 // not fit beyond dim 96: a call WITH records then ran on another kernel family than the same call without).
 // ---------------------------------------------------------------------------------
+bool gmm_wide_supported(int32_t dim, int32_t n_comp);        // gmm_wide.hip: mixtures at 132 .. 256 dims (five to eight tiles)
+bool gmm_wide_shift_supported(int32_t dim, int32_t n_comp);  // gmm_wide_shift.hip: ... and the widths off multiples of 4 between 126 and 254
+int launch_langevin_chain_gmm_wide(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                   const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
+int launch_langevin_chain_gmm_wide_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                         const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 bool gmm_shift_supported(int32_t dim, int32_t n_comp);  // gmm_shift.hip
 int launch_langevin_chain_gmm_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                     const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
@@ -222,6 +228,9 @@ bool matrix_langevin_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t 
   static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
   if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_shift_supported(dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   if (e.kind == EBM_ENERGY_GMM && gmm_shift_supported(dim, e.n_comp) && !no_shift) return diag::plan_classes(n_chains, dim, d);
+  static const bool no_wide = ab_switch("EBM_GMM_NOWIDE");
+  if (e.kind == EBM_ENERGY_GMM && gmm_wide_shift_supported(dim, e.n_comp) && !no_wide) return diag::plan_classes(n_chains, dim, d);
+  if (e.kind == EBM_ENERGY_GMM && gmm_wide_supported(dim, e.n_comp) && !no_wide) return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
   const int32_t pack = e.kind == EBM_ENERGY_GAUSSIAN ? gauss_pack_factor(dim, n_chains) : 0;
   const bool mix = e.kind == EBM_ENERGY_GMM && gmm_mfma_supported(dim, e.n_comp) && !(dim == 32 && e.n_comp <= 8);
   if (!(pack >= 1 || mix)) return false;
@@ -263,6 +272,10 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
   if (!matrix_langevin_diag_plan(e, n_chains, dim, a.diag))
     return fail(EBM_EDIM, "ebm_langevin_chain_f32: no matrix-layout diagnostics records for this energy / dim %d", dim);
   const bool mixture = e.kind == EBM_ENERGY_GMM;
+  if (mixture && (gmm_wide_supported(dim, e.n_comp) || gmm_wide_shift_supported(dim, e.n_comp)))  // five to eight tiles
+    return (gmm_wide_supported(dim, e.n_comp) ? launch_langevin_chain_gmm_wide : launch_langevin_chain_gmm_wide_shift)(
+        e, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, noise, seed, offset,
+        diag_partials, st);
   if (a.diag.E < 0 && mixture)  // interleaved classes: the shifted-row kernels
     return launch_langevin_chain_gmm_shift(e, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
                                            thin, traj, noise, seed, offset, diag_partials, st);

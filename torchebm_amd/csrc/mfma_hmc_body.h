@@ -159,7 +159,7 @@ struct GmmE {
   using M = gmm3::Mixture<NT, KR>;
   static constexpr int kLdsFloats = M::kLdsFloats;
   static constexpr bool kEvalGivesEnergy = false;
-  static constexpr bool kCarry = true;
+  static constexpr bool kCarry = NT <= 4;  // (five to eight tiles: the parked force, 16 KB per tile, does not fit beside the operands)
   __device__ static __forceinline__ gmm3::Params params(const GaussHmcArgs& a) {
     return gmm3::Params{a.gm_means, a.gm_logw, a.n_comp, a.dim, a.inv2s2, a.invs2, a.sh_lo};
   }
