@@ -33,7 +33,9 @@ def _finish(layout, rec, n, dim, n_kept, dev):
     return {k: v.cpu() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("dim,n", [(21, 300), (30, 131), (33, 1), (50, 514), (51, 300), (70, 259), (99, 300), (126, 77), (130, 300), (157, 203)])
+@pytest.mark.parametrize("dim,n", [(21, 300), (30, 131), (33, 1), (50, 514), (51, 300), (70, 259), (99, 300), (126, 77), (130, 300), (157, 203),
+                                   # shifted rows reaching 161 .. 256 tile coordinates: the streamed evaluation, one pre-split image per class
+                                   (159, 150), (161, 300), (190, 131), (222, 97), (253, 203), (254, 300)])
 @pytest.mark.parametrize("mass", [None, 2.5, "diag"])
 def test_injected_draws_against_the_oracle(cuda_device, dim, n, mass):
     T, L, eps, thin = 4, 5, 0.06, 2
@@ -80,7 +82,7 @@ def test_injected_draws_against_the_oracle(cuda_device, dim, n, mass):
     assert torch.equal(states[0], states[1])  # records change nothing
 
 
-@pytest.mark.parametrize("dim", [25, 50, 99, 150])
+@pytest.mark.parametrize("dim", [25, 50, 99, 150, 201, 254])
 def test_native_draws_are_the_flat_field(cuda_device, dim):
     """Native RNG: momenta = the normal field at step offset + 2 t, uniforms = the uniform field at offset + 2 t + 1 --
     materialised with ebm_noise_fill_f32 and injected, the chains are bit-identical."""

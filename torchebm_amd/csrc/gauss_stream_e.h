@@ -41,6 +41,11 @@ struct GaussStreamE {
                    : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
     }
   }
+  __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds, int lo) {  // shifted rows (a.prec_image: this class's)
+    for (int i = threadIdx.x; i < 32 * NT; i += kBlock) lds[kSlabFloats + i] = (i >= lo && i - lo < a.dim) ? a.mean[i - lo] : 0.0f;
+    dma(a, lds, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
     for (int i = threadIdx.x; i < 32 * NT; i += kBlock) lds[kSlabFloats + i] = i < a.dim ? a.mean[i] : 0.0f;
     dma(a, lds, 0, 0);  // the first evaluation's first stage (the body's barrier follows)

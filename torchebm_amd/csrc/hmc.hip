@@ -38,6 +38,13 @@ int launch_hmc_chain_gauss_shift_diag(const ebm_energy_t&, float*, int64_t, int3
                                       double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t,
                                       uint64_t, float*, hipStream_t);
 bool gauss_hmc_stream_supported(const ebm_energy_t& e, int32_t dim);  // gauss_hmc_stream.hip: dims 164 .. 256 with the pre-split image
+bool gauss_hmc_stream_shift_supported(const ebm_energy_t& e, int32_t dim);  // gauss_hmc_stream_shift.hip: ... and the widths between them
+int launch_hmc_chain_gauss_stream_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
+                                        double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t,
+                                        uint64_t, float*, hipStream_t);
+int launch_hmc_chain_gauss_stream_shift_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
+                                             double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
+                                             uint64_t, uint64_t, float*, hipStream_t);
 int launch_hmc_chain_gauss_stream(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
                                   const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
 bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);
@@ -88,6 +95,7 @@ static bool hmc_matrix_records(const ebm_energy_t& e, int64_t n_chains, int32_t 
   // widths off multiples of 4 from 21: shifted rows, the records of their alignment classes interleaved (diag.h)
   static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
   if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_hmc_shift_supported(dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
+  if (gauss_hmc_stream_shift_supported(e, dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   if (e.kind == EBM_ENERGY_GMM && gmm_hmc_shift_supported(dim, e.n_comp, EBM_MASS_NONE, true) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   return matrix_hmc_diag_plan(e, n_chains, dim, d);
 }
@@ -106,6 +114,10 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
                      const float* u, uint64_t seed, uint64_t offset, float* diag_partials, hipStream_t st) {
   if (diag_partials) {
     diag::DiagArgs dm;
+    if (hmc_matrix_records(e, n_chains, dim, dm) && dm.E < 0 && gauss_hmc_stream_shift_supported(e, dim))
+      return launch_hmc_chain_gauss_stream_shift_diag(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
+                                                      mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset,
+                                                      diag_partials, st);
     if (hmc_matrix_records(e, n_chains, dim, dm) && dm.E < 0 && e.kind == EBM_ENERGY_GMM)
       return launch_hmc_chain_gmm_shift_diag(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
                                              thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, diag_partials, st);
@@ -136,6 +148,12 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     if (!no_shift)
       return launch_hmc_chain_gmm_shift(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
                                         thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, nullptr, st);
+  }
+  if (!diag_partials && gauss_hmc_stream_shift_supported(e, dim)) {
+    static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+    if (!no_shift)
+      return launch_hmc_chain_gauss_stream_shift(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag,
+                                                 thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, nullptr, st);
   }
   if (!diag_partials && gauss_hmc_stream_supported(e, dim))
     return launch_hmc_chain_gauss_stream(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag, thin,

@@ -53,6 +53,7 @@ struct GaussHmcArgs {
   diag::DiagArgs diag;     // per-workgroup diagnostics records at the kept transitions (DIAG kernels)
   int32_t sh_classes = 1;  // SHIFTED rows (SH kernels): 4 / gcd(dim, 4) alignment classes of chains, one per workgroup
   int32_t sh_lo = 0;       // ... and, set by the body in its own copy, this workgroup's row offset (what the energies see)
+  int64_t sh_image_stride = 0;  // bytes between the classes' pre-split images (the streamed evaluation on shifted rows)
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -207,6 +208,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   const int lo = SH ? ((a_in.dim * sh_s) & 3) : 0;
   GaussHmcArgs a_sh = a_in;  // (SH: the energies see this workgroup's row offset)
   a_sh.sh_lo = lo;
+  if (SH && a_in.prec_image) a_sh.prec_image = a_in.prec_image + (int64_t)sh_s * a_in.sh_image_stride;  // this class's image
   const GaussHmcArgs& a = SH ? a_sh : a_in;
   E en{};  // (state of the evaluation across calls, if it has any: GaussStreamE's buffer parity)
   constexpr int DIM = 32 * NT;

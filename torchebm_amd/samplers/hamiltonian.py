@@ -130,12 +130,11 @@ class HamiltonianMonteCarlo(BaseSampler):
             spec = fused_spec_for(self.model, x, model_kwargs)
             if spec is not None and not spec.hmc:
                 spec = None  # (a wide MLP energy: fused for Langevin only)
-            if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None and spec.dim > 128
-                    and not spec.dim <= 157  # (132 .. 160: five tiles, the split operands still fit LDS -- multiples of 4, and the widths between them up to 157 on shifted rows, csrc/gauss_hmc_shift.hip)
-                    and not (spec.dim == 160)
-                    and not (spec.dim <= 256 and spec.dim % 4 == 0 and spec.aux is not None)  # (164 .. 256: the slabs stream from the pre-split image)
+            if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None
+                    and spec.dim > 160  # (up to 160: the split operands stay in LDS -- five tiles; widths off multiples of 4 on shifted rows)
+                    and not (spec.dim <= 256 and spec.aux is not None)  # (161 .. 256: the slabs stream from the pre-split image -- one per alignment class off multiples of 4, up to 254)
                     and x.shape[0] >= 16384 and self.capture_graph is not False and self._graph_eligible(model_kwargs)):
-                # Above 160 dims (and off multiples of 4 above 157) the transition kernel is the lane-group mat-vec (2 TFLOP/s); the per-transition route -- the
+                # Above 256 dims (255 included) the transition kernel is the lane-group mat-vec (2 TFLOP/s); the per-transition route -- the
                 # gradient and the energy as one library GEMM each (GaussianModel), kick / drift / accept kernels on the same
                 # random field, replayed from a HIP graph -- is 1.5 - 30x faster there (scripts/bench_gauss_hmc_big.py), for
                 # batches that fill the GEMMs and calls that can be replayed; otherwise the one fused launch is kept.
