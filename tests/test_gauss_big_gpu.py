@@ -145,9 +145,9 @@ def test_diagnostics_come_from_in_kernel_records(cuda_device, dim, n):
         torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("dim", [162, 1024])
+@pytest.mark.parametrize("dim", [258, 1024])
 def test_widths_without_a_matrix_chain_kernel_take_the_gemm_step_route(cuda_device, dim):
-    """dim 162 (not a multiple of 4 and beyond the shifted-row kernels, tests/test_gauss_shift_gpu.py) / 1024 (above 512): the sampler runs the per-step route -- the gradient as one library
+    """dim 258 (not a multiple of 4 and beyond the shifted-row kernels, tests/test_gauss_shift_gpu.py) / 1024 (above 512): the sampler runs the per-step route -- the gradient as one library
     GEMM (GaussianModel's closed form above 128 dims), the update kernel on the native field -- not the lane-group chain
     kernel; same chains as that kernel on the same seed (shared (seed, step, element) field), to fp32 round-off.  The reroute
     is for batches that fill the GEMM and calls that can be replayed from a graph: few chains, or

@@ -1,4 +1,4 @@
-"""Dense Gaussians at widths that are not a multiple of 4, 21 .. 157, on SHIFTED rows (csrc/gauss_shift.hip,
+"""Dense Gaussians at widths that are not a multiple of 4, 17 .. 254, on SHIFTED rows (csrc/gauss_shift.hip, gauss_res_shift.hip,
 gauss_mfma_body.h SH): a workgroup takes the chains of one alignment class c = K j + s and lays its tiles over the aligned
 flat range that contains the row, so that a register quad is one float4 / one Philox counter of the flat field.  Against the
 oracle on injected noise (every class, ragged chain counts, clamp, trajectory), the native field bit-identical to the
@@ -16,7 +16,8 @@ from torchebm_amd.samplers.langevin import em_coefficients
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [21, 25, 30, 33, 50, 51, 66, 70, 99, 126, 130, 157]
+DIMS = [17, 19, 21, 25, 30, 33, 50, 51, 66, 70, 99, 126, 130, 157,
+        159, 161, 190, 222, 253, 254]  # (from 159: the streamed kernel, one pre-split image per alignment class)
 
 
 def _model(dim, device, seed=0):
@@ -50,7 +51,7 @@ def test_injected_noise_against_the_oracle(cuda_device, dim, n):
     torch.testing.assert_close(got, want, rtol=3e-5, atol=3e-5)
 
 
-@pytest.mark.parametrize("dim", [21, 50, 99, 157])
+@pytest.mark.parametrize("dim", [21, 50, 99, 157, 161, 254])
 def test_clamp_and_trajectory_against_the_oracle(cuda_device, dim):
     model, ref = _model(dim, cuda_device, seed=2)
     g = torch.Generator().manual_seed(dim)
@@ -90,7 +91,7 @@ def test_native_field_is_the_materialised_one(cuda_device, dim):
     assert (flat[: dim + pad] == 7.0).all() and (flat[dim + pad + n * dim:] == 7.0).all()
 
 
-@pytest.mark.parametrize("dim,n", [(30, 1000), (50, 514), (33, 129), (99, 1001), (126, 700), (150, 333)])
+@pytest.mark.parametrize("dim,n", [(30, 1000), (50, 514), (33, 129), (99, 1001), (126, 700), (150, 333), (161, 515), (222, 300), (253, 129)])
 def test_records_interleave_the_classes_and_change_nothing(cuda_device, dim, n):
     model, _ = _model(dim, cuda_device, seed=4)
     layout = _lib.diag_layout(model.fused_spec().to_c(), _lib.DIAG_LANGEVIN, n, dim)
@@ -129,10 +130,11 @@ def test_a_nan_chain_does_not_reach_its_neighbours(cuda_device):
 
 
 def test_the_sampler_keeps_the_chain_kernel_above_128(cuda_device):
-    """Widths off multiples of 4 up to 157 have a chain kernel now: the sampler no longer reroutes them to the GEMM step route."""
-    model, _ = _model(150, cuda_device, seed=6)
-    s = ta.LangevinDynamics(model, step_size=0.02, device=cuda_device)
-    x0 = torch.randn(1 << 15, 150, device=cuda_device)
-    c0 = hip_calls("ebm_langevin_chain_f32")
-    s.sample(x=x0, n_steps=20)
-    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    """Widths off multiples of 4 up to 254 have a chain kernel now: the sampler no longer reroutes them to the GEMM step route."""
+    for dim in (150, 201):
+        model, _ = _model(dim, cuda_device, seed=6)
+        s = ta.LangevinDynamics(model, step_size=0.02, device=cuda_device)
+        x0 = torch.randn(1 << 15, dim, device=cuda_device)
+        c0 = hip_calls("ebm_langevin_chain_f32")
+        s.sample(x=x0, n_steps=20)
+        assert hip_calls("ebm_langevin_chain_f32") == c0 + 1

@@ -80,6 +80,9 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int3
 int launch_langevin_chain_gmm_mfma(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
                                    const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t,
                                    hipStream_t);
+bool gauss_res_shift_supported(const ebm_energy_t& e, int32_t dim);  // gauss_res_shift.hip: widths off multiples of 4 up to 254, per-class images
+int launch_langevin_chain_gauss_res_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                          const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 bool gmm_wide_supported(int32_t dim, int32_t n_comp);        // gmm_wide.hip: mixtures at 132 .. 256 dims (five to eight tiles)
 bool gmm_wide_shift_supported(int32_t dim, int32_t n_comp);  // gmm_wide_shift.hip: ... and the widths off multiples of 4 between 126 and 254
 int launch_langevin_chain_gmm_wide(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -285,6 +288,12 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (!no_shift)
       return launch_langevin_chain_gauss_shift(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
                                                clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
+  }
+  if (!heun && gauss_res_shift_supported(*energy, dim)) {
+    static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
+    if (!no_shift)
+      return launch_langevin_chain_gauss_res_shift(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table,
+                                                   clamp_on, cmin, cmax, thin, traj, noise, seed, offset, nullptr, (hipStream_t)stream);
   }
   if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_pack_factor(dim, n_chains) >= 1) {
     // A/B switch for tests and profiling: EBM_GAUSS_ROWS=1 keeps the LDS mat-vec kernel

@@ -75,6 +75,8 @@ struct BigArgs {
   float* grad_out;      // x is read, not written
   const char* prec_image;  // IMG kernels: Ps pre-split in slab order (ebm_gauss_prec_image_f32; ebm_energy_t.aux), else null
   diag::DiagArgs diag;  // records of the kept steps (diag.h: one per wave-tile of 32 chains, E = 32 dim, S = dim); partials == nullptr: none
+  int32_t sh_classes = 1;       // SHIFTED rows (the resident kernel's SH instantiations: widths off multiples of 4): alignment classes,
+  int64_t sh_image_stride = 0;  // and the bytes between the classes' images in prec_image
 };
 
 struct Tri {
@@ -557,9 +559,12 @@ struct FoldPlan {
   }
 };
 
-template <int OT, bool DIAG = false, bool IMG = false, bool FOLD = false>
+// SH: SHIFTED rows (gauss_mfma_body.h says how) -- widths off multiples of 4 whose rows reach 161 .. 256 tile coordinates: a
+// workgroup takes the chains of one alignment class and streams that class's image (of the shifted matrix).
+template <int OT, bool DIAG = false, bool IMG = false, bool FOLD = false, bool SH = false>
 __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   static_assert(!FOLD || (IMG && !DIAG), "FOLD is the plain call on the image");
+  static_assert(!SH || (IMG && !FOLD), "shifted rows: on the per-class images");
   using C = ResCfg<OT>;
   constexpr int UPT = C::UPT, SLABU = C::SLABU;
   extern __shared__ __align__(16) unsigned char big_smem[];
@@ -567,19 +572,36 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   float* mus = reinterpret_cast<float*>(big_smem + 2 * C::SLAB);        // [32 OT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
   const int dim = a.dim;
-  for (int i = tid; i < 32 * OT; i += 256) mus[i] = i < dim ? a.mean[i] : 0.0f;
-  const int64_t chain = ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
+  const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a.sh_classes) : 0;
+  const int lo = SH ? ((dim * sh_s) & 3) : 0, hi = lo + dim;  // the row's tile coordinates
+  [[maybe_unused]] const char* image = a.prec_image + (SH ? (int64_t)sh_s * a.sh_image_stride : 0);
+  for (int i = tid; i < 32 * OT; i += 256) mus[i] = (i >= lo && i < hi) ? a.mean[i - lo] : 0.0f;
+  const int64_t chain = SH ? (((int64_t)(blockIdx.x / (unsigned)a.sh_classes) * 4 + wave) * 32 + m) * a.sh_classes + sh_s
+                           : ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
   const bool active = chain < a.n_chains;
-  const int64_t row = active ? chain * (int64_t)dim : 0;
+  const int64_t row = active ? chain * (int64_t)dim - lo : 0;  // flat element of tile coordinate 0
 
   f32x16 x[OT];
   static_for<OT * 4>([&](auto ic) {
     constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
     const int k0 = 32 * t + 8 * q + 4 * h;
+    if constexpr (SH) {
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (active && k0 >= lo && k0 + 3 < hi) {
+        v = *reinterpret_cast<const f32x4*>(a.x + row + k0);
+      } else if (active && k0 + 3 >= lo && k0 < hi) {  // a quad shared with a neighbouring chain: its own elements only
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (k0 + i >= lo && k0 + i < hi) v[i] = a.x[row + k0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[t][4 * q + i] = v[i];
+    } else {
     const bool ok = active && k0 < dim;
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + row + (ok ? k0 : 0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[t][4 * q + i] = ok ? v[i] : 0.0f;  // padding stays exactly 0: zero rows / columns of Ps, never stored
+    }
   });
 
   // The slab of a stage: rows 0 .. 32 OT - 1 of Ps at the stage's 32 columns -- one 128 B line per row, EIGHT lanes per line:
@@ -645,7 +667,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   [[maybe_unused]] const uint32_t slab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)big_smem;
   [[maybe_unused]] auto dma_stage = [&](int buf, int s) {
     constexpr uint32_t STAGE_BYTES = 3u * SLABU * 16u;
-    const char* src = a.prec_image + big_image_bytes<OT, 1>(32 * OT) + (size_t)s * STAGE_BYTES;
+    const char* src = image + big_image_bytes<OT, 1>(32 * OT) + (size_t)s * STAGE_BYTES;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t dst = slab_lds + (uint32_t)buf * STAGE_BYTES;
     for (int piece = wv; piece < (int)(STAGE_BYTES / 1024u); piece += 4) {
@@ -675,7 +697,8 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   // Records (DIAG): the column sums of a kept state come from the registers right after its update; its energy 0.5 d . P d
   // is what the NEXT step's contraction computes (g = P d), so the energy share of a record is written one step late and only
   // a kept LAST step costs a contraction of its own (one more trip of the loop, without an update).
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+  // (SH: the records of the classes interleave -- record (group, class), diag.h plan_classes)
+  const int64_t wave_id = SH ? ((int64_t)(blockIdx.x / (unsigned)a.sh_classes) * 4 + wave) * a.sh_classes + sh_s : (int64_t)blockIdx.x * 4 + wave;
   [[maybe_unused]] int rec_keep = 0, rec_pending = -1;
   const int n_trips = a.k_steps + ((DIAG && a.k_steps > 0 && a.k_steps % a.thin == 0) ? 1 : 0);
   for (int step = 0; step < n_trips; ++step) {
@@ -854,7 +877,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       if (step >= a.k_steps) break;  // the extra trip of a kept last step
     }
     // ---- Euler-Maruyama update in the reference's op order, one Philox counter per register quad; all in registers
-    uint64_t e_row = (uint64_t)chain * (uint64_t)dim;
+    uint64_t e_row = (uint64_t)chain * (uint64_t)dim - (uint64_t)lo;
     asm volatile("" : "+v"(e_row));
     const bool keep_now = a.traj && until_keep == 1;
     static_for<OT>([&](auto tc) {
@@ -869,6 +892,13 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         } else if constexpr (EBM_BIG_EXP & 2) {
           eps = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
         } else if (a.noise) {
+          if constexpr (SH) {  // (an injected field restarts at step * n * dim: no alignment to count on)
+            eps = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* nz = a.noise + (int64_t)step * a.n_chains * dim + (active ? (int64_t)e_row : 0) + k0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (active && k0 + i >= lo && k0 + i < hi) eps[i] = nz[i];
+          } else
           eps = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)step * a.n_chains * dim + (active ? (int64_t)e_row : 0) + (ok ? k0 : 0));
         } else {
           const F4 n4 = normal4_at(a.key, (e_row + (uint64_t)k0) >> 2, a.step0 + (uint64_t)step);
@@ -883,8 +913,17 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
             nv = x1 + noise_coef * dw;
           }
           if (a.clamp_on) nv = clamp_nanprop(nv, a.cmin, a.cmax);
-          x[t][4 * q + i] = ok ? nv : 0.0f;  // padding held at 0
+          if constexpr (SH) x[t][4 * q + i] = (active && k0 + i >= lo && k0 + i < hi) ? nv : 0.0f;
+          else x[t][4 * q + i] = ok ? nv : 0.0f;  // padding held at 0
         }
+        if constexpr (SH) {
+          if (keep_now && active) {  // (a kept row starts wherever (chain * n_kept + kept) * dim falls)
+            float* tr = a.traj + ((int64_t)chain * a.n_kept + kept) * (int64_t)dim + (k0 - lo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (k0 + i >= lo && k0 + i < hi) tr[i] = x[t][4 * q + i];
+          }
+        } else
         if (keep_now && ok) {
           const f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
           *reinterpret_cast<f32x4*>(a.traj + ((int64_t)e_row * a.n_kept + kept * (int64_t)dim) + k0) = v;
@@ -897,7 +936,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       until_keep = a.thin;
       ++kept;
       if constexpr (DIAG) {
-        diag::wave_record<OT>(a.diag.partials, a.diag.n_blocks, rec_keep, wave_id, dim, [&](int t, int r) { return x[t][r]; }, active, lane);
+        diag::wave_record<OT>(a.diag.partials, a.diag.n_blocks, rec_keep, wave_id, dim, [&](int t, int r) { return x[t][r]; }, active, lane, 0, lo);
         rec_pending = rec_keep++;
       }
     }
@@ -905,11 +944,39 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   static_for<OT * 4>([&](auto ic) {
     constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
     const int k0 = 32 * t + 8 * q + 4 * h;
+    if constexpr (SH) {
+      if (active && k0 >= lo && k0 + 3 < hi) {
+        const f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(a.x + row + k0) = v;
+      } else if (active && k0 + 3 >= lo && k0 < hi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (k0 + i >= lo && k0 + i < hi) a.x[row + k0 + i] = x[t][4 * q + i];
+      }
+    } else
     if (active && k0 < dim) {
       const f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
       *reinterpret_cast<f32x4*>(a.x + row + k0) = v;
     }
   });
+}
+
+// the SH instantiations' launcher (gauss_res_shift.hip)
+template <int OT>
+int launch_res_shift(const BigArgs& a, hipStream_t st) {
+  using C = ResCfg<OT>;
+  static DeviceOnce attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, true, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+  }
+  const int64_t blocks = ceil_div64(ceil_div64(a.n_chains, a.sh_classes), 128) * a.sh_classes;  // class-major inside blockIdx: b % K
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
+  if (a.diag.partials) hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, true, true, false, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, true, false, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  return check_launch("ebm_langevin_chain_f32");
 }
 
 template <int OT, bool IMG>

@@ -210,6 +210,9 @@ int launch_langevin_chain_gmm_mfma(const ebm_energy_t& e, float* x, int64_t n_ch
 // wave of 32 chains from the C/D registers (round 3; rounds 1-2 went through an LDS tile of the workgroup's chains, which did
 // not fit beyond dim 96: a call WITH records then ran on another kernel family than the same call without).
 // ---------------------------------------------------------------------------------
+bool gauss_res_shift_supported(const ebm_energy_t& e, int32_t dim);  // gauss_res_shift.hip: widths off multiples of 4 up to 254, per-class images
+int launch_langevin_chain_gauss_res_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
+                                          const float*, int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
 bool gmm_wide_supported(int32_t dim, int32_t n_comp);        // gmm_wide.hip: mixtures at 132 .. 256 dims (five to eight tiles)
 bool gmm_wide_shift_supported(int32_t dim, int32_t n_comp);  // gmm_wide_shift.hip: ... and the widths off multiples of 4 between 126 and 254
 int launch_langevin_chain_gmm_wide(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float,
@@ -227,6 +230,7 @@ bool matrix_langevin_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t 
   // widths off multiples of 4 from 21: shifted rows, the records of their alignment classes interleaved
   static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");
   if (e.kind == EBM_ENERGY_GAUSSIAN && gauss_shift_supported(dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
+  if (gauss_res_shift_supported(e, dim) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   if (e.kind == EBM_ENERGY_GMM && gmm_shift_supported(dim, e.n_comp) && !no_shift) return diag::plan_classes(n_chains, dim, d);
   static const bool no_wide = ab_switch("EBM_GMM_NOWIDE");
   if (e.kind == EBM_ENERGY_GMM && gmm_wide_shift_supported(dim, e.n_comp) && !no_wide) return diag::plan_classes(n_chains, dim, d);
@@ -279,6 +283,9 @@ int launch_langevin_chain_matrix_diag(const ebm_energy_t& e, float* x, int64_t n
   if (a.diag.E < 0 && mixture)  // interleaved classes: the shifted-row kernels
     return launch_langevin_chain_gmm_shift(e, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
                                            thin, traj, noise, seed, offset, diag_partials, st);
+  if (a.diag.E < 0 && gauss_res_shift_supported(e, dim))
+    return launch_langevin_chain_gauss_res_shift(e, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
+                                                 thin, traj, noise, seed, offset, diag_partials, st);
   if (a.diag.E < 0)
     return launch_langevin_chain_gauss_shift(e, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
                                              thin, traj, noise, seed, offset, diag_partials, st);

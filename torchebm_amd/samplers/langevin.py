@@ -73,9 +73,9 @@ def _record_scratch_done(sampler) -> None:
 
 def _gaussian_chain_on_matrix_cores(dim: int) -> bool:
     """Widths at which ``ebm_langevin_chain_f32`` runs the dense Gaussian on the matrix cores (csrc/gauss_mfma.hip: up to 128,
-    packed rows below 20 included; csrc/gauss_shift.hip: widths off multiples of 4 up to 157 on shifted rows;
+    packed rows below 20 included; csrc/gauss_shift.hip, gauss_res_shift.hip: widths off multiples of 4 up to 254 on shifted rows;
     csrc/gauss_big.hip: multiples of 4 up to 512)."""
-    return dim <= 128 or (dim % 4 == 0 and dim <= 512) or dim <= 157
+    return dim <= 254 or (dim % 4 == 0 and dim <= 512)
 
 
 def _replay_or_step(sampler, g, first: bool, more: bool) -> None:
