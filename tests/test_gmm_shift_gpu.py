@@ -92,3 +92,56 @@ def test_hmc_against_the_oracle(cuda_device, K, dim, mass):
             assert torch.equal(traj2, traj)
         torch.testing.assert_close(diag["acceptance_rate"].cpu(), want["diagnostics"]["acceptance_rate"], rtol=0, atol=1e-6)
         torch.testing.assert_close(diag["mean"].cpu(), want["diagnostics"]["mean"], rtol=1e-3, atol=1e-3)
+
+
+# 129 .. 256 dims: five to eight tiles of the transition body (csrc/gmm_hmc_wide.hip; widths off multiples of 4 on shifted rows,
+# gmm_hmc_wide_shift.hip) -- no mass vector there (the lane-group kernels keep it)
+@pytest.mark.parametrize("K", [8, 16, 32])
+@pytest.mark.parametrize("dim,mass", [(126, None), (129, 1.7), (132, None), (158, 0.6), (160, None), (190, None), (200, 1.3), (224, None),
+                                      (253, None), (254, 0.8), (256, None), (200, "diag")])
+def test_wide_hmc_against_the_oracle(cuda_device, K, dim, mass):
+    model, en, g = _mixture(K, dim, cuda_device, seed=2)
+    if mass == "diag":
+        mass = torch.rand(dim, generator=g) + 0.5
+    n, T, L, thin, eps = 161, 4, 5, 2, 0.08
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L,
+                                 mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass, device=cuda_device)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    seed = 8000 + K + dim
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    traj, acc = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True, return_diagnostics=False,
+                         generator=torch.Generator(device=cuda_device).manual_seed(seed)), None
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    p = _field((n, dim), _rng.kernel_seed(seed), range(0, 2 * T, 2), cuda_device).cpu()
+    u = _field((n,), _rng.kernel_seed(seed), range(1, 2 * T, 2), cuda_device, kind=_lib.NOISE_UNIFORM).cpu()
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, mass=mass, thin=thin, want_traj=True)
+    err = ((traj.cpu() - want["trajectory"]).abs() / want["trajectory"].abs().clamp(min=1.0)).reshape(n, -1).amax(dim=1)
+    if want["margin"] > 1e-4:
+        assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()
+        assert err.median().item() <= 2e-5
+    else:
+        assert (err <= 5e-4).float().mean().item() >= 0.9
+
+
+@pytest.mark.parametrize("dim", [132, 200, 254, 256])
+def test_wide_hmc_injected_draws_give_the_oracles_accept_mask(cuda_device, dim):
+    """Through the C ABI with injected momenta and uniforms: the accept mask is the oracle's, bit for bit (seeds without a
+    borderline decision), and a NaN chain stays where it is without touching its neighbours."""
+    K, n, T, L, eps = 16, 130, 3, 4, 0.1
+    model, en, g = _mixture(K, dim, cuda_device, seed=3)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    x0[7, 3] = float("nan")
+    p, u = torch.randn(T, n, dim, generator=g), torch.rand(T, n, generator=g)
+    ref = oracle.hmc_chain(en, x0, p, u, [eps] * T, L)
+    xd, p_d, u_d = x0.to(cuda_device), p.to(cuda_device), u.to(cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    spec = model.fused_spec()
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), xd.data_ptr(), n, dim, T, L, eps, None, 0, 0.0, None, 1, None, None,
+              mask.data_ptr(), None, p_d.data_ptr(), u_d.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    got = xd.cpu()
+    if ref["margin"] > 1e-4:
+        assert torch.equal(mask.cpu().bool(), ref["accepted"])
+    assert not mask[:, 7].any() and torch.isnan(got[7, 3])
+    keep = torch.ones(n, dtype=torch.bool); keep[7] = False
+    err = ((got[keep] - ref["x"][keep]).abs() / ref["x"][keep].abs().clamp(min=1.0)).amax(dim=1)
+    assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()

@@ -55,6 +55,13 @@ int launch_hmc_chain_gmm_shift(const ebm_energy_t&, float*, int64_t, int32_t, in
 int launch_hmc_chain_gmm_shift_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t,
                                     double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t,
                                     uint64_t, float*, hipStream_t);
+bool gmm_hmc_wide_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);        // gmm_hmc_wide.hip: mixtures at 132 .. 224 dims
+bool gmm_hmc_wide_shift_supported(int32_t dim, int32_t n_comp, int32_t mass_kind);  // gmm_hmc_wide_shift.hip: ... and the widths between
+int launch_hmc_chain_gmm_wide(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
+                              const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
+int launch_hmc_chain_gmm_wide_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
+                                    const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t,
+                                    hipStream_t);
 bool matrix_hmc_diag_plan(const ebm_energy_t&, int64_t, int32_t, diag::DiagArgs&);
 int launch_hmc_chain_matrix_diag(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*,
                                  int32_t, double, const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*,
@@ -170,6 +177,15 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     if (!force_rows)
       return launch_hmc_chain_gmm_mfma(e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar,
                                        mass_diag, thin, traj, accept_mask, accept_count, p_noise, u, seed, offset, st);
+  }
+  // Mixtures at 129 .. 224 dims (no mass vector, no records): five to seven tiles of the same body, where they beat the lane-group kernels
+  if (!diag_partials && e.kind == EBM_ENERGY_GMM &&
+      (gmm_hmc_wide_supported(dim, e.n_comp, mass_kind) || gmm_hmc_wide_shift_supported(dim, e.n_comp, mass_kind))) {
+    static const bool force_rows = ab_switch("EBM_GMM_ROWS");
+    if (!force_rows)
+      return (gmm_hmc_wide_supported(dim, e.n_comp, mass_kind) ? launch_hmc_chain_gmm_wide : launch_hmc_chain_gmm_wide_shift)(
+          e, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag, thin, traj, accept_mask, accept_count,
+          p_noise, u, seed, offset, st);
   }
   Geometry geo;
   if (!hmc_geometry(e, dim, geo)) return fail(EBM_EDIM, "ebm_hmc_chain_f32: dim %d > 1024 is not supported by the fused kernel", dim);
