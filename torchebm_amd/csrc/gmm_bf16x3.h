@@ -91,14 +91,14 @@ struct Mixture {
       }
     }
     sum += __shfl_xor(sum, 32);
-    f32x16 acc[NT];
-    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, acc, lane,
+    // (the weighted mean accumulates in g itself and becomes the gradient in place: no third array beside x and g)
+    gauss3::contract_general<NT, KBC, false>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, g, lane,
                                              [&](auto ord) { fill(std::integral_constant<int, 12 * NT + decltype(ord)::value>{}); });
     const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[t][r] = a.invs2 * (x[t][r] - acc[t][r] * inv);
+      for (int r = 0; r < 16; ++r) g[t][r] = a.invs2 * (x[t][r] - g[t][r] * inv);
     return sum;
   }
   // the exact energy, difference form, online logsumexp over the components
