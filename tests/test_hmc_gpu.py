@@ -214,3 +214,46 @@ def test_step_route_carry_force_halves_the_gradient_calls(cuda_device):
     assert torch.equal(outs[False, False], outs[True, False])
     assert torch.equal(outs[False, False], outs[False, True])
     assert torch.equal(outs[False, False], outs[True, True])
+
+
+@pytest.mark.parametrize("kind", ["dw", "har"])
+@pytest.mark.parametrize("dim,mass", [(9, None), (12, 1.7), (18, None), (24, "diag"), (33, None), (40, 0.6), (48, None), (70, "diag"),
+                                      (96, None), (130, 1.3), (192, None), (300, None), (384, "diag"), (600, None), (768, 0.8)])
+def test_elementwise_hmc_three_vectors_per_lane(cuda_device, kind, dim, mass):
+    """Element-wise energies at row widths in (2^k, 1.5 2^k] float4 vectors run with three vectors per lane (csrc/hmc.hip
+    hmc_geometry; csrc/hmc_kernel.h NV == 3): injected draws against the oracle -- accept masks bit for bit, states, kept
+    rows -- over the mass forms, widths on and off multiples of 4, with and without records."""
+    g = torch.Generator().manual_seed(31 * dim + (kind == "har"))
+    n, T, L, thin, eps = 77, 4, 7, 2, 0.07
+    if kind == "dw":
+        model, en = ta.DoubleWellModel(device=cuda_device), oracle.DoubleWell()
+    else:
+        model, en = ta.HarmonicModel(device=cuda_device), oracle.Harmonic()
+    if mass == "diag":
+        mass = torch.rand(dim, generator=g) + 0.5
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    p, u = torch.randn(T, n, dim, generator=g), torch.rand(T, n, generator=g)
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, mass=mass, thin=thin, want_traj=True)
+    x = x0.to(cuda_device)
+    mask = torch.full((T, n), 7, dtype=torch.uint8, device=cuda_device)
+    counts = torch.zeros(T, dtype=torch.int32, device=cuda_device)
+    traj = torch.full((n, T // thin, dim), float("nan"), device=cuda_device)
+    _hmc_call(model.fused_spec(), x, [eps] * T, L, mass_to(mass, cuda_device), thin, traj, mask, counts,
+              p.to(cuda_device), u.to(cuda_device))
+    if want["margin"] > 1e-4:
+        assert torch.equal(mask.cpu().bool(), want["accepted"])
+        assert torch.equal(counts.cpu().long(), want["accepted"].sum(dim=1))
+        assert ((x.cpu() - want["x"]).abs() / want["x"].abs().clamp(min=1.0)).max().item() <= 5e-4
+        tscale = want["trajectory"].abs().clamp(min=1.0)
+        assert ((traj.cpu() - want["trajectory"]).abs() / tscale).max().item() <= 5e-4
+    # through the sampler with native draws and records: the diagnostics are those of the trajectory it returns
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, device=cuda_device,
+                                 mass=mass.to(cuda_device) if torch.is_tensor(mass) else mass)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    tr, diag = s.sample(x=x0.to(cuda_device), n_steps=T, thin=thin, return_trajectory=True, return_diagnostics=True,
+                        generator=torch.Generator(device=cuda_device).manual_seed(dim))
+    assert hip_calls("ebm_hmc_chain_f32") == c0 + 1
+    plain = s.sample(x=x0.to(cuda_device), n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(dim))
+    assert torch.equal(tr[:, -1], plain)
+    torch.testing.assert_close(diag["mean"].double(), tr.double().mean(dim=0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(diag["var"].double(), tr.double().var(dim=0, unbiased=False), rtol=1e-4, atol=1e-7)

@@ -90,6 +90,14 @@ static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
   // ... and at dim 64 / 128 four vectors per lane on 4 / 8 lanes (0.32 vs 0.36 ms at dim 128)
   else if ((dim == 64 || dim == 128) && nv_env == 0 && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC))
     geo = Geometry{dim / 16, 4, true};
+  // ... and THREE vectors per lane where a power-of-two group leaves more than a quarter of its lanes without a vector
+  // (rows of 2^k + 1 .. 1.5 2^k vectors: dims 9 .. 12, 17 .. 24, 33 .. 48, 65 .. 96, 129 .. 192, 257 .. 384, 513 .. 768)
+  else if (nv_env == 0 && (e.kind == EBM_ENERGY_DOUBLE_WELL || e.kind == EBM_ENERGY_HARMONIC)) {
+    const int nvec = (dim + 3) / 4;
+    int g3 = 1;
+    while (3 * g3 < nvec) g3 <<= 1;
+    if (g3 <= 64 && 3 * g3 < geo.G * geo.NV) geo = Geometry{g3, 3, false};
+  }
   return true;
 }
 

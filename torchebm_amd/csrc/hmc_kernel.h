@@ -478,6 +478,18 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
       case 32: if (geo.full) EBM_HMC_G(32, 1, true); else EBM_HMC_G(32, 1, false); break;
       default: if (geo.full) EBM_HMC_G(64, 1, true); else EBM_HMC_G(64, 1, false); break;
     }
+  } else if (geo.NV == 3) {  // element-wise energies, row widths in (2^k, 1.5 2^k] vectors: three vectors per lane (hmc.hip: hmc_geometry)
+    if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL || KIND == EBM_ENERGY_HARMONIC) {
+      switch (geo.G) {
+        case 1:  EBM_HMC_G(1, 3, false);  break;
+        case 2:  EBM_HMC_G(2, 3, false);  break;
+        case 4:  EBM_HMC_G(4, 3, false);  break;
+        case 8:  EBM_HMC_G(8, 3, false);  break;
+        case 16: EBM_HMC_G(16, 3, false); break;
+        case 32: EBM_HMC_G(32, 3, false); break;
+        default: EBM_HMC_G(64, 3, false); break;
+      }
+    }
   } else if (geo.G == 64 && geo.NV == 2) {
     EBM_HMC_G(64, 2, false);
   } else if (geo.G == 64 && geo.NV == 4) {
