@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 4
+#define EBM_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -361,6 +361,12 @@ EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32
  * `prec` is the SYMMETRIC matrix handed over as dev1.  0 bytes = this width has no image.  Since ABI version 4. */
 EBM_API size_t ebm_gauss_prec_image_bytes(int32_t dim);
 EBM_API int ebm_gauss_prec_image_f32(const float* prec, int32_t dim, void* image, void* stream);
+
+/* The active-column hint of EBM_ENERGY_GMM (its `aux`), computed on the device in ONE small launch (since ABI version 5):
+ * out[0] = sum_v 2^v * [ the component means differ somewhere in columns 4v..4v+3 ],  means [n_comp, dim], dim % 4 == 0,
+ * dim <= 32.  Replaces the seven tensor ops the Python model spent on it at every sample() call (45 us of launches in
+ * front of a 0.1 - 1 ms kernel).  `!=` as IEEE: a NaN mean differs from everything. */
+EBM_API int ebm_gmm_active_columns_i32(const float* means, int32_t n_comp, int32_t dim, int32_t* out, void* stream);
 
 EBM_API size_t ebm_mlp_w1_image_bytes(int32_t hidden, int32_t dim);
 EBM_API int ebm_mlp_w1_image_f32(const float* params, int32_t hidden, int32_t dim, void* image, void* stream);

@@ -138,3 +138,28 @@ def test_means_written_through_data_do_not_leave_a_stale_hint(cuda_device):
     b = ta.HamiltonianMonteCarlo(fresh, step_size=0.1, n_leapfrog_steps=5, device=cuda_device).sample(
         x=x0, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(4))
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dim", [4, 8, 16, 20, 32])
+def test_active_column_hint_is_one_launch_and_the_tensor_formula(cuda_device, dim):
+    """ebm_gmm_active_columns_i32 (ABI 5) against the definition, over random sparsity patterns, a NaN mean (differs from
+    everything) and a single component (nothing differs); widths the hint does not cover get none."""
+    g = torch.Generator().manual_seed(dim)
+    for trial in range(8):
+        K = [1, 2, 5, 8, 13, 32, 64, 3][trial]
+        means = torch.randn(1, dim, generator=g).repeat(K, 1)
+        cols = torch.rand(dim, generator=g) < 0.25
+        means[:, cols] += torch.randn(K, int(cols.sum()), generator=g)
+        if trial == 7:
+            means[1, dim - 1] = float("nan")
+        want = 0
+        for v in range(dim // 4):
+            if (means[:, 4 * v:4 * v + 4] != means[:1, 4 * v:4 * v + 4]).any():
+                want |= 1 << v
+        model = ta.GaussianMixtureModel(means, sigma=1.0, device=cuda_device)
+        c0 = _lib.call_counts["ebm_gmm_active_columns_i32"]
+        spec = model.fused_spec()
+        assert _lib.call_counts["ebm_gmm_active_columns_i32"] == c0 + 1
+        assert spec.aux.dtype == torch.int32 and int(spec.aux.item()) == want, (trial, K, want)
+    assert ta.GaussianMixtureModel(torch.randn(4, 36), sigma=1.0, device=cuda_device).fused_spec().aux is None
+    assert ta.GaussianMixtureModel(torch.randn(4, 6), sigma=1.0, device=cuda_device).fused_spec().aux is None

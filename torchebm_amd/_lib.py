@@ -18,7 +18,7 @@ import torch  # imported first on purpose: it loads the HIP runtime (libamdhip64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # energy kinds / enums: keep in sync with include/ebm_hip.h
 ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM, ENERGY_MLP = 0, 1, 2, 3, 4
@@ -57,6 +57,7 @@ EXPORTS = (
     "ebm_mlp_w1_image_f32",
     "ebm_gauss_prec_image_bytes",
     "ebm_gauss_prec_image_f32",
+    "ebm_gmm_active_columns_i32",
 )
 
 #: number of calls made through each entry point in this process (tests use it to
@@ -120,6 +121,7 @@ _PROTOTYPES = {
     "ebm_mlp_w1_image_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ebm_gauss_prec_image_bytes": (C.c_size_t, [_i32]),
     "ebm_gauss_prec_image_f32": (C.c_int, [_p, _i32, _p, _p]),
+    "ebm_gmm_active_columns_i32": (C.c_int, [_p, _i32, _i32, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -50,6 +50,7 @@ int launch_descent_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t,
                          int32_t, float*, hipStream_t);
 int launch_descent_step(const float*, const float*, float*, float*, int64_t, float, float, hipStream_t);
 int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStream_t);
+int launch_gmm_active_columns(const float*, int32_t, int32_t, int32_t*, hipStream_t);
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
                       uint64_t, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
@@ -488,6 +489,14 @@ int ebm_pcd_gather_f32(const float* buffer, int64_t buffer_size, int32_t dim, fl
   if (!buffer || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, offsets, rows_out, seed, offset,
                            (hipStream_t)stream);
+}
+
+int ebm_gmm_active_columns_i32(const float* means, int32_t n_comp, int32_t dim, int32_t* out, void* stream) {
+  const char* who = "ebm_gmm_active_columns_i32";
+  if (n_comp < 1 || dim < 4 || dim > 32 || (dim % 4) != 0)
+    return fail(EBM_EINVAL, "%s: bad sizes (n_comp %d, dim %d: a multiple of 4 up to 32)", who, n_comp, dim);
+  if (!means || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_gmm_active_columns(means, n_comp, dim, out, (hipStream_t)stream);
 }
 
 int ebm_pcd_scatter_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,

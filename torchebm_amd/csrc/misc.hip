@@ -761,6 +761,27 @@ int launch_lookahead(const float* x, const float* v, float* out, int64_t n_elem,
   return check_launch("ebm_lookahead_f32");
 }
 
+// bit v of out[0]: the component means differ somewhere in columns 4v .. 4v + 3 (the EBM_ENERGY_GMM hint; one workgroup)
+__global__ __launch_bounds__(kBlock) void gmm_active_columns_kernel(const float* __restrict__ means, int32_t n_comp, int32_t dim,
+                                                                    int32_t* __restrict__ out) {
+  __shared__ unsigned mask;
+  if (threadIdx.x == 0) mask = 0u;
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int i = threadIdx.x; i < n_comp * dim; i += kBlock) {
+    const int c = i % dim;
+    if (means[i] != means[c]) mine |= 1u << (c >> 2);
+  }
+  if (mine) atomicOr(&mask, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (int32_t)mask;
+}
+
+int launch_gmm_active_columns(const float* means, int32_t n_comp, int32_t dim, int32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(gmm_active_columns_kernel, dim3(1), dim3(kBlock), 0, st, means, n_comp, dim, out);
+  return check_launch("ebm_gmm_active_columns_i32");
+}
+
 int launch_pcd_gather(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,
                       const int64_t* offsets, int64_t* rows_out, uint64_t seed, uint64_t offset, hipStream_t st) {
   const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
