@@ -394,8 +394,10 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         gen = torch.Generator(device=device).manual_seed(1234)
         x0 = torch.randn(n, dim, device=device, generator=gen)
         fn = lambda: s.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
-        t = timed(fn, reps=5, warm=2, device=device)
-        kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 3, device)
+        # (a 1.2 ms call: ten of them untimed first -- this leg may start on a GPU that sat idle through a CPU baseline,
+        #  and three calls do not bring its clocks back: 1.22 ms per launch against 1.11 in steady state)
+        t = timed(fn, reps=20, warm=10, device=device)
+        kms = kernel_ms_of("ebm_hmc_chain_f32", fn, 10, device)
         _, d = s.sample(x=x0, n_steps=T, thin=T, return_diagnostics=True, generator=gen)
         # Work actually executed.  The ring's modes differ in columns 0..1 only; the kernel (csrc/hmc_ring.hip:
         # hmc_slot1_kernel<2>) runs the two K x 2 passes over those columns and treats the other 30 as the shared quadratic
@@ -408,8 +410,8 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         dense = ta.GaussianMixtureModel(torch.randn(8, dim, generator=gd) * 2.0, sigma=1.0, device=device)
         sd = ta.HamiltonianMonteCarlo(dense, step_size=0.1, n_leapfrog_steps=L, device=device)
         fd = lambda: sd.sample(x=x0, n_steps=T, generator=gen)  # noqa: E731
-        td = timed(fd, reps=3, warm=1, device=device)
-        kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 3, device)
+        td = timed(fd, reps=6, warm=3, device=device)
+        kd = kernel_ms_of("ebm_hmc_chain_f32", fd, 4, device)
         dense_flops = n * T * (L + 1) * (2 * 2 * 8 * dim + 4 * dim) + n * T * L * 4 * dim  # L + 1 evaluations (csrc/hmc_gmm32.hip)
         return {
             "name": "config3_hmc_gmm8", "workload": "HamiltonianMonteCarlo.sample, L=20, 8-mode GaussianMixture, n_chains=2^18, dim=32, "
