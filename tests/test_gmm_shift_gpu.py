@@ -34,7 +34,10 @@ def _mixture(K, dim, device, seed=0):
 
 @pytest.mark.parametrize("K,dim", [(K, d) for K in (3, 8, 9, 16, 32) for d in (21, 30, 33, 50, 65, 99, 125)] +
                          # 129 .. 256 dims: five to eight tiles (csrc/gmm_wide.hip), multiples of 4 and shifted rows
-                         [(K, d) for K in (8, 16, 32) for d in (126, 129, 132, 158, 160, 190, 200, 253, 254, 256)])
+                         [(K, d) for K in (8, 16, 32) for d in (126, 129, 132, 158, 160, 190, 200, 253, 254, 256)] +
+                         # more than eight components: the one-tile kernels from 9 / 12 dims (below 20 the lane-group kernels lose to them)
+                         [(K, d) for K in (9, 16, 32) for d in (9, 12, 13, 16, 18, 19, 20)] +
+                         [(K, d) for K in (3, 8) for d in (17, 18, 19, 29)])  # up to eight components: shifted rows from 17 dims
 def test_langevin_against_the_oracle(cuda_device, K, dim):
     model, en, g = _mixture(K, dim, cuda_device)
     n, k, thin = 203, 8, 2
@@ -61,7 +64,8 @@ def test_langevin_against_the_oracle(cuda_device, K, dim):
 
 
 @pytest.mark.parametrize("K", [3, 9, 16, 32])
-@pytest.mark.parametrize("dim,mass", [(21, None), (30, 1.7), (33, "diag"), (50, None), (65, "diag"), (93, 0.6), (99, None), (125, 1.3)])
+@pytest.mark.parametrize("dim,mass", [(21, None), (30, 1.7), (33, "diag"), (50, None), (65, "diag"), (93, 0.6), (99, None), (125, 1.3),
+                                      (9, None), (12, 1.7), (13, "diag"), (16, None), (18, "diag"), (19, 0.6)])
 def test_hmc_against_the_oracle(cuda_device, K, dim, mass):
     model, en, g = _mixture(K, dim, cuda_device, seed=1)
     if mass == "diag":

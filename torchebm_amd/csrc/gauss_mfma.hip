@@ -150,7 +150,9 @@ int launch_langevin_chain_gauss_mfma(const ebm_energy_t& e, float* x, int64_t n_
 // ---------------------------------------------------------------------------------
 // Gaussian mixture Langevin chain on the matrix layout
 // ---------------------------------------------------------------------------------
-bool gmm_mfma_supported(int32_t dim, int32_t n_comp) { return dim >= 20 && dim <= 128 && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32; }
+// (more than eight components: from 12 dims -- the one-tile kernel costs what it costs at 32, and the lane-group kernels'
+//  K x dim passes grow with K: K = 16, 2^16 chains x 20 steps, dims 13 / 16 / 19: 0.152 / 0.157 / 0.252 ms there, 0.103 here)
+bool gmm_mfma_supported(int32_t dim, int32_t n_comp) { return dim >= (n_comp > 8 ? 12 : 20) && dim <= 128 && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32; }
 
 namespace {
 template <int NT, int GKR>

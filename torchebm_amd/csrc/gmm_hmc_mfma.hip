@@ -7,7 +7,7 @@ bool gmm_hmc_mfma_supported(int32_t dim, int32_t n_comp, int32_t mass_kind) {
   // up to four tiles (the mixture's contractions are narrow -- one tile of components -- so, unlike the Gaussian's, the
   // split's transients fit beside x, p and the force); a diagonal mass: three tiles (four spill 0.6 - 0.9 KB)
   const int max_dim = mass_kind == EBM_MASS_DIAG ? 96 : 128;
-  return dim >= 20 && dim <= max_dim && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32;
+  return dim >= (n_comp > 8 ? 12 : 20) && dim <= max_dim && (dim % 4) == 0 && n_comp >= 1 && n_comp <= 32;
 }
 
 namespace {

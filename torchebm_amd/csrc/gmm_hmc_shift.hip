@@ -17,11 +17,10 @@ constexpr bool kRecords = false;
 
 #ifndef EBM_SHIFT_DIAG
 // plain calls: up to four tiles, three under a diagonal mass (gmm_hmc_mfma.hip); with records: three (the layout query is
-// not told the mass form); one tile with up to eight components stays on the lane-group kernel
+// not told the mass form); up to eight components from 17 dims, more from 9 (gmm_shift.hip)
 bool gmm_hmc_shift_supported(int32_t dim, int32_t n_comp, int32_t mass_kind, bool records) {
   const int max_ext = (records || mass_kind == EBM_MASS_DIAG) ? 96 : 128;
-  return dim >= 21 && (dim % 4) != 0 && shift_extent(dim) <= max_ext && n_comp >= 1 && n_comp <= 32 &&
-         !(shift_extent(dim) <= 32 && n_comp <= 8);
+  return dim >= (n_comp > 8 ? 9 : 17) && (dim % 4) != 0 && shift_extent(dim) <= max_ext && n_comp >= 1 && n_comp <= 32;
 }
 #else
 bool gmm_hmc_shift_supported(int32_t dim, int32_t n_comp, int32_t mass_kind, bool records);

@@ -49,10 +49,10 @@ int launch_gmm_shift_nt(const GaussArgs& a, hipStream_t st) {
 inline int32_t shift_extent(int32_t dim) { return dim + ((dim & 1) ? 3 : 2); }  // tile coordinates a row can reach
 }  // namespace
 
-// (one tile with up to eight components stays on the lane-group kernel -- one lane per chain, the means as scalar operands --
-//  as dim 32 itself does)
 bool gmm_shift_supported(int32_t dim, int32_t n_comp) {
-  return dim >= 21 && (dim % 4) != 0 && shift_extent(dim) <= 128 && n_comp >= 1 && n_comp <= 32 && !(shift_extent(dim) <= 32 && n_comp <= 8);
+  // (up to eight components: from 17 dims -- below, the lane-group kernels' groups of 1 .. 4 lanes are as fast; more: from 9.
+  //  K = 8, 2^16 chains x 20 steps, dims 19 / 21 / 29: 0.19 ms on the lane-group kernel, 0.11 here)
+  return dim >= (n_comp > 8 ? 9 : 17) && (dim % 4) != 0 && shift_extent(dim) <= 128 && n_comp >= 1 && n_comp <= 32;
 }
 
 int launch_langevin_chain_gmm_shift(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,

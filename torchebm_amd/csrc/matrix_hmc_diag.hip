@@ -12,7 +12,7 @@ bool gauss_hmc_stream_supported(const ebm_energy_t& e, int32_t dim);  // gauss_h
 
 bool matrix_hmc_diag_plan(const ebm_energy_t& e, int64_t n_chains, int32_t dim, diag::DiagArgs& d) {
   const bool gauss = e.kind == EBM_ENERGY_GAUSSIAN && (gauss_hmc_mfma_supported(dim, EBM_MASS_NONE) || gauss_hmc_stream_supported(e, dim));
-  const bool mix = e.kind == EBM_ENERGY_GMM && dim >= 20 && dim <= 96 && dim % 4 == 0 && e.n_comp >= 1 && e.n_comp <= 32 &&
+  const bool mix = e.kind == EBM_ENERGY_GMM && dim >= (e.n_comp > 8 ? 12 : 20) && dim <= 96 && dim % 4 == 0 && e.n_comp >= 1 && e.n_comp <= 32 &&
                    !(dim == 32 && e.n_comp <= 8);
   if (!gauss && !mix) return false;
   return diag::plan(n_chains, dim, 32 * (int64_t)dim, d);
