@@ -491,9 +491,20 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
       }
     }
   } else if (geo.G == 64 && geo.NV == 2) {
-    EBM_HMC_G(64, 2, false);
+    // (element-wise energies at exactly 512 / 1024 dims: the full-row form -- no per-element masks)
+    if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL || KIND == EBM_ENERGY_HARMONIC) {
+      if (geo.full) EBM_HMC_G(64, 2, true);
+      else EBM_HMC_G(64, 2, false);
+    } else {
+      EBM_HMC_G(64, 2, false);
+    }
   } else if (geo.G == 64 && geo.NV == 4) {
-    EBM_HMC_G(64, 4, false);
+    if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL || KIND == EBM_ENERGY_HARMONIC) {
+      if (geo.full) EBM_HMC_G(64, 4, true);
+      else EBM_HMC_G(64, 4, false);
+    } else {
+      EBM_HMC_G(64, 4, false);
+    }
   } else if (geo.NV == 4 && geo.full && (geo.G == 4 || geo.G == 8)) {  // element-wise energies at dim 64 / 128
     if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL || KIND == EBM_ENERGY_HARMONIC) {
       if (geo.G == 4) EBM_HMC_G(4, 4, true);
