@@ -32,3 +32,17 @@ def _library_built():
         import __graft_entry__
 
         __graft_entry__.build()
+
+
+@pytest.fixture(autouse=True)
+def _seeded_default_generators(request):
+    """Every test starts from default torch generators (CPU and GPU) seeded by its own node id: an input drawn without an
+    explicit generator is then the same in every run.  (Unseeded inputs made two mixture tests trip their per-chain
+    tolerance about once in thirty runs -- a chain that passes near a tie between two components amplifies fp32 round-off.)"""
+    import zlib
+
+    import torch
+
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)  # (seeds the CUDA generators too, lazily when there is no GPU)
+    yield
