@@ -388,6 +388,9 @@ template <int DT>
 int launch_slab(const WideArgs& a, int fast, hipStream_t st, const char* who);
 template <> int launch_slab<3>(const WideArgs& a, int fast, hipStream_t st, const char* who);
 template <> int launch_slab<4>(const WideArgs& a, int fast, hipStream_t st, const char* who);
+// H = 128, dim <= 32, the plain call at two waves per SIMD (scripts/experiments/mlp_quad.hip: four waves share a chain tile) --
+// a round-5 experiment that lost to the one-wave kernel (docs/design/mlp_wide.md, "Round 5"); linked by scripts/build_quad_ab.sh only
+int launch_quad(const WideArgs& a, hipStream_t st, const char* who);
 inline bool wide_fast_shape(const WideArgs& a) {  // (with or without records)
   return a.k_steps > 0 && !a.noise && !a.clamp_on && ((a.dim & 3) == 0 || a.dim == 2);
 }
@@ -399,6 +402,11 @@ int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
   if constexpr (HT == 4 && DT >= 3) {
     if (a.w1_image && (reinterpret_cast<uintptr_t>(a.w1_image) & 15) == 0)
       return launch_slab<DT>(a, wide_fast_shape(a) ? (a.diag_partials ? 2 : 1) : 0, st, who);
+  }
+#endif
+#ifdef EBM_MLP_QUAD_EXPERIMENT
+  if constexpr (HT == 4 && DT == 1) {
+    if (wide_fast_shape(a) && !a.diag_partials && !ab_switch("EBM_MLP_NO_QUAD")) return launch_quad(a, st, who);
   }
 #endif
   if constexpr (MODE == 2) {
