@@ -521,6 +521,22 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
             "vs_fp32_matrix_peak": mlp_flops / tk / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
             "issued_bf16_TFLOPs": issued / tk / 1e12, "frac_of_bf16_matrix_peak": issued / tk / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
         }
+        # the WHOLE training step -- start points, the fused chain, the buffer write, loss, backward, Adam -- captured once and
+        # replayed as one HIP graph (utils.GraphedTrainingStep, opt-in: the ABI-6 entry points read their RNG coordinates from
+        # device memory); same recipe, Adam(capturable=True)
+        from torchebm_amd.utils import GraphedTrainingStep
+
+        torch.manual_seed(0)
+        gmodel = ta.MLPEnergy(2, device=device)
+        gsampler = ta.LangevinDynamics(gmodel, step_size=0.1, noise_scale=1.0, device=device)
+        gpcd = ta.ContrastiveDivergence(gmodel, gsampler, k_steps=k, persistent=True, buffer_size=n, init_steps=0, device=device)
+        gstep = GraphedTrainingStep(gpcd, torch.optim.Adam(gmodel.parameters(), lr=1e-3, capturable=True))
+        tg = timed(lambda: gstep(data), reps=30, warm=5, device=device)
+        res["whole_step_hip_graph"] = {
+            "training_steps_per_s": 1 / tg, "ms_per_step": tg * 1e3, "replays": gstep.replays,
+            "what": "GraphedTrainingStep: one graph launch per training step (fused MLP chain inside); bit-identical to the eager "
+                    "loop for the same seed when the step has no torch-side draws (tests/test_graphed_step_gpu.py)",
+        }
         res["cpu_baseline"] = cpu_config5() if cpu else None
         res["value"] = 1 / (t_graph if default_graph else t_eager)
         res["chain_steps_per_s"] = n * k * res["value"]

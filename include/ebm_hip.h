@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 5
+#define EBM_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -274,6 +274,32 @@ EBM_API int ebm_pcd_gather_f32(const float* buffer, int64_t buffer_size, int32_t
                                uint64_t seed, uint64_t offset, void* stream);
 EBM_API int ebm_pcd_scatter_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples,
                                 int64_t batch, int64_t write_pos, void* stream);
+
+/*
+ * ABI 6 -- the three launches of a persistent-CD TRAINING STEP with every per-step coordinate in DEVICE memory, so that the
+ * whole step (start points, the k-fused chain, the FIFO write, the caller's loss / backward / optimiser) can be captured in
+ * ONE HIP graph and replayed with fresh draws and an advancing write position: what the host would otherwise bake into the
+ * kernel arguments at capture time lives in two small device buffers that launches inside the graph read and that a
+ * one-element add inside the same graph advances (torchebm_amd/utils/graphed_step.py; reference call sites:
+ * torchebm/losses/contrastive_divergence.py:82-155, core/base_loss.py:266-337,390-426).  Same convention as
+ * ebm_langevin_step_dev_f32 / ebm_noise_fill_dev_f32: rng_state = {seed, step}; the launch draws at step rng_state[1] + step_delta.
+ *   ebm_langevin_chain_dev_f32: ebm_langevin_chain_f32 with native draws (no injected noise, no diagnostics records) at steps
+ *       rng_state[1] + step_delta .. + k_steps - 1.  Energies: EBM_ENERGY_MLP (every shape the chain kernel takes); EBM_EKIND
+ *       for the others (their kernels take the coordinates by value).
+ *   ebm_pcd_gather_dev_f32: ebm_pcd_gather_f32 with native offsets drawn at step rng_state[1] + step_delta.
+ *   ebm_pcd_scatter_dev_f32: ebm_pcd_scatter_f32 with the write position read from *write_pos (device int64, 0 <= *write_pos
+ *       < buffer_size; advancing it is the caller's: (pos + batch) % buffer_size).
+ */
+EBM_API int ebm_langevin_chain_dev_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                                       int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
+                                       const float* coef_table, int32_t clamp_on, float cmin, float cmax,
+                                       int32_t thin, float* traj, const uint64_t* rng_state, uint64_t step_delta,
+                                       void* stream);
+EBM_API int ebm_pcd_gather_dev_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch,
+                                   int64_t stride, int64_t* rows_out, const uint64_t* rng_state, uint64_t step_delta,
+                                   void* stream);
+EBM_API int ebm_pcd_scatter_dev_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples,
+                                    int64_t batch, const int64_t* write_pos, void* stream);
 
 /* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
  * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */

@@ -675,3 +675,26 @@ def test_descriptor_keeps_its_tensors_alive():
     del desc
     gc.collect()
     assert all(r() is None for r in refs)
+
+
+def test_thin_mlp_training_backward_equals_autograd_cpu():
+    """core.energies._ThinMLPEnergy (the hand-written parameter-gradient backward MLPEnergy.forward takes on CUDA inputs that need
+    no gradient) against autograd through the same network, in float64 on the CPU."""
+    from torchebm_amd.core.energies import _ThinMLPEnergy, _tall_gram
+
+    torch.manual_seed(0)
+    m = ta.MLPEnergy(3, 64).double()
+    x = torch.randn(50, 3, dtype=torch.float64)
+    n = m.net
+    e = _ThinMLPEnergy.apply(x, n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
+    e2 = n(x).squeeze(-1)
+    assert torch.equal(e, e2)
+    g = torch.autograd.grad((e ** 2).sum() + e.sum(), list(m.parameters()))
+    g2 = torch.autograd.grad((e2 ** 2).sum() + e2.sum(), list(m.parameters()))
+    for a, b in zip(g, g2):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+    a, b = torch.randn(64, 5, dtype=torch.float64), torch.randn(64, 3, dtype=torch.float64)
+    torch.testing.assert_close(_tall_gram(a, b), a.t() @ b)
+    # the CPU forward of the energy is the plain network (the fast path is for CUDA inputs)
+    assert type(m(x).grad_fn).__name__ != "_ThinMLPEnergyBackward"

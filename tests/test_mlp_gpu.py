@@ -240,3 +240,36 @@ def test_adopted_sequential_takes_the_fused_route_and_trains(cuda_device):
         opt.step()
     after = sampler.sample(x=data, n_steps=3, generator=torch.Generator(device=cuda_device).manual_seed(1))
     assert hip_calls("ebm_langevin_chain_f32") == c0 + 5 and not torch.equal(before, after)
+
+
+# ------------------------------------------------------------------------------------------
+# Round 5: the TRAINING forward (parameter gradients only) -- hand-written backward of MLPEnergy.forward
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("in_dim,n", [(2, 65536), (2, 1000), (4, 8192), (1, 4096)])
+def test_training_forward_parameter_gradients_match_autograd(cuda_device, in_dim, n):
+    """MLPEnergy.forward on an input that needs no gradient takes _ThinMLPEnergy (core/energies.py): the same forward ops
+    (energies bit-identical to self.net) and parameter gradients formed as row-block batched products instead of K = batch
+    GEMMs.  Bar: no further from the fp64 gradients than autograd's own fp32 graph is (x 2), per parameter."""
+    cpu, gpu = _models(cuda_device, in_dim, seed=7 + in_dim, scale=1.5)
+    x = torch.randn(n, in_dim, device=cuda_device)
+    e_fast = gpu(x)
+    assert e_fast.grad_fn is not None and type(e_fast.grad_fn).__name__.startswith("_ThinMLPEnergy")
+    e_ref = gpu.net(x).squeeze(-1)
+    assert torch.equal(e_fast, e_ref)
+    obj = lambda e: e.mean() + 0.1 * (e ** 2).mean()  # noqa: E731  (the shape of the CD loss)
+    g_fast = torch.autograd.grad(obj(e_fast), list(gpu.parameters()))
+    g_auto = torch.autograd.grad(obj(e_ref), list(gpu.parameters()))
+    m64 = copy.deepcopy(gpu).double()
+    g_64 = torch.autograd.grad(obj(m64.net(x.double()).squeeze(-1)), list(m64.parameters()))
+    for (name, _), gf, ga, g6 in zip(gpu.named_parameters(), g_fast, g_auto, g_64):
+        scale = g6.abs().max().item() + 1e-12
+        err_fast = (gf.double() - g6).abs().max().item() / scale
+        err_auto = (ga.double() - g6).abs().max().item() / scale
+        assert gf.shape == ga.shape
+        assert err_fast <= max(2.0 * err_auto, 2e-6), (name, err_fast, err_auto)
+    # an input that needs its own gradient keeps autograd's graph through self.net (the samplers' step route, second derivatives)
+    xr = x[:64].clone().requires_grad_(True)
+    e = gpu(xr)
+    assert not type(e.grad_fn).__name__.startswith("_ThinMLPEnergy")
+    (gx,) = torch.autograd.grad(e.sum(), xr, create_graph=True)
+    assert gx.requires_grad

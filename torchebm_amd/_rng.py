@@ -69,3 +69,24 @@ def reserve(generator: Optional[torch.Generator], device: torch.device, n_steps:
     offset = _get_offset(gen)
     _set_offset(gen, offset + 4 * int(n_steps))
     return seed, offset // 4
+
+
+class DeviceCoords:
+    """RNG coordinates in DEVICE memory for launches captured in a HIP graph (``utils.graphed_step``): ``tensor`` is
+    ``int64[2] = {kernel seed, step}`` as raw 64-bit patterns; a launch inside the capture asks ``take(n)`` for its
+    offset from ``step`` (the ``step_delta`` argument of the ``*_dev_f32`` entry points) -- the deltas are handed out in
+    program order, exactly as ``reserve`` would have advanced the generator between the same calls."""
+
+    def __init__(self, device: torch.device):
+        self.tensor = torch.zeros(2, dtype=torch.int64, device=device)
+        self.taken = 0
+
+    def take(self, n_steps: int) -> int:
+        delta = self.taken
+        self.taken += int(n_steps)
+        return delta
+
+    @staticmethod
+    def as_i64(v: int) -> int:
+        """The int64 with the bit pattern of the uint64 ``v``."""
+        return v - (1 << 64) if v >= (1 << 63) else v

@@ -402,6 +402,53 @@ class GaussianMixtureModel(BaseModel):
         )
 
 
+def _tall_gram(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a^T b`` for two tall matrices ``[n, p]``, ``[n, q]``: a small ``p x q`` output over K = n.  The library's GEMM for it is
+    one 32 x 32 macro tile per workgroup and no split over K -- 16 workgroups of a 256-CU chip, 216 us at n = 65 536, p = q = 128;
+    as a batched product over 32 row blocks + a sum it is 28 us (and sums pairwise: ten times closer to the fp64 value), and the
+    thin cases (p = 1: 49 -> 26 us; q = 3: 96 + 26 -> 47 us at n = 131 072) beat broadcast product + column reduction too
+    (scripts/probes/thin_linear_ops.py)."""
+    n = a.shape[0]
+    blocks = 32
+    if a.is_cuda and n >= 8192 and n % blocks == 0:
+        return torch.bmm(a.view(blocks, n // blocks, -1).transpose(1, 2), b.view(blocks, n // blocks, -1)).sum(0)
+    return a.t() @ b
+
+
+class _ThinMLPEnergy(torch.autograd.Function):
+    """``E = w3 . silu(W2 silu(W1 x + b1) + b2) + b3`` for inputs that need no gradient: the forward of
+    ``Linear - SiLU - Linear - SiLU - Linear`` op for op, the parameter gradients with the thin layers' weight gradients as
+    broadcast product + column reduction instead of K = batch GEMMs (``MLPEnergy.forward``)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
+        import torch.nn.functional as F
+
+        a1 = F.linear(x, w1, b1)
+        h1 = F.silu(a1)
+        a2 = F.linear(h1, w2, b2)
+        h2 = F.silu(a2)
+        e = F.linear(h2, w3, b3).squeeze(-1)
+        ctx.save_for_backward(x, a1, h1, a2, h2, w2, w3)
+        return e
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ge):
+        x, a1, h1, a2, h2, w2, w3 = ctx.saved_tensors
+        col = ge.unsqueeze(1)
+        d_b3 = ge.sum().reshape(1)
+        d_w3 = _tall_gram(col, h2)                                   # [1, H]
+        dz2 = torch.ops.aten.silu_backward(col * w3, a2)
+        d_b2 = dz2.sum(0)
+        d_w2 = _tall_gram(dz2, h1)
+        dz1 = torch.ops.aten.silu_backward(dz2 @ w2, a1)
+        # first layer: weight and bias gradient in one product against [x 1] (a [H, in + 1] output; the bias column rides along)
+        g1 = _tall_gram(dz1, torch.cat((x, x.new_ones(x.shape[0], 1)), dim=1))
+        d_w1, d_b1 = g1[:, :-1], g1[:, -1]
+        return None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
+
+
 class MLPEnergy(BaseModel):
     r"""Two-hidden-layer SiLU MLP energy ``E(x) = w_3^\top \mathrm{silu}(W_2\,\mathrm{silu}(W_1 x + b_1) + b_2) + b_3``
     -- the trainable energy of the reference's PCD example
@@ -458,8 +505,40 @@ class MLPEnergy(BaseModel):
         self.net = net
         return self
 
+    #: widest input for which the parameter gradients of the first layer are formed column by column (see ``forward``)
+    THIN_GRAD_MAX_IN = 4
+    #: a row's energy does not depend on the other rows of the batch (no batch statistics): a loss may evaluate data and negatives
+    #: in one call (losses/cd.py)
+    ROWS_INDEPENDENT = True
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # The TRAINING forward of config 5's caller (ContrastiveDivergence.compute_loss: energies of the data and of the detached
+        # negatives, gradients with respect to the PARAMETERS only).  Same forward ops as ``self.net`` -- the energies are
+        # bit-identical -- with a hand-written backward: autograd forms the weight gradients of the two THIN layers
+        # (Linear(2, 128), Linear(128, 1)) as library GEMMs with K = batch, for which the library has no kernel worth the name
+        # (65 536 rows: 190 + 100 us per call, 1.05 of the 2.4 ms of a whole training step: profiles/r05_c5_step_kernels.txt);
+        # as a broadcast product + column reduction they take 68 + 34 us (scripts/probes/thin_linear_ops.py).  Only when the
+        # input needs no gradient (the sampler's step route, score-based losses and anything that differentiates twice keep
+        # autograd's own graph through ``self.net``).
+        if (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not x.requires_grad
+                and self.in_dim <= self.THIN_GRAD_MAX_IN and self._plain_net() and not torch.is_autocast_enabled()):
+            n = self.net
+            return _ThinMLPEnergy.apply(x, n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
         return self.net(x).squeeze(-1)
+
+    def _plain_net(self) -> bool:
+        """``self.net`` is the stack ``fused_spec`` packs, with nothing hooked into it (hooks see module calls; the
+        hand-written training forward makes none)."""
+        from torch import nn
+
+        n = self.net
+        if type(self) is not MLPEnergy or not isinstance(n, nn.Sequential) or len(n) != 5:
+            return False
+        mods = (self, n, *n)
+        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None) for m in mods):
+            return False
+        return (type(n[0]) is nn.Linear and type(n[2]) is nn.Linear and type(n[4]) is nn.Linear and type(n[1]) is nn.SiLU
+                and type(n[3]) is nn.SiLU and n[4].out_features == 1 and all(l.bias is not None for l in (n[0], n[2], n[4])))
 
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(MLPEnergy) or self.hidden not in self.FUSED_HIDDEN or self.in_dim > self.FUSED_MAX_DIM:

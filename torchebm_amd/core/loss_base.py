@@ -82,6 +82,10 @@ class BaseContrastiveDivergence(BaseLoss):
         self.register_buffer("buffer_ptr", torch.tensor(0, dtype=torch.long, device=self.device))
         self._write_pos = 0  # host copy of buffer_ptr: the FIFO never reads the device scalar
         self.buffer_initialized = False
+        #: set by ``utils.graphed_step.GraphedTrainingStep`` while it captures: the buffer kernels then take their RNG
+        #: coordinates and the write position from device memory (``_rng.DeviceCoords``, ``buffer_ptr``)
+        self._graph_coords = None
+        self._graph_fifo_rows = 0  # rows the captured step appends to the FIFO per replay (0: whole-buffer overwrite or no buffer)
 
     # ---- replay buffer ------------------------------------------------------------------
     def initialize_buffer(
@@ -147,11 +151,18 @@ class BaseContrastiveDivergence(BaseLoss):
             stride = self.buffer_size // batch
             row_elems = self.replay_buffer[0].numel()
             starts = torch.empty((batch,) + tuple(self.replay_buffer.shape[1:]), dtype=self.dtype, device=self.device)
-            seed, step = _rng.reserve(generator, self.replay_buffer.device, 1)
-            _lib.call(
-                "ebm_pcd_gather_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch,
-                stride, None, None, seed, step, _lib.stream_handle(self.replay_buffer.device),
-            )
+            if self._graph_coords is not None:  # being captured: the draw's step is read from device memory at every replay
+                _lib.call(
+                    "ebm_pcd_gather_dev_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch,
+                    stride, None, _lib.ptr(self._graph_coords.tensor), self._graph_coords.take(1),
+                    _lib.stream_handle(self.replay_buffer.device),
+                )
+            else:
+                seed, step = _rng.reserve(generator, self.replay_buffer.device, 1)
+                _lib.call(
+                    "ebm_pcd_gather_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch,
+                    stride, None, None, seed, step, _lib.stream_handle(self.replay_buffer.device),
+                )
         else:
             stride = self.buffer_size // batch
             base = torch.arange(0, batch, device=self.device) * stride
@@ -198,6 +209,17 @@ class BaseContrastiveDivergence(BaseLoss):
         if batch >= cap:
             self.replay_buffer[:] = samples[-cap:]
             new_pos = 0
+        elif self._hip_buffer() and samples.is_cuda and self._graph_coords is not None:
+            # being captured: the write position is the DEVICE scalar, advanced inside the graph; the host copy follows
+            # arithmetically after every replay (GraphedTrainingStep -> _graph_replayed)
+            src = _lib.dense_f32(samples)
+            _lib.call(
+                "ebm_pcd_scatter_dev_f32", _lib.ptr(self.replay_buffer), cap, self.replay_buffer[0].numel(), _lib.ptr(src),
+                batch, _lib.ptr(self.buffer_ptr), _lib.stream_handle(self.replay_buffer.device),
+            )
+            self.buffer_ptr.add_(batch).remainder_(cap)
+            self._graph_fifo_rows = batch
+            return
         elif self._hip_buffer() and samples.is_cuda:
             new_pos = (pos + batch) % cap
             src = _lib.dense_f32(samples)
@@ -215,6 +237,11 @@ class BaseContrastiveDivergence(BaseLoss):
                 self.replay_buffer[:new_pos] = samples[head:]
         self._write_pos = new_pos
         self.buffer_ptr.fill_(new_pos)
+
+    def _graph_replayed(self) -> None:
+        """Host bookkeeping after one replay of a captured training step: the FIFO position the graph advanced on the device."""
+        if self._graph_fifo_rows:
+            self._write_pos = (self._write_pos + self._graph_fifo_rows) % self.buffer_size
 
     def mix_buffer_across_ranks(self, process_group=None, generator: Optional[torch.Generator] = None) -> None:
         """Shuffle the union of all ranks' buffers with one shared permutation and keep this

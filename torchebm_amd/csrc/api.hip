@@ -52,11 +52,12 @@ int launch_descent_step(const float*, const float*, float*, float*, int64_t, flo
 int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStream_t);
 int launch_gmm_active_columns(const float*, int32_t, int32_t, int32_t*, hipStream_t);
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
-                      uint64_t, hipStream_t);
-int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, hipStream_t);
+                      uint64_t, const uint64_t*, hipStream_t);
+int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, const int64_t*, hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
-                              int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t);
+                              int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t,
+                              const uint64_t* rng_dev = nullptr);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
@@ -351,6 +352,24 @@ int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chain
                              noise_coef, coef_table, clamp_on, cmin, cmax, thin, traj, diag_partials, noise, seed, offset, stream);
 }
 
+int ebm_langevin_chain_dev_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
+                               float eta, float sqrt_eta, float noise_coef, const float* coef_table, int32_t clamp_on,
+                               float cmin, float cmax, int32_t thin, float* traj, const uint64_t* rng_state,
+                               uint64_t step_delta, void* stream) {
+  const char* who = "ebm_langevin_chain_dev_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
+  if (!rng_state) return fail(EBM_EINVAL, "%s: rng_state is NULL", who);
+  if (energy->kind != EBM_ENERGY_MLP)
+    return fail(EBM_EKIND, "%s: device-resident RNG coordinates are taken by the EBM_ENERGY_MLP chain kernels only", who);
+  if (n_chains == 0 || k_steps == 0) return 0;
+  if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)))
+    return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_langevin_chain_mlp(*energy, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
+                                   thin, traj, nullptr, 0, step_delta, nullptr, (hipStream_t)stream, rng_state);
+}
+
 int ebm_langevin_heun_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                                 int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                 const float* coef_table, int32_t clamp_on, float cmin, float cmax,
@@ -487,7 +506,20 @@ int ebm_pcd_gather_f32(const float* buffer, int64_t buffer_size, int32_t dim, fl
                 (long long)batch, (long long)stride);
   if (batch == 0) return 0;
   if (!buffer || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
-  return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, offsets, rows_out, seed, offset,
+  return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, offsets, rows_out, seed, offset, nullptr,
+                           (hipStream_t)stream);
+}
+
+int ebm_pcd_gather_dev_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch,
+                           int64_t stride, int64_t* rows_out, const uint64_t* rng_state, uint64_t step_delta,
+                           void* stream) {
+  const char* who = "ebm_pcd_gather_dev_f32";
+  if (buffer_size < 1 || dim < 1 || batch < 0 || stride < 1 || stride > 0x7fffffffLL)
+    return fail(EBM_EINVAL, "%s: bad sizes (buffer %lld, dim %d, batch %lld, stride %lld)", who, (long long)buffer_size, dim,
+                (long long)batch, (long long)stride);
+  if (batch == 0) return 0;
+  if (!buffer || !out || !rng_state) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, nullptr, rows_out, 0, step_delta, rng_state,
                            (hipStream_t)stream);
 }
 
@@ -507,7 +539,17 @@ int ebm_pcd_scatter_f32(float* buffer, int64_t buffer_size, int32_t dim, const f
                 (long long)batch, (long long)write_pos);
   if (batch == 0) return 0;
   if (!buffer || !samples) return fail(EBM_EINVAL, "%s: NULL pointer", who);
-  return launch_pcd_scatter(buffer, buffer_size, dim, samples, batch, write_pos, (hipStream_t)stream);
+  return launch_pcd_scatter(buffer, buffer_size, dim, samples, batch, write_pos, nullptr, (hipStream_t)stream);
+}
+
+int ebm_pcd_scatter_dev_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,
+                            const int64_t* write_pos, void* stream) {
+  const char* who = "ebm_pcd_scatter_dev_f32";
+  if (buffer_size < 1 || dim < 1 || batch < 0 || batch > buffer_size)
+    return fail(EBM_EINVAL, "%s: bad sizes (buffer %lld, batch %lld)", who, (long long)buffer_size, (long long)batch);
+  if (batch == 0) return 0;
+  if (!buffer || !samples || !write_pos) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_pcd_scatter(buffer, buffer_size, dim, samples, batch, 0, write_pos, (hipStream_t)stream);
 }
 
 int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(kBlock) void lookahead_kernel(const float* __restri
 __global__ __launch_bounds__(kBlock) void pcd_gather_kernel(const float* __restrict__ buffer, int64_t buffer_size,
                                                             int32_t dim, float* __restrict__ out, int64_t batch,
                                                             int64_t stride, const int64_t* __restrict__ offsets,
-                                                            int64_t* __restrict__ rows_out, RngKey key, uint64_t step) {
+                                                            int64_t* __restrict__ rows_out, RngKey key, uint64_t step,
+                                                            const uint64_t* __restrict__ rng_dev) {
+  resolve_rng(rng_dev, key, step);
   const int64_t n = batch * dim;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
     const int64_t i = e / dim;
@@ -162,7 +164,9 @@ __global__ __launch_bounds__(kBlock) void pcd_gather_kernel(const float* __restr
 
 __global__ __launch_bounds__(kBlock) void pcd_scatter_kernel(float* __restrict__ buffer, int64_t buffer_size,
                                                              int32_t dim, const float* __restrict__ samples,
-                                                             int64_t batch, int64_t write_pos) {
+                                                             int64_t batch, int64_t write_pos,
+                                                             const int64_t* __restrict__ pos_dev) {
+  if (pos_dev) write_pos = ((*pos_dev % buffer_size) + buffer_size) % buffer_size;  // (a position out of range cannot leave the buffer)
   const int64_t n = batch * dim;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
     const int64_t i = e / dim;
@@ -783,17 +787,18 @@ int launch_gmm_active_columns(const float* means, int32_t n_comp, int32_t dim, i
 }
 
 int launch_pcd_gather(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,
-                      const int64_t* offsets, int64_t* rows_out, uint64_t seed, uint64_t offset, hipStream_t st) {
+                      const int64_t* offsets, int64_t* rows_out, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
+                      hipStream_t st) {
   const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
   hipLaunchKernelGGL(pcd_gather_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim, out,
-                     batch, stride, offsets, rows_out, key, offset);
+                     batch, stride, offsets, rows_out, key, offset, rng_dev);
   return check_launch("ebm_pcd_gather_f32");
 }
 
 int launch_pcd_scatter(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,
-                       int64_t write_pos, hipStream_t st) {
+                       int64_t write_pos, const int64_t* pos_dev, hipStream_t st) {
   hipLaunchKernelGGL(pcd_scatter_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim,
-                     samples, batch, write_pos);
+                     samples, batch, write_pos, pos_dev);
   return check_launch("ebm_pcd_scatter_f32");
 }
 

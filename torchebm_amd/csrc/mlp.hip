@@ -22,7 +22,8 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
-                    float* grad_out, float* diag_partials, const void* w1_image, hipStream_t st, const char* who);
+                    float* grad_out, float* diag_partials, const void* w1_image, hipStream_t st, const char* who,
+                    const uint64_t* rng_dev = nullptr);
 
 namespace {
 
@@ -45,11 +46,11 @@ bool mlp_diag_plan(const ebm_energy_t& e, bool hmc, int64_t n_chains, int32_t di
 int launch_langevin_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,
                               float eta, float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on,
                               float cmin, float cmax, int32_t thin, float* traj, const float* noise, uint64_t seed,
-                              uint64_t offset, float* diag_partials, hipStream_t st) {
-  const char* who = "ebm_langevin_chain_f32";
+                              uint64_t offset, float* diag_partials, hipStream_t st, const uint64_t* rng_dev) {
+  const char* who = rng_dev ? "ebm_langevin_chain_dev_f32" : "ebm_langevin_chain_f32";
   if (int r = mlp_check(e, dim, who, false)) return r;
   return launch_mlp_wide(e.n_comp, e.dev0, x, n_chains, dim, k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin, cmax,
-                         thin, traj, noise, seed, offset, nullptr, nullptr, diag_partials, e.aux, st, who);
+                         thin, traj, noise, seed, offset, nullptr, nullptr, diag_partials, e.aux, st, who, rng_dev);
 }
 
 int launch_hmc_chain_mlp(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh, int32_t n_leapfrog,

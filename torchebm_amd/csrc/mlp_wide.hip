@@ -41,8 +41,10 @@ bool mlp_wide_supported(int32_t hidden, int32_t dim) {
 int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t k_steps, float eta,
                     float sqrt_eta, float noise_coef, const float* coef_table, int clamp_on, float cmin, float cmax,
                     int32_t thin, float* traj, const float* noise, uint64_t seed, uint64_t offset, float* energy_out,
-                    float* grad_out, float* diag_partials, const void* w1_image, hipStream_t st, const char* who) {
+                    float* grad_out, float* diag_partials, const void* w1_image, hipStream_t st, const char* who,
+                    const uint64_t* rng_dev) {
   WideArgs a{};
+  a.rng_dev = rng_dev;
   a.w1_image = static_cast<const char*>(w1_image);
   a.x = x; a.n_chains = n_chains; a.dim = dim; a.k_steps = k_steps;
   a.eta = eta; a.sqrt_eta = sqrt_eta; a.noise_coef = noise_coef;

@@ -57,6 +57,7 @@ struct WideArgs {
   float* diag_partials;  // in-kernel diagnostics records (one per WAVE: 32 chains), or null
   int64_t diag_blocks;   // records per kept step = ceil(n_chains / 32)
   const char* w1_image;  // MODE 3: the pre-split W1 image (ebm_mlp_w1_image_f32), or null
+  const uint64_t* rng_dev;  // ebm_langevin_chain_dev_f32: {seed, step} in device memory (step0 is then an offset from it), or null
 };
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
@@ -216,6 +217,14 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   float eta = a.eta, sqrt_eta = a.sqrt_eta, noise_coef = a.noise_coef;
   int until_keep = a.thin;
   int64_t keep_off = 0;
+  // RNG coordinates: by value, or (a launch captured in a HIP graph) read from device memory -- wave-uniform, two scalar loads
+  RngKey rkey = a.key;
+  uint64_t rstep0 = a.step0;
+  if (a.rng_dev) {
+    const uint64_t seed_dev = a.rng_dev[0];
+    rkey = RngKey{(uint32_t)seed_dev, (uint32_t)(seed_dev >> 32)};
+    rstep0 += a.rng_dev[1];
+  }
   // Diagnostics: the reference reports the mean energy of the KEPT state, i.e. of x after the update; that energy is what
   // the NEXT step's evaluation computes anyway, so the record's energy share is written one evaluation late and only a
   // kept LAST step costs an evaluation of its own (the loop runs one more time, without an update).
@@ -285,12 +294,12 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
               for (int i = 0; i < 4; ++i)
                 if (c0 + i < dim) eps[i] = a.noise[((int64_t)step * a.n_chains + smp) * dim + c0 + i];
           } else if (quads) {  // the quad is exactly one Philox counter
-            const F4 nrm = normal4_at(a.key, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, a.step0 + (uint64_t)step);
+            const F4 nrm = normal4_at(rkey, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, rstep0 + (uint64_t)step);
 #pragma unroll
             for (int i = 0; i < 4; ++i) eps[i] = nrm.v[i];
           } else if constexpr (FAST != 0) {  // dim == 2 (config 5's shape): a chain's two elements are half a Philox counter
             if (td == 0 && q == 0) {
-              const F4 nrm = normal4_at(a.key, (uint64_t)smp >> 1, a.step0 + (uint64_t)step);
+              const F4 nrm = normal4_at(rkey, (uint64_t)smp >> 1, rstep0 + (uint64_t)step);
               const bool odd = (smp & 1) != 0;
               eps[0] = odd ? nrm.v[2] : nrm.v[0];
               eps[1] = odd ? nrm.v[3] : nrm.v[1];
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
               const uint64_t e = (uint64_t)smp * (uint64_t)dim + (uint64_t)(c0 + i);
               if ((e >> 2) != have) {
                 have = e >> 2;
-                nrm = normal4_at(a.key, have, a.step0 + (uint64_t)step);
+                nrm = normal4_at(rkey, have, rstep0 + (uint64_t)step);
               }
               const int w = (int)(e & 3);
               eps[i] = w == 0 ? nrm.v[0] : (w == 1 ? nrm.v[1] : (w == 2 ? nrm.v[2] : nrm.v[3]));

@@ -86,13 +86,23 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
         with torch.set_grad_enabled(True):
             if kwargs.get("add_noise_to_real", self.add_noise_to_real):
                 jitter = kwargs.get("noise_scale", self.noise_scale) * torch.randn_like(x, generator=generator)
-                e_data = self.model(x + jitter, **cond)
+                real = x + jitter
             else:
-                e_data = self.model(x, **cond)
-            e_model = self.model(pred_x, **cond)
+                real = x
+            if (getattr(self.model, "ROWS_INDEPENDENT", False) and not cond and real.is_cuda and real.shape == pred_x.shape
+                    and not real.requires_grad and not pred_x.requires_grad):
+                # one evaluation of both halves for an energy that declares every row's value independent of the batch around it
+                # (MLPEnergy): the same arithmetic per row in half the launches -- the loss's forward / backward is some sixty
+                # small kernels whose dispatch gaps, not their work, are a tenth of a captured training step
+                e_both = self.model(torch.cat((real, pred_x)))
+                e_data, e_model = e_both[: real.shape[0]], e_both[real.shape[0] :]
+            else:
+                e_data = self.model(real, **cond)
+                e_model = self.model(pred_x, **cond)
         loss = torch.mean(e_data) - torch.mean(e_model)
         reg = kwargs.get("energy_reg_weight", self.energy_reg_weight)
         if reg > 0:
             loss = loss + reg * (torch.mean(e_data**2) + torch.mean(e_model**2))
         # a non-finite loss must not poison the optimiser: constant fallback, no host sync
-        return torch.where(torch.isfinite(loss), loss, torch.tensor(0.1, device=loss.device, dtype=loss.dtype))
+        # (new_full: a fill kernel -- torch.tensor(0.1, device=...) is a pageable host-to-device copy, which a HIP graph cannot capture)
+        return torch.where(torch.isfinite(loss), loss, loss.new_full((), 0.1))

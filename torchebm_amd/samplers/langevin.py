@@ -458,6 +458,14 @@ class LangevinDynamics(BaseSampler):
         else:
             a, sq, coef = rows[row0]
             tab = (self._coef_table(rows, x.device) if table is None else table)[row0 : row0 + k]
+        coords = getattr(self, "_graph_coords", None)
+        if coords is not None:  # being captured in a HIP graph: `step` is an offset from the device-resident coordinates
+            _lib.call(
+                "ebm_langevin_chain_dev_f32",
+                spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(tab),
+                clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(coords.tensor), step, stream,
+            )
+            return
         entry = "ebm_langevin_heun_chain_f32" if type(self.integrator) is HeunIntegrator else "ebm_langevin_chain_f32"
         _lib.call(
             entry,
@@ -481,10 +489,20 @@ class LangevinDynamics(BaseSampler):
             state = state.clone()  # the kernel updates in place; never touch the caller's tensor unless it was donated
         traj, diag = self._new_outputs(x, n_kept, want_traj, want_diag)
         _, rows = self._coef_rows(n_steps)
-        seed, step0 = _rng.reserve(generator, x.device, n_steps)
+        coords = getattr(self, "_graph_coords", None)
+        heun = type(self.integrator) is HeunIntegrator
+        if coords is not None:
+            # utils.graphed_step is capturing this call: coordinates come from device memory (ebm_langevin_chain_dev_f32)
+            if want_diag or heun or spec.kind != _lib.ENERGY_MLP or len(rows) != 1:
+                raise RuntimeError(
+                    "torchebm_amd: only the plain fused call on an MLPEnergy (constant step size / noise scale, no diagnostics) "
+                    "can be captured in a training-step graph"
+                )
+            seed, step0 = 0, coords.take(n_steps)
+        else:
+            seed, step0 = _rng.reserve(generator, x.device, n_steps)
         stream = _lib.stream_handle(x.device)
         spec_c = spec.to_c()
-        heun = type(self.integrator) is HeunIntegrator
 
         if n_steps > 0 and n > 0:
             layout = None

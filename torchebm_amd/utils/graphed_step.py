@@ -1,0 +1,219 @@
+"""A whole contrastive-divergence TRAINING STEP as one HIP graph (opt-in).
+
+BASELINE config 5's training step is ``loss, neg = cd(x); opt.zero_grad(); loss.backward(); opt.step()``
+(reference: torchebm/losses/contrastive_divergence.py:82-155, core/base_loss.py:266-337, the loop of
+examples/20-training/01-mcmc-losses/02-persistent-cd/main.py).  With the fused sampler the chain itself is one
+0.5 ms launch, and what is left -- the loss forward / backward of a 2-128-128-1 network and Adam, some sixty small
+kernels -- is launch-bound: 2.0 of the step's 2.55 ms (profiles/r04_bench_n1.json).  ``GraphedTrainingStep`` captures the
+WHOLE step -- start points from the replay buffer, the k-fused chain, the FIFO write, loss, backward, optimiser -- once
+and replays it: one graph launch per training step.
+
+What makes the step replayable: everything the host would bake into kernel arguments changes from step to step, so it
+lives in device memory that launches inside the graph read and that the graph itself advances --
+
+* the kernels' Philox coordinates ``{seed, step}`` (``_rng.DeviceCoords``; the ``*_dev_f32`` entry points of
+  include/ebm_hip.h, ABI 6): every launch draws at ``step + delta`` with the deltas handed out in program order exactly
+  as ``_rng.reserve`` advances the generator between the same calls of the eager step, and a one-element add at the
+  end of the graph moves ``step`` past the whole training step.  The host mirrors that on the ``torch.Generator``
+  (no device read), so the generator ends where the eager loop leaves it and **the same seed gives the same chains,
+  losses and weights as the eager loop** as long as no torch-side draw is part of the step
+  (``new_sample_ratio = 0``, ``add_noise_to_real = False``); with torch-side draws in the step (the buffer's
+  ``new_sample_ratio`` bump: ``randperm`` / ``randn``) those come from torch's own graph-safe generator state -- the same
+  law at other offsets than the eager loop's;
+* the FIFO write position of the replay buffer (``buffer_ptr``, advanced in the graph; the host copy follows);
+* the weights: parameters, gradients and optimiser state are ordinary tensors updated in place by the captured
+  optimiser step (``capturable=True`` for Adam-family optimisers), and the fused sampler re-packs the parameters
+  inside the graph, so every replay samples from the weights the previous replay left.
+
+One caveat that is not this package's: EAGER steps of a second ``Adam(capturable=True)`` run between the replays of a
+captured one make the captured one drift from its eager loop -- plain PyTorch on this stack does the same
+(scripts/probes/torch_graph_adam_interference.py); a trainer that owns its GPU stream, as every training loop does, is
+bit-identical to its eager loop (tests/test_graphed_step_gpu.py).
+
+Refusals (``ValueError`` at construction or at the first call, each naming its reason): a sampler call that is not the
+plain fused call on an ``MLPEnergy`` (the only chain kernels that take device-resident coordinates), scheduled step
+sizes, conditioning kwargs, an optimiser that is not capturable, a model holding attributes a replay could not see
+change (``core.module.graph_blind_spots`` -- the same rule the samplers' own step-route graphs follow).
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib, _rng
+from ..core.loss_base import BaseContrastiveDivergence
+from ..core.module import graph_blind_spots, graph_state_key
+
+__all__ = ["GraphedTrainingStep"]
+
+
+class GraphedTrainingStep:
+    """``step = GraphedTrainingStep(cd_loss, optimizer); loss, negatives = step(x)`` -- one training step per call.
+
+    The first ``eager_steps`` calls (default 2) run the ordinary eager step: they initialise the replay buffer, the
+    optimiser state and the allocator.  The next call captures the graph, and it and every later one replay it.  A new
+    batch shape, or a model / loss whose Python-side state changed (``train()`` / ``eval()``, a replaced parameter),
+    re-captures.  ``loss`` is a fresh 0-dim tensor; ``negatives`` is the graph's static output buffer -- valid until the
+    next call (``.clone()`` it to keep it).
+
+    ``enabled=False`` makes every call the eager step (same code path as the warm-up): the switch the tests use to
+    compare the two.
+    """
+
+    def __init__(self, loss_fn: BaseContrastiveDivergence, optimizer: torch.optim.Optimizer, *,
+                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, enabled: bool = True, force: bool = False):
+        if not isinstance(loss_fn, BaseContrastiveDivergence):
+            raise ValueError("GraphedTrainingStep drives a contrastive-divergence loss (BaseContrastiveDivergence)")
+        self.loss_fn, self.optimizer, self.generator = loss_fn, optimizer, generator
+        self.eager_steps, self.enabled, self.force = max(1, int(eager_steps)), enabled, force
+        self.calls = 0
+        self.replays = 0
+        self._g = None
+        self._stream = None
+        reason = self._static_refusal()
+        if reason and enabled:
+            raise ValueError(f"GraphedTrainingStep: {reason}")
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _static_refusal(self) -> Optional[str]:
+        from ..samplers.langevin import LangevinDynamics
+
+        lf = self.loss_fn
+        if torch.device(lf.device).type != "cuda" or lf.dtype != torch.float32:
+            return "the loss must live on a CUDA device in float32"
+        s = lf.sampler
+        if type(s) is not LangevinDynamics:
+            return "the sampler must be torchebm_amd.LangevinDynamics (its fused chain kernel is the one that takes device-resident RNG coordinates)"
+        if not (s.schedulers["step_size"].is_constant() and s.schedulers["noise_scale"].is_constant()):
+            return "scheduled step sizes / noise scales advance on the host; a replay would repeat the captured values"
+        for group in self.optimizer.param_groups:
+            if "capturable" in group and not group["capturable"]:
+                return f"{type(self.optimizer).__name__} must be built with capturable=True (its step counter has to live on the device)"
+        if not self.force:
+            blind = graph_blind_spots(lf.model)
+            if blind:
+                return ("the model holds attributes a replay could not see change (" + ", ".join(blind[:4]) +
+                        "); pass force=True if they never change")
+        return None
+
+    def _route_refusal(self, x: torch.Tensor) -> Optional[str]:
+        s = self.loss_fn.sampler
+        route, spec = s._route(x.detach(), {})
+        if route != "fused" or spec is None or spec.kind != _lib.ENERGY_MLP:
+            return ("the sampler call must be the fused chain launch on an MLPEnergy (got the '" + route + "' route): the other chain "
+                    "kernels take their RNG coordinates by value and would repeat the captured draws")
+        return None
+
+    def _eager(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        loss, neg = self.loss_fn(x, generator=self.generator)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), neg
+
+    def _side_stream(self, device: torch.device) -> torch.cuda.Stream:
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device)
+        return self._stream
+
+    def _warmup(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """A real (eager) training step on the SIDE stream the capture will use.  Autograd pins a parameter's
+        gradient-accumulation node to the stream it first ran on; had the warm-up run on the caller's stream, the captured
+        backward would hand its gradients across streams (torch warns that this "may break CUDA graph capture").  The
+        pattern torch's own documentation prescribes for whole-network capture."""
+        if not x.is_cuda:
+            return self._eager(x)
+        cur, side = torch.cuda.current_stream(x.device), self._side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            loss, neg = self._eager(x)
+        cur.wait_stream(side)
+        loss.record_stream(cur)
+        neg.record_stream(cur)
+        return loss, neg
+
+    def _key(self, x: torch.Tensor):
+        lf = self.loss_fn
+        return (tuple(x.shape), x.device, x.dtype, graph_state_key(lf.model), lf.training, lf.persistent, lf.buffer_size,
+                lf.k_steps, getattr(lf, "new_sample_ratio", None), getattr(lf, "energy_reg_weight", None),
+                getattr(lf, "add_noise_to_real", None))
+
+    def _capture(self, x: torch.Tensor, key) -> dict:
+        lf, dev = self.loss_fn, x.device
+        coords = _rng.DeviceCoords(dev)
+        static_x = x.detach().clone()
+        advance = torch.zeros(1, dtype=torch.int64, device=dev)  # steps the graph moves the coordinates by (filled below)
+        self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
+        graph = torch.cuda.CUDAGraph()
+        if self.generator is not None:
+            graph.register_generator_state(self.generator)
+        import gc
+
+        from ..samplers.langevin import _CAPTURE_LOCK  # the cyclic GC must not run inside a capture (see samplers.langevin)
+
+        lf._graph_coords = coords
+        lf.sampler._graph_coords = coords
+        lf._graph_fifo_rows = 0
+        with _CAPTURE_LOCK:
+            gc_was_on = gc.isenabled()
+            try:
+                gc.disable()
+                with torch.cuda.graph(graph, stream=self._side_stream(dev), capture_error_mode="thread_local"):
+                    loss, neg = lf(static_x, generator=self.generator)
+                    loss.backward()
+                    self.optimizer.step()
+                    coords.tensor[1:2].add_(advance)
+            finally:
+                lf._graph_coords = None
+                lf.sampler._graph_coords = None
+                if gc_was_on:
+                    gc.enable()
+        advance.fill_(coords.taken)
+        return {"key": key, "graph": graph, "x": static_x, "loss": loss, "neg": neg, "coords": coords, "advance": advance,
+                "kernel_steps": coords.taken, "torch_steps": None, "expected": None, "pinned": None}
+
+    def _sync_coords(self, g: dict) -> Tuple[torch.Generator, int]:
+        """Make the device coordinates those of the generator (host bookkeeping only; a write happens when the generator
+        is not where the previous replay left it: the first replay, or the user re-seeded)."""
+        gen = _rng._resolve(self.generator, g["x"].device)
+        seed, offset = _rng.kernel_seed(gen.initial_seed()), _rng._get_offset(gen)
+        if g["expected"] != (seed, offset):
+            host = torch.tensor([_rng.DeviceCoords.as_i64(seed), offset // 4], dtype=torch.int64).pin_memory()
+            g["coords"].tensor.copy_(host, non_blocking=True)
+            g["pinned"] = host  # alive until the copy has certainly run (replaced at the next re-seed only)
+        return gen, offset
+
+    def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        self.calls += 1
+        if not self.enabled:
+            return self._eager(x)
+        if self.calls <= self.eager_steps:
+            return self._warmup(x)
+        if not (x.is_cuda and x.dtype == torch.float32):
+            raise ValueError("GraphedTrainingStep: the batch must be a CUDA float32 tensor")
+        key = self._key(x)
+        g = self._g
+        if g is None or g["key"] != key:
+            reason = self._static_refusal() or self._route_refusal(x)
+            if reason:
+                raise ValueError(f"GraphedTrainingStep: {reason}")
+            g = self._g = self._capture(x, key)
+        if g["x"].data_ptr() != x.data_ptr():
+            g["x"].copy_(x)
+        gen, offset = self._sync_coords(g)
+        g["graph"].replay()
+        self.replays += 1
+        # the generator: torch's own replay bookkeeping moved it past the step's torch-side draws; the kernels' steps follow
+        after_torch = _rng._get_offset(gen)
+        if g["torch_steps"] is None:
+            # first replay: now the torch-side share of a step is known -- from here on the graph moves the coordinates past it too
+            g["torch_steps"] = (after_torch - offset) // 4
+            if g["torch_steps"]:
+                g["coords"].tensor[1:2].add_(g["torch_steps"])
+                g["advance"].fill_(g["kernel_steps"] + g["torch_steps"])
+        _rng._set_offset(gen, after_torch + 4 * g["kernel_steps"])
+        g["expected"] = (_rng.kernel_seed(gen.initial_seed()), after_torch + 4 * g["kernel_steps"])
+        self.loss_fn._graph_replayed()
+        return g["loss"].detach().clone(), g["neg"]
