@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 import torchebm_amd as ta  # noqa: E402
 from torchebm_amd import _lib  # noqa: E402
 
+N_CUS, CLOCK_GHZ = 256, 2.4  # MI355X_MICROARCH.md, chip-level parameters (4 SIMD-32 per CU, max clock)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy ceiling is measured live next to it
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector (non-matrix) peak
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
@@ -67,16 +68,26 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)  # 0.7 s timed at config 2: long enough for an outside GPU-busy sampler
     ap.add_argument("--warmup", type=int, default=3)
     # workload overrides (tests / experiments); the defaults are BASELINE config 2
-    ap.add_argument("--n-chains", type=int, default=1 << 20, help="chains PER GPU")
-    ap.add_argument("--dim", type=int, default=64)
-    ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--n-chains", type=int, default=None, help="chains PER GPU (default 2^20)")
+    ap.add_argument("--dim", type=int, default=None, help="default 64 (--config 4: 128)")
+    ap.add_argument("--k", type=int, default=None, help="default 200 (--config 4: 500)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4],
                     help="4 = BASELINE configs[3]'s per-GPU shard as the timed step (2^20 chains, dim 128, k 500: at 8 ranks "
                          "the timed run IS configs[3]); default 2 = configs[1]")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = plumbing dry-run (gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (the `extra` array)")
-    return ap.parse_args()
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-run two launches under rocprofv3 --pmc for roofline.traffic "
+                                                              "(the committed profiles/traffic.json is used instead)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # the process rocprofv3 wraps: three launches, no output
+    args = ap.parse_args()
+    # --config 4 = BASELINE configs[3]'s per-GPU shard: args.n_chains, args.dim, args.k = 1 << 20, 128, 500 unless given explicitly
+    # (a reduced shard lets the 8-rank code path run on CPU ranks: tests/test_distributed.py)
+    preset = (1 << 20, 128, 500) if args.config == 4 else (1 << 20, 64, 200)
+    args.n_chains = preset[0] if args.n_chains is None else args.n_chains
+    args.dim = preset[1] if args.dim is None else args.dim
+    args.k = preset[2] if args.k is None else args.k
+    return args
 
 
 # ---------------------------------------------------------------------------------------
@@ -236,7 +247,7 @@ def issue_costs(device, blocks=256 * 8, iters=2048, reps=3):
         "plain": 1.0,
     }
     loop = sum(LEAN_LOOP_MIX[k] * units[k] for k in LEAN_LOOP_MIX)
-    # kind 7: the loop's own static mix (77 instructions per trip), dependency-free at eight waves per SIMD: seconds per
+    # kind 7: the loop's own static mix (76 instructions per trip), dependency-free at eight waves per SIMD: seconds per
     # wave-trip, whole chip -- the ceiling of a kernel made of exactly this mix
     # eight rounds of workgroups per launch (the kernel's launch is 32 rounds deep: a single round pays the ramp and the tail in
     # full), the fastest of three: a ceiling, not an average
@@ -348,6 +359,60 @@ def read_traffic():
             return json.load(f)
     except Exception:
         return None
+
+
+def traffic_child(args) -> int:
+    """What `measure_traffic` runs under rocprofv3: the timed workload's launch, three times, nothing else."""
+    device = torch.device("cuda", 0)
+    s = ta.LangevinDynamics(ta.DoubleWellModel(device=device), step_size=ETA, noise_scale=SIGMA, device=device)
+    s.donate_input = True
+    x = torch.randn(args.n_chains, args.dim, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+    for _ in range(3):
+        x = s.sample(x=x, n_steps=args.k)
+    torch.cuda.synchronize(device)
+    return 0
+
+
+def measure_traffic(args, kernel_substring="langevin_chain_lean_kernel"):
+    """HBM bytes per launch of the dominant kernel, measured NOW: this file re-run under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes: the TCC slots do not hold both; counters only, no trace domain), three launches each.
+    FETCH_SIZE is doubled (gfx950: 64 B tallied per 128-B request on wide coalesced reads, MI355X_MICROARCH.md, HBM section;
+    confirmed on a pure copy in profiles/r02_pmc.json); both counters are in KiB.  None when rocprofv3 is not on PATH or a pass
+    fails -- the caller then falls back to the committed profiles/traffic.json and says so."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child", "--n-chains", str(args.n_chains), "--dim", str(args.dim), "--k", str(args.k)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=240, check=True)
+            except Exception:
+                return None
+            vals = []
+            for root, _, files in os.walk(tmp):
+                for name in files:
+                    if name.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, name)) as f:
+                            for r in csv.DictReader(f):
+                                if r.get("Counter_Name") == counter and kernel_substring in r.get("Kernel_Name", ""):
+                                    vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            got[counter] = sum(vals) / len(vals) * 1024.0
+    read = 2.0 * got["FETCH_SIZE"]
+    return {"hbm_bytes_per_launch": read + got["WRITE_SIZE"], "hbm_read_bytes_corrected": read, "hbm_write_bytes": got["WRITE_SIZE"],
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of three launches each "
+                      f"(FETCH_SIZE x 2, gfx950 correction); {time.perf_counter() - t0:.0f} s"}
 
 
 def timed(fn, reps, warm, device):
@@ -692,6 +757,8 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
 
 def main():
     args = parse()
+    if args.traffic_child:
+        return traffic_child(args)
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
@@ -704,7 +771,7 @@ def main():
     if on_gpu and torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} (local {local_rank}) has no GPU: {torch.cuda.device_count()} visible", file=sys.stderr)
         return 2
-    backend = None
+    backend, backend_world = None, None
     if world > 1:
         import torch.distributed as dist
 
@@ -720,13 +787,12 @@ def main():
         else:
             dist.init_process_group("gloo")
         backend = dist.get_backend()
+        backend_world = dist.get_world_size()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}",
               file=sys.stderr)
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
 
-    if args.config == 4:
-        args.n_chains, args.dim, args.k = 1 << 20, 128, 500
     n, dim, k = args.n_chains, args.dim, args.k
     model = ta.DoubleWellModel(barrier_height=2.0, b=1.0, device=device)
     sampler = ta.LangevinDynamics(model, step_size=ETA, noise_scale=SIGMA, device=device)
@@ -864,7 +930,9 @@ def main():
         valu_rate = None
         if kernel_ms:
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-            traffic = read_traffic()
+            traffic = None if (args.no_traffic or world > 1) else measure_traffic(args)
+            if traffic is None:
+                traffic = read_traffic()
             valu_rate = plain_valu_rate(device)
             costs = issue_costs(device)  # per-class issue costs measured in THIS run -> the loop's price
             loop_units = costs["issue_units_per_float4_group_step"]
@@ -872,6 +940,27 @@ def main():
             issue_limit_ms = (n * dim / 4 / 64) * k * loop_units / valu_rate * 1e3
             # the bound: the same number of wave-trips of the loop's exact static instruction mix, issued dependency-free
             mixed_ceiling_ms = (n * dim / 4 / 64) * k * costs["mixed_stream_s_per_wave_trip"] * 1e3
+            # An INDEPENDENT ceiling next to the measured one -- no probe, only the instruction count and the pipe's documented rates:
+            # wave-trips per SIMD x cycles per trip / clock.  MI355X_MICROARCH.md gives v_fma_f32 (wave64, SIMD-32) 2 cycles, 256 CUs x
+            # 4 SIMDs, 2.4 GHz; the other classes at their ISA rate classes relative to it (packed f32: two results per lane = 2x;
+            # transcendental and the 32 x 32 -> 64 multiply-add: quarter rate = 4x; v_bitop3_b32: full rate).
+            trips_per_simd = (n * dim / 4 / 64) * k / (N_CUS * 4)
+            rate_class_cycles = {"plain": 2, "bitop3": 2, "packed_f32": 4, "transcendental": 8, "mad_u64_u32": 8}
+            cycles_all_full_rate = 2 * sum(LEAN_LOOP_MIX.values())
+            cycles_rate_classes = sum(LEAN_LOOP_MIX[c] * rate_class_cycles[c] for c in LEAN_LOOP_MIX)
+            independent = {
+                "instructions_per_float4_group_step": sum(LEAN_LOOP_MIX.values()), "mix": LEAN_LOOP_MIX, "cycles_per_class": rate_class_cycles,
+                "wave_trips_per_simd": trips_per_simd, "clock_GHz": CLOCK_GHZ, "simds": N_CUS * 4,
+                "cycles_per_trip_measured": kernel_ms * 1e-3 * CLOCK_GHZ * 1e9 / trips_per_simd,
+                "cycles_per_trip_if_every_instruction_issued_like_v_fma": cycles_all_full_rate,
+                "cycles_per_trip_at_rate_classes": cycles_rate_classes,
+                "floor_ms_all_full_rate": trips_per_simd * cycles_all_full_rate / (CLOCK_GHZ * 1e9) * 1e3,
+                "ceiling_ms_at_rate_classes": trips_per_simd * cycles_rate_classes / (CLOCK_GHZ * 1e9) * 1e3,
+                "kernel_over_rate_class_ceiling": trips_per_simd * cycles_rate_classes / (CLOCK_GHZ * 1e9) * 1e3 / kernel_ms,
+                "reading": "76 instructions per group-step cost 152 cycles if each issued like v_fma_f32 and 348 at their pipe rate classes; the "
+                           "kernel's measured cycles per trip sit between the two, within a few percent of the rate-class figure (the nominal "
+                           "2.4 GHz over-counts cycles when the chip clocks lower): the instruction count, not waiting, is the time",
+            }
             roof = {
                 # The kernel keeps the state in registers for all k steps, so it is NOT memory-shaped: the physical
                 # limiter is VALU issue (Philox-10 + Box-Muller).  `achieved`/`peak`/`frac` keep BASELINE.json's
@@ -883,6 +972,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "definition": "step-equivalent: n_chains*k*8*dim bytes / kernel time (BASELINE.md section 3)",
+                # flat copies of the figures that ARE bounds (a consumer that keeps only the top level of this object still gets them):
+                "bound_frac": min(1.0, mixed_ceiling_ms / kernel_ms),          # the one fraction that is <= 1: measured VALU issue ceiling / kernel
+                "valu_frac": mixed_ceiling_ms / kernel_ms,
+                "valu_insts_per_group_step": sum(LEAN_LOOP_MIX.values()),
+                "valu_rate_class_ceiling_frac": independent["kernel_over_rate_class_ceiling"],
+                "hbm_physical_frac": physical / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "valu": {
                     "issue_units_per_float4_group_step": loop_units,
                     "issue_costs_measured_in_run": costs,
@@ -895,6 +990,7 @@ def main():
                     "per_class_sum_ms": issue_limit_ms,
                     "per_class_sum_note": "sum of per-class costs x static counts: a calibration that over-prices a mixed stream "
                                           "(classes overlap), NOT a ceiling -- kept for continuity with rounds 1-3",
+                    "independent_of_the_probe": independent,
                 },
                 "hbm_physical": {
                     "bytes_per_launch": physical,
@@ -933,6 +1029,7 @@ def main():
                 "k_steps": k,
                 "parallelism": f"chains sharded x{world}",
                 "ranks": world,
+                "backend_world_size": backend_world,  # torch.distributed's own count (None: single process)
                 "backend": backend,
                 "launcher": ("bench.py self-launch (torch.distributed.run)" if os.environ.get("EBM_BENCH_SELF_LAUNCHED")
                              else ("torch.distributed.run" if world > 1 else "single process")),

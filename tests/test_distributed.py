@@ -158,9 +158,37 @@ def test_bench_config4_preset_is_baseline_config_4s_shard():
         a = mod.parse()
     finally:
         sys.argv = argv
-    assert a.config == 4
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "args.n_chains, args.dim, args.k = 1 << 20, 128, 500" in src
+    assert a.config == 4 and (a.n_chains, a.dim, a.k) == (1 << 20, 128, 500)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = mod.parse()
+    finally:
+        sys.argv = argv
+    assert (a.n_chains, a.dim, a.k) == (1 << 20, 64, 200)  # BASELINE configs[1]
+
+
+def test_bench_contract_eight_processes_cpu_config4_shape():
+    """the exact 8-rank code path of BASELINE configs[3] (--config 4: dim 128, k steps per call, the
+    pipelined read-back of every rank's shard, the rank-ordered gather, per-rank spread), executed once -- on 8 gloo CPU ranks at
+    a reduced shard (64 chains per rank, k = 3), launched as the driver launches N > 1.  Reference for the semantics:
+    torchebm/utils/distributed.py:43-70 (rank-ordered concatenation), tests/distributed/test_generator_ranks.py:38-51."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--device", "cpu", "--config", "4", "--n-chains", "64", "--k", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["ranks"] == 8 and rec["config"]["backend_world_size"] == 8
+    assert rec["config"]["backend"] == "gloo" and rec["config"]["dim"] == 128 and rec["config"]["k_steps"] == 3
+    assert rec["value"] == pytest.approx(8 * 64 * 3 * 2 / (rec["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    rb = rec["readback"]
+    assert rb["bytes_per_rank"] == 64 * 128 * 4 and rb["gathered_bytes_per_rank"] == 8 * 64 * 128 * 4
+    assert rb["allgather_error"] is None and rb["allgather_alone_ms"] > 0
+    assert rb["algbw_GBps"] == pytest.approx(7 * 64 * 128 * 4 / (rb["allgather_alone_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert len(rb["per_rank_ms_per_step"]["all"]) == 8
+    assert rec["config"]["readback"] is not None
 
 
 def test_bench_contract_single_process_cpu():
