@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""fp64 referee for the HMC grid fixtures on the quartic well (tests/golden/grid/hmc*_dw_*.pt).
+"""fp64 referee for EVERY HMC grid fixture (tests/golden/grid/hmc*.pt; round 4 had the quartic well only).
 
 The HMC state is a tolerance tier: 160 leapfrog steps in the double well amplify a last-bit difference of the force
 sum by up to 1e4, so "the kernel differs from the reference's fp32 run by 5e-4" says little about which of the two is
@@ -22,20 +22,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
-from helpers import grid_inputs, oracle_energy  # noqa: E402
+from helpers import grid_inputs, oracle_energy, to64  # noqa: E402
 
 OUT = os.path.join(HERE, "grid_referee")
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(1)
 
-for path in sorted(glob.glob(os.path.join(HERE, "grid", "hmc*_dw_*.pt"))):
+for path in sorted(glob.glob(os.path.join(HERE, "grid", "hmc*.pt"))):
     fx = torch.load(path, weights_only=False)
     x0, p, u = grid_inputs(fx)
     mass = fx["mass"]
     m64 = mass.double() if torch.is_tensor(mass) else mass
     f32 = oracle.hmc_chain(oracle_energy(fx["energy"]), x0, p, u, fx["eps"], fx["L"], mass=mass)
     assert torch.equal(f32["x"][:256], fx["ref"]["x_rows"]) and torch.equal(f32["accepted"], fx["accepted"]), fx["name"]
-    f64 = oracle.hmc_chain(oracle_energy(fx["energy"]), x0.double(), p.double(), u.double(), fx["eps"], fx["L"], mass=m64,
+    f64 = oracle.hmc_chain(to64(oracle_energy(fx["energy"])), x0.double(), p.double(), u.double(), fx["eps"], fx["L"], mass=m64,
                            forced_accept=fx["accepted"])
     err = (f32["x"][:256].double() - f64["x"][:256]).abs().amax(dim=1)
     torch.save({"name": fx["name"], "x_rows_f64": f64["x"][:256].clone(), "ref_f32_err_median": float(err.median()),

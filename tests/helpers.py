@@ -32,6 +32,29 @@ def oracle_energy(spec):
     raise ValueError(kind)
 
 
+def to64(energy):
+    """The same oracle energy with its parameters upcast EXACTLY (the fp32 precision matrix / means / log-weights an fp32 run
+    uses): what an fp64 referee run of the oracle evaluates (tests/golden/make_referee.py, the yardstick tests)."""
+    for attr in ("mean", "cov_inv", "means", "log_weights"):
+        if hasattr(energy, attr) and torch.is_tensor(getattr(energy, attr)):
+            setattr(energy, attr, getattr(energy, attr).double())
+    return energy
+
+
+def yardstick(got, ref32, ref64, *, k_med, k_max, k_chain, what=""):
+    """`got` (the kernel, fp32) may be no further from the fp64 run than the REFERENCE's own fp32 run is, up to the factors given:
+    population median and maximum of the per-chain error, and per chain against that chain's own reference error (floored at the
+    population's median reference error -- a chain whose fp32 run lands on the fp64 one to the last bit is no yardstick)."""
+    err_ref = (ref32.double() - ref64).abs().amax(dim=1)
+    err_hip = (got.double() - ref64).abs().amax(dim=1)
+    floor = err_ref.median().clamp(min=1e-30)
+    ratio = (err_hip / torch.maximum(err_ref, floor)).max().item()
+    stats = {"what": what, "hip_med": err_hip.median().item(), "ref_med": err_ref.median().item(), "hip_max": err_hip.max().item(),
+             "ref_max": err_ref.max().item(), "chain_ratio_max": ratio}
+    assert stats["hip_med"] <= k_med * stats["ref_med"] and stats["hip_max"] <= k_max * stats["ref_max"] and ratio <= k_chain, stats
+    return stats
+
+
 def package_model(spec, device=None):
     kind = spec["kind"]
     if kind == "double_well":

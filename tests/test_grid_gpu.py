@@ -104,19 +104,23 @@ def test_langevin_grid(cuda_device, name):
     torch.testing.assert_close(x2.cpu()[:256], fx["ref"]["x_rows"], rtol=3e-5, atol=3e-5)
 
 
-def _referee(name, got_rows, ref_rows, n_leapfrog):
-    """The quartic well: beside the flat tolerance, an fp64 referee (tests/golden/make_referee.py: the same transitions in
-    float64 on the same draws and accept decisions).  The kernel must be as close to the fp64 chain as the reference's own
-    fp32 arithmetic is:
-      * population: its median error <= the reference's, its 99th percentile <= 2 x and its maximum <= 4 x the reference's
-        (measured on MI355X: medians 0.5 - 0.8 x -- fused multiply-adds round once where the eager ops round twice);
-      * per chain: err_hip <= 4 x the chain's yardstick at L = 5, 16 x at L = 20 (160 steps in the well amplify ONE differing
-        rounding by up to 1e4, and which chain draws it is independent between two fp32 runs), the yardstick being the
-        reference's error on that chain with the population's median reference error as its floor (a chain whose fp32 run
-        happens to land on the fp64 one to the last bit is no yardstick)."""
+def _referee(name, got_rows, ref_rows, n_leapfrog, coupled):
+    """Beside the flat tolerance, an fp64 yardstick for EVERY HMC fixture (tests/golden/make_referee.py: the same transitions in
+    float64 on the same draws and accept decisions; round 4 had it for the quartic well only).  The kernel must be as close to
+    the fp64 chain as the reference's own fp32 arithmetic is:
+      * element-wise energies (quartic well, harmonic): population median error <= the reference's, 99th percentile <= 2 x,
+        maximum <= 4 x (measured on MI355X: medians 0.5 - 0.8 x -- fused multiply-adds round once where the eager ops round
+        twice); per chain err_hip <= 4 x the chain's yardstick at L = 5, 16 x at L = 20 (160 steps in the well amplify ONE
+        differing rounding by up to 1e4, and which chain draws it is independent between two fp32 runs), the yardstick being
+        the reference's error on that chain with the population's median reference error as its floor;
+      * row-coupled energies (dense Gaussian, mixtures): the row contraction sums in another order than torch's bmm / logsumexp
+        (split-bf16 products accumulated in fp32 on the matrix pipe, lane-group reductions), so neither fp32 run is the other's
+        rounding: median <= 1.5 x the reference's, 99th percentile <= 2 x, maximum <= 4.5 x; per chain 6 x / 32 x.  Measured over
+        the 20 coupled fixtures: medians 0.3 - 1.45 x, 99th percentiles 0.25 - 1.6 x, maxima 0.4 - 4.2 x, per chain up to 5.1 (L = 5)
+        and 22.8 (L = 20: mixture chains near a tie between two components -- in a fixture whose population figures are all
+        BELOW the reference's)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_referee", name + ".pt")
-    if not os.path.exists(path):
-        return
+    assert os.path.exists(path), f"no fp64 referee for {name}: run tests/golden/make_referee.py"
     f64 = torch.load(path, weights_only=False)["x_rows_f64"]
     err_ref = (ref_rows.double() - f64).abs().amax(dim=1)
     err_hip = (got_rows.double() - f64).abs().amax(dim=1)
@@ -124,8 +128,10 @@ def _referee(name, got_rows, ref_rows, n_leapfrog):
     q = lambda t, f: float(t.double().quantile(f))  # noqa: E731
     stats = {"name": name, "hip": [q(err_hip, 0.5), q(err_hip, 0.99), float(err_hip.max())],
              "ref": [q(err_ref, 0.5), q(err_ref, 0.99), float(err_ref.max())], "ratio_max": float(ratio.max())}
-    assert stats["hip"][0] <= stats["ref"][0] and stats["hip"][1] <= 2.0 * stats["ref"][1] and stats["hip"][2] <= 4.0 * stats["ref"][2], stats
-    assert stats["ratio_max"] <= (4.0 if n_leapfrog <= 5 else 16.0), stats
+    k_med, k_p99, k_max = (1.5, 2.0, 4.5) if coupled else (1.0, 2.0, 4.0)
+    assert stats["hip"][0] <= k_med * stats["ref"][0] and stats["hip"][1] <= k_p99 * stats["ref"][1] and stats["hip"][2] <= k_max * stats["ref"][2], stats
+    per_chain = (6.0 if n_leapfrog <= 5 else 32.0) if coupled else (4.0 if n_leapfrog <= 5 else 16.0)
+    assert stats["ratio_max"] <= per_chain, stats
 
 
 @pytest.mark.parametrize("name", grid_names("hmc"))
@@ -161,7 +167,8 @@ def test_hmc_grid(cuda_device, name):
         assert (err <= 5e-4).float().mean().item() >= 0.99 and err.max().item() <= 5e-3, (err.max().item(), (err > 5e-4).sum().item())
 
     check_states(got)
-    _referee(name, got[:256], fx["ref"]["x_rows"], L)
+    coupled = fx["energy"]["kind"] in ("gaussian", "gmm")
+    _referee(name, got[:256], fx["ref"]["x_rows"], L, coupled)
     assert torch.equal(diag["acceptance_rate"], fx["ref"]["diagnostics"]["acceptance_rate"])
     _check_diag(diag, fx["ref"]["diagnostics"], ("mean", "energy"))
     torch.testing.assert_close(diag["var"], fx["ref"]["diagnostics"]["var"], rtol=2e-3, atol=1e-5)
@@ -169,3 +176,4 @@ def test_hmc_grid(cuda_device, name):
     got2, mask2 = run(None)
     assert torch.equal(mask2, fx["accepted"])
     check_states(got2)
+    _referee(name, got2[:256], fx["ref"]["x_rows"], L, coupled)

@@ -11,6 +11,7 @@ from scipy import stats
 
 import oracle
 import torchebm_amd as ta
+from helpers import hip_calls
 from torchebm_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -138,3 +139,40 @@ def test_matrix_pipe_kernels_sample_the_target_law(cuda_device):
     ref = xc.double().numpy()
     for c in (0, 9, 31):
         assert stats.ks_2samp(got[:, c], ref[:, c]).pvalue > P_MIN, c
+
+
+def test_config3_native_rng_acceptance_and_marginals_match_the_oracle(cuda_device):
+    """VERDICT r4 item 4 / BASELINE.md section 5: BASELINE config 3's OWN energy (8-mode ring mixture, dim 32, L = 20, eps = 0.1)
+    through `sample()` with the in-kernel draws (n = 2^16) against the oracle's CPU chain with independent mt19937 draws
+    (n = 2^14): the acceptance rate of every transition within 4 sigma of the binomial error of the two populations, and the
+    radial and per-column marginals after the last transition by two-sample Kolmogorov-Smirnov.  Tolerance source:
+    torchebm/tests/samplers/test_hmc.py:668-703 (statistical recovery), samplers/hmc.py:243-312 (the transition)."""
+    n_gpu, n_cpu, dim, T, L, eps = 1 << 16, 1 << 14, 32, 10, 20, 0.1
+    model = ta.core.ring_mixture(8, dim, device=cuda_device)
+    means = model.means.detach().cpu()
+    g = torch.Generator().manual_seed(33)
+    x0 = torch.randn(n_cpu, dim, generator=g)
+    p, u = torch.randn(T, n_cpu, dim, generator=g), torch.rand(T, n_cpu, generator=g)
+    want = oracle.hmc_chain(oracle.GaussianMixture(means, 1.0), x0, p, u, [eps] * T, L, want_diag=True)
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, device=cuda_device)
+    # (fixed seeds on both sides: the p-values below are deterministic; over three GPU seeds the smallest two-sample p of all 32
+    #  columns was 3.5e-4 / 0.015 / 0.007 -- the first an unlucky pairing with the CPU sample's own column 2, p = 0.006 against N(0, 1))
+    gen = torch.Generator(device=cuda_device).manual_seed(35)
+    start = torch.randn(n_gpu, dim, device=cuda_device, generator=gen)
+    c0 = hip_calls("ebm_hmc_chain_f32")
+    got, diag = s.sample(x=start, n_steps=T, return_diagnostics=True, generator=gen)
+    assert hip_calls("ebm_hmc_chain_f32") > c0  # the fused route (config 3's own kernels), not per-transition launches
+    acc_gpu = diag["acceptance_rate"].double().cpu().numpy()
+    acc_cpu = want["accepted"].double().mean(dim=1).numpy()
+    assert acc_gpu.shape == acc_cpu.shape == (T,)
+    for t in range(T):
+        pbar = (acc_gpu[t] * n_gpu + acc_cpu[t] * n_cpu) / (n_gpu + n_cpu)
+        sigma = np.sqrt(max(pbar * (1.0 - pbar), 1e-6) * (1.0 / n_gpu + 1.0 / n_cpu))
+        assert abs(acc_gpu[t] - acc_cpu[t]) < 4.0 * sigma + 1e-4, (t, acc_gpu[t], acc_cpu[t], sigma)
+    gx, wx = got.cpu().double().numpy(), want["x"].double().numpy()
+    assert np.isfinite(gx).all()
+    assert stats.ks_2samp(np.hypot(gx[:, 0], gx[:, 1]), np.hypot(wx[:, 0], wx[:, 1])).pvalue > P_MIN  # distance from the ring's axis
+    for c in (0, 1, 2, 17, 31):
+        assert stats.ks_2samp(gx[:, c], wx[:, c]).pvalue > P_MIN, c
+    # the inactive columns are exact unit Gaussians under the target; 10 transitions of trajectory length 2 from N(0, 1) keep them so
+    assert stats.kstest(gx[:, 20], "norm").pvalue > P_MIN
