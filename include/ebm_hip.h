@@ -235,6 +235,22 @@ EBM_API int ebm_hmc_accept_f32(float* x, const float* x_prop, const float* h0, c
                        const float* u, uint8_t* accept_mask, uint32_t* accept_count,
                        int64_t n_chains, int32_t dim, uint64_t seed, uint64_t offset, void* stream);
 
+/*
+ * ABI 6 -- the AUDIT form of ebm_hmc_chain_f32 for the element-wise energies (double well, harmonic; dim <= 256; no records):
+ * same arguments, same transitions, but the trajectory is the reference's safe-mode leapfrog step LITERALLY
+ * (torchebm/integrators/leapfrog.py:156-185): the force re-evaluated at the top of every step, two separate half kicks, every
+ * multiply and add rounded on its own, the drift divided by max(m, 1e-10) per step, both nan_to_num_ scrubs on every step,
+ * energy and force re-evaluated at the top of every transition (samplers/hmc.py:243-256).  Given the same accept decisions the
+ * state is the reference's BIT FOR BIT (tests/test_hmc_audit_gpu.py: torch.equal on the recorded fixtures).  For tests: it exists
+ * so that what the fast body of ebm_hmc_chain_f32 trades away (merged kicks, fused multiply-adds, the hoisted eps / m) is a measured
+ * quantity; it costs 2 L + 2 evaluations per transition where the fast body spends L.  EBM_EKIND for other energies.
+ */
+EBM_API int ebm_hmc_chain_audit_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
+                                    int32_t n_mh, int32_t n_leapfrog, float eps, const float* eps_table,
+                                    int32_t mass_kind, double mass_scalar, const float* mass_diag, int32_t thin,
+                                    float* traj, uint8_t* accept_mask, uint32_t* accept_count,
+                                    const float* p_noise, const float* u, uint64_t seed, uint64_t offset, void* stream);
+
 /* The accept step with the RNG coordinates in DEVICE memory (rng_state = {seed, step}; the uniforms
  * are drawn at step rng_state[1] + step_delta): the graph-capturable form, see
  * ebm_langevin_step_dev_f32.  No injected-uniform form. */

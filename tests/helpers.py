@@ -41,17 +41,26 @@ def to64(energy):
     return energy
 
 
-def yardstick(got, ref32, ref64, *, k_med, k_max, k_chain, what=""):
+def yardstick(got, ref32, ref64, *, k_med, k_max=None, k_chain=None, k_q90=None, what=""):
     """`got` (the kernel, fp32) may be no further from the fp64 run than the REFERENCE's own fp32 run is, up to the factors given:
-    population median and maximum of the per-chain error, and per chain against that chain's own reference error (floored at the
-    population's median reference error -- a chain whose fp32 run lands on the fp64 one to the last bit is no yardstick)."""
+    population median, 90th percentile and maximum of the per-chain error, and per chain against that chain's own reference error
+    (floored at the population's median reference error -- a chain whose fp32 run lands on the fp64 one to the last bit is no
+    yardstick).  The maximum and the per-chain ratio of a few hundred chains are heavy-tailed where single chains amplify
+    round-off (a mixture chain near a tie between two components): bars on them are for populations that do not do that."""
     err_ref = (ref32.double() - ref64).abs().amax(dim=1)
     err_hip = (got.double() - ref64).abs().amax(dim=1)
     floor = err_ref.median().clamp(min=1e-30)
     ratio = (err_hip / torch.maximum(err_ref, floor)).max().item()
-    stats = {"what": what, "hip_med": err_hip.median().item(), "ref_med": err_ref.median().item(), "hip_max": err_hip.max().item(),
-             "ref_max": err_ref.max().item(), "chain_ratio_max": ratio}
-    assert stats["hip_med"] <= k_med * stats["ref_med"] and stats["hip_max"] <= k_max * stats["ref_max"] and ratio <= k_chain, stats
+    stats = {"what": what, "hip_med": err_hip.median().item(), "ref_med": err_ref.median().item(),
+             "hip_q90": err_hip.quantile(0.9).item(), "ref_q90": err_ref.quantile(0.9).item(),
+             "hip_max": err_hip.max().item(), "ref_max": err_ref.max().item(), "chain_ratio_max": ratio}
+    assert stats["hip_med"] <= k_med * stats["ref_med"], stats
+    if k_q90 is not None:
+        assert stats["hip_q90"] <= k_q90 * stats["ref_q90"], stats
+    if k_max is not None:
+        assert stats["hip_max"] <= k_max * stats["ref_max"], stats
+    if k_chain is not None:
+        assert ratio <= k_chain, stats
     return stats
 
 

@@ -76,7 +76,10 @@ def test_native_rng_ragged_dims_langevin(cuda_device, dim, n):
             # ... and, round 5, a yardstick instead of a guess: the same seven steps in float64 -- the kernel is no further from
             # them than the oracle's own fp32 run (a chain near a tie between two components amplifies either run's round-off)
             want64, _, _ = oracle.langevin_chain(to64(oracle.GaussianMixture(means, 0.9)), x0.double(), noise.cpu().double(), [0.02] * k, [1.0] * k)
-            yardstick(got2.cpu(), want2, want64, k_med=2.0, k_max=4.0, k_chain=8.0, what=f"mixture langevin dim {dim}")
+            # (the 90th percentile of nine chains is their maximum: the quantile bar is for populations)
+            st = yardstick(got2.cpu(), want2, want64, k_med=1.5, k_q90=3.0 if n >= 32 else None, what=f"mixture langevin dim {dim}")
+            if SEED_SHIFT:
+                print("YARDSTICK", st)
 
 
 @pytest.mark.parametrize("mass", [None, 2.0, "diag"])
@@ -113,7 +116,9 @@ def test_lane_per_chain_mixture_hmc(cuda_device, mass):
         m64 = mass.double() if torch.is_tensor(mass) else mass
         want64 = oracle.hmc_chain(to64(oracle.GaussianMixture(means, 0.9, log_weights=torch.log(weights))), x0.double(), p.cpu().double(),
                                   torch.stack(us).cpu().double(), [eps] * T, L, mass=m64, forced_accept=want["accepted"])
-        yardstick(got.cpu(), want["x"], want64["x"], k_med=2.0, k_max=4.0, k_chain=8.0, what=f"lane-per-chain mixture hmc, mass {mass if not torch.is_tensor(mass) else 'diag'}")
+        st = yardstick(got.cpu(), want["x"], want64["x"], k_med=1.5, k_q90=3.0, what=f"lane-per-chain mixture hmc, mass {mass if not torch.is_tensor(mass) else 'diag'}")
+        if SEED_SHIFT:
+            print("YARDSTICK", st)
         # (45 leapfrog steps through a mixture: a chain that passes near a tie between two components amplifies fp32 round-off
         #  of the logits -- reference and kernel alike; unseeded inputs tripped an all-chains 5e-4 bar about once in thirty runs)
         assert close.float().mean().item() >= 0.99 and (err <= 5e-3).all(), err.max().item()
@@ -465,7 +470,7 @@ def test_mixture_matrix_path_gradient_is_fp32_accurate(cuda_device, dim, K):
     # |x|^2 - 2 x.mu + |mu|^2 (the x.mu products ARE the matrix pass), whose rounding is relative to |x|^2 + |mu|^2, where torch's
     # (x - mu)^2 rounds relative to the distance itself; on a ridge the two largest logits differ by O(1) and the softmax weights
     # inherit that absolute error.  Hence 16 x on the maximum, and the absolute bound below in terms of the expansion's own scale.
-    stats = yardstick(x.cpu(), step32, step64, k_med=2.0, k_max=16.0, k_chain=float("inf"), what=f"mixture gradient dim {dim} K {K}")
+    stats = yardstick(x.cpu(), step32, step64, k_med=2.0, k_max=16.0, what=f"mixture gradient dim {dim} K {K}")
     d = (x0.double()[:, None, :] - means.double()[None])
     logit_scale = (x0.double().square().sum(dim=1) + means.double().square().sum(dim=1).max()) / (2.0 * sigma ** 2)  # the expansion's magnitude
     natural = x0.double().abs().amax(dim=1) + eta * d.abs().amax(dim=(1, 2)) / sigma ** 2 * (1.0 + logit_scale)

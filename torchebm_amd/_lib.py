@@ -36,6 +36,7 @@ EXPORTS = (
     "ebm_langevin_chain_f32",
     "ebm_langevin_heun_chain_f32",
     "ebm_hmc_chain_f32",
+    "ebm_hmc_chain_audit_f32",
     "ebm_leapfrog_kick_drift_f32",
     "ebm_leapfrog_kick_f32",
     "ebm_hmc_accept_f32",
@@ -101,6 +102,10 @@ _PROTOTYPES = {
     "ebm_hmc_chain_f32": (
         C.c_int,
         [_ENERGY_P, _p, _i64, _i32, _i32, _i32, _f, _p, _i32, _d, _p, _i32, _p, _p, _p, _p, _p, _p, _u64, _u64, _p],
+    ),
+    "ebm_hmc_chain_audit_f32": (
+        C.c_int,
+        [_ENERGY_P, _p, _i64, _i32, _i32, _i32, _f, _p, _i32, _d, _p, _i32, _p, _p, _p, _p, _p, _u64, _u64, _p],
     ),
     "ebm_diag_layout": (C.c_int, [_ENERGY_P, _i32, _i64, _i32, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),

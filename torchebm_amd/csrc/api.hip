@@ -51,6 +51,8 @@ int launch_descent_chain(const ebm_energy_t&, float*, int64_t, int32_t, int32_t,
 int launch_descent_step(const float*, const float*, float*, float*, int64_t, float, float, hipStream_t);
 int launch_lookahead(const float*, const float*, float*, int64_t, float, hipStream_t);
 int launch_gmm_active_columns(const float*, int32_t, int32_t, int32_t*, hipStream_t);
+int launch_hmc_chain_audit(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
+                           const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t, hipStream_t);
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
                       uint64_t, const uint64_t*, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, const int64_t*, hipStream_t);
@@ -412,6 +414,24 @@ int ebm_hmc_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, in
   return launch_hmc_chain(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind,
                           mass_scalar, mass_diag, thin, traj, accept_mask, accept_count, p_noise, u,
                           seed, offset, diag_partials, (hipStream_t)stream);
+}
+
+int ebm_hmc_chain_audit_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim, int32_t n_mh, int32_t n_leapfrog,
+                            float eps, const float* eps_table, int32_t mass_kind, double mass_scalar, const float* mass_diag,
+                            int32_t thin, float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise,
+                            const float* u, uint64_t seed, uint64_t offset, void* stream) {
+  const char* who = "ebm_hmc_chain_audit_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (n_mh < 0 || thin < 1 || n_leapfrog < 1)
+    return fail(EBM_EINVAL, "%s: n_mh=%d thin=%d n_leapfrog=%d", who, n_mh, thin, n_leapfrog);
+  if (mass_kind < EBM_MASS_NONE || mass_kind > EBM_MASS_DIAG || (mass_kind == EBM_MASS_DIAG && !mass_diag))
+    return fail(EBM_EINVAL, "%s: bad mass specification (kind %d)", who, mass_kind);
+  if ((p_noise == nullptr) != (u == nullptr)) return fail(EBM_EINVAL, "%s: p_noise and u must be given together", who);
+  if (n_chains == 0 || n_mh == 0) return 0;
+  if ((traj && !aligned16(traj)) || (p_noise && !aligned16(p_noise))) return fail(EBM_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  return launch_hmc_chain_audit(*energy, x, n_chains, dim, n_mh, n_leapfrog, eps, eps_table, mass_kind, mass_scalar, mass_diag, thin, traj,
+                                accept_mask, accept_count, p_noise, u, seed, offset, (hipStream_t)stream);
 }
 
 int ebm_leapfrog_kick_drift_f32(const float* x, const float* p, const float* force, float* x_new,

@@ -20,6 +20,9 @@ void launch_double_well_diag(const rows::Geometry&, dim3, size_t, hipStream_t, c
 void launch_harmonic_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 void launch_gaussian_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 void launch_gmm_diag(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+// hmc_literal.hip: the audit form for the element-wise energies (ebm_hmc_chain_audit_f32)
+void launch_literal_double_well(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
+void launch_literal_harmonic(const rows::Geometry&, dim3, size_t, hipStream_t, const HmcArgs&);
 // hmc_ring.hip: the mixture whose means differ in columns 0..3 only, at four waves per SIMD
 bool hmc_slot1_applies(const ebm_energy_t&, const rows::Geometry&, int32_t mass_kind);
 void launch_slot1(dim3, hipStream_t, HmcArgs);
@@ -248,6 +251,40 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
     default:                     hmc::launch_gmm(geo, grid, smem, st, a); break;
   }
   return check_launch("ebm_hmc_chain_f32");
+}
+
+// ebm_hmc_chain_audit_f32: the literal leapfrog sequence (hmc_kernel.h: leapfrog_literal) -- element-wise energies, dim <= 256
+int launch_hmc_chain_audit(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t n_mh, int32_t n_leapfrog, float eps,
+                           const float* eps_table, int32_t mass_kind, double mass_scalar, const float* mass_diag, int32_t thin,
+                           float* traj, uint8_t* accept_mask, uint32_t* accept_count, const float* p_noise, const float* u,
+                           uint64_t seed, uint64_t offset, hipStream_t st) {
+  const char* who = "ebm_hmc_chain_audit_f32";
+  if (e.kind != EBM_ENERGY_DOUBLE_WELL && e.kind != EBM_ENERGY_HARMONIC)
+    return fail(EBM_EKIND, "%s: the audit form exists for the element-wise energies (double well, harmonic)", who);
+  Geometry geo;
+  if (!pick_geometry(dim, geo) || geo.NV != 1) return fail(EBM_EDIM, "%s: dim %d > 256", who, dim);
+  geo.full = false;
+  HmcArgs a{};
+  a.x = x; a.n_chains = n_chains; a.dim = dim; a.n_mh = n_mh; a.n_leapfrog = n_leapfrog;
+  a.eps = eps; a.eps_table = eps_table; a.mass_kind = mass_kind;
+  a.mass_raw = (float)mass_scalar;
+  a.mass_sqrt = (float)sqrt(mass_scalar);
+  a.mass_safe = (float)(mass_scalar < 1e-10 ? 1e-10 : mass_scalar);
+  a.mass_diag = mass_diag; a.thin = thin; a.n_kept = n_mh / thin; a.traj = traj;
+  a.accept_mask = accept_mask; a.accept_count = accept_count; a.p_noise = p_noise; a.u = u;
+  a.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  a.step0 = offset;
+  size_t smem = 0;
+  plan_params(e, dim, geo, a.energy, a.param_floats, smem);
+  a.park_offset_floats = (int)(smem / sizeof(float));
+  a.diag = diag::DiagArgs{nullptr, 0, 0, 0};
+  a.diag_offset_floats = (int)(smem / sizeof(float));
+  const int64_t blocks = blocks_for(n_chains, geo);
+  if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
+  const dim3 grid((unsigned)blocks);
+  if (e.kind == EBM_ENERGY_DOUBLE_WELL) hmc::launch_literal_double_well(geo, grid, smem, st, a);
+  else hmc::launch_literal_harmonic(geo, grid, smem, st, a);
+  return check_launch(who);
 }
 
 }  // namespace ebm

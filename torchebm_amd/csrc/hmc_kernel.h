@@ -180,6 +180,46 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
   return e;
 }
 
+// The AUDIT form of the trajectory (ebm_hmc_chain_audit_f32; tests only): the reference's safe-mode leapfrog step literally
+// (integrators/leapfrog.py:156-185, restated in oracle/hmc.py) -- the force re-evaluated at the top of every step, two separate
+// half kicks, every multiply and add rounded on its own (this file is compiled with -ffp-contract=off and nothing below is an
+// explicit FMA), the drift divided by max(m, 1e-10) per step, both nan_to_num_ scrubs on every step.  For the element-wise
+// energies the gradient is bit-identical to autograd's (rows.h), so given the same accept decisions the STATE is the reference's
+// bit for bit: what the fast body above (merged kicks, FMAs, the hoisted eps / m) trades away is then a measured quantity
+// (tests/test_hmc_audit_gpu.py), not a claim.  2 L evaluations per transition + 1 for E(x'), like the reference.
+template <bool HAS_MASS, class En, class LaneT>
+__device__ __forceinline__ float leapfrog_literal(const En& en, const LaneT& L, Slice<LaneT::NV>& x, Slice<LaneT::NV>& p,
+                                                  const Slice<HAS_MASS ? LaneT::NV : 1>& m_clamped, float eps, float half_eps,
+                                                  int n_steps) {
+  constexpr int NV = LaneT::NV;
+  Slice<NV> g;
+  for (int l = 0; l < n_steps; ++l) {
+    (void)en.template eval<true>(L, x, g);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float force = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+        const float ph = p.a[v][i] + half_eps * force;          // p + (0.5 eps) * force
+        float step = eps * ph;                                   // eps * p_half
+        if constexpr (HAS_MASS) step = step / m_clamped.a[v][i]; // ... / max(m, 1e-10)
+        p.a[v][i] = ph;
+        x.a[v][i] = L.ok(v, i) ? x.a[v][i] + step : 0.0f;
+      }
+    (void)en.template eval<true>(L, x, g);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float force = clamp_nanprop(-g.a[v][i], -1e6f, 1e6f);
+        const float pn = p.a[v][i] + half_eps * force;
+        x.a[v][i] = nan_to_num0(x.a[v][i]);
+        p.a[v][i] = L.ok(v, i) ? nan_to_num0(pn) : 0.0f;
+      }
+  }
+  return en.template eval<true>(L, x, g);  // model(x'), on the scrubbed proposal (samplers/hmc.py:270-274)
+}
+
 // MASS: 0 = identity mass (no mass registers at all), 1 = scalar or diagonal mass (three
 // per-slot forms kept in VGPRs).  XC_LDS: park the accepted state in a lane-private LDS slot
 // while the proposal is integrated (wide rows: frees 4*NV VGPRs).
@@ -187,8 +227,10 @@ __device__ __forceinline__ float leapfrog_steps(const En& en, const LaneT& L, Sl
 // diag::emit cost the one-lane-per-chain mixture kernel 4 % through register pressure even when never taken).
 // CARRY: carry energy and force from transition to transition (see below); false re-evaluates both at the top of
 // every transition, the reference's own sequence (kept for A/B measurements).
-template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG, bool CARRY = true>
+// LITERAL: the audit form (leapfrog_literal; requires CARRY = false: energy and force re-evaluated at the top of every transition).
+template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG, bool CARRY = true, bool LITERAL = false>
 __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
+  static_assert(!LITERAL || !CARRY, "the audit form re-evaluates at the top of every transition");
   using LaneT = Lane<G, NV, FULL>;
   constexpr bool XC_LDS = NV >= 4;
   LaneT L;
@@ -224,6 +266,8 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (diag_mass) {
+          // (sqrtf is correctly rounded here -- hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; torch's CPU sqrt is NOT:
+          //  it lands on the wrong side of near-halfway cases, differently on different hosts -- tests/test_hmc_audit_gpu.py)
           m_sqrt.a[v][i] = sqrtf(m_raw.a[v][i]);
           m_safe.a[v][i] = m_raw.a[v][i] < 1e-10f ? 1e-10f : m_raw.a[v][i];
         } else {
@@ -351,7 +395,10 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
     if constexpr (!XC_LDS) x = xc;
     const int n_lf = init ? 1 : a.n_leapfrog;
     float e1;
-    if constexpr (has_mass) {
+    if constexpr (LITERAL) {
+      if constexpr (has_mass) e1 = leapfrog_literal<true>(en, L, x, p, m_safe, eps_t, half_eps, n_lf);
+      else e1 = leapfrog_literal<false>(en, L, x, p, m_safe, eps_t, half_eps, n_lf);
+    } else if constexpr (has_mass) {
       // drift x += eps * p / max(m, 1e-10): the quotient eps / m is formed once per transition (an IEEE
       // division per coordinate per LEAPFROG STEP cost 40 % of the massed kernel), the step is one FMA
       Slice<NV> drift_scale;
@@ -439,6 +486,29 @@ __device__ __forceinline__ void hmc_chain_body(const HmcArgs& a) {
 template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock) void hmc_chain_kernel(HmcArgs a) {
   hmc_chain_body<KIND, G, NV, FULL, MASS, DIAG>(a);
+}
+
+// The audit instantiation: one vector per lane, the plain geometry of pick_geometry (dims up to 256), no records.
+template <int KIND, int G, int MASS>
+__global__ __launch_bounds__(kBlock) void hmc_chain_kernel_literal(HmcArgs a) {
+  hmc_chain_body<KIND, G, 1, false, MASS, false, false, true>(a);
+}
+
+template <int KIND>
+void launch_literal(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, const HmcArgs& a) {
+  const dim3 block(kBlock);
+#define EBM_HMC_LIT(GV)                                                                                       \
+  case GV:                                                                                                    \
+    if (a.mass_kind == EBM_MASS_NONE) hipLaunchKernelGGL((hmc_chain_kernel_literal<KIND, GV, 0>), grid, block, smem, st, a); \
+    else hipLaunchKernelGGL((hmc_chain_kernel_literal<KIND, GV, 1>), grid, block, smem, st, a);              \
+    break;
+  switch (geo.G) {
+    EBM_HMC_LIT(1) EBM_HMC_LIT(2) EBM_HMC_LIT(4) EBM_HMC_LIT(8) EBM_HMC_LIT(16) EBM_HMC_LIT(32)
+    default:
+      if (a.mass_kind == EBM_MASS_NONE) hipLaunchKernelGGL((hmc_chain_kernel_literal<KIND, 64, 0>), grid, block, smem, st, a);
+      else hipLaunchKernelGGL((hmc_chain_kernel_literal<KIND, 64, 1>), grid, block, smem, st, a);
+  }
+#undef EBM_HMC_LIT
 }
 
 // Same body held to 256 VGPRs (two waves per SIMD).  For the one-lane-per-chain mixture kernel:
