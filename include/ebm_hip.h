@@ -57,10 +57,14 @@ enum {
   EBM_ENERGY_DOUBLE_WELL = 0, /* E = h * sum_j (x_j^2 - b^2)^2   base_model.py:130-148  s[0]=h  s[1]=(float)(b*b)           */
   EBM_ENERGY_HARMONIC    = 1, /* E = (0.5*k) * sum_j x_j^2       base_model.py:213-229  s[0]=(float)(0.5*k)                 */
   EBM_ENERGY_GAUSSIAN    = 2, /* E = 0.5 d^T P d, d = x - mu     base_model.py:151-210  dev0=mu[dim] dev1=P[dim*dim] (P=cov^-1)
-                                 aux = NULL, or (dims 132 .. 512, since ABI version 4) the device image that
-                                 ebm_gauss_prec_image_f32 built from THIS dev1: the tiled kernels (dims 228 .. 512) then move
-                                 their slabs of P by LDS-direct loads instead of loading, splitting and storing fp32 rows
-                                 every stage.  A stale image gives the old matrix's samples; NULL is always safe.          */
+                                 aux = NULL, or (since ABI version 4) the device image that ebm_gauss_prec_image_f32 built from
+                                 THIS dev1 -- multiples of 4 from 132 to 512, and (ABI version 5) the widths 158 .. 254 that
+                                 are NOT a multiple of 4, where the image holds one shifted copy per alignment class (4 for an
+                                 odd width, 2 for width = 2 mod 4; ebm_gauss_prec_image_bytes gives the size, 0 = no image at
+                                 this width): the tiled kernels then move their slabs of P by LDS-direct loads instead of
+                                 loading, splitting and storing fp32 rows every stage, and the streamed kernels of the shifted
+                                 widths (Langevin 158 .. 254, HMC 161 .. 254) REQUIRE it (without it those widths take the
+                                 lane-group kernels).  A stale image gives the old matrix's samples; NULL is always safe.     */
   EBM_ENERGY_GMM         = 3, /* E = -logsumexp_k(logw_k - |x-mu_k|^2 * s[0])  (not in the reference: SURVEY §8 a6)
                                  s[0]=1/(2 sigma^2)  s[1]=1/sigma^2  n_comp=K  dev0=mu[K*dim] dev1=logw[K]
                                  aux = NULL, or device int32[1]: bit v set <=> the component means differ somewhere in
@@ -71,12 +75,12 @@ enum {
                                  A wrong mask gives wrong samples; NULL is always safe.                                    */
   EBM_ENERGY_MLP         = 4  /* E = w3 . silu(W2 silu(W1 x + b1) + b2) + b3   (the energy of the reference's
                                  examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31)
-                                 n_comp = hidden width H (64, 128 or 256), dim <= 128 (the reference's benchmark network
+                                 n_comp = hidden width H (64 or 128; 256 only in a build made with `make H256=1`), dim <= 128 (the reference's benchmark network
                                  benchmarks/registry.py:372-387 at dim 8 / 32 / 128),
                                  dev0 = packed fp32 parameters W1[H,dim] b1[H] W2[H,H] b2[H] w3[H] b3[1] (torch Linear layout).
                                  Supported by ebm_langevin_chain_f32, ebm_energy_grad_f32 and ebm_hmc_chain_f32 (EBM_EDIM for
-                                 other widths).  H = 256 reads
-                                 the weights from dev0 throughout the launch: dev0 must then be 16-byte aligned.
+                                 other widths).  (H = 256, where built, reads
+                                 the weights from dev0 throughout the launch: dev0 must then be 16-byte aligned.)
                                  aux = NULL, or (H = 128, 64 < dim <= 128, since ABI version 4) the device image that
                                  ebm_mlp_w1_image_f32 built from THIS dev0 (cast to const int32_t*): with it the Langevin
                                  and energy / gradient entries run their contractions on the bf16 matrix pipe with
@@ -361,7 +365,15 @@ EBM_API int ebm_noise_fill_dev_f32(float* out, int64_t n_elem, int32_t kind, con
  *   the records are those of n_chains * dim / S rows: call ebm_diag_finish_f32 with (n_chains * dim / S, S) and fold
  *   the S columns onto the dim coordinates -- mean = average of the S / dim column means of a coordinate, var = average
  *   of their variances + the (biased) variance of those column means, energy divided by S / dim
- *   (torchebm_amd/samplers/langevin.py, _fused_with_records).  Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
+ *   (torchebm_amd/samplers/langevin.py, _fused_with_records).
+ *   block_elems < 0 (since ABI version 5) means records of INTERLEAVED ALIGNMENT CLASSES: the shifted-row kernels (dense
+ *   Gaussians and mixtures at widths that are not a multiple of 4, 17 .. 254) give a workgroup the chains of ONE alignment
+ *   class -- K = 4 / gcd(dim, 4) classes (4 for an odd width, 2 for width = 2 mod 4) -- so record b = (group b / K, class b % K)
+ *   holds the 32 chains 32 K g + K m + s, m = 0 .. 31, of group g = b / K and class s = b % K; block_elems = -32 * dim,
+ *   slots = dim, and n_blocks = ceil(n_chains / (32 K)) * K.  Treat the value as opaque: allocate diag_partials with the
+ *   n_blocks and slots returned and hand block_elems to ebm_diag_finish_f32 unchanged (it accepts the negative form); a caller
+ *   that computes with block_elems itself must take |block_elems| / dim = 32 chains per record and the interleaving above.
+ *   Returns EBM_EDIM / EBM_EKIND when the configuration has no in-kernel form (then take the
  *   statistics from the state with ebm_chain_stats_f32 / ebm_energy_grad_f32 between launches).
  * ebm_diag_finish_f32: mean_out / var_out = float[n_kept][dim] (biased variance clamped to [1e-10, 1e10], zero for a
  *   single chain), energy_out = float[n_kept] (mean per-chain energy), accept_out = NULL or float[n_kept]
@@ -399,7 +411,9 @@ EBM_API int ebm_probe_issue_f32(float* out, int32_t blocks, int32_t iters, int32
  * entry).  No counterpart in the reference: there the network is nn.Linear modules evaluated by autograd every step
  * (samplers/langevin_dynamics.py:168-172).  Since ABI version 4. */
 /* The same for an EBM_ENERGY_GAUSSIAN precision matrix at dims 132 .. 512 (multiples of 4): the three bf16 pieces of P
- * (hi + mid + lo = the fp32 value) in the order the stages of the tiled Langevin kernel consume them, 1.5 x the size of P.
+ * (hi + mid + lo = the fp32 value) in the order the stages of the tiled Langevin kernel consume them, 1.5 x the size of P --
+ * and, since ABI version 5, at the widths 158 .. 254 that are not a multiple of 4: one image per alignment class of the
+ * shifted rows (K = 4 / gcd(dim, 4) of them, each laid out for the row shifted by that class's offset), K x the size.
  * `prec` is the SYMMETRIC matrix handed over as dev1.  0 bytes = this width has no image.  Since ABI version 4. */
 EBM_API size_t ebm_gauss_prec_image_bytes(int32_t dim);
 EBM_API int ebm_gauss_prec_image_f32(const float* prec, int32_t dim, void* image, void* stream);

@@ -24,7 +24,8 @@ def cuda_device():
 @pytest.fixture(scope="session", autouse=True)
 def _library_built():
     """A fresh checkout has no libebm_hip.so yet (it is git-ignored): build it once per session, the same way
-    __graft_entry__.build() does (hipcc cross-compiles for gfx950 without a GPU, ~40 s).  The product code
+    __graft_entry__.build() does (hipcc cross-compiles for gfx950 without a GPU; a CLEAN build is ~41 CPU-minutes, 6 - 7 minutes
+    of wall time on 8 cores -- profiles/r05_build_times.txt -- so ship the built library with the tree wherever the tests run).  The product code
     never builds or falls back on its own -- a missing library is an error there."""
     from torchebm_amd import _lib
 

@@ -16,6 +16,14 @@ from torchebm_amd.samplers.langevin import em_coefficients
 
 pytestmark = pytest.mark.gpu
 
+H256 = 256 in ta.MLPEnergy.FUSED_HIDDEN  # the streamed-weight family is not in the shipped library since round 5 (make H256=1)
+
+
+def _built(shapes):
+    """The parametrisation without the hidden-256 shapes unless this build has their kernels."""
+    return [s for s in shapes if H256 or 256 not in s[1:2]]
+
+
 
 def _models(cuda_device, in_dim, hidden, seed=0, scale=1.0):
     torch.manual_seed(seed)
@@ -26,8 +34,8 @@ def _models(cuda_device, in_dim, hidden, seed=0, scale=1.0):
     return cpu, copy.deepcopy(cpu).to(cuda_device)
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (5, 128), (33, 128), (100, 128), (64, 64), (7, 64),
-                                           (128, 64), (2, 64), (32, 256), (8, 256), (33, 256), (64, 256), (100, 256), (128, 256)])
+@pytest.mark.parametrize("in_dim,hidden", _built([(8, 128), (32, 128), (128, 128), (5, 128), (33, 128), (100, 128), (64, 64), (7, 64),
+                                           (128, 64), (2, 64), (32, 256), (8, 256), (33, 256), (64, 256), (100, 256), (128, 256)]))
 def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
     cpu, gpu = _models(cuda_device, in_dim, hidden, seed=in_dim + hidden, scale=1.5)
     spec = gpu.fused_spec()
@@ -51,7 +59,7 @@ def test_energy_and_gradient_match_autograd(cuda_device, in_dim, hidden):
     torch.testing.assert_close(g.cpu(), want_g, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 128), (128, 128), (30, 64), (32, 256), (30, 256), (128, 256)])
+@pytest.mark.parametrize("in_dim,hidden", _built([(8, 128), (32, 128), (128, 128), (30, 64), (32, 256), (30, 256), (128, 256)]))
 def test_fused_chain_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden):
     """The k-fused chain against the CPU autograd chain on the same noise, refereed by the fp64 network's chain: both
     fp32 chains drift from it at the rate the dynamics amplify round-off, and the kernel may not drift faster than
@@ -139,10 +147,10 @@ class _CpuMlpEnergy:
         return self.model.gradient(x)
 
 
-@pytest.mark.parametrize("in_dim,hidden,mass", [(8, 128, None), (32, 128, 1.7), (30, 128, "diag"), (64, 128, None), (33, 64, "diag"),
+@pytest.mark.parametrize("in_dim,hidden,mass", _built([(8, 128, None), (32, 128, 1.7), (30, 128, "diag"), (64, 128, None), (33, 64, "diag"),
                                                 (64, 64, 0.6), (5, 64, None), (32, 256, None), (17, 256, "diag"), (8, 256, 2.0),
                                                 (96, 128, None), (100, 128, "diag"), (128, 128, 1.3), (128, 64, "diag"), (90, 64, None),
-                                                (64, 256, None), (50, 256, "diag"), (96, 256, None), (100, 256, "diag"), (128, 256, 0.8)])
+                                                (64, 256, None), (50, 256, "diag"), (96, 256, None), (100, 256, "diag"), (128, 256, 0.8)]))
 def test_wide_hmc_kernel_matches_cpu_autograd_chain_with_injected_noise(cuda_device, in_dim, hidden, mass):
     """csrc/mlp_wide_hmc.hip through the C ABI against the oracle's HMC on the CPU autograd network: same momenta, same
     uniforms, every mass form, thinning; accept decisions identical except within fp32 round-off of u."""
@@ -187,7 +195,7 @@ def test_wide_hmc_kernel_matches_cpu_autograd_chain_with_injected_noise(cuda_dev
     assert torch.equal(traj[:, -1], x)
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(16, 128), (48, 64), (32, 256), (128, 128), (100, 64), (64, 256), (128, 256)])
+@pytest.mark.parametrize("in_dim,hidden", _built([(16, 128), (48, 64), (32, 256), (128, 128), (100, 64), (64, 256), (128, 256)]))
 def test_sampler_hmc_on_the_wide_mlp_is_one_launch_on_the_shared_field(cuda_device, in_dim, hidden):
     class Sub(ta.MLPEnergy):
         def forward(self, x):
@@ -229,6 +237,7 @@ def test_wide_hmc_safe_mode_on_extreme_states(cuda_device):
     assert clean.shape == (197, 24)
 
 
+@pytest.mark.skipif(not H256, reason="hidden width 256 is not in this build (make H256=1)")
 @pytest.mark.parametrize("in_dim", [32, 30, 128])
 def test_hidden_256_sampler_is_one_launch_on_the_shared_field(cuda_device, in_dim):
     """Hidden width 256 (the streamed-weight variant): ``LangevinDynamics`` is one ``ebm_langevin_chain_f32`` launch, its
@@ -256,7 +265,7 @@ def test_hidden_256_sampler_is_one_launch_on_the_shared_field(cuda_device, in_di
     torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(8, 128), (32, 256), (100, 64)])
+@pytest.mark.parametrize("in_dim,hidden", _built([(8, 128), (32, 256), (100, 64)]))
 def test_gradient_is_one_hip_launch(cuda_device, in_dim, hidden):
     """``MLPEnergy.gradient`` on a CUDA fp32 state is one ``ebm_energy_grad_f32`` launch (forward + input gradient on the
     matrix cores), equal to autograd within fp32 summation order; conditioning kwargs, a subclass with its own
@@ -295,8 +304,8 @@ def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
             return super().forward(x)
 
     torch.manual_seed(3)
-    fast = ta.MLPEnergy(80, 256, device=cuda_device)
-    slow = Sub(80, 256, device=cuda_device)
+    fast = ta.MLPEnergy(80, 128, device=cuda_device)
+    slow = Sub(80, 128, device=cuda_device)
     slow.load_state_dict(fast.state_dict())
     x0 = torch.randn(2000, 80, device=cuda_device)
     outs = []
@@ -313,6 +322,7 @@ def test_hmc_on_the_wide_mlp_uses_the_hip_gradient(cuda_device):
     torch.testing.assert_close(outs[0][1]["acceptance_rate"], outs[1][1]["acceptance_rate"], rtol=0, atol=5e-3)
 
 
+@pytest.mark.skipif(not H256, reason="hidden width 256 is not in this build (make H256=1)")
 def test_streamed_weights_must_be_16_byte_aligned(cuda_device):
     """H = 256 reads its weights with 16-byte loads straight from the parameter block: a misaligned block is refused by
     the C ABI (EBM_EINVAL -> ValueError), never read."""
@@ -333,7 +343,7 @@ def test_streamed_weights_must_be_16_byte_aligned(cuda_device):
     assert torch.equal(x, torch.zeros_like(x))
 
 
-@pytest.mark.parametrize("in_dim,hidden", [(20, 128), (70, 64), (40, 256)])
+@pytest.mark.parametrize("in_dim,hidden", _built([(20, 128), (70, 64), (40, 256)]))
 def test_wide_hmc_edge_shapes_schedule_and_prefix_identity(cuda_device, in_dim, hidden):
     """One chain, a batch that is not a multiple of the 32-chain tile, a scheduled step size with thinning that does not
     divide the transitions, and prefix identity: a chain's native-RNG trajectory depends on its index and the seed only,
@@ -365,7 +375,7 @@ def test_wide_hmc_edge_shapes_schedule_and_prefix_identity(cuda_device, in_dim, 
     assert torch.equal(x0, x0.clone())                                # the caller's tensor is not the in/out buffer
 
 
-@pytest.mark.parametrize("in_dim,hidden,n", [(2, 128, 4099), (32, 128, 1000), (64, 128, 515), (33, 64, 777), (32, 256, 300), (100, 128, 257)])
+@pytest.mark.parametrize("in_dim,hidden,n", _built([(2, 128, 4099), (32, 128, 1000), (64, 128, 515), (33, 64, 777), (32, 256, 300), (100, 128, 257)]))
 def test_langevin_diagnostics_come_from_records_of_the_one_chain_launch(cuda_device, in_dim, hidden, n):
     """return_diagnostics=True on the MLP energy stays ONE chain launch -- every wave stores the record
     of its 32 chains at the kept steps (the energy share one evaluation later), ebm_diag_finish_f32 merges them -- and
@@ -388,7 +398,7 @@ def test_langevin_diagnostics_come_from_records_of_the_one_chain_launch(cuda_dev
         torch.testing.assert_close(diag["energy"].double(), want_e, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("in_dim,hidden,mass", [(2, 128, None), (32, 128, 1.7), (48, 64, "diag"), (32, 256, None)])
+@pytest.mark.parametrize("in_dim,hidden,mass", _built([(2, 128, None), (32, 128, 1.7), (48, 64, "diag"), (32, 256, None)]))
 def test_hmc_diagnostics_come_from_records_of_the_one_chain_launch(cuda_device, in_dim, hidden, mass):
     torch.manual_seed(3 + in_dim)
     model = ta.MLPEnergy(in_dim, hidden, device=cuda_device)

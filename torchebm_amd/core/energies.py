@@ -257,11 +257,15 @@ class GaussianModel(BaseModel):
         """The energy for a SAMPLER's own use (the accept step of the per-transition HMC route, diagnostics): one contraction pass
         of the tiled kernel at the widths it covers, ``None`` elsewhere (the caller then calls ``forward``).  Not reachable
         through ``model(x)``: the public forward reads ``cov_inv`` live and rounds the same way with and without autograd --
-        this path reads sym(P) from the spec cache, which the sampler refreshes at the top of every ``sample()`` call."""
+        this path reads sym(P) from the spec cache (``fused_spec``: keyed on the matrix's storage and version; see
+        ``invalidate_cache`` for the one kind of write that key cannot see).  Same guards as ``_hip_gradient`` /
+        ``fused_spec_for``: parameters on the state's device, no mixed precision -- and no forward hooks registered, since this
+        path does not go through ``Module.__call__``."""
         d = self.mean.shape[0]
         if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] > 1 and x.shape[1] == d
                 and not torch.is_autocast_enabled() and self._on_matrix_cores(x) and self._is_exactly(GaussianModel)
-                and self.cov_inv.dtype == torch.float32):
+                and self.cov_inv.dtype == torch.float32 and self.cov_inv.device == x.device and self.mean.device == x.device
+                and not getattr(self, "use_mixed_precision", False) and not self._forward_hooks and not self._forward_pre_hooks):
             return None
         spec = self.fused_spec()
         if spec is None:
@@ -316,9 +320,25 @@ class GaussianModel(BaseModel):
                 if n_img:
                     image = torch.empty(n_img // 4, dtype=torch.int32, device=sym.device)
                     _lib.call("ebm_gauss_prec_image_f32", sym.data_ptr(), int(sym.shape[0]), image.data_ptr(), _lib.stream_handle(sym.device))
-            self._sym_cache = (key, sym, image)
+            # the stream the two were built on: a later call on ANOTHER stream must not read them before that work has run
+            built = torch.cuda.Event() if sym.is_cuda else None
+            if built is not None:
+                built.record(torch.cuda.current_stream(sym.device))
+            self._sym_cache = (key, sym, image, built, torch.cuda.current_stream(sym.device) if sym.is_cuda else None)
+        elif self._sym_cache[3] is not None:
+            here = torch.cuda.current_stream(self._sym_cache[1].device)
+            if here != self._sym_cache[4]:
+                here.wait_event(self._sym_cache[3])
         return FusedSpec(_lib.ENERGY_GAUSSIAN, dev0=self.mean.contiguous(), dev1=self._sym_cache[1], aux=self._sym_cache[2],
                          dim=int(self.mean.shape[0]))
+
+    def invalidate_cache(self) -> None:
+        """Drop the symmetrised precision matrix and its pre-split image.  They are rebuilt whenever ``cov_inv``'s storage or
+        version counter changes -- every in-place tensor op, ``load_state_dict``, ``.to()`` -- but a write THROUGH ``.data``
+        (``model.cov_inv.data.copy_(new)``) changes neither, exactly as it hides from autograd: call this after such a write,
+        or the fused kernels keep sampling from the old matrix while ``forward()`` (which reads ``cov_inv`` live) already
+        evaluates the new one."""
+        self._sym_cache = None
 
 
 class GaussianMixtureModel(BaseModel):
@@ -454,7 +474,7 @@ class MLPEnergy(BaseModel):
     -- the trainable energy of the reference's PCD example
     (examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).
 
-    With ``hidden`` 64, 128 or 256 and ``in_dim <= 128`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
+    With ``hidden`` 64 or 128 and ``in_dim <= 128`` on a CUDA device, ``LangevinDynamics`` runs all k steps --
     forward, input-gradient on the matrix cores, update, noise -- in one ``ebm_langevin_chain_f32``
     launch instead of one autograd round trip per step: the reference's benchmark network
     ``Linear(dim, 128) - SiLU - Linear(128, 128) - SiLU - Linear(128, 1)`` at dim 8 / 32 / 128
@@ -465,12 +485,14 @@ class MLPEnergy(BaseModel):
     ``sample()`` call.
     """
 
-    FUSED_HIDDEN = (64, 128, 256)
+    #: hidden widths with fused kernels in the shipped library (256 -- the streamed-weight family, csrc/mlp_stream*.hip -- only in a
+    #: build made with ``make H256=1``; set this to (64, 128, 256) then: the reference's own network is 128 wide, benchmarks/registry.py:370)
+    FUSED_HIDDEN = (64, 128)
     HIP_GRADIENT = True
     FUSED_MAX_DIM = 128
     #: HamiltonianMonteCarlo's transition kernels: hidden width -> widest input (csrc/mlp_wide_hmc.hip: state, momentum
     #: and force ride in registers next to the evaluation's own)
-    HMC_MAX_DIM = {64: 128, 128: 128, 256: 128}
+    HMC_MAX_DIM = {64: 128, 128: 128, 256: 128}  # (256: see FUSED_HIDDEN)
 
     def __init__(self, in_dim: int = 2, hidden: int = 128, *args, **kwargs):
         super().__init__(*args, **kwargs)

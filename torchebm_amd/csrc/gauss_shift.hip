@@ -1,4 +1,4 @@
-// Dense Gaussian Langevin chains at widths that are NOT a multiple of 4 (21 .. 157) on the matrix cores: the SHIFTED-row
+// Dense Gaussian Langevin chains at widths that are NOT a multiple of 4 (17 .. 158) on the matrix cores: the SHIFTED-row
 // instantiations of the matrix-layout body (gauss_mfma_body.h, SH) -- one alignment class of chains per workgroup, the
 // precision matrix staged shifted by that class's offset.  The flat element order, hence the Philox field and every
 // element's update, is that of the flat kernels.
@@ -60,7 +60,7 @@ inline int32_t shift_extent(int32_t dim) { return dim + ((dim & 1) ? 3 : 2); }
 
 }  // namespace
 
-// below 21 the packed rows stay (gauss_pack_factor: the padding of a 32-wide tile outweighs the block-diagonal waste there)
+// below 17 the packed rows stay (gauss_pack_factor: the padding of a 32-wide tile outweighs the block-diagonal waste there)
 bool gauss_shift_supported(int32_t dim) { return dim >= 17 && (dim % 4) != 0 && shift_extent(dim) <= 160; }
 
 int launch_langevin_chain_gauss_shift(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t dim, int32_t k_steps,

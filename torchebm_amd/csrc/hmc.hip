@@ -33,7 +33,7 @@ void launch_gmm32(dim3, hipStream_t, HmcArgs);
 using hmc::HmcArgs;
 
 bool gauss_hmc_mfma_supported(int32_t dim, int32_t mass_kind);
-bool gauss_hmc_shift_supported(int32_t dim);  // gauss_hmc_shift.hip: widths off multiples of 4, 21 .. 157, on shifted rows
+bool gauss_hmc_shift_supported(int32_t dim);  // gauss_hmc_shift.hip: widths off multiples of 4, 17 .. 158, on shifted rows
 int launch_hmc_chain_gauss_shift(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, int32_t, float, const float*, int32_t, double,
                                  const float*, int32_t, float*, uint8_t*, uint32_t*, const float*, const float*, uint64_t, uint64_t,
                                  float*, hipStream_t);
@@ -228,10 +228,14 @@ int launch_hmc_chain(const ebm_energy_t& e, float* x, int64_t n_chains, int32_t 
   const int64_t blocks = blocks_for(n_chains, geo);
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_hmc_chain_f32: too many chains for one launch");
   const dim3 grid((unsigned)blocks);
-  // A mixture that carries an active-column mask: the kernels specialised for mask == 1 go first and return at once
-  // for any other mask; the general kernel behind them returns at once for mask == 1 (each reads the mask itself).
+  // A mixture at dim 32 with K <= 8 and identity mass, one lane per chain: two kernels are launched back to back and each
+  // reads the active-column mask itself -- hmc_ring.hip does the work when the means differ inside ONE four-column slot
+  // (gmm_single_slot: any slot, not only the first) and returns at once otherwise; hmc_gmm32.hip does it for every other
+  // mask and returns at once for a single slot.  (Both index chains with 32 bits: a dim-32 state of 2^32 chains is 512 GiB.)
+  if ((hmc::hmc_slot1_applies(e, geo, mass_kind) || hmc::hmc_gmm32_applies(e, geo, mass_kind)) && n_chains >= (1LL << 32))
+    return fail(EBM_EINVAL, "ebm_hmc_chain_f32: more than 2^32 - 1 chains in one launch");
   if (hmc::hmc_slot1_applies(e, geo, mass_kind)) hmc::launch_slot1(grid, st, a);
-  if (hmc::hmc_gmm32_applies(e, geo, mass_kind)) {  // (returns at once for mask == 1)
+  if (hmc::hmc_gmm32_applies(e, geo, mass_kind)) {  // (returns at once when the mask names a single slot)
     hmc::launch_gmm32(grid, st, a);
     return check_launch("ebm_hmc_chain_f32");
   }

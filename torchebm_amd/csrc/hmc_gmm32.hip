@@ -31,7 +31,7 @@ constexpr int kParkFloats = (NV + 1) * 4 * kBlock;  // parked state [v][thread] 
 
 template <bool DIAG>
 __device__ __forceinline__ void dense_body(const HmcArgs& a) {
-  const uint32_t chain32 = blockIdx.x * (uint32_t)kBlock + threadIdx.x;  // n_chains < 2^31 (hmc_gmm32_applies)
+  const uint32_t chain32 = blockIdx.x * (uint32_t)kBlock + threadIdx.x;  // n_chains < 2^32 (checked by the launcher, hmc.hip)
   const bool active = (int64_t)chain32 < a.n_chains;
   auto chain_now = [&]() -> uint64_t {  // the only per-lane address register that lives through the kernel (hmc_ring.hip)
     uint32_t c = chain32;

@@ -524,8 +524,6 @@ template <int KIND, int G, int NV, bool FULL, int MASS, bool DIAG>
 __global__ __launch_bounds__(kBlock, 2) void hmc_chain_kernel_w2(HmcArgs a) {
   if constexpr (KIND == EBM_ENERGY_GMM && G == 1 && FULL && NV >= 4) {
     if (gmm_is_slot1(a.energy)) {
-      // identity mass: hmc_slot1_kernel (hmc_ring.hip), launched in front of this one, has done the work
-      if constexpr (MASS == 0 && NV == 8) return;
       hmc_chain_body<kGmmSlot1, G, NV, FULL, MASS, DIAG, true>(a);
       return;
     }
@@ -585,7 +583,9 @@ void launch_geo(const Geometry& geo, dim3 grid, size_t smem, hipStream_t st, con
   } else if (geo.G == 2 && geo.NV == 4) {
     EBM_HMC_G(2, 4, true);
   } else if constexpr (KIND == EBM_ENERGY_GMM) {
-    hipLaunchKernelGGL((hmc_chain_kernel_w2<KIND, 1, 8, true, MASS, DIAG>), grid, block, smem, st, a);
+    // (1, 8) is the small-mixture geometry (K <= 8 at dim 32, hmc.hip: hmc_geometry); with identity mass those calls never get
+    // here -- hmc_ring.hip / hmc_gmm32.hip serve them, records included -- so only the massed form is instantiated
+    if constexpr (MASS != 0) hipLaunchKernelGGL((hmc_chain_kernel_w2<KIND, 1, 8, true, MASS, DIAG>), grid, block, smem, st, a);
   } else {
     EBM_HMC_G(1, 8, true);
   }

@@ -54,7 +54,7 @@ __device__ __forceinline__ void slot1_body(const HmcArgs& a, float* const tab, c
   // The lane's chain index is the ONLY per-lane address register that lives through the kernel: every global address
   // is formed from it where it is used (chain_now() hides it from the optimiser, which otherwise hoists row offsets,
   // Philox counters and pointers out of the transition loop -- a dozen 64-bit registers, spilled and reloaded).
-  const uint32_t chain32 = blockIdx.x * (uint32_t)kBlock + threadIdx.x;  // n_chains < 2^31 (hmc_slot1_applies)
+  const uint32_t chain32 = blockIdx.x * (uint32_t)kBlock + threadIdx.x;  // n_chains < 2^32 (checked by the launcher, hmc.hip)
   const bool active = (int64_t)chain32 < a.n_chains;
   auto chain_now = [&]() -> uint64_t {
     uint32_t c = chain32;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kBlock, 4) void hmc_slot1_kernel(HmcArgs a) {
 // match the mask returns at once (a wave-uniform read of the mask: no host read of device memory).
 bool hmc_slot1_applies(const ebm_energy_t& e, const rows::Geometry& geo, int32_t mass_kind) {
   return e.kind == EBM_ENERGY_GMM && e.aux != nullptr && e.n_comp >= 1 && e.n_comp <= 8 && geo.G == 1 && geo.NV == 8 &&
-         geo.full && mass_kind == EBM_MASS_NONE;  // (one lane per chain: the launcher caps the grid below 2^31 chains)
+         geo.full && mass_kind == EBM_MASS_NONE;  // (one lane per chain; the launcher refuses 2^32 chains and more)
 }
 
 // a.diag.partials != nullptr: the records of the lane-group layout (diag::plan over kBlock rows per workgroup)

@@ -30,7 +30,7 @@ namespace {
 int mlp_check(const ebm_energy_t& e, int32_t dim, const char* who, bool hmc) {
   if (!e.dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
   if (hmc ? !mlp_wide_hmc_supported(e.n_comp, dim) : !mlp_wide_supported(e.n_comp, dim))
-    return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64, 128 or 256 and 1 <= dim <= 128 (got %d, %d)", who,
+    return fail(EBM_EDIM, "%s: the fused MLP energy supports hidden width 64 or 128 (256 in a build made with H256=1) and 1 <= dim <= 128 (got %d, %d)", who,
                 e.n_comp, dim);
   return 0;
 }

@@ -34,7 +34,11 @@ using namespace widemlp;
 int launch_mlp_stream(const widemlp::WideArgs& a, int dt, hipStream_t st, const char* who);  // mlp_stream.hip
 
 bool mlp_wide_supported(int32_t hidden, int32_t dim) {
-  return (hidden == 64 || hidden == 128 || hidden == 256) && dim >= 1 && dim <= 128;
+#ifdef EBM_MLP_H256  // (make H256=1: the streamed-weight family of round 2, mlp_stream*.hip -- not in the shipped library since round 5:
+  return (hidden == 64 || hidden == 128 || hidden == 256) && dim >= 1 && dim <= 128;  // the reference's network is 128 wide)
+#else
+  return (hidden == 64 || hidden == 128) && dim >= 1 && dim <= 128;
+#endif
 }
 
 // k_steps == 0: evaluation into energy_out / grad_out; else the k-fused chain
@@ -63,7 +67,9 @@ int launch_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_cha
     default: return launch_one<HTV, 4>(a, st, who);      \
   }
   if (hidden == 64) { EBM_WIDE(2) }
+#ifdef EBM_MLP_H256
   if (hidden == 256) return launch_mlp_stream(a, dt, st, who);
+#endif
   EBM_WIDE(4)
 #undef EBM_WIDE
 }

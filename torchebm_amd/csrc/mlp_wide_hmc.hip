@@ -20,7 +20,11 @@ int launch_hmc_mlp_wide_diag(const widemlp::WideHmcArgs& a, int hidden, int dt, 
 // of the evaluation's own; H = 256 at three or four state tiles runs with 1.4-1.8 KB of scratch per lane)
 bool mlp_wide_hmc_supported(int32_t hidden, int32_t dim) {
   if (dim < 1) return false;
+#ifdef EBM_MLP_H256
   return (hidden == 64 || hidden == 128 || hidden == 256) && dim <= 128;
+#else
+  return (hidden == 64 || hidden == 128) && dim <= 128;
+#endif
 }
 
 int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int64_t n_chains, int32_t dim, int32_t n_mh,
@@ -52,7 +56,11 @@ int launch_hmc_chain_mlp_wide(int32_t hidden, const float* params, float* x, int
   if (hidden == 64) { EBM_WIDE_HMC(2) }
   if (hidden == 128) { EBM_WIDE_HMC(4) }
 #undef EBM_WIDE_HMC
+#ifdef EBM_MLP_H256
   return launch_hmc_mlp_stream(a, dt, st, who);
+#else
+  return fail(EBM_EDIM, "%s: hidden width %d has no transition kernel in this build", who, hidden);
+#endif
 }
 
 }  // namespace ebm
