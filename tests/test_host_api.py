@@ -698,3 +698,45 @@ def test_thin_mlp_training_backward_equals_autograd_cpu():
     torch.testing.assert_close(_tall_gram(a, b), a.t() @ b)
     # the CPU forward of the energy is the plain network (the fast path is for CUDA inputs)
     assert type(m(x).grad_fn).__name__ != "_ThinMLPEnergyBackward"
+
+
+def test_graphed_training_step_host_side_rules():
+    """utils.GraphedTrainingStep on the CPU: refuses to capture (nothing to capture on), `enabled=False` is the plain training loop,
+    the device-coordinate bookkeeping (`_rng.DeviceCoords`) hands out offsets the way `_rng.reserve` advances a generator."""
+    import pytest as _pytest
+
+    from torchebm_amd import _rng
+    from torchebm_amd.utils import GraphedTrainingStep
+
+    torch.manual_seed(0)
+    model = ta.MLPEnergy(2)
+    sampler = ta.LangevinDynamics(model, step_size=0.1)
+    cd = ta.ContrastiveDivergence(model, sampler, k_steps=3, persistent=True, buffer_size=64, init_steps=0, new_sample_ratio=0.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    with _pytest.raises(ValueError, match="CUDA"):
+        GraphedTrainingStep(cd, opt)
+    with _pytest.raises(ValueError, match="contrastive-divergence"):
+        GraphedTrainingStep(model, opt)
+    step = GraphedTrainingStep(cd, opt, enabled=False, generator=torch.Generator().manual_seed(3))
+    x = torch.randn(32, 2)
+    before = [p.detach().clone() for p in model.parameters()]
+    losses = [step(x)[0] for _ in range(3)]
+    assert all(torch.isfinite(l) for l in losses) and step.replays == 0 and step.calls == 3
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    assert cd._write_pos == (3 * 32) % 64
+    # the same three steps by hand
+    torch.manual_seed(0)
+    m2 = ta.MLPEnergy(2)
+    s2 = ta.LangevinDynamics(m2, step_size=0.1)
+    cd2 = ta.ContrastiveDivergence(m2, s2, k_steps=3, persistent=True, buffer_size=64, init_steps=0, new_sample_ratio=0.0)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    g2 = torch.Generator().manual_seed(3)
+    for want in losses:
+        loss, _ = cd2(x, generator=g2)
+        o2.zero_grad()
+        loss.backward()
+        o2.step()
+        assert torch.equal(loss.detach(), want)
+    c = _rng.DeviceCoords(torch.device("cpu"))
+    assert [c.take(1), c.take(20), c.take(5)] == [0, 1, 21] and c.taken == 26
+    assert _rng.DeviceCoords.as_i64((1 << 64) - 1) == -1 and _rng.DeviceCoords.as_i64(5) == 5
