@@ -72,3 +72,9 @@ x1 = torch.cat((xx, torch.ones(N2, 1, device=dev)), 1)
 t("dW1+db1 2n : bmm blocks dz^T [x 1] + sum", lambda: torch.bmm(dzz.view(S, N2 // S, 128).transpose(1, 2), x1.view(S, N2 // S, 3)).sum(0))
 t("db 2n  : dz.sum(0)", lambda: dzz.sum(0))
 t("db 2n  : bmm blocks ones^T dz + sum", lambda: torch.bmm(torch.ones(S, 1, N2 // S, device=dev), dzz.view(S, N2 // S, 128)).sum(0))
+# ---- wider inputs (the reference's benchmark network at dim 8 / 32 / 128): is the first layer's weight gradient slow there too?
+for d in (8, 32, 128):
+    xd = torch.randn(N, d, device=dev)
+    x1d = torch.cat((xd, torch.ones(N, 1, device=dev)), 1)
+    t(f"dW1 d={d}: g.t() @ x", lambda xd=xd: g.t() @ xd)
+    t(f"dW1+db1 d={d}: bmm blocks g^T [x 1] + sum", lambda x1d=x1d: torch.bmm(g.view(32, N // 32, 128).transpose(1, 2), x1d.view(32, N // 32, x1d.shape[1])).sum(0))

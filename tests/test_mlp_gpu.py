@@ -245,7 +245,7 @@ def test_adopted_sequential_takes_the_fused_route_and_trains(cuda_device):
 # ------------------------------------------------------------------------------------------
 # Round 5: the TRAINING forward (parameter gradients only) -- hand-written backward of MLPEnergy.forward
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("in_dim,n", [(2, 65536), (2, 1000), (4, 8192), (1, 4096)])
+@pytest.mark.parametrize("in_dim,n", [(2, 65536), (2, 1000), (4, 8192), (1, 4096), (8, 16384), (32, 65536), (100, 8192)])
 def test_training_forward_parameter_gradients_match_autograd(cuda_device, in_dim, n):
     """MLPEnergy.forward on an input that needs no gradient takes _ThinMLPEnergy (core/energies.py): the same forward ops
     (energies bit-identical to self.net) and parameter gradients formed as row-block batched products instead of K = batch

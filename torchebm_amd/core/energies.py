@@ -527,8 +527,9 @@ class MLPEnergy(BaseModel):
         self.net = net
         return self
 
-    #: widest input for which the parameter gradients of the first layer are formed column by column (see ``forward``)
-    THIN_GRAD_MAX_IN = 4
+    #: widest input for which ``forward`` takes the hand-written parameter-gradient backward (every weight gradient is a
+    #: tall-K product whatever the input width: ``_tall_gram``)
+    THIN_GRAD_MAX_IN = 128
     #: a row's energy does not depend on the other rows of the batch (no batch statistics): a loss may evaluate data and negatives
     #: in one call (losses/cd.py)
     ROWS_INDEPENDENT = True
