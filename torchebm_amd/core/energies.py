@@ -469,6 +469,66 @@ class _ThinMLPEnergy(torch.autograd.Function):
         return None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
 
 
+def _gram_rows(a_t: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a_t @ b`` for ``a_t`` given HIDDEN-major ``[p, n]`` (rows contiguous, row stride >= n) and ``b`` ``[n, q]``: the same
+    row-block product as ``_tall_gram`` for the layout ``ebm_mlp_backward_acts_f32`` stores its activations in."""
+    p, n = a_t.shape
+    blocks = 32
+    if n >= 8192 and n % blocks == 0:
+        nb = n // blocks
+        return torch.bmm(a_t.unflatten(1, (blocks, nb)).permute(1, 0, 2), b.view(blocks, nb, -1)).sum(0)
+    return a_t @ b
+
+
+class _FusedMLPTraining(torch.autograd.Function):
+    """The training forward / backward of ``MLPEnergy`` through the HIP library (round 5): energies from the forward pass of the
+    fused evaluation (``ebm_energy_grad_f32`` with no gradient asked for), and in the backward ONE launch that re-evaluates the
+    network, runs the seed-scaled backward through it on the matrix cores and stores the four activations the parameter gradients
+    are made of (``ebm_mlp_backward_acts_f32``) -- where autograd's graph of the same step writes and re-reads some forty
+    ``[n, H]`` arrays.  The parameter gradients are then small-output products over K = n (``_gram_rows``).  Energies and
+    gradients are those of the kernel: fp32-accurate (split-bf16 contractions, fp32 accumulation), not bit-identical to
+    ``self.net`` -- the tolerance tier of every other use of this energy's kernels."""
+
+    @staticmethod
+    def forward(ctx, x, packed, hidden, *params):
+        n, dim = x.shape
+        spec = FusedSpec(_lib.ENERGY_MLP, n_comp=hidden, dev0=packed, langevin_only=True, dim=dim)
+        energy = torch.empty(n, dtype=torch.float32, device=x.device)
+        if n:
+            _lib.call("ebm_energy_grad_f32", spec.to_c(), x.data_ptr(), n, dim, energy.data_ptr(), None, _lib.stream_handle(x.device))
+        ctx.save_for_backward(x, packed)
+        ctx.hidden = hidden
+        return energy
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ge):
+        x, packed = ctx.saved_tensors
+        n, dim = x.shape
+        hidden = ctx.hidden
+        n_pad = (n + 127) // 128 * 128
+        acts = torch.empty(4, hidden, n_pad, dtype=torch.float32, device=x.device)
+        seed = torch.zeros(n_pad, dtype=torch.float32, device=x.device)
+        seed[:n] = ge
+        x1 = torch.zeros(n_pad, dim + 1, dtype=torch.float32, device=x.device)  # [x 1]: the bias column rides along
+        x1[:n, :dim] = x
+        x1[:n, dim] = 1.0
+        spec = FusedSpec(_lib.ENERGY_MLP, n_comp=hidden, dev0=packed, langevin_only=True, dim=dim)
+        if n:
+            _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, seed.data_ptr(), None, None, acts.data_ptr(),
+                      _lib.stream_handle(x.device))
+        else:
+            acts.zero_()
+        h1, h2, d2, d1 = acts[0], acts[1], acts[2], acts[3]  # [H, n_pad]; the padding columns carry seed 0 (d2 = d1 = 0 there)
+        g1 = _gram_rows(d1, x1)
+        d_w1, d_b1 = g1[:, :dim], g1[:, dim]
+        d_w2 = _gram_rows(d2, h1.t())
+        d_b2 = d2.sum(dim=1)
+        d_w3 = _gram_rows(h2, seed.unsqueeze(1)).t()
+        d_b3 = ge.sum().reshape(1)
+        return None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
+
+
 class MLPEnergy(BaseModel):
     r"""Two-hidden-layer SiLU MLP energy ``E(x) = w_3^\top \mathrm{silu}(W_2\,\mathrm{silu}(W_1 x + b_1) + b_2) + b_3``
     -- the trainable energy of the reference's PCD example
@@ -530,6 +590,11 @@ class MLPEnergy(BaseModel):
     #: widest input for which ``forward`` takes the hand-written parameter-gradient backward (every weight gradient is a
     #: tall-K product whatever the input width: ``_tall_gram``)
     THIN_GRAD_MAX_IN = 128
+    #: the training forward / backward (inputs that need no gradient) through the HIP library where the shape has the kernels
+    #: (hidden 64 / 128, in_dim <= 64): one launch each way instead of autograd's forty passes over ``[n, H]`` arrays; energies and
+    #: parameter gradients are then the KERNEL's (fp32-accurate, not bit-identical to ``self.net``).  False: torch ops forward
+    #: (bit-identical to ``self.net``) with the hand-written torch backward (``_ThinMLPEnergy``).
+    fused_training = True
     #: a row's energy does not depend on the other rows of the batch (no batch statistics): a loss may evaluate data and negatives
     #: in one call (losses/cd.py)
     ROWS_INDEPENDENT = True
@@ -546,7 +611,13 @@ class MLPEnergy(BaseModel):
         if (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not x.requires_grad
                 and self.in_dim <= self.THIN_GRAD_MAX_IN and self._plain_net() and not torch.is_autocast_enabled()):
             n = self.net
-            return _ThinMLPEnergy.apply(x, n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
+            params = (n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
+            if (self.fused_training and self.hidden in (64, 128) and self.in_dim <= 64 and self.hidden in self.FUSED_HIDDEN
+                    and x.is_contiguous() and x.data_ptr() % 16 == 0 and _lib.is_built() and all(p.is_cuda for p in params)):
+                with torch.no_grad():
+                    packed = torch.cat([p.reshape(-1) for p in params])
+                return _FusedMLPTraining.apply(x, packed, int(self.hidden), *params)
+            return _ThinMLPEnergy.apply(x, *params)
         return self.net(x).squeeze(-1)
 
     def _plain_net(self) -> bool:

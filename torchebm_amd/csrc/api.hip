@@ -61,6 +61,7 @@ int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t,
                               const uint64_t* rng_dev = nullptr);
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
+int launch_mlp_backward_acts(int32_t, const float*, const float*, int64_t, int32_t, const float*, float*, float*, float*, hipStream_t, const char*);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 size_t mlp_w1_image_bytes(int32_t hidden, int32_t dim);  // mlp_wide_slab.hip
@@ -586,6 +587,21 @@ int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_ch
     if (!force_rows) return launch_energy_grad_gauss_big(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
   }
   return launch_energy_grad(*energy, x, n_chains, dim, energy_out, grad_out, (hipStream_t)stream);
+}
+
+int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim, const float* seed,
+                              float* energy_out, float* grad_out, float* acts, void* stream) {
+  const char* who = "ebm_mlp_backward_acts_f32";
+  if (int r = check_energy(energy, dim, who)) return r;
+  if (int r = check_state(x, n_chains, dim, who)) return r;
+  if (energy->kind != EBM_ENERGY_MLP) return fail(EBM_EKIND, "%s: EBM_ENERGY_MLP only", who);
+  if (!energy->dev0) return fail(EBM_EINVAL, "%s: packed MLP parameters pointer is NULL", who);
+  if ((energy->n_comp != 64 && energy->n_comp != 128) || dim < 1 || dim > 64)
+    return fail(EBM_EDIM, "%s: hidden width 64 or 128 and dim <= 64 (got %d, %d)", who, energy->n_comp, dim);
+  if (n_chains == 0) return 0;
+  if (!acts || !aligned16(acts) || (grad_out && !aligned16(grad_out))) return fail(EBM_EINVAL, "%s: acts / grad_out must be 16-byte aligned pointers", who);
+  if (((n_chains + 127) / 128 * 128) * 20 >= (1LL << 32)) return fail(EBM_EINVAL, "%s: too many rows for 32-bit lane offsets", who);
+  return launch_mlp_backward_acts(energy->n_comp, energy->dev0, x, n_chains, dim, seed, energy_out, grad_out, acts, (hipStream_t)stream, who);
 }
 
 int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, float* mean_out,

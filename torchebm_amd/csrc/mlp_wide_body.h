@@ -58,6 +58,9 @@ struct WideArgs {
   int64_t diag_blocks;   // records per kept step = ceil(n_chains / 32)
   const char* w1_image;  // MODE 3: the pre-split W1 image (ebm_mlp_w1_image_f32), or null
   const uint64_t* rng_dev;  // ebm_langevin_chain_dev_f32: {seed, step} in device memory (step0 is then an offset from it), or null
+  const float* seed;        // FAST = 3 (ebm_mlp_backward_acts_f32): dL/dE[n] of a training backward, or null (= 1)
+  float* acts;              // FAST = 3: the four activation arrays [4][H][act_stride] (h1 | h2 | d2 | d1), hidden-major
+  int64_t act_stride;       // ... their row length: n_chains rounded up to whole workgroups of 128 chains (no lane, no wave needs masking)
 };
 
 extern __shared__ __attribute__((aligned(16))) float wide_smem[];
@@ -240,7 +243,15 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
   for (int step = 0; step < n_evals; ++step) {
     EBM_STAMP();
     constexpr bool eval_block_cuts = FAST != 0;
+    constexpr bool eval_store_acts = FAST == 3;  // the backward pass of a training step: seed-scaled, activations stored (eval_b16.inc)
+    [[maybe_unused]] float* act_base = a.acts;
+    [[maybe_unused]] size_t act_row_bytes = (size_t)a.act_stride * sizeof(float);
+    if constexpr (FAST == 3) asm volatile("" : "+s"(act_base), "+s"(act_row_bytes));  // (formed at their stores, not hoisted)
+    [[maybe_unused]] const uint32_t act_lane = (uint32_t)(((size_t)sample + 4u * (size_t)h * (size_t)a.act_stride) * sizeof(float));
+    [[maybe_unused]] const float act_seed = (FAST == 3 && active && a.seed) ? a.seed[sample] : (FAST == 3 && !active ? 0.0f : 1.0f);
     bool eval_energy_only = FAST != 1 && a.k_steps > 0 && step >= a.k_steps;  // the extra evaluation of a kept last step
+    // (evaluation only, and nothing but the energy asked for: the forward pass alone -- the energies of a training forward)
+    if (FAST == 0 && a.k_steps == 0 && !a.grad_out) eval_energy_only = true;
     // FAST: never -- but left as an opaque (always false) scalar: the branch it guards cuts the evaluation's one basic block in
     // two, and without that cut the scheduler stretches live ranges until 160 registers spill (19 with it)
     if constexpr (FAST == 1) {
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
     }
     if (FAST != 1 && a.k_steps > 0 && step >= a.k_steps) break;  // the extra evaluation of a kept last step
 
-    if (FAST == 0 && a.k_steps == 0) {  // evaluation only
+    if ((FAST == 0 || FAST == 3) && a.k_steps == 0) {  // evaluation only
       if (active) {
         if (a.energy_out && h == 0) a.energy_out[sample] = energy;
         if (a.grad_out) {
@@ -392,6 +403,13 @@ int launch_fast_diag(const WideArgs& a, hipStream_t st, const char* who);
   template <> int launch_fast_diag<HTV, DTV>(const WideArgs& a, hipStream_t st, const char* who);
 EBM_FAST_DECL(2, 1) EBM_FAST_DECL(2, 2) EBM_FAST_DECL(2, 3) EBM_FAST_DECL(2, 4) EBM_FAST_DECL(4, 1) EBM_FAST_DECL(4, 2)
 #undef EBM_FAST_DECL
+// FAST = 3 (mlp_wide_train.hip): the evaluation as the backward pass of a training step (seed-scaled, activations stored)
+template <int HT, int DT>
+int launch_train(const WideArgs& a, hipStream_t st, const char* who);
+template <> int launch_train<2, 1>(const WideArgs& a, hipStream_t st, const char* who);
+template <> int launch_train<2, 2>(const WideArgs& a, hipStream_t st, const char* who);
+template <> int launch_train<4, 1>(const WideArgs& a, hipStream_t st, const char* who);
+template <> int launch_train<4, 2>(const WideArgs& a, hipStream_t st, const char* who);
 // MODE 3 (mlp_wide_slab.hip): H = 128, dim 65 .. 128 with the W1 image at hand; fast = 0 general, 1 plain call, 2 records
 template <int DT>
 int launch_slab(const WideArgs& a, int fast, hipStream_t st, const char* who);
