@@ -333,8 +333,8 @@ EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int6
  * backward through it with the per-row seed dL/dE (seed[n]; NULL = 1) on the matrix cores, everything on-chip, and stores the
  * four activations the parameter gradients are made of, HIDDEN-major:
  *   acts = float[4][H][n_pad],  n_pad = n rounded up to a multiple of 128 (columns n .. n_pad - 1 are written too -- h1 / h2 of an
- *   all-zero row, d2 = d1 = 0: ignore them, or let them ride along in the products: they contribute nothing):  [0] h1 = silu(W1 x + b1)   [1] h2 = silu(W2 h1 + b2)   [2] d2 = seed w3 silu'(a2)   [3] d1 = (W2^T d2) silu'(a1)
- * from which   dW2 = d2 h1^T,  db2 = d2 1,  dW1 = d1 x,  db1 = d1 1,  dw3 = h2 seed,  db3 = sum seed   are small-output products over
+ *   all-zero row, d2 = d1 = 0: ignore them, or let them ride along in the products: they contribute nothing):  [0] h1 = silu(W1 x + b1)   [1] seed h2 = seed silu(W2 h1 + b2)   [2] d2 = seed w3 silu'(a2)   [3] d1 = (W2^T d2) silu'(a1)
+ * from which   dW2 = d2 h1^T,  db2 = d2 1,  dW1 = d1 x,  db1 = d1 1,  dw3 = (seed h2) 1 (a row sum),  db3 = sum seed   are small-output products over
  * K = n (torchebm_amd/core/energies.py: _ThinMLPEnergy).  energy_out (optional): E(x)[n];  grad_out (optional): seed dE/dx [n, dim].
  * The autograd graph of the same step materialises a1, h1, a2, h2 and their gradients -- some forty passes over [n, H] arrays;
  * this is one.  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  The matching forward is ebm_energy_grad_f32 with

@@ -78,3 +78,16 @@ for d in (8, 32, 128):
     x1d = torch.cat((xd, torch.ones(N, 1, device=dev)), 1)
     t(f"dW1 d={d}: g.t() @ x", lambda xd=xd: g.t() @ xd)
     t(f"dW1+db1 d={d}: bmm blocks g^T [x 1] + sum", lambda x1d=x1d: torch.bmm(g.view(32, N // 32, 128).transpose(1, 2), x1d.view(32, N // 32, x1d.shape[1])).sum(0))
+# ---- the HIDDEN-major layout of ebm_mlp_backward_acts_f32 ([H, n] rows contiguous): products with thin right-hand sides
+A = torch.randn(128, N2, device=dev)
+B2 = torch.randn(128, N2, device=dev)
+v1 = torch.randn(N2, device=dev)
+x3 = torch.randn(N2, 3, device=dev)
+t("[H,n] : A.sum(1)", lambda: A.sum(1))
+t("[H,n] : torch.mv(A, v)", lambda: torch.mv(A, v1))
+t("[H,n] : (A * v).sum(1)", lambda: (A * v1).sum(1))
+t("[H,n] : A @ x3  (q = 3)", lambda: A @ x3)
+t("[H,n] : bmm blocks A @ x3", lambda: torch.bmm(A.unflatten(1, (32, N2 // 32)).permute(1, 0, 2), x3.view(32, N2 // 32, 3)).sum(0))
+t("[H,n] : 3 x torch.mv(A, x3[:, c])", lambda: [torch.mv(A, x3[:, c].contiguous()) for c in range(3)])
+t("[H,n] : A @ B^T (dW2)", lambda: A @ B2.t())
+t("[H,n] : bmm blocks A @ B^T", lambda: torch.bmm(A.unflatten(1, (32, N2 // 32)).permute(1, 0, 2), B2.t().view(32, N2 // 32, 128) if False else B2.unflatten(1, (32, N2 // 32)).permute(1, 2, 0)).sum(0))

@@ -508,23 +508,28 @@ class _FusedMLPTraining(torch.autograd.Function):
         hidden = ctx.hidden
         n_pad = (n + 127) // 128 * 128
         acts = torch.empty(4, hidden, n_pad, dtype=torch.float32, device=x.device)
-        seed = torch.zeros(n_pad, dtype=torch.float32, device=x.device)
-        seed[:n] = ge
-        x1 = torch.zeros(n_pad, dim + 1, dtype=torch.float32, device=x.device)  # [x 1]: the bias column rides along
-        x1[:n, :dim] = x
-        x1[:n, dim] = 1.0
+        ones = x.new_ones(n, 1)
+        if n_pad == n:  # (whole workgroups: nothing to pad)
+            seed = ge.contiguous()
+            x1 = torch.cat((x, ones), dim=1)  # [x 1]: the bias column rides along
+        else:
+            seed = torch.zeros(n_pad, dtype=torch.float32, device=x.device)
+            seed[:n] = ge
+            x1 = torch.zeros(n_pad, dim + 1, dtype=torch.float32, device=x.device)
+            x1[:n] = torch.cat((x, ones), dim=1)
         spec = FusedSpec(_lib.ENERGY_MLP, n_comp=hidden, dev0=packed, langevin_only=True, dim=dim)
         if n:
             _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, seed.data_ptr(), None, None, acts.data_ptr(),
                       _lib.stream_handle(x.device))
         else:
             acts.zero_()
-        h1, h2, d2, d1 = acts[0], acts[1], acts[2], acts[3]  # [H, n_pad]; the padding columns carry seed 0 (d2 = d1 = 0 there)
+        # [H, n_pad] each; the padding columns carry seed 0 (seed h2 = d2 = d1 = 0 there; h1 is that of an all-zero row, times 0)
+        h1, sh2, d2, d1 = acts[0], acts[1], acts[2], acts[3]
         g1 = _gram_rows(d1, x1)
         d_w1, d_b1 = g1[:, :dim], g1[:, dim]
         d_w2 = _gram_rows(d2, h1.t())
         d_b2 = d2.sum(dim=1)
-        d_w3 = _gram_rows(h2, seed.unsqueeze(1)).t()
+        d_w3 = sh2.sum(dim=1).unsqueeze(0)
         d_b3 = ge.sum().reshape(1)
         return None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
 

@@ -201,6 +201,10 @@ template <int HT, int DT, int MODE, int FAST = 0>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
 #include "mlp_wide_setup.inc"
 
+  // Evaluation-only launches (k_steps == 0: energies / gradients, the training backward) come back here for their next tile of
+  // 32 chains per wave: the grid is one workgroup per CU and each sweeps the batch, so the weight images are staged 256 times per
+  // launch instead of once per 128 rows (staging was 40 of the 65 us a forward pass over 131 072 rows took).
+tile_again:
   // the state in the C/D layout: xr[td][r] = x[sample][32 td + row_of(r, h)], zero beyond dim
   float xr[DT][16];
 #pragma unroll
@@ -280,7 +284,18 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
             }
         }
       }
-      if constexpr (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no slab transfer outlives its workgroup)
+      if constexpr (SLAB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no slab transfer outlives its workgroup)
+      } else {
+        // the wave's next tile (no barrier in the evaluation of these modes: every wave sweeps on its own); FAST = 3 also visits
+        // the padding columns of the activation arrays
+        sample += (int64_t)gridDim.x * (kBlock / 64) * 32;
+        const int64_t extent = FAST == 3 ? a.act_stride : a.n_chains;
+        if (__builtin_amdgcn_readfirstlane((int)((sample - m) < extent))) {
+          active = sample < a.n_chains;
+          goto tile_again;
+        }
+      }
       return;
     }
 
@@ -387,8 +402,13 @@ int launch_variant(const WideArgs& a, hipStream_t st, const char* who) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wide_chain_kernel<HT, DT, MODE, FAST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  const int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
+  int64_t blocks = ceil_div64(a.n_chains, 32 * (kBlock / 64));
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "%s: too many chains for one launch", who);
+  if (a.k_steps == 0 && MODE != 3) {  // evaluation only: one workgroup per CU sweeps the batch (the kernel's tile loop)
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && blocks > cus) blocks = cus;
+  }
   hipLaunchKernelGGL((mlp_wide_chain_kernel<HT, DT, MODE, FAST>), dim3((unsigned)blocks), dim3(kBlock), smem, st, a);
   return check_launch(who);
 }
