@@ -416,15 +416,21 @@ def measure_traffic(args, kernel_substring="langevin_chain_lean_kernel"):
 
 
 def timed(fn, reps, warm, device):
-    """Wall seconds per call, device-synchronised around the timed block."""
+    """Wall seconds per call, device-synchronised around each timed block: the MEDIAN of three blocks of ceil(reps / 2) calls.
+    (One block is at the mercy of whatever else the box does in those milliseconds: a round-5 run printed config 3 at 2.6 ms per call
+    between two runs at 1.15 -- same binary, same kernel time.  The headline's own timed region is exactly K steps and is not this.)"""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize(device)
-    return (time.perf_counter() - t0) / reps
+    per_block = max(1, (reps + 1) // 2)
+    blocks = []
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(per_block):
+            fn()
+        torch.cuda.synchronize(device)
+        blocks.append((time.perf_counter() - t0) / per_block)
+    return sorted(blocks)[1]
 
 
 def kernel_ms_of(entry, fn, reps, device):
