@@ -740,3 +740,29 @@ def test_graphed_training_step_host_side_rules():
     c = _rng.DeviceCoords(torch.device("cpu"))
     assert [c.take(1), c.take(20), c.take(5)] == [0, 1, 21] and c.taken == 26
     assert _rng.DeviceCoords.as_i64((1 << 64) - 1) == -1 and _rng.DeviceCoords.as_i64(5) == 5
+
+
+def test_paired_cd_loss_equals_the_op_by_op_form():
+    """losses.cd._PairedCDLoss (the analytic value + gradient of the CD loss on the energies of one model call) against the
+    reference's op-by-op form under autograd (contrastive_divergence.py:141-155), the non-finite guard included."""
+    from torchebm_amd.losses.cd import _PairedCDLoss
+
+    torch.manual_seed(1)
+    for reg in (0.0, 0.01):
+        e = torch.randn(600, dtype=torch.float64, requires_grad=True)
+        n = 300
+        got = _PairedCDLoss.apply(e, n, reg)
+        (g_got,) = torch.autograd.grad(got * 1.7, e)
+        e2 = e.view(2, n)
+        want = e2[0].mean() - e2[1].mean() + reg * ((e2[0] ** 2).mean() + (e2[1] ** 2).mean())
+        (g_want,) = torch.autograd.grad(want * 1.7, e)
+        torch.testing.assert_close(got, want, rtol=1e-14, atol=1e-14)
+        torch.testing.assert_close(g_got, g_want, rtol=1e-13, atol=1e-16)
+    assert torch.autograd.gradcheck(lambda t: _PairedCDLoss.apply(t, 4, 0.1), torch.randn(8, dtype=torch.float64, requires_grad=True))
+    bad = torch.randn(10)
+    bad[2] = float("nan")
+    bad.requires_grad_(True)
+    out = _PairedCDLoss.apply(bad, 5, 0.01)
+    assert out.item() == pytest.approx(0.1)
+    (gb,) = torch.autograd.grad(out, bad)
+    assert (gb[torch.arange(10) != 2] == 0).all()  # the constant sends no gradient (the NaN row's own entry is NaN * 0, as in autograd)
