@@ -687,6 +687,8 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
 
     def wide(hidden, kind, n=65536, dim=32):
         # the same network at another hidden width (256: weights streamed from L2), Langevin k = 20 or HMC L = 10, 10 transitions
+        if hidden not in ta.MLPEnergy.FUSED_HIDDEN:
+            return {"skipped": f"hidden {hidden} is not in this build (make H256=1; MLPEnergy.FUSED_HIDDEN = {ta.MLPEnergy.FUSED_HIDDEN})"}
         torch.manual_seed(0)
         m = ta.MLPEnergy(dim, hidden, device=device)
         x0 = torch.randn(n, dim, device=device)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 6
+#define EBM_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -342,6 +342,24 @@ EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int6
  */
 EBM_API int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,
                                       const float* seed, float* energy_out, float* grad_out, float* acts, void* stream);
+
+/*
+ * ABI 7 -- the parameter gradients themselves, from the planes ebm_mlp_backward_acts_f32 stored (acts = float[4][H][n_pad], n_pad = n_rows
+ * rounded up to a multiple of 128) and the rows x[n_rows, dim] they were made from, in ONE pass over the planes (the products above as six
+ * library launches read them 2.2 times):
+ *   grads_out = float[H dim + H + H H + H + H + 1], the packed parameter order of EBM_ENERGY_MLP:  dW1 | db1 | dW2 | db2 | dw3 | db3.
+ * seed (optional, [n_rows]): the per-row dL/dE applied HERE, on load -- for planes stored with seed = NULL, so that one
+ * ebm_mlp_backward_acts_f32 launch in the forward pass of a training step (energies + unit-seed planes) serves the backward pass too
+ * (d2, d1 and the h2 row sum are linear in the seed); NULL = the planes are already scaled (db3 is then n_rows).
+ * The products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation); every workgroup writes one partial record into
+ * `work` and a second kernel adds the records in a fixed order: same inputs, same bits, whatever the scheduling.
+ * work: device float[work_floats], work_floats >= ebm_mlp_param_grads_work_f32(hidden, dim, n_rows) (a per-device figure: one record per
+ * CU; 0 for an unsupported shape).  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  Reference: what autograd does for
+ * loss.backward() through the nn.Linear weights (torchebm/losses/contrastive_divergence.py:128-155).
+ */
+EBM_API int64_t ebm_mlp_param_grads_work_f32(int32_t hidden, int32_t dim, int64_t n_rows);
+EBM_API int ebm_mlp_param_grads_f32(const float* acts, int64_t n_rows, int32_t hidden, const float* x, int32_t dim, const float* seed,
+                                    float* work, int64_t work_floats, float* grads_out, void* stream);
 
 /* Column statistics for the sampler diagnostics (samplers/langevin_dynamics.py:173-185):
  * mean[dim], biased var[dim] clamped to [1e-10, 1e10].  `work` = device double[2*dim + 1], zeroed once by

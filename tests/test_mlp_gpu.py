@@ -323,3 +323,47 @@ def test_mlp_backward_acts_entry_against_torch(cuda_device):
     aa = torch.empty(4, 128, 128, device=cuda_device)
     with pytest.raises(RuntimeError, match="dim <= 64"):
         _lib.call("ebm_mlp_backward_acts_f32", wide.to_c(), xx.data_ptr(), 64, 100, None, None, None, aa.data_ptr(), _lib.stream_handle(cuda_device))
+
+
+@pytest.mark.parametrize("hidden,in_dim,n", [(128, 2, 65536), (128, 2, 1000), (64, 20, 333), (128, 64, 4097), (64, 33, 8192), (128, 7, 32), (128, 32, 131072)])
+@pytest.mark.parametrize("seeded", [True, False])
+def test_mlp_param_grads_entry_against_fp64_products(cuda_device, hidden, in_dim, n, seeded):
+    """ebm_mlp_param_grads_f32 through the C ABI (ABI 7): every parameter gradient from the stored planes in one pass -- fp32 MFMA
+    products over K = n, partial records added in a fixed order.  Referee: the same products in fp64 from the same planes; bar: the
+    fp32 result within 4 x what torch's own fp32 matmul makes of it (and 2e-6 relative to the largest entry), two launches bit-equal."""
+    g = torch.Generator(device=cuda_device).manual_seed(hidden + in_dim + n)
+    n_pad = (n + 127) // 128 * 128
+    acts = torch.randn(4, hidden, n_pad, device=cuda_device, generator=g)
+    acts[1:, :, n:] = 0  # what ebm_mlp_backward_acts_f32 leaves in the padding columns (h1 there is finite, d2 = d1 = seed h2 = 0)
+    x = torch.randn(n, in_dim, device=cuda_device, generator=g)
+    seed = torch.randn(n, device=cuda_device, generator=g) if seeded else None
+    lib = _lib.lib()
+    wf = int(lib.ebm_mlp_param_grads_work_f32(hidden, in_dim, n))
+    assert wf > 0 and int(lib.ebm_mlp_param_grads_work_f32(256, in_dim, n)) == 0
+    work = torch.empty(wf, device=cuda_device)
+    sizes = (hidden * in_dim, hidden, hidden * hidden, hidden, hidden, 1)
+    outs = []
+    for _ in range(2):
+        out = torch.full((sum(sizes),), float("nan"), device=cuda_device)
+        work.normal_()  # the workspace needs no initialisation
+        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), in_dim, seed.data_ptr() if seeded else None,
+                  work.data_ptr(), wf, out.data_ptr(), _lib.stream_handle(cuda_device))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    s32 = seed if seeded else torch.ones(n, device=cuda_device)
+    def products(dt):
+        h1, h2, d2, d1 = (acts[i, :, :n].to(dt) for i in range(4))
+        sd = s32.to(dt)
+        return ((d1 * sd) @ x.to(dt), (d1 * sd).sum(1), (d2 * sd) @ h1.t(), (d2 * sd).sum(1), (h2 * sd).sum(1), sd.sum().reshape(1))
+    got = outs[0].split(sizes)
+    for name, gk, r32, r64 in zip(("dW1", "db1", "dW2", "db2", "dw3", "db3"), got, products(torch.float32), products(torch.float64)):
+        scale = r64.abs().max().item() + 1e-30
+        err = (gk.double() - r64.reshape(-1)).abs().max().item() / scale
+        err32 = (r32.double() - r64).abs().max().item() / scale
+        assert err <= max(4 * err32, 2e-6), (name, err, err32)
+    with pytest.raises(ValueError, match="workspace"):
+        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), in_dim, None, work.data_ptr(), wf - 1, outs[0].data_ptr(),
+                  _lib.stream_handle(cuda_device))
+    with pytest.raises(RuntimeError, match="dim <= 64"):
+        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), 100, None, work.data_ptr(), wf, outs[0].data_ptr(),
+                  _lib.stream_handle(cuda_device))

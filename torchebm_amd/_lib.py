@@ -18,7 +18,7 @@ import torch  # imported first on purpose: it loads the HIP runtime (libamdhip64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # energy kinds / enums: keep in sync with include/ebm_hip.h
 ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM, ENERGY_MLP = 0, 1, 2, 3, 4
@@ -51,6 +51,8 @@ EXPORTS = (
     "ebm_pcd_scatter_dev_f32",
     "ebm_energy_grad_f32",
     "ebm_mlp_backward_acts_f32",
+    "ebm_mlp_param_grads_work_f32",
+    "ebm_mlp_param_grads_f32",
     "ebm_chain_stats_f32",
     "ebm_noise_fill_f32",
     "ebm_noise_fill_dev_f32",
@@ -128,6 +130,8 @@ _PROTOTYPES = {
     "ebm_pcd_scatter_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_mlp_backward_acts_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "ebm_mlp_param_grads_work_f32": (C.c_int64, [_i32, _i32, _i64]),
+    "ebm_mlp_param_grads_f32": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i64, _p, _p]),
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),
     "ebm_noise_fill_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _u64, _p]),

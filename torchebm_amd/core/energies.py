@@ -481,57 +481,56 @@ def _gram_rows(a_t: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 class _FusedMLPTraining(torch.autograd.Function):
-    """The training forward / backward of ``MLPEnergy`` through the HIP library (round 5): energies from the forward pass of the
-    fused evaluation (``ebm_energy_grad_f32`` with no gradient asked for), and in the backward ONE launch that re-evaluates the
-    network, runs the seed-scaled backward through it on the matrix cores and stores the four activations the parameter gradients
-    are made of (``ebm_mlp_backward_acts_f32``) -- where autograd's graph of the same step writes and re-reads some forty
-    ``[n, H]`` arrays.  The parameter gradients are then small-output products over K = n (``_gram_rows``).  Energies and
-    gradients are those of the kernel: fp32-accurate (split-bf16 contractions, fp32 accumulation), not bit-identical to
-    ``self.net`` -- the tolerance tier of every other use of this energy's kernels."""
+    """The training forward / backward of ``MLPEnergy`` through the HIP library (round 5).
+
+    Forward, when a parameter gradient will be asked for: ONE launch (``ebm_mlp_backward_acts_f32`` with a unit seed) evaluates the
+    network, writes the energies, runs the backward through the network on the matrix cores and stores the four activation planes the
+    parameter gradients are made of -- where autograd's graph of the same step writes and re-reads some forty ``[n, H]`` arrays.
+    Backward: ONE pass over those planes (``ebm_mlp_param_grads_f32``: fp32 MFMA products over K = n, the per-row seed ``dL/dE``
+    applied on load -- the planes are linear in it --, partial records added in a fixed order) yields every parameter gradient.
+    Without a gradient to prepare (``no_grad``, frozen parameters) the forward is the energy-only evaluation
+    (``ebm_energy_grad_f32``).  Energies and gradients are those of the kernels: fp32-accurate (split-bf16 contractions with fp32
+    accumulation in the network, exact fp32 products in the gradient pass), not bit-identical to ``self.net`` -- the tolerance tier
+    of every other use of this energy's kernels."""
 
     @staticmethod
     def forward(ctx, x, packed, hidden, *params):
         n, dim = x.shape
         spec = FusedSpec(_lib.ENERGY_MLP, n_comp=hidden, dev0=packed, langevin_only=True, dim=dim)
         energy = torch.empty(n, dtype=torch.float32, device=x.device)
-        if n:
-            _lib.call("ebm_energy_grad_f32", spec.to_c(), x.data_ptr(), n, dim, energy.data_ptr(), None, _lib.stream_handle(x.device))
-        ctx.save_for_backward(x, packed)
         ctx.hidden = hidden
+        ctx.with_planes = bool(n) and any(ctx.needs_input_grad[3:])
+        if ctx.with_planes:
+            n_pad = (n + 127) // 128 * 128
+            acts = torch.empty(4, hidden, n_pad, dtype=torch.float32, device=x.device)
+            _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, None, energy.data_ptr(), None, acts.data_ptr(),
+                      _lib.stream_handle(x.device))
+            ctx.save_for_backward(x, acts)
+        else:
+            if n:
+                _lib.call("ebm_energy_grad_f32", spec.to_c(), x.data_ptr(), n, dim, energy.data_ptr(), None, _lib.stream_handle(x.device))
+            ctx.save_for_backward(x)
         return energy
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, ge):
-        x, packed = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         n, dim = x.shape
         hidden = ctx.hidden
-        n_pad = (n + 127) // 128 * 128
-        acts = torch.empty(4, hidden, n_pad, dtype=torch.float32, device=x.device)
-        ones = x.new_ones(n, 1)
-        if n_pad == n:  # (whole workgroups: nothing to pad)
+        sizes = (hidden * dim, hidden, hidden * hidden, hidden, hidden, 1)
+        if not ctx.with_planes:  # (an empty batch: every gradient is zero)
+            flat = x.new_zeros(sum(sizes))
+        else:
+            acts = ctx.saved_tensors[1]
+            work_floats = int(_lib.lib().ebm_mlp_param_grads_work_f32(hidden, dim, n))
+            work = torch.empty(work_floats, dtype=torch.float32, device=x.device)
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
             seed = ge.contiguous()
-            x1 = torch.cat((x, ones), dim=1)  # [x 1]: the bias column rides along
-        else:
-            seed = torch.zeros(n_pad, dtype=torch.float32, device=x.device)
-            seed[:n] = ge
-            x1 = torch.zeros(n_pad, dim + 1, dtype=torch.float32, device=x.device)
-            x1[:n] = torch.cat((x, ones), dim=1)
-        spec = FusedSpec(_lib.ENERGY_MLP, n_comp=hidden, dev0=packed, langevin_only=True, dim=dim)
-        if n:
-            _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, seed.data_ptr(), None, None, acts.data_ptr(),
-                      _lib.stream_handle(x.device))
-        else:
-            acts.zero_()
-        # [H, n_pad] each; the padding columns carry seed 0 (seed h2 = d2 = d1 = 0 there; h1 is that of an all-zero row, times 0)
-        h1, sh2, d2, d1 = acts[0], acts[1], acts[2], acts[3]
-        g1 = _gram_rows(d1, x1)
-        d_w1, d_b1 = g1[:, :dim], g1[:, dim]
-        d_w2 = _gram_rows(d2, h1.t())
-        d_b2 = d2.sum(dim=1)
-        d_w3 = sh2.sum(dim=1).unsqueeze(0)
-        d_b3 = ge.sum().reshape(1)
-        return None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
+            _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), dim, seed.data_ptr(), work.data_ptr(), work_floats,
+                      flat.data_ptr(), _lib.stream_handle(x.device))
+        d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = flat.split(sizes)
+        return None, None, None, d_w1.view(hidden, dim), d_b1, d_w2.view(hidden, hidden), d_b2, d_w3.view(1, hidden), d_b3
 
 
 class MLPEnergy(BaseModel):
