@@ -331,21 +331,24 @@ EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int6
  * for loss.backward() through the energies of torchebm/losses/contrastive_divergence.py:128-155; the network of
  * examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).  One launch evaluates the network on x[n, dim] and runs the
  * backward through it with the per-row seed dL/dE (seed[n]; NULL = 1) on the matrix cores, everything on-chip, and stores the
- * four activations the parameter gradients are made of, HIDDEN-major:
- *   acts = float[4][H][n_pad],  n_pad = n rounded up to a multiple of 128 (columns n .. n_pad - 1 are written too -- h1 / h2 of an
- *   all-zero row, d2 = d1 = 0: ignore them, or let them ride along in the products: they contribute nothing):  [0] h1 = silu(W1 x + b1)   [1] seed h2 = seed silu(W2 h1 + b2)   [2] d2 = seed w3 silu'(a2)   [3] d1 = (W2^T d2) silu'(a1)
+ * four activations the parameter gradients are made of, in TILES of 32 rows, hidden-major within a tile:
+ *   acts = float[n_pad / 32][4][H][32],  n_pad = n rounded up to a multiple of 128 (tile t = rows 32 t .. 32 t + 31, one contiguous
+ *   block of 16 H floats -- what one wavefront writes and what one step of ebm_mlp_param_grads_f32 reads; rows n .. n_pad - 1 are
+ *   written too -- h1 of an all-zero row, the others 0: they contribute nothing to the products):
+ *   [.][0] h1 = silu(W1 x + b1)   [.][1] seed h2 = seed silu(W2 h1 + b2)   [.][2] d2 = seed w3 silu'(a2)   [.][3] d1 = (W2^T d2) silu'(a1)
  * from which   dW2 = d2 h1^T,  db2 = d2 1,  dW1 = d1 x,  db1 = d1 1,  dw3 = (seed h2) 1 (a row sum),  db3 = sum seed   are small-output products over
- * K = n (torchebm_amd/core/energies.py: _ThinMLPEnergy).  energy_out (optional): E(x)[n];  grad_out (optional): seed dE/dx [n, dim].
+ * K = n (ebm_mlp_param_grads_f32 below makes them in one pass).  energy_out (optional): E(x)[n];  grad_out (optional): seed dE/dx [n, dim].
  * The autograd graph of the same step materialises a1, h1, a2, h2 and their gradients -- some forty passes over [n, H] arrays;
- * this is one.  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  The matching forward is ebm_energy_grad_f32 with
- * grad_out = NULL, which then runs the forward pass only.
+ * this is one.  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  With seed = NULL and energy_out set it IS the training
+ * forward (energies + unit-seed planes; the seed is then applied by ebm_mlp_param_grads_f32); without a gradient to prepare the
+ * forward is ebm_energy_grad_f32 with grad_out = NULL, which runs the forward pass only.
  */
 EBM_API int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,
                                       const float* seed, float* energy_out, float* grad_out, float* acts, void* stream);
 
 /*
- * ABI 7 -- the parameter gradients themselves, from the planes ebm_mlp_backward_acts_f32 stored (acts = float[4][H][n_pad], n_pad = n_rows
- * rounded up to a multiple of 128) and the rows x[n_rows, dim] they were made from, in ONE pass over the planes (the products above as six
+ * ABI 7 -- the parameter gradients themselves, from the planes ebm_mlp_backward_acts_f32 stored (acts = float[n_pad / 32][4][H][32], n_pad =
+ * n_rows rounded up to a multiple of 128; ABI 6 had them as [4][H][n_pad]) and the rows x[n_rows, dim] they were made from, in ONE pass over the planes (the products above as six
  * library launches read them 2.2 times):
  *   grads_out = float[H dim + H + H H + H + H + 1], the packed parameter order of EBM_ENERGY_MLP:  dW1 | db1 | dW2 | db2 | dw3 | db3.
  * seed (optional, [n_rows]): the per-row dL/dE applied HERE, on load -- for planes stored with seed = NULL, so that one

@@ -299,11 +299,12 @@ def test_mlp_backward_acts_entry_against_torch(cuda_device):
         x = torch.randn(n, in_dim, device=cuda_device)
         seed = torch.randn(n, device=cuda_device)
         n_pad = (n + 127) // 128 * 128
-        acts = torch.full((4, hidden, n_pad), float("nan"), device=cuda_device)
+        tiles = torch.full((n_pad // 32, 4, hidden, 32), float("nan"), device=cuda_device)  # tiles of 32 rows: [4][H][32] each
         e = torch.empty(n, device=cuda_device)
         g = torch.empty(n, in_dim, device=cuda_device)
         _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, in_dim, seed.data_ptr(), e.data_ptr(), g.data_ptr(),
-                  acts.data_ptr(), _lib.stream_handle(cuda_device))
+                  tiles.data_ptr(), _lib.stream_handle(cuda_device))
+        acts = tiles.permute(1, 2, 0, 3).reshape(4, hidden, n_pad)
         net = model.net
         xr = x.clone().requires_grad_(True)
         a1 = net[0](xr); h1 = net[1](a1); a2 = net[2](h1); h2 = net[3](a2); en = net[4](h2).squeeze(-1)  # noqa: E702
@@ -335,6 +336,7 @@ def test_mlp_param_grads_entry_against_fp64_products(cuda_device, hidden, in_dim
     n_pad = (n + 127) // 128 * 128
     acts = torch.randn(4, hidden, n_pad, device=cuda_device, generator=g)
     acts[1:, :, n:] = 0  # what ebm_mlp_backward_acts_f32 leaves in the padding columns (h1 there is finite, d2 = d1 = seed h2 = 0)
+    tiles = acts.view(4, hidden, n_pad // 32, 32).permute(2, 0, 1, 3).contiguous()  # the layout of the entry: tiles of 32 rows
     x = torch.randn(n, in_dim, device=cuda_device, generator=g)
     seed = torch.randn(n, device=cuda_device, generator=g) if seeded else None
     lib = _lib.lib()
@@ -346,7 +348,7 @@ def test_mlp_param_grads_entry_against_fp64_products(cuda_device, hidden, in_dim
     for _ in range(2):
         out = torch.full((sum(sizes),), float("nan"), device=cuda_device)
         work.normal_()  # the workspace needs no initialisation
-        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), in_dim, seed.data_ptr() if seeded else None,
+        _lib.call("ebm_mlp_param_grads_f32", tiles.data_ptr(), n, hidden, x.data_ptr(), in_dim, seed.data_ptr() if seeded else None,
                   work.data_ptr(), wf, out.data_ptr(), _lib.stream_handle(cuda_device))
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
@@ -362,8 +364,8 @@ def test_mlp_param_grads_entry_against_fp64_products(cuda_device, hidden, in_dim
         err32 = (r32.double() - r64).abs().max().item() / scale
         assert err <= max(4 * err32, 2e-6), (name, err, err32)
     with pytest.raises(ValueError, match="workspace"):
-        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), in_dim, None, work.data_ptr(), wf - 1, outs[0].data_ptr(),
+        _lib.call("ebm_mlp_param_grads_f32", tiles.data_ptr(), n, hidden, x.data_ptr(), in_dim, None, work.data_ptr(), wf - 1, outs[0].data_ptr(),
                   _lib.stream_handle(cuda_device))
     with pytest.raises(RuntimeError, match="dim <= 64"):
-        _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), 100, None, work.data_ptr(), wf, outs[0].data_ptr(),
+        _lib.call("ebm_mlp_param_grads_f32", tiles.data_ptr(), n, hidden, x.data_ptr(), 100, None, work.data_ptr(), wf, outs[0].data_ptr(),
                   _lib.stream_handle(cuda_device))

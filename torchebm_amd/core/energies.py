@@ -502,7 +502,7 @@ class _FusedMLPTraining(torch.autograd.Function):
         ctx.with_planes = bool(n) and any(ctx.needs_input_grad[3:])
         if ctx.with_planes:
             n_pad = (n + 127) // 128 * 128
-            acts = torch.empty(4, hidden, n_pad, dtype=torch.float32, device=x.device)
+            acts = torch.empty(n_pad // 32, 4, hidden, 32, dtype=torch.float32, device=x.device)  # tiles of 32 rows: h1 | h2 | d2 | d1
             _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, None, energy.data_ptr(), None, acts.data_ptr(),
                       _lib.stream_handle(x.device))
             ctx.save_for_backward(x, acts)

@@ -8,8 +8,9 @@
 // are small-output products over K = n rows (131 072 for BASELINE config 5): 4 GFLOP next to 268 MB of planes -- an HBM-bound pass
 // if the planes are read ONCE.  The library route reads them 2.2 times in six launches (two row-block batched GEMMs at 2.5 TB/s,
 // four row reductions); this kernel reads every plane once:
-//   * one workgroup per CU walks chunks of KC = 32 rows (columns of the hidden-major planes): global -> registers (seed scaling,
-//     the row sums) -> LDS, two stages, one barrier per chunk;
+//   * one workgroup per CU walks chunks of KC = 32 rows -- one tile of the planes, a contiguous 16 H-float block: every load
+//     instruction of a wave is 1 KB of consecutive addresses --: global -> registers (seed scaling, the row sums) -> LDS, two
+//     stages, one barrier per chunk;
 //   * the products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): wave w owns a quadrant of dW2 and row
 //     tile w of dW1; both operands of a K-step come from the same [row][k] walk over an LDS tile (one ds_read_b128 = four K-steps);
 //     a K-step's two K indices are 8 t + e and 8 t + 4 + e -- any pairing works as long as both operands use it;
@@ -21,13 +22,14 @@ namespace ebm {
 namespace mlpgrads {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // (a native vector: HIP's float4 struct is copied through private memory)
 constexpr int kThreads = 256, KC = 32, PITCH = KC + 4;
 
 template <int HT, int DT>
 struct Shape {
   static constexpr int H = 32 * HT, DP = 32 * DT, XP = DP + 1;
   static constexpr int plane_floats = H * PITCH;
-  static constexpr int stage_floats = 3 * plane_floats + KC * XP;
+  static constexpr int stage_floats = 3 * plane_floats + KC * XP + 4;  // (+ 4: where the x staging slots a thread does not have land)
   static constexpr size_t smem_bytes = (size_t)2 * stage_floats * sizeof(float);
   // one partial record: W1 [H][DP] | b1 [H] | W2 [H][H] | b2 [H] | w3 [H] | b3
   static constexpr int off_w1 = 0, off_b1 = H * DP, off_w2 = off_b1 + H, off_b2 = off_w2 + H * H, off_w3 = off_b2 + H, off_b3 = off_w3 + H;
@@ -35,7 +37,7 @@ struct Shape {
 };
 
 struct Args {
-  const float* acts;   // [4][H][stride]: h1 | h2 | d2 | d1
+  const float* acts;   // [stride / 32][4][H][32]: h1 | h2 | d2 | d1 of 32 rows each, hidden-major (ebm_mlp_backward_acts_f32)
   int64_t stride;      // n rounded up to a multiple of 128
   const float* x;      // [n][dim]
   int64_t n;
@@ -60,64 +62,68 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
   const auto stage = [](int i) { return grads_smem + i * S::stage_floats; };
 
   // x staging: element idx = t + 256 i of the chunk's [KC][dim] block (fixed per thread)
-  int xrow[XI], xcol[XI];
+  int xrow[XI], xcol[XI], xoff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int idx = t + kThreads * i;
     xrow[i] = idx < KC * dim ? idx / dim : -1;
     xcol[i] = idx < KC * dim ? idx - (idx / dim) * dim : 0;
+    xoff[i] = 3 * S::plane_floats + (xrow[i] >= 0 ? xrow[i] * XP + xcol[i] : KC * XP);  // (no slot: the spare word behind the block)
   }
   for (int i = t; i < KC * XP; i += kThreads) {  // columns dim .. DP - 1 stay zero
     stage(0)[3 * S::plane_floats + i] = 0.0f;
     stage(1)[3 * S::plane_floats + i] = 0.0f;
   }
 
-  float4 rh1[HT], rh2[HT], rd2[HT], rd1[HT], rs;
-  float xr[XI];
+  struct Regs {  // one chunk on its way from global memory to LDS
+    f32x4 h1[HT], h2[HT], d2[HT], d1[HT], s;
+    float x[XI];
+  };
+  Regs ra, rb;  // two chunks in flight: a chunk is requested two products ahead of the one that needs it (HBM latency under load
+                // is longer than one chunk's 5 k cycles of MFMAs)
   float sum_d2[HT], sum_d1[HT], sum_h2[HT], sum_seed = 0.0f;
 #pragma unroll
   for (int j = 0; j < HT; ++j) sum_d2[j] = sum_d1[j] = sum_h2[j] = 0.0f;
 
-  const auto load_chunk = [&](int64_t c) __attribute__((always_inline)) {
+  const auto load_chunk = [&](Regs& q, int64_t c) __attribute__((always_inline)) {
     const int64_t col = c * KC + 4 * c4;
-    const float* p = a.acts + (int64_t)r0 * a.stride + col;
+    // chunk c = tile c of the planes: one contiguous [4][H][32] block; thread t reads floats 4 t .. 4 t + 3 of every 32-row slab
+    const float* p = a.acts + c * (int64_t)(4 * H * KC) + 4 * t;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
-      const int64_t row = (int64_t)32 * j * a.stride;
-      rh1[j] = *reinterpret_cast<const float4*>(p + row);
-      rh2[j] = *reinterpret_cast<const float4*>(p + row + (int64_t)H * a.stride);
-      rd2[j] = *reinterpret_cast<const float4*>(p + row + (int64_t)2 * H * a.stride);
-      rd1[j] = *reinterpret_cast<const float4*>(p + row + (int64_t)3 * H * a.stride);
+      q.h1[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC);
+      q.h2[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + H * KC);
+      q.d2[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + 2 * H * KC);
+      q.d1[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + 3 * H * KC);
     }
     // (rows n .. stride - 1: the planes hold zeros there, and the seed is zero too -- db3 counts real rows only)
-    rs.x = col + 0 < a.n ? (a.seed ? a.seed[col + 0] : 1.0f) : 0.0f;
-    rs.y = col + 1 < a.n ? (a.seed ? a.seed[col + 1] : 1.0f) : 0.0f;
-    rs.z = col + 2 < a.n ? (a.seed ? a.seed[col + 2] : 1.0f) : 0.0f;
-    rs.w = col + 3 < a.n ? (a.seed ? a.seed[col + 3] : 1.0f) : 0.0f;
+    q.s.x = col + 0 < a.n ? (a.seed ? a.seed[col + 0] : 1.0f) : 0.0f;
+    q.s.y = col + 1 < a.n ? (a.seed ? a.seed[col + 1] : 1.0f) : 0.0f;
+    q.s.z = col + 2 < a.n ? (a.seed ? a.seed[col + 2] : 1.0f) : 0.0f;
+    q.s.w = col + 3 < a.n ? (a.seed ? a.seed[col + 3] : 1.0f) : 0.0f;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int64_t k = c * KC + xrow[i];
-      xr[i] = (xrow[i] >= 0 && k < a.n) ? a.x[k * dim + xcol[i]] : 0.0f;
+      q.x[i] = (xrow[i] >= 0 && k < a.n) ? a.x[k * dim + xcol[i]] : 0.0f;
     }
   };
-  const auto mul4 = [](float4 v, float4 s) { return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w); };
-  const auto add4 = [](float4 v) { return (v.x + v.y) + (v.z + v.w); };
-  const auto store_chunk = [&](float* st) __attribute__((always_inline)) {
-    if (r0 == 0) sum_seed += add4(rs);
+  const auto add4 = [](f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
+  // the register -> LDS pass of a chunk: seed scaling, the row sums, the three planes the products read
+  const auto store_chunk = [&](const Regs& q, float* st) __attribute__((always_inline)) {
+    sum_seed += r0 == 0 ? add4(q.s) : 0.0f;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
-      const float4 d2 = mul4(rd2[j], rs), d1 = mul4(rd1[j], rs), h2 = mul4(rh2[j], rs);
+      const f32x4 d2 = q.d2[j] * q.s, d1 = q.d1[j] * q.s, h2 = q.h2[j] * q.s;
       sum_d2[j] += add4(d2);
       sum_d1[j] += add4(d1);
       sum_h2[j] += add4(h2);
       const int o = (r0 + 32 * j) * PITCH + 4 * c4;
-      *reinterpret_cast<float4*>(st + o) = d2;
-      *reinterpret_cast<float4*>(st + S::plane_floats + o) = rh1[j];
-      *reinterpret_cast<float4*>(st + 2 * S::plane_floats + o) = d1;
+      *reinterpret_cast<f32x4*>(st + o) = d2;
+      *reinterpret_cast<f32x4*>(st + S::plane_floats + o) = q.h1[j];
+      *reinterpret_cast<f32x4*>(st + 2 * S::plane_floats + o) = d1;
     }
 #pragma unroll
-    for (int i = 0; i < XI; ++i)
-      if (xrow[i] >= 0) st[3 * S::plane_floats + xrow[i] * XP + xcol[i]] = xr[i];
+    for (int i = 0; i < XI; ++i) st[xoff[i]] = q.x[i];
   };
 
   f32x16 acc2[RT][CT], acc1[DT];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
 #pragma unroll
   for (int j = 0; j < DT; ++j) acc1[j] = (f32x16)(0.0f);
   const int rt0 = (w >> 1) * RT, ct0 = (w & 1) * CT;
-  const bool has_w1 = w < HT;  // row tile w of dW1
+  const bool has_w1 = HT >= kThreads / 64 || w < HT;  // row tile w of dW1 (H = 128: every wave has one)
 
   const auto compute = [&](const float* st) __attribute__((always_inline)) {
     const float* d2s = st;
@@ -138,15 +144,15 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
 #pragma unroll
     for (int tt = 0; tt < KC / 8; ++tt) {
       const int ko = 8 * tt + 4 * hf;
-      float4 av[RT], bv[CT];
+      f32x4 av[RT], bv[CT];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const float4*>(d2s + (32 * (rt0 + i) + r) * PITCH + ko);
+      for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const f32x4*>(d2s + (32 * (rt0 + i) + r) * PITCH + ko);
 #pragma unroll
-      for (int j = 0; j < CT; ++j) bv[j] = *reinterpret_cast<const float4*>(h1s + (32 * (ct0 + j) + r) * PITCH + ko);
-      float4 a1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int j = 0; j < CT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(h1s + (32 * (ct0 + j) + r) * PITCH + ko);
+      f32x4 a1 = (f32x4)(0.0f);
       float xb[4][DT];
       if (has_w1) {
-        a1 = *reinterpret_cast<const float4*>(d1s + (32 * w + r) * PITCH + ko);
+        a1 = *reinterpret_cast<const f32x4*>(d1s + (32 * w + r) * PITCH + ko);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -158,29 +164,47 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
         for (int i = 0; i < RT; ++i)
 #pragma unroll
           for (int j = 0; j < CT; ++j)
-            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float*)&av[i])[e], ((const float*)&bv[j])[e], acc2[i][j], 0, 0, 0);
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc2[i][j], 0, 0, 0);
         if (has_w1) {
 #pragma unroll
-          for (int j = 0; j < DT; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float*)&a1)[e], xb[e][j], acc1[j], 0, 0, 0);
+          for (int j = 0; j < DT; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], xb[e][j], acc1[j], 0, 0, 0);
         }
       }
     }
   };
 
-  int64_t c = blockIdx.x;
-  load_chunk(c);
+  // chunk k of this workgroup = tile blockIdx.x + k G; it travels in ra (k even) / rb (k odd) and is multiplied out of stage k & 1
+  const int64_t nk = (a.chunks - blockIdx.x + G - 1) / G;
+  const auto chunk_of = [&](int64_t k) { return (int64_t)blockIdx.x + k * G; };
+  load_chunk(ra, chunk_of(0));
+  if (nk > 1) load_chunk(rb, chunk_of(1));
   __syncthreads();  // the zeroed x columns
-  store_chunk(stage(0));
+  store_chunk(ra, stage(0));
   __syncthreads();
-  for (int it = 0;; ++it) {
-    const int64_t cn = c + G;
-    const bool more = cn < a.chunks;
-    if (more) load_chunk(cn);
-    compute(stage(it & 1));
-    if (!more) break;
-    store_chunk(stage((it + 1) & 1));
+  // (Measured, MI355X, n = 131 072: 83 - 87 us = 3.2 TB/s of plane reads, the same with one chunk in flight per thread or two, with
+  //  the register -> LDS pass behind the products or sliced between them: the pass is bound by memory, and the memory system is also
+  //  still writing back the 268 MB of planes the launch before this one produced.)
+  for (int64_t k = 0;; k += 2) {  // stage 0 holds chunk k; rb holds chunk k + 1, if there is one
+    if (k + 1 >= nk) {
+      compute(stage(0));
+      break;
+    }
+    if (k + 2 < nk) load_chunk(ra, chunk_of(k + 2));  // in flight behind the products of two chunks ...
+    __builtin_amdgcn_sched_barrier(0);
+    compute(stage(0));
+    __builtin_amdgcn_sched_barrier(0);  // ... and first touched after them
+    store_chunk(rb, stage(1));
     __syncthreads();
-    c = cn;
+    if (k + 2 >= nk) {
+      compute(stage(1));
+      break;
+    }
+    if (k + 3 < nk) load_chunk(rb, chunk_of(k + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(stage(1));
+    __builtin_amdgcn_sched_barrier(0);
+    store_chunk(ra, stage(0));
+    __syncthreads();
   }
 
   // ---- this workgroup's partial record

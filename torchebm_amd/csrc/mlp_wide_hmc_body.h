@@ -172,7 +172,6 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
       }
       constexpr bool eval_energy_only = false, eval_block_cuts = false, eval_store_acts = false;
       [[maybe_unused]] float* const act_base = nullptr;
-      [[maybe_unused]] constexpr size_t act_row_bytes = 0;
       [[maybe_unused]] constexpr uint32_t act_lane = 0;
       [[maybe_unused]] constexpr float act_seed = 1.0f;
       [[maybe_unused]] constexpr bool slab_more = true;  // MODE 3: every evaluation asks for the next one's first slab (drained at the end)
