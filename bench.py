@@ -605,9 +605,21 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         tg = timed(lambda: gstep(data), reps=30, warm=5, device=device)
         res["whole_step_hip_graph"] = {
             "training_steps_per_s": 1 / tg, "ms_per_step": tg * 1e3, "replays": gstep.replays,
-            "what": "GraphedTrainingStep: one graph launch per training step (fused MLP chain inside); bit-identical to the eager "
-                    "loop for the same seed when the step has no torch-side draws (tests/test_graphed_step_gpu.py)",
+            "what": "GraphedTrainingStep: one graph launch per training step (start points with the exploration noise, fused MLP chain, "
+                    "FIFO write, loss, forward + activation planes, parameter gradients in one pass, Adam); bit-identical to the eager "
+                    "loop for the same seed (tests/test_graphed_step_gpu.py)",
         }
+        # the same step with torch's single-kernel Adam (fused=True: an implementation choice of the optimiser, outside this package)
+        try:
+            torch.manual_seed(0)
+            fm = ta.MLPEnergy(2, device=device)
+            fsm = ta.LangevinDynamics(fm, step_size=0.1, noise_scale=1.0, device=device)
+            fcd = ta.ContrastiveDivergence(fm, fsm, k_steps=k, persistent=True, buffer_size=n, init_steps=0, device=device)
+            fstep = GraphedTrainingStep(fcd, torch.optim.Adam(fm.parameters(), lr=1e-3, capturable=True, fused=True))
+            tfa = timed(lambda: fstep(data), reps=30, warm=5, device=device)
+            res["whole_step_hip_graph"]["with_torch_fused_adam"] = {"training_steps_per_s": 1 / tfa, "ms_per_step": tfa * 1e3}
+        except Exception as exc:  # (an optimiser option of the installed torch, not of this package)
+            res["whole_step_hip_graph"]["with_torch_fused_adam"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         res["cpu_baseline"] = cpu_config5() if cpu else None
         res["value"] = 1 / (t_graph if default_graph else t_eager)
         res["chain_steps_per_s"] = n * k * res["value"]

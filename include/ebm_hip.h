@@ -321,6 +321,21 @@ EBM_API int ebm_pcd_gather_dev_f32(const float* buffer, int64_t buffer_size, int
 EBM_API int ebm_pcd_scatter_dev_f32(float* buffer, int64_t buffer_size, int32_t dim, const float* samples,
                                     int64_t batch, const int64_t* write_pos, void* stream);
 
+/*
+ * ABI 7 -- the chain starts of a persistent-CD step in ONE launch: the stratified gather of ebm_pcd_gather_f32 (row i of out = buffer
+ * row i stride + U_i, U_i uniform in [0, stride)) AND the reference's exploration noise on a random subset of exactly n_noise rows
+ * (core/base_loss.py:316-332: start_points[randperm(batch)[:n_new]] += 0.01 randn; n_noise = max(1, int(batch new_sample_ratio)),
+ * noise_scale = 0.01 there).  The subset is { i : pi(i) < n_noise } for a keyed pseudo-random bijection pi of [0, batch) (six-round
+ * Feistel network on ceil(log2 batch) bits with cycle walking; round keys from the Philox field): every subset of that size
+ * (pseudo-)equally likely, as randperm's prefix is -- no sort, no index list, no torch-side draw, so the step replays from a HIP
+ * graph with the same numbers as the eager loop.  Consumes THREE steps of the field: step (offsets, as the gather), step + 1 (round
+ * keys: groups 0, 1), step + 2 (the normals, element e of out).  rng_state (optional): {seed, step0} in device memory, `step` is then
+ * an offset from step0 and `seed` is ignored (the _dev form of the other entries).  batch < 2^31.  n_noise = 0: the plain gather.
+ */
+EBM_API int ebm_pcd_start_points_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch,
+                                     int64_t stride, int64_t n_noise, float noise_scale, uint64_t seed, uint64_t step,
+                                     const uint64_t* rng_state, void* stream);
+
 /* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
  * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */
 EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains,

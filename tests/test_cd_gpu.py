@@ -6,6 +6,8 @@ kernel drew (materialised with ebm_noise_fill_f32); the CD loss then agrees too.
 
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 from torch import nn
@@ -162,3 +164,77 @@ def test_pcd_loss_uses_the_buffer_kernels(cuda_device):
     assert pcd._write_pos == (5 * 64) % 256 and pcd.buffer_ptr.item() == pcd._write_pos
     assert torch.equal(pcd.replay_buffer[:64], neg)  # the last batch landed at rows 0..63 after the wrap
     assert torch.isfinite(loss)
+
+
+# ------------------------------------------------------------------------------------------
+# Round 5 (ABI 7): the chain starts with the exploration noise in ONE launch -- ebm_pcd_start_points_f32
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cap,batch,dim,n_noise", [(5000, 1000, 3, 50), (65536, 65536, 2, 3276), (4096, 1000, 1, 1), (777, 259, 5, 259),
+                                                   (64, 3, 2, 1), (1 << 20, 1 << 17, 2, 6553), (100, 1, 4, 1), (4096, 1024, 7, 0)])
+def test_pcd_start_points_equal_the_oracle(cuda_device, cap, batch, dim, n_noise):
+    """Against the numpy restatement (oracle/pcd.py): the gathered rows and the noisy subset bit for bit (integer work), the noise
+    itself to a few ulps of the normals (hardware log / sin / cos), and the device-coordinate form equal to the by-value form."""
+    from oracle import pcd as oracle_pcd
+
+    g = torch.Generator().manual_seed(cap + batch)
+    buf = torch.randn(cap, dim, generator=g)
+    buf_d = buf.to(cuda_device)
+    stride, seed, step = cap // batch, 0x1234567 + cap, 40 + batch
+    out = torch.empty(batch, dim, device=cuda_device)
+    _lib.call("ebm_pcd_start_points_f32", buf_d.data_ptr(), cap, dim, out.data_ptr(), batch, stride, n_noise, 0.01, seed, step, None,
+              _lib.stream_handle(cuda_device))
+    want, rows, noisy = oracle_pcd.start_points(buf.numpy(), batch, stride, n_noise, 0.01, seed, step)
+    assert int(noisy.sum()) == n_noise
+    got = out.cpu().numpy()
+    clean = torch.empty(batch, dim, device=cuda_device)
+    rows_d = torch.empty(batch, dtype=torch.int64, device=cuda_device)
+    _lib.call("ebm_pcd_gather_f32", buf_d.data_ptr(), cap, dim, clean.data_ptr(), batch, stride, None, rows_d.data_ptr(), seed, step,
+              _lib.stream_handle(cuda_device))
+    assert np.array_equal(rows_d.cpu().numpy(), rows)  # the same stratified rows as the plain gather at the same step
+    changed = (got != clean.cpu().numpy()).any(axis=1)
+    assert np.array_equal(changed | ~noisy, np.ones(batch, dtype=bool)) and not (changed & ~noisy).any()  # exactly the oracle's subset
+    assert np.array_equal(got[~noisy], want[~noisy])
+    np.testing.assert_allclose(got[noisy], want[noisy], rtol=0, atol=0.01 * 4e-6 * 8)  # the normals: a few fp32 ulps of |z| <= ~6
+    # device-resident coordinates: {seed, step0} + offset
+    rng = torch.tensor([seed, step - 7], dtype=torch.int64, device=cuda_device)
+    out_dev = torch.empty_like(out)
+    _lib.call("ebm_pcd_start_points_f32", buf_d.data_ptr(), cap, dim, out_dev.data_ptr(), batch, stride, n_noise, 0.01, 0, 7, rng.data_ptr(),
+              _lib.stream_handle(cuda_device))
+    assert torch.equal(out_dev, out)
+
+
+def test_pcd_start_points_subset_is_uniform_over_rows_and_steps(cuda_device):
+    """The LAW of the reference's ``randperm(batch)[:n_new]`` (core/base_loss.py:318-321): every row equally likely (chi-square over rows
+    across 400 steps), pairs of rows independent up to the fixed subset size (adjacent and far pairs: co-selection rate n(n-1)/(b(b-1))),
+    the noise N(0, 0.01^2) (KS), and a different subset at every step."""
+    import scipy.stats as st
+
+    cap = batch = 2048
+    dim, n_noise, steps = 2, 205, 400
+    buf = torch.zeros(cap, dim, device=cuda_device)
+    out = torch.empty(batch, dim, device=cuda_device)
+    hits = np.zeros(batch)
+    pair_adj = pair_far = 0
+    noise = []
+    prev = None
+    for s in range(steps):
+        _lib.call("ebm_pcd_start_points_f32", buf.data_ptr(), cap, dim, out.data_ptr(), batch, 1, n_noise, 0.01, 99, 3 * s, None,
+                  _lib.stream_handle(cuda_device))
+        o = out.cpu().numpy()
+        sel = (o != 0).any(axis=1)
+        assert sel.sum() == n_noise
+        assert prev is None or (sel != prev).any()
+        prev = sel
+        hits += sel
+        pair_adj += (sel[:-1] & sel[1:]).sum()
+        pair_far += (sel[: batch // 2] & sel[batch // 2:]).sum()
+        if s < 40:
+            noise.append(o[sel].ravel() / 0.01)
+    p = n_noise / batch
+    chi2 = ((hits - steps * p) ** 2 / (steps * p * (1 - p))).sum()  # ~ chi-square(batch - 1) (the fixed subset size costs one degree)
+    assert st.chi2.sf(chi2, batch - 1) > 1e-4 and st.chi2.cdf(chi2, batch - 1) > 1e-4, chi2
+    pp = n_noise * (n_noise - 1) / (batch * (batch - 1))
+    for count, n_pairs in ((pair_adj, (batch - 1) * steps), (pair_far, batch // 2 * steps)):
+        z = (count - n_pairs * pp) / np.sqrt(n_pairs * pp * (1 - pp))
+        assert abs(z) < 4.5, (count, n_pairs * pp, z)
+    assert st.kstest(np.concatenate(noise), "norm").pvalue > 1e-4

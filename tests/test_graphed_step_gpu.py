@@ -40,9 +40,12 @@ def _run(step, data, steps, keep=(0, 2, 3, 17, 49)):
     return torch.stack(losses), negs
 
 
+@pytest.mark.parametrize("ratio", [0.0, 0.05])
 @pytest.mark.parametrize("n,buffer_size", [(4096, 8192), (4096, 4096), (1000, 5000)])
-def test_graphed_step_equals_the_eager_loop(cuda_device, n, buffer_size):
-    """No torch-side draw in the step (new_sample_ratio = 0): identical losses, negatives, weights, generator, FIFO position.
+def test_graphed_step_equals_the_eager_loop(cuda_device, n, buffer_size, ratio):
+    """No torch-side draw in the step: identical losses, negatives, weights, generator, FIFO position -- with the loss's default
+    exploration noise too (new_sample_ratio = 0.05: the random subset and its normals come from ebm_pcd_start_points_f32, i.e. from
+    the kernels' own field, since ABI 7).
     buffer = 2 n: stratified gather with in-kernel offsets + FIFO scatter through the device pointer; buffer = n: whole-buffer
     overwrite; buffer = 5 n with n off the workgroup size: the FIFO wraps ten times in 50 steps.
     The eager loop runs to its end first: EAGER steps of a second Adam(capturable=True) between the replays of a captured one
@@ -50,10 +53,10 @@ def test_graphed_step_equals_the_eager_loop(cuda_device, n, buffer_size):
     this package's kernels."""
     k, steps = 5, 50
     data = two_moons(n, 0.05, seed=0, device=cuda_device)
-    m_e, cd_e, _, g_e, eager = _setup(cuda_device, n, k, buffer_size, 0.0, enabled=False)
+    m_e, cd_e, _, g_e, eager = _setup(cuda_device, n, k, buffer_size, ratio, enabled=False)
     losses_e, negs_e = _run(eager, data, steps)
     torch.cuda.synchronize()
-    m_g, cd_g, _, g_g, graphed = _setup(cuda_device, n, k, buffer_size, 0.0, enabled=True)
+    m_g, cd_g, _, g_g, graphed = _setup(cuda_device, n, k, buffer_size, ratio, enabled=True)
     c0 = hip_calls("ebm_langevin_chain_dev_f32")
     losses_g, negs_g = _run(graphed, data, steps)
     assert graphed.replays == steps - graphed.eager_steps
@@ -94,12 +97,13 @@ def test_graphed_step_follows_a_reseeded_generator_and_an_eager_call_in_between(
 
 
 def test_graphed_step_with_torch_side_draws_in_the_step(cuda_device):
-    """new_sample_ratio > 0 (the loss's default 0.05): randperm / randn run inside the graph on torch's graph-safe generator
-    state -- the same law at other offsets than the eager loop's, so the bar is statistical: finite, training moves, fresh
-    draws on every replay, and the kernels' coordinates advance past torch's share too."""
+    """A torch-side draw in the step (add_noise_to_real: randn_like on the data) runs inside the graph on torch's graph-safe
+    generator state -- the same law at other offsets than the eager loop's, so the bar is statistical: finite, training moves,
+    fresh draws on every replay, and the kernels' coordinates advance past torch's share too."""
     n, k = 65536, 20
     data = two_moons(n, 0.05, seed=0, device=cuda_device)
     model, cd, opt, gen, step = _setup(cuda_device, n, k, n, 0.05)
+    cd.add_noise_to_real = True
     negs, losses = [], []
     for i in range(8):
         off0 = gen.get_offset()
@@ -110,7 +114,8 @@ def test_graphed_step_with_torch_side_draws_in_the_step(cuda_device):
     assert step.replays == 6 and all(map(lambda v: v == v, losses))
     assert not torch.equal(negs[-1], negs[-2])
     g = step._g
-    assert g["torch_steps"] > 0 and int(g["advance"]) == g["kernel_steps"] + g["torch_steps"] == (k + 1) + g["torch_steps"]
+    # the kernels' share of a step: three steps of the field for the start points (offsets, subset keys, normals) + k for the chain
+    assert g["torch_steps"] > 0 and int(g["advance"]) == g["kernel_steps"] + g["torch_steps"] == (k + 3) + g["torch_steps"]
     # the device coordinates are where the generator is
     torch.cuda.synchronize()
     assert int(g["coords"].tensor[1]) == gen.get_offset() // 4

@@ -49,6 +49,7 @@ EXPORTS = (
     "ebm_langevin_chain_dev_f32",
     "ebm_pcd_gather_dev_f32",
     "ebm_pcd_scatter_dev_f32",
+    "ebm_pcd_start_points_f32",
     "ebm_energy_grad_f32",
     "ebm_mlp_backward_acts_f32",
     "ebm_mlp_param_grads_work_f32",
@@ -128,6 +129,7 @@ _PROTOTYPES = {
     ),
     "ebm_pcd_gather_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _u64, _p]),
     "ebm_pcd_scatter_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),
+    "ebm_pcd_start_points_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i64, C.c_float, _u64, _u64, _p, _p]),
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_mlp_backward_acts_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "ebm_mlp_param_grads_work_f32": (C.c_int64, [_i32, _i32, _i64]),

@@ -151,6 +151,20 @@ class BaseContrastiveDivergence(BaseLoss):
             stride = self.buffer_size // batch
             row_elems = self.replay_buffer[0].numel()
             starts = torch.empty((batch,) + tuple(self.replay_buffer.shape[1:]), dtype=self.dtype, device=self.device)
+            if self.new_sample_ratio > 0.0 and batch < 2**31:
+                # ... and the exploration noise in the same launch (ebm_pcd_start_points_f32): the random subset of n_new rows comes
+                # from a keyed bijection instead of randperm's sort, the normals from the kernels' Philox field -- no torch-side draw,
+                # so a graph-captured step replays the eager loop's numbers (utils.graphed_step)
+                n_new = max(1, int(batch * self.new_sample_ratio))
+                if self._graph_coords is not None:
+                    seed, step, coords = 0, self._graph_coords.take(3), _lib.ptr(self._graph_coords.tensor)
+                else:
+                    (seed, step), coords = _rng.reserve(generator, self.replay_buffer.device, 3), None
+                _lib.call(
+                    "ebm_pcd_start_points_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch, stride,
+                    n_new, 0.01, seed, step, coords, _lib.stream_handle(self.replay_buffer.device),
+                )
+                return starts
             if self._graph_coords is not None:  # being captured: the draw's step is read from device memory at every replay
                 _lib.call(
                     "ebm_pcd_gather_dev_f32", _lib.ptr(self.replay_buffer), self.buffer_size, row_elems, _lib.ptr(starts), batch,

@@ -56,6 +56,8 @@ int launch_hmc_chain_audit(const ebm_energy_t&, float*, int64_t, int32_t, int32_
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
                       uint64_t, const uint64_t*, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, const int64_t*, hipStream_t);
+int launch_pcd_start_points(const float*, int64_t, int32_t, float*, int64_t, int64_t, int64_t, float, uint64_t, uint64_t, const uint64_t*,
+                            hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
 int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float, float, const float*,
                               int, float, float, int32_t, float*, const float*, uint64_t, uint64_t, float*, hipStream_t,
@@ -544,6 +546,17 @@ int ebm_pcd_gather_dev_f32(const float* buffer, int64_t buffer_size, int32_t dim
   if (!buffer || !out || !rng_state) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, nullptr, rows_out, 0, step_delta, rng_state,
                            (hipStream_t)stream);
+}
+
+int ebm_pcd_start_points_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,
+                             int64_t n_noise, float noise_scale, uint64_t seed, uint64_t step, const uint64_t* rng_state, void* stream) {
+  const char* who = "ebm_pcd_start_points_f32";
+  if (buffer_size < 1 || dim < 1 || batch < 0 || batch > 0x7fffffffLL || stride < 1 || stride > 0x7fffffffLL || n_noise < 0 || n_noise > batch)
+    return fail(EBM_EINVAL, "%s: bad sizes (buffer %lld, dim %d, batch %lld, stride %lld, n_noise %lld)", who, (long long)buffer_size, dim,
+                (long long)batch, (long long)stride, (long long)n_noise);
+  if (batch == 0) return 0;
+  if (!buffer || !out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_pcd_start_points(buffer, buffer_size, dim, out, batch, stride, n_noise, noise_scale, seed, step, rng_state, (hipStream_t)stream);
 }
 
 int ebm_gmm_active_columns_i32(const float* means, int32_t n_comp, int32_t dim, int32_t* out, void* stream) {

@@ -162,6 +162,54 @@ __global__ __launch_bounds__(kBlock) void pcd_gather_kernel(const float* __restr
   }
 }
 
+// ... and the same gather with the reference's exploration noise folded in (core/base_loss.py:316-332: `randperm(batch)[:n_new]` rows
+// get `+ 0.01 randn`): the random subset is { i : pi(i) < n_noise } for a keyed bijection pi of [0, batch) -- a six-round Feistel
+// network on ceil(log2 batch) bits (alternating halves, a 32-bit multiply-xorshift mixer as round function, six round keys from the
+// launch's Philox field) walked until it lands inside [0, batch) -- so exactly n_noise rows are chosen, each subset of that size
+// (pseudo-)equally likely, and no sort, no index list and no second pass over the rows is needed.  Steps of the field: `step` the
+// in-stride offsets (as ebm_pcd_gather_f32), `step + 1` the round keys (groups 0 and 1), `step + 2` the normals (element e of out).
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x21f0aaadu; h ^= h >> 15; h *= 0x735a2d97u; h ^= h >> 15;
+  return h;
+}
+__device__ __forceinline__ uint32_t feistel6(uint32_t v, int a_bits, int b_bits, const uint32_t (&k)[6]) {
+  uint32_t L = v >> b_bits, R = v & ((1u << b_bits) - 1u);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    if ((r & 1) == 0) L ^= mix32(R ^ k[r]) >> (32 - a_bits);
+    else R ^= mix32(L ^ k[r]) >> (32 - b_bits);
+  }
+  return (L << b_bits) | R;
+}
+
+__global__ __launch_bounds__(kBlock) void pcd_start_points_kernel(const float* __restrict__ buffer, int64_t buffer_size, int32_t dim,
+                                                                  float* __restrict__ out, int64_t batch, int64_t stride,
+                                                                  int64_t n_noise, float noise_scale, int bits, RngKey key, uint64_t step,
+                                                                  const uint64_t* __restrict__ rng_dev) {
+  resolve_rng(rng_dev, key, step);
+  const U4 k0 = philox_at(key, 0, step + 1), k1 = philox_at(key, 1, step + 1);
+  const uint32_t rk[6] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y};
+  const int a_bits = bits >> 1, b_bits = bits - a_bits;
+  const int64_t n = batch * dim;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = e / dim;
+    const int d = (int)(e - i * dim);
+    const uint32_t o = pick(philox_at(key, (uint64_t)i >> 2, step), (int)(i & 3));
+    const int64_t r = (int64_t)(((uint64_t)o * (uint64_t)stride) >> 32);  // multiply-shift: uniform in [0, stride)
+    const int64_t row = (i * stride + r) % buffer_size;
+    float v = buffer[row * dim + d];
+    uint32_t p = (uint32_t)i;
+    do p = feistel6(p, a_bits, b_bits, rk); while ((int64_t)p >= batch);  // cycle walking: a bijection of [0, batch)
+    if ((int64_t)p < n_noise) {
+      const F4 z = normal4_at(key, (uint64_t)e >> 2, step + 2);
+      const int c = (int)(e & 3);
+      const float zn = c == 0 ? z.v[0] : c == 1 ? z.v[1] : c == 2 ? z.v[2] : z.v[3];
+      v = v + zn * noise_scale;
+    }
+    out[e] = v;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void pcd_scatter_kernel(float* __restrict__ buffer, int64_t buffer_size,
                                                              int32_t dim, const float* __restrict__ samples,
                                                              int64_t batch, int64_t write_pos,
@@ -793,6 +841,16 @@ int launch_pcd_gather(const float* buffer, int64_t buffer_size, int32_t dim, flo
   hipLaunchKernelGGL(pcd_gather_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim, out,
                      batch, stride, offsets, rows_out, key, offset, rng_dev);
   return check_launch("ebm_pcd_gather_f32");
+}
+
+int launch_pcd_start_points(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,
+                            int64_t n_noise, float noise_scale, uint64_t seed, uint64_t step, const uint64_t* rng_dev, hipStream_t st) {
+  const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  int bits = 2;  // the Feistel network needs a bit on either side
+  while (bits < 31 && (1LL << bits) < batch) ++bits;
+  hipLaunchKernelGGL(pcd_start_points_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim, out, batch,
+                     stride, n_noise, noise_scale, bits, key, step, rng_dev);
+  return check_launch("ebm_pcd_start_points_f32");
 }
 
 int launch_pcd_scatter(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,

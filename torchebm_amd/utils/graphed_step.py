@@ -16,9 +16,10 @@ lives in device memory that launches inside the graph read and that the graph it
   as ``_rng.reserve`` advances the generator between the same calls of the eager step, and a one-element add at the
   end of the graph moves ``step`` past the whole training step.  The host mirrors that on the ``torch.Generator``
   (no device read), so the generator ends where the eager loop leaves it and **the same seed gives the same chains,
-  losses and weights as the eager loop** as long as no torch-side draw is part of the step
-  (``new_sample_ratio = 0``, ``add_noise_to_real = False``); with torch-side draws in the step (the buffer's
-  ``new_sample_ratio`` bump: ``randperm`` / ``randn``) those come from torch's own graph-safe generator state -- the same
+  losses and weights as the eager loop** as long as no torch-side draw is part of the step -- true of the loss's defaults,
+  exploration noise included (``new_sample_ratio > 0``: the random subset of rows and its normals come from
+  ``ebm_pcd_start_points_f32``, i.e. from the kernels' own field); with a torch-side draw in the step
+  (``add_noise_to_real = True``: ``randn_like`` on the data) that draw comes from torch's own graph-safe generator state -- the same
   law at other offsets than the eager loop's;
 * the FIFO write position of the replay buffer (``buffer_ptr``, advanced in the graph; the host copy follows);
 * the weights: parameters, gradients and optimiser state are ordinary tensors updated in place by the captured
