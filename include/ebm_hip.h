@@ -336,6 +336,21 @@ EBM_API int ebm_pcd_start_points_f32(const float* buffer, int64_t buffer_size, i
                                      int64_t stride, int64_t n_noise, float noise_scale, uint64_t seed, uint64_t step,
                                      const uint64_t* rng_state, void* stream);
 
+/*
+ * ABI 7 -- the contrastive-divergence loss of ONE model call on [data | negatives] (losses/contrastive_divergence.py:128-155):
+ *   L = mean(E+) - mean(E-) + reg (mean(E+^2) + mean(E-^2)),   e_both = float[2 n] = E+ | E-;
+ * a non-finite L becomes the constant 0.1 and sends no gradient (:150-155).  ebm_cd_loss_f32: one launch -- block partials of the
+ * four sums in fp64, added in block order by the last block to finish -- writes loss_out[1] and finite_out[1] (1.0 / 0.0).
+ * work: device memory of ebm_cd_loss_work_bytes() bytes, 8-byte aligned, ZEROED once by the caller (the ticket counter in it is left
+ * at zero again by every launch, so consecutive calls on one stream share it).  ebm_cd_loss_backward_f32: the per-row seed
+ * seed_out[2 n] = dL/dE_i = (+-1 + 2 reg E_i) / n * upstream[0] * finite[0] (upstream: dL_total/dL, a device scalar) -- what
+ * ebm_mlp_param_grads_f32 takes as `seed`.  torch's graph of the same arithmetic is some twenty launches of 4 - 5 us.
+ */
+EBM_API int64_t ebm_cd_loss_work_bytes(void);
+EBM_API int ebm_cd_loss_f32(const float* e_both, int64_t n, float reg, void* work, float* loss_out, float* finite_out, void* stream);
+EBM_API int ebm_cd_loss_backward_f32(const float* e_both, int64_t n, float reg, const float* upstream, const float* finite,
+                                     float* seed_out, void* stream);
+
 /* Energy E(x)[n_chains] and gradient dE/dx[n_chains, dim] of a fused analytic energy
  * (either output may be NULL).  core/base_model.py:143-148,181-210,224-229. */
 EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains,

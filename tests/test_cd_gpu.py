@@ -238,3 +238,49 @@ def test_pcd_start_points_subset_is_uniform_over_rows_and_steps(cuda_device):
         z = (count - n_pairs * pp) / np.sqrt(n_pairs * pp * (1 - pp))
         assert abs(z) < 4.5, (count, n_pairs * pp, z)
     assert st.kstest(np.concatenate(noise), "norm").pvalue > 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 5, 300, 65536, 100003])
+@pytest.mark.parametrize("reg", [0.0, 0.01])
+def test_cd_loss_kernels_equal_the_fp64_loss(cuda_device, n, reg):
+    """ebm_cd_loss_f32 / ebm_cd_loss_backward_f32 (losses.cd._PairedCDLossHip) against the op-by-op loss of the reference
+    (contrastive_divergence.py:141-155) evaluated in fp64: the value to one fp32 rounding of each mean (the kernel adds in fp64), the
+    per-row gradient to two roundings; the same bits on every call (fixed-order partial sums; the workspace is shared by the calls)."""
+    from torchebm_amd.losses.cd import _PairedCDLossHip
+
+    g = torch.Generator(device=cuda_device).manual_seed(n)
+    e = (torch.randn(2 * n, device=cuda_device, generator=g) * 3 + 1).requires_grad_(True)
+    work = torch.zeros(int(_lib.lib().ebm_cd_loss_work_bytes()) // 8 + 1, dtype=torch.float64, device=cuda_device)
+    vals, grads = [], []
+    for _ in range(3):
+        loss = _PairedCDLossHip.apply(e, n, reg, work)
+        (ge,) = torch.autograd.grad(loss * 1.7, e)
+        vals.append(loss.detach().clone())
+        grads.append(ge)
+    assert torch.equal(vals[0], vals[1]) and torch.equal(vals[1], vals[2]) and torch.equal(grads[0], grads[2])
+    e64 = e.detach().double().requires_grad_(True)
+    e2 = e64.view(2, n)
+    want = e2[0].mean() - e2[1].mean() + reg * ((e2[0] ** 2).mean() + (e2[1] ** 2).mean())
+    (g_want,) = torch.autograd.grad(want * 1.7, e64)
+    scale = e2.abs().mean().item() + reg * (e2 ** 2).mean().item()
+    assert abs(vals[0].item() - want.item()) <= 4 * 6e-8 * scale + 1e-12
+    torch.testing.assert_close(grads[0].double(), g_want, rtol=4e-7, atol=1e-12)
+    assert (work == 0).all() or int(work.view(torch.int32)[-4:].abs().sum()) == 0  # the ticket is back at zero (the partials are scratch)
+
+
+def test_cd_loss_kernel_guard_on_a_non_finite_loss(cuda_device):
+    from torchebm_amd.losses.cd import _PairedCDLossHip
+
+    work = torch.zeros(int(_lib.lib().ebm_cd_loss_work_bytes()) // 8 + 1, dtype=torch.float64, device=cuda_device)
+    bad = torch.randn(10, device=cuda_device)
+    bad[2] = float("nan")
+    bad.requires_grad_(True)
+    out = _PairedCDLossHip.apply(bad, 5, 0.01, work)
+    assert out.item() == pytest.approx(0.1)
+    (gb,) = torch.autograd.grad(out, bad)
+    assert (gb[torch.arange(10, device=cuda_device) != 2] == 0).all()  # the constant sends no gradient (contrastive_divergence.py:150-155)
+    inf = torch.full((8,), 3e38, device=cuda_device, requires_grad=True)  # E^2 overflows fp32: the regulariser is inf
+    out = _PairedCDLossHip.apply(inf, 4, 0.01, work)
+    assert out.item() == pytest.approx(0.1)
+    good = torch.randn(8, device=cuda_device, requires_grad=True)  # ... and the workspace is fine for the next call
+    assert torch.isfinite(_PairedCDLossHip.apply(good, 4, 0.01, work))

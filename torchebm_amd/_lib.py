@@ -50,6 +50,9 @@ EXPORTS = (
     "ebm_pcd_gather_dev_f32",
     "ebm_pcd_scatter_dev_f32",
     "ebm_pcd_start_points_f32",
+    "ebm_cd_loss_work_bytes",
+    "ebm_cd_loss_f32",
+    "ebm_cd_loss_backward_f32",
     "ebm_energy_grad_f32",
     "ebm_mlp_backward_acts_f32",
     "ebm_mlp_param_grads_work_f32",
@@ -129,6 +132,9 @@ _PROTOTYPES = {
     ),
     "ebm_pcd_gather_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _u64, _p]),
     "ebm_pcd_scatter_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),
+    "ebm_cd_loss_work_bytes": (C.c_int64, []),
+    "ebm_cd_loss_f32": (C.c_int, [_p, _i64, C.c_float, _p, _p, _p, _p]),
+    "ebm_cd_loss_backward_f32": (C.c_int, [_p, _i64, C.c_float, _p, _p, _p, _p]),
     "ebm_pcd_start_points_f32": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i64, C.c_float, _u64, _u64, _p, _p]),
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_mlp_backward_acts_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p, _p, _p]),

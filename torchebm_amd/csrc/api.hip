@@ -56,6 +56,9 @@ int launch_hmc_chain_audit(const ebm_energy_t&, float*, int64_t, int32_t, int32_
 int launch_pcd_gather(const float*, int64_t, int32_t, float*, int64_t, int64_t, const int64_t*, int64_t*, uint64_t,
                       uint64_t, const uint64_t*, hipStream_t);
 int launch_pcd_scatter(float*, int64_t, int32_t, const float*, int64_t, int64_t, const int64_t*, hipStream_t);
+int64_t cd_loss_work_bytes();  // misc.hip
+int launch_cd_loss(const float*, int64_t, float, void*, float*, float*, hipStream_t);
+int launch_cd_loss_seed(const float*, int64_t, float, const float*, const float*, float*, hipStream_t);
 int launch_pcd_start_points(const float*, int64_t, int32_t, float*, int64_t, int64_t, int64_t, float, uint64_t, uint64_t, const uint64_t*,
                             hipStream_t);
 int launch_noise_fill(float*, int64_t, int32_t, uint64_t, uint64_t, const uint64_t*, hipStream_t);
@@ -546,6 +549,24 @@ int ebm_pcd_gather_dev_f32(const float* buffer, int64_t buffer_size, int32_t dim
   if (!buffer || !out || !rng_state) return fail(EBM_EINVAL, "%s: NULL pointer", who);
   return launch_pcd_gather(buffer, buffer_size, dim, out, batch, stride, nullptr, rows_out, 0, step_delta, rng_state,
                            (hipStream_t)stream);
+}
+
+int64_t ebm_cd_loss_work_bytes(void) { return cd_loss_work_bytes(); }
+
+int ebm_cd_loss_f32(const float* e_both, int64_t n, float reg, void* work, float* loss_out, float* finite_out, void* stream) {
+  const char* who = "ebm_cd_loss_f32";
+  if (n < 1) return fail(EBM_EINVAL, "%s: n < 1", who);
+  if (!e_both || !work || !loss_out || !finite_out || (reinterpret_cast<uintptr_t>(work) & 7) != 0)
+    return fail(EBM_EINVAL, "%s: NULL pointer, or work not 8-byte aligned", who);
+  return launch_cd_loss(e_both, n, reg, work, loss_out, finite_out, (hipStream_t)stream);
+}
+
+int ebm_cd_loss_backward_f32(const float* e_both, int64_t n, float reg, const float* upstream, const float* finite, float* seed_out,
+                             void* stream) {
+  const char* who = "ebm_cd_loss_backward_f32";
+  if (n < 1) return fail(EBM_EINVAL, "%s: n < 1", who);
+  if (!e_both || !upstream || !finite || !seed_out) return fail(EBM_EINVAL, "%s: NULL pointer", who);
+  return launch_cd_loss_seed(e_both, n, reg, upstream, finite, seed_out, (hipStream_t)stream);
 }
 
 int ebm_pcd_start_points_f32(const float* buffer, int64_t buffer_size, int32_t dim, float* out, int64_t batch, int64_t stride,

@@ -224,6 +224,77 @@ __global__ __launch_bounds__(kBlock) void pcd_scatter_kernel(float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------
+// The contrastive-divergence loss of one model call on [data | negatives] (losses/contrastive_divergence.py:128-155):
+//   L = mean(E+) - mean(E-) + reg (mean(E+^2) + mean(E-^2)),  a non-finite L becomes the constant 0.1 and sends no gradient.
+// Forward: one launch -- block partials of the four sums in fp64, the last block to finish adds them in block order (a ticket
+// counter it leaves at zero again) and writes L and the finite flag: the value depends on no scheduling.  Backward: one
+// elementwise launch, dL/dE_i = (+-1 + 2 reg E_i) / n * (upstream * finite).  torch's graph of the same arithmetic is some
+// twenty launches of 4 - 5 us on two scalars and two vectors -- a tenth of a captured training step.
+// ---------------------------------------------------------------------------------
+constexpr int kCdLossBlocks = 128;
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_down(v, m, 64);
+  return v;
+}
+__global__ __launch_bounds__(kBlock) void cd_loss_kernel(const float* __restrict__ e_both, int64_t n, float reg, double* __restrict__ partials,
+                                                         unsigned int* __restrict__ ticket, float* __restrict__ loss_out,
+                                                         float* __restrict__ finite_out) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};  // sum E+, sum E-, sum E+^2, sum E-^2
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double p = e_both[i], q = e_both[n + i];
+    s[0] += p; s[1] += q; s[2] += p * p; s[3] += q * q;
+  }
+  __shared__ double part[kBlock / 64][4];
+  __shared__ bool last;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double w = wave_sum(s[c]);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double b = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) b += part[w][threadIdx.x];
+    partials[(int64_t)blockIdx.x * 4 + threadIdx.x] = b;
+    __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (unsigned g = 0; g < gridDim.x; ++g) t += __builtin_nontemporal_load(&partials[(int64_t)g * 4 + threadIdx.x]);
+    part[0][threadIdx.x] = t / (double)n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // the reference's order of operations on fp32 means: (mean+ - mean-) + reg * (meansq+ + meansq-)
+    const float mp = (float)part[0][0], mn = (float)part[0][1], sp = (float)part[0][2], sn = (float)part[0][3];
+    float loss = mp - mn;
+    if (reg > 0.0f) loss = loss + reg * (sp + sn);
+    const bool ok = isfinite(loss);
+    *loss_out = ok ? loss : 0.1f;
+    *finite_out = ok ? 1.0f : 0.0f;
+    *ticket = 0u;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cd_loss_seed_kernel(const float* __restrict__ e_both, int64_t n, float reg,
+                                                              const float* __restrict__ upstream, const float* __restrict__ finite,
+                                                              float* __restrict__ seed_out) {
+  const float scale = *upstream * *finite;  // (a non-finite loss sends no gradient: contrastive_divergence.py:150-155)
+  const float inv_n = 1.0f / (float)n, two_reg_n = 2.0f * reg / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < 2 * n; i += (int64_t)gridDim.x * kBlock) {
+    float g = i < n ? inv_n : -inv_n;
+    if (reg > 0.0f) g = g + e_both[i] * two_reg_n;
+    seed_out[i] = g * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Metropolis accept, one lane-group of `lanes` lanes per chain row (samplers/hmc.py:277-292)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void hmc_accept_kernel(
@@ -851,6 +922,22 @@ int launch_pcd_start_points(const float* buffer, int64_t buffer_size, int32_t di
   hipLaunchKernelGGL(pcd_start_points_kernel, dim3(grid_for(batch * dim)), dim3(kBlock), 0, st, buffer, buffer_size, dim, out, batch,
                      stride, n_noise, noise_scale, bits, key, step, rng_dev);
   return check_launch("ebm_pcd_start_points_f32");
+}
+
+int64_t cd_loss_work_bytes() { return (int64_t)kCdLossBlocks * 4 * sizeof(double) + 16; }
+int launch_cd_loss(const float* e_both, int64_t n, float reg, void* work, float* loss_out, float* finite_out, hipStream_t st) {
+  int64_t blocks = ceil_div64(n, (int64_t)kBlock * 4);
+  if (blocks > kCdLossBlocks) blocks = kCdLossBlocks;
+  if (blocks < 1) blocks = 1;
+  double* partials = (double*)work;
+  unsigned int* ticket = (unsigned int*)((char*)work + (int64_t)kCdLossBlocks * 4 * sizeof(double));
+  hipLaunchKernelGGL(cd_loss_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, e_both, n, reg, partials, ticket, loss_out, finite_out);
+  return check_launch("ebm_cd_loss_f32");
+}
+int launch_cd_loss_seed(const float* e_both, int64_t n, float reg, const float* upstream, const float* finite, float* seed_out,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(cd_loss_seed_kernel, dim3(grid_for(2 * n)), dim3(kBlock), 0, st, e_both, n, reg, upstream, finite, seed_out);
+  return check_launch("ebm_cd_loss_backward_f32");
 }
 
 int launch_pcd_scatter(float* buffer, int64_t buffer_size, int32_t dim, const float* samples, int64_t batch,

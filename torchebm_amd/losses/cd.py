@@ -15,11 +15,41 @@ from ..core.loss_base import BaseContrastiveDivergence
 from ..core.module import warn_once
 
 
-class _PairedCDLoss(torch.autograd.Function):
+class _PairedCDLossHip(torch.autograd.Function):
     """``mean(E+) - mean(E-) + reg (mean(E+^2) + mean(E-^2))`` of the energies ``[E+ | E-]`` of ONE model call, with its analytic
     gradient ``dL/dE_i = (+-1 + 2 reg E_i) / n`` and the reference's guard (a non-finite loss becomes the constant 0.1 and sends
-    no gradient: contrastive_divergence.py:150-155).  Same value as the op-by-op form below; autograd's graph of those few scalar
-    ops is some twenty launches of 3 - 5 us -- a tenth of a captured training step -- this is five."""
+    no gradient: contrastive_divergence.py:150-155).  Two launches of the HIP library (``ebm_cd_loss_f32``: fp64 block partials
+    added in a fixed order; ``ebm_cd_loss_backward_f32``: the per-row seed) where autograd's graph of the same scalar arithmetic is
+    some twenty launches of 4 - 5 us -- a tenth of a captured training step.  ``work``: the loss object's zeroed workspace."""
+
+    @staticmethod
+    def forward(ctx, e_both, n, reg, work):
+        from .. import _lib
+
+        e_both = e_both.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=e_both.device)  # loss | finite flag
+        _lib.call("ebm_cd_loss_f32", e_both.data_ptr(), n, float(reg), work.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(),
+                  _lib.stream_handle(e_both.device))
+        ctx.save_for_backward(e_both, out)
+        ctx.n, ctx.reg = n, float(reg)
+        return out[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import _lib
+
+        e_both, out = ctx.saved_tensors
+        g = g.to(device=e_both.device, dtype=torch.float32).contiguous()
+        seed = torch.empty_like(e_both)
+        _lib.call("ebm_cd_loss_backward_f32", e_both.data_ptr(), ctx.n, ctx.reg, g.data_ptr(), out[1:2].data_ptr(), seed.data_ptr(),
+                  _lib.stream_handle(e_both.device))
+        return seed, None, None, None
+
+
+class _PairedCDLoss(torch.autograd.Function):
+    """The same loss and analytic gradient in torch ops (any dtype / device; five launches instead of autograd's twenty): what
+    ``_PairedCDLossHip`` is checked against, and the route of energies that are not float32."""
 
     @staticmethod
     def forward(ctx, e_both, n, reg):
@@ -100,6 +130,15 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
         loss = self.compute_loss(x, negatives, *args, model_kwargs=model_kwargs, generator=generator, **kwargs)
         return loss, negatives
 
+    def _paired_loss_work(self, device: torch.device) -> torch.Tensor:
+        """The zeroed workspace of ``ebm_cd_loss_f32`` (every launch leaves it zeroed again); one per loss object and device."""
+        from .. import _lib
+
+        work = getattr(self, "_loss_work", None)
+        if work is None or work.device != device:
+            work = self._loss_work = torch.zeros(int(_lib.lib().ebm_cd_loss_work_bytes()) // 8 + 1, dtype=torch.float64, device=device)
+        return work
+
     def compute_loss(
         self,
         x: torch.Tensor,
@@ -127,6 +166,8 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
                 # both halves' statistics from the [2, n] view: two row reductions instead of four means and two squares (every one
                 # of these is a 10 us graph node on a 65 536-element vector)
                 reg = float(kwargs.get("energy_reg_weight", self.energy_reg_weight))
+                if e_both.dtype == torch.float32 and real.shape[0] > 0:
+                    return _PairedCDLossHip.apply(e_both, int(real.shape[0]), reg, self._paired_loss_work(e_both.device))
                 return _PairedCDLoss.apply(e_both, int(real.shape[0]), reg)
             e_data = self.model(real, **cond)
             e_model = self.model(pred_x, **cond)
