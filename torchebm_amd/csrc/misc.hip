@@ -264,10 +264,13 @@ __global__ __launch_bounds__(kBlock) void cd_loss_kernel(const float* __restrict
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (threadIdx.x < 4) {
+  {  // wave c adds column c of the partials: lane l takes blocks l, l + 64, ... in order, then the fixed shuffle tree
+    const int c = threadIdx.x >> 6, l = threadIdx.x & 63;
     double t = 0.0;
-    for (unsigned g = 0; g < gridDim.x; ++g) t += __builtin_nontemporal_load(&partials[(int64_t)g * 4 + threadIdx.x]);
-    part[0][threadIdx.x] = t / (double)n;
+    for (unsigned g = l; g < gridDim.x; g += 64) t += __builtin_nontemporal_load(&partials[(int64_t)g * 4 + c]);
+    t = wave_sum(t);
+    __syncthreads();  // (part[] of the block's own partial sums has been read)
+    if (l == 0) part[0][c] = t / (double)n;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
