@@ -420,3 +420,27 @@ def test_hmc_diagnostics_come_from_records_of_the_one_chain_launch(cuda_device, 
     moved = (traj != prev).any(dim=2).double().mean(dim=0)     # an accepted proposal moves the chain
     torch.testing.assert_close(diag["acceptance_rate"].double(), moved, rtol=0, atol=1e-6)
     assert 0.2 < float(diag["acceptance_rate"].mean()) <= 1.0
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_thin_input_kernels_track_the_matrix_pipe_kernels(cuda_device, hidden):
+    """dim <= 2 (config 5's shape): the plain call runs the MODE 4 kernels -- W1's two contractions on the vector unit in exact fp32,
+    csrc/mlp_wide_thin.hip -- while a call with an (inactive) clamp takes the general MODE 2 kernel on the same noise field (same
+    generator seed): two fp32-accurate evaluations of the same chain.  Bar: after k steps they differ by no more than fp32 chain
+    drift (the fp64 chain is the referee in the tests above; here 2e-4 of the state's scale at k = 15), and the energies / gradients
+    of the two agree to 1e-5 relative."""
+    cpu, gpu = _models(cuda_device, 2, hidden, seed=9, scale=1.3)
+    n, k = 4099, 15
+    x0 = torch.randn(n, 2, device=cuda_device)
+    plain = ta.LangevinDynamics(gpu, step_size=0.02, noise_scale=1.0, device=cuda_device)
+    clamped = ta.LangevinDynamics(gpu, step_size=0.02, noise_scale=1.0, clamp=(-1e30, 1e30), device=cuda_device)
+    a = plain.sample(x=x0, n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(5))
+    b = clamped.sample(x=x0, n_steps=k, generator=torch.Generator(device=cuda_device).manual_seed(5))
+    assert not torch.equal(a, x0) and torch.isfinite(a).all()
+    scale = b.abs().max().item()
+    assert (a - b).abs().max().item() <= 2e-4 * scale, ((a - b).abs().max().item(), scale)
+    # the training forward (ebm_mlp_backward_acts_f32 on the thin kernel) against autograd
+    e = gpu(x0)
+    assert type(e.grad_fn).__name__.startswith("_FusedMLPTraining")
+    ref = gpu.net(x0).squeeze(-1)
+    assert ((e - ref).abs() / (1 + ref.abs())).max().item() <= 2e-5

@@ -17,7 +17,10 @@ constexpr int kBlock = 256;
 // L2, exact-f32 MFMA); 2 = B16 (three bf16 split images in LDS, bf16 MFMA at fp32 accuracy: mlp_b16.h) wherever the images fit
 // the 160 KiB: H = 64 at every input width, H = 128 up to dim 64; 3 = SLAB (round 4: H = 128, dim 65 .. 128 -- the W2 image in
 // LDS, the W1 image PRE-SPLIT in global memory and walked slab by slab through two 24 KB LDS buffers: mlp_b16.h "MODE 3"),
-// chosen at run time when the caller hands over the image (WideArgs::w1_image).  -DEBM_MLP_F32LDS (scripts only): round 2.
+// chosen at run time when the caller hands over the image (WideArgs::w1_image); 4 = THIN (round 5: dim <= 2 -- config 5's shape --: B16 for
+// W2, while the two contractions with W1 are 2 FMAs per hidden unit and run on the vector unit in exact fp32 from a transposed fp32
+// copy of W1 in LDS: no operand splits of x and d1, no W1 image, 96 MFMAs and ~230 vector instructions fewer per evaluation in a
+// kernel whose cost is its instruction count).  -DEBM_MLP_F32LDS (scripts only): round 2.
 __host__ __device__ constexpr int b16_cols(int dt) { return dt == 1 ? 32 : (dt == 2 ? 64 : 128); }  // width of the W1 image
 __host__ __device__ constexpr int wide_mode(int ht, int dt) {
 #ifdef EBM_MLP_F32LDS
@@ -29,6 +32,7 @@ __host__ __device__ constexpr int wide_mode(int ht, int dt) {
 __host__ __device__ constexpr size_t wide_smem_bytes(int ht, int dt, int mode) {
   const int H = 32 * ht, DP = 32 * dt;
   return mode == 3 ? (size_t)3 * H * sizeof(float) + 2 * mlpb16::kSlabBytes + mlpb16::image_bytes(H, H)
+         : mode == 4 ? (size_t)5 * H * sizeof(float) + mlpb16::image_bytes(H, H)
          : mode == 1 ? (size_t)(16 * ht * kBlock + 3 * H) * sizeof(float)
          : mode == 2 ? (size_t)3 * H * sizeof(float) + mlpb16::image_bytes(H, H) + mlpb16::image_bytes(H, b16_cols(dt))
                      : (size_t)(H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
@@ -310,6 +314,7 @@ tile_again:
     for (int td = 0; td < DT; ++td)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        if (MODE == 4 && q > 0) continue;  // (THIN: the state is columns 0 and 1)
         const int c0 = 32 * td + 8 * q + 4 * h;
         float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         // (FAST: dim % 4 == 0 or dim == 2, and dim > 32 (DT - 1) -- only the last tile has quads past dim)
@@ -347,6 +352,7 @@ tile_again:
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (MODE == 4 && i > 1) continue;
           const int r = 4 * q + i;
           const float x1 = xr[td][r] - eta * g[td][r];
           const float dw = eps[i] * sqrt_eta;
@@ -430,6 +436,11 @@ template <> int launch_train<2, 1>(const WideArgs& a, hipStream_t st, const char
 template <> int launch_train<2, 2>(const WideArgs& a, hipStream_t st, const char* who);
 template <> int launch_train<4, 1>(const WideArgs& a, hipStream_t st, const char* who);
 template <> int launch_train<4, 2>(const WideArgs& a, hipStream_t st, const char* who);
+// MODE 4 (mlp_wide_thin.hip): dim <= 2; fast = 1 the plain call, 2 the same with records, 3 the training forward / backward
+template <int HT>
+int launch_thin(const WideArgs& a, int fast, hipStream_t st, const char* who);
+template <> int launch_thin<2>(const WideArgs& a, int fast, hipStream_t st, const char* who);
+template <> int launch_thin<4>(const WideArgs& a, int fast, hipStream_t st, const char* who);
 // MODE 3 (mlp_wide_slab.hip): H = 128, dim 65 .. 128 with the W1 image at hand; fast = 0 general, 1 plain call, 2 records
 template <int DT>
 int launch_slab(const WideArgs& a, int fast, hipStream_t st, const char* who);
@@ -441,6 +452,7 @@ int launch_quad(const WideArgs& a, hipStream_t st, const char* who);
 inline bool wide_fast_shape(const WideArgs& a) {  // (with or without records)
   return a.k_steps > 0 && !a.noise && !a.clamp_on && ((a.dim & 3) == 0 || a.dim == 2);
 }
+// (dim == 1 takes the general kernel: FAST draws a chain's noise as half a Philox counter, which is dim == 2's addressing)
 
 template <int HT, int DT>
 int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
@@ -454,6 +466,11 @@ int launch_one(const WideArgs& a, hipStream_t st, const char* who) {
 #ifdef EBM_MLP_QUAD_EXPERIMENT
   if constexpr (HT == 4 && DT == 1) {
     if (wide_fast_shape(a) && !a.diag_partials && !ab_switch("EBM_MLP_NO_QUAD")) return launch_quad(a, st, who);
+  }
+#endif
+#ifndef EBM_MLP_NO_THIN
+  if constexpr (MODE == 2 && DT == 1 && (HT == 2 || HT == 4)) {
+    if (a.dim <= 2 && wide_fast_shape(a) && !ab_switch("EBM_MLP_NO_THIN")) return launch_thin<HT>(a, a.diag_partials ? 2 : 1, st, who);
   }
 #endif
   if constexpr (MODE == 2) {

@@ -27,6 +27,9 @@ int launch_mlp_backward_acts(int32_t hidden, const float* params, const float* x
   a.thin = 1; a.params = params; a.energy_out = energy_out; a.grad_out = grad_out; a.seed = seed; a.acts = acts; a.act_stride = (n_chains + 127) / 128 * 128;  // whole workgroups of 4 x 32 chains: no lane, no wave needs masking
   a.diag_blocks = ceil_div64(n_chains, 32);
   const int dt = (dim + 31) / 32;
+#ifndef EBM_MLP_NO_THIN
+  if (dim <= 2 && !ab_switch("EBM_MLP_NO_THIN")) return hidden == 64 ? launch_thin<2>(a, 3, st, who) : launch_thin<4>(a, 3, st, who);
+#endif
   if (hidden == 64) return dt == 1 ? launch_train<2, 1>(a, st, who) : launch_train<2, 2>(a, st, who);
   return dt == 1 ? launch_train<4, 1>(a, st, who) : launch_train<4, 2>(a, st, who);
 }
