@@ -583,7 +583,7 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
         tf_sample = timed(fn, reps=10, warm=2, device=device)
         kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 5, device)
         mlp_flops = n * k * 2 * (2 * 128 * 128 + 2 * 2 * 128)  # two HxH contractions + the two thin ones, per chain-step
-        issued = n * k * 2 * (2 * 128 * 128 + 2 * 32 * 128) * 6    # bf16 products issued: input width padded to 32, six terms
+        issued = n * k * 2 * (2 * 128 * 128) * 6    # bf16 products issued: the two HxH contractions, six terms (dim 2: W1's run on the vector unit, round 5)
         tk = kms * 1e-3 if kms else tf_sample
         res["fused_mlp_kernel"] = {
             "training_steps_per_s": 1 / tf, "sampler_ms": tf_sample * 1e3, "kernel_ms": kms,
