@@ -88,13 +88,14 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
   const auto load_chunk = [&](Regs& q, int64_t c) __attribute__((always_inline)) {
     const int64_t col = c * KC + 4 * c4;
     // chunk c = tile c of the planes: one contiguous [4][H][32] block; thread t reads floats 4 t .. 4 t + 3 of every 32-row slab
+    // (nontemporal, like the stores that wrote them: read once)
     const float* p = a.acts + c * (int64_t)(4 * H * KC) + 4 * t;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
-      q.h1[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC);
-      q.h2[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + H * KC);
-      q.d2[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + 2 * H * KC);
-      q.d1[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * KC + 3 * H * KC);
+      q.h1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC));
+      q.h2[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + H * KC));
+      q.d2[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + 2 * H * KC));
+      q.d1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + 3 * H * KC));
     }
     // (rows n .. stride - 1: the planes hold zeros there, and the seed is zero too -- db3 counts real rows only)
     q.s.x = col + 0 < a.n ? (a.seed ? a.seed[col + 0] : 1.0f) : 0.0f;
