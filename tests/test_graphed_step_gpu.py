@@ -195,3 +195,34 @@ def test_dev_entry_points_equal_the_by_value_ones(cuda_device):
     _lib.call("ebm_pcd_scatter_f32", buf_a.data_ptr(), 5000, 3, rows.data_ptr(), 1000, 4500, _lib.stream_handle(dev))
     _lib.call("ebm_pcd_scatter_dev_f32", buf_b.data_ptr(), 5000, 3, rows.data_ptr(), 1000, pos.data_ptr(), _lib.stream_handle(dev))
     assert torch.equal(buf_a, buf_b) and torch.equal(buf_a[4500:], rows[:500]) and torch.equal(buf_a[:500], rows[500:])
+
+
+@pytest.mark.parametrize("in_dim,hidden,persistent,reg,ratio,n,buffer", [
+    (2, 64, True, 0.001, 0.05, 4096, 4096),      # the thin-input kernels at H = 64
+    (1, 128, True, 0.001, 0.05, 4096, 4096),     # a 1-D energy: general chain kernel, thin training forward
+    (3, 128, True, 0.0, 0.05, 4096, 4096),       # no energy regulariser
+    (32, 128, True, 0.001, 0.05, 4096, 12288),   # the benchmark network's width, buffer = 3 batches
+    (2, 128, False, 0.001, 0.0, 4096, 4096),     # CD-k: the chains start at the data
+    (64, 64, True, 0.01, 0.1, 1000, 5000),       # a ragged batch, dim 64
+])
+def test_graphed_step_equals_the_eager_loop_across_shapes(cuda_device, in_dim, hidden, persistent, reg, ratio, n, buffer):
+    """The whole-step graph against the eager loop (losses and final weights torch.equal after 12 steps) across the kernel variants a
+    step can route to: MODE 4 / MODE 2 chain kernels, the training forward at several widths, PCD with and without exploration noise,
+    plain CD-k, a batch off the tile size."""
+    k, steps = 5, 12
+    runs = []
+    for enabled in (False, True):
+        torch.manual_seed(0)
+        m = ta.MLPEnergy(in_dim, hidden, device=cuda_device)
+        s = ta.LangevinDynamics(m, step_size=0.05, noise_scale=1.0, device=cuda_device)
+        cd = ta.ContrastiveDivergence(m, s, k_steps=k, persistent=persistent, buffer_size=buffer, init_steps=0, new_sample_ratio=ratio,
+                                      energy_reg_weight=reg, device=cuda_device)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+        step = GraphedTrainingStep(cd, opt, generator=torch.Generator(device=cuda_device).manual_seed(3), enabled=enabled)
+        data = torch.randn(n, in_dim, device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(1))
+        losses = torch.stack([step(data)[0] for _ in range(steps)])
+        torch.cuda.synchronize()
+        runs.append((losses, [p.detach().clone() for p in m.parameters()]))
+        assert not enabled or step.replays == steps - step.eager_steps
+    assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
