@@ -11,7 +11,10 @@
 namespace ebm {
 namespace widemlp {
 
-constexpr int kBlock = 256;
+#ifndef EBM_MLP_KBLOCK
+#define EBM_MLP_KBLOCK 256  // (512: scripts/experiments -- two waves per SIMD sharing one image)
+#endif
+constexpr int kBlock = EBM_MLP_KBLOCK;
 
 // How a shape keeps its weights (MODE of the kernels): 0 = fp32 in LDS, exact-f32 MFMA; 1 = STREAM (H = 256: fp32 read from
 // L2, exact-f32 MFMA); 2 = B16 (three bf16 split images in LDS, bf16 MFMA at fp32 accuracy: mlp_b16.h) wherever the images fit
@@ -216,12 +219,13 @@ tile_again:
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c0 = 32 * td + 8 * q + 4 * h;
-      if (quads && active && c0 + 3 < dim) {
+      if (MODE != 4 && quads && active && c0 + 3 < dim) {
         const float4 v = *reinterpret_cast<const float4*>(a.x + sample * dim + c0);
         xr[td][4 * q] = v.x; xr[td][4 * q + 1] = v.y; xr[td][4 * q + 2] = v.z; xr[td][4 * q + 3] = v.w;
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[td][4 * q + i] = (active && c0 + i < dim) ? a.x[sample * dim + c0 + i] : 0.0f;
+        for (int i = 0; i < 4; ++i)  // (THIN: columns 0 and 1 are all there is -- the other registers are the constant 0)
+          xr[td][4 * q + i] = (MODE == 4 && (q > 0 || i > 1)) ? 0.0f : ((active && c0 + i < dim) ? a.x[sample * dim + c0 + i] : 0.0f);
       }
     }
 
