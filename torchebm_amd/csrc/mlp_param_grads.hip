@@ -256,8 +256,10 @@ __global__ __launch_bounds__(256) void mlp_param_grads_reduce_kernel(const float
   __shared__ float part[8][32];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
   float s = 0.0f;
-  if (e < S::record)
-    for (int g = q; g < G; g += 8) s += partials[(int64_t)g * S::record + e];
+  if (e < S::record) {
+#pragma unroll 8  // (eight loads in flight per thread; the sum keeps its order)
+    for (int g = q; g < G; g += 8) s += __builtin_nontemporal_load(&partials[(int64_t)g * S::record + e]);
+  }
   part[q][threadIdx.x & 31] = s;
   __syncthreads();
   if (q == 0 && e < S::record) {
