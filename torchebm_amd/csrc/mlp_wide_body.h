@@ -204,8 +204,14 @@ __device__ __forceinline__ void contract_cols(f32x16 (&out)[NT], Ld1 ld1, Bval b
 // with everything else compiled out (the injected-noise and per-element Philox paths, the clamp, the record code and its
 // out-of-line call): the update loses its uniform branches, the kernel a third of its code.  FAST = 2: the same call WITH records
 // (return_diagnostics=True otherwise falls to the general kernel, 8 % slower: 512 registers and spills where this one has neither).
+// Workgroups per CU: H = 128 -- one (the W2 image alone is 96 KB, an evaluation holds 350 - 512 registers).  H = 64 at dim <= 64: TWO (the
+// images are 36 - 48 KB and the FAST evaluation fits 256 registers without a spill, so the second workgroup's waves fill the issue
+// slots a lone wave leaves empty: one instruction per ~6.5 cycles alone, ~3.1 with two waves on a SIMD).
+__host__ __device__ constexpr int wide_min_blocks(int ht, int dt, int mode, int fast) {
+  return (ht == 2 && dt <= 2 && (mode == 2 || mode == 4) && fast == 1) ? 2 : 1;
+}
 template <int HT, int DT, int MODE, int FAST = 0>
-__global__ __launch_bounds__(kBlock, 1) void mlp_wide_chain_kernel(WideArgs a) {
+__global__ __launch_bounds__(kBlock, wide_min_blocks(HT, DT, MODE, FAST)) void mlp_wide_chain_kernel(WideArgs a) {
 #include "mlp_wide_setup.inc"
 
   // Evaluation-only launches (k_steps == 0: energies / gradients, the training backward) come back here for their next tile of
