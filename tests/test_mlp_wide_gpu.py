@@ -444,3 +444,37 @@ def test_thin_input_kernels_track_the_matrix_pipe_kernels(cuda_device, hidden):
     assert type(e.grad_fn).__name__.startswith("_FusedMLPTraining")
     ref = gpu.net(x0).squeeze(-1)
     assert ((e - ref).abs() / (1 + ref.abs())).max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_thin_chain_kernel_against_the_fp64_chain_on_its_own_noise(cuda_device, hidden):
+    """The MODE 4 chain kernel (dim 2, native Philox noise -- the plain call) with the fp64 network's chain as referee: the noise
+    field of the launch is materialised with ebm_noise_fill_f32 (same seed, same steps) and fed to the CPU chains; the kernel may
+    not drift from the fp64 chain faster than 4 x what torch's own fp32 arithmetic does (the bar of the injected-noise tests above,
+    which run the general kernel)."""
+    from torchebm_amd.samplers.langevin import em_coefficients
+
+    cpu, gpu = _models(cuda_device, 2, hidden, seed=21, scale=1.2)
+    cpu64 = copy.deepcopy(cpu).double()
+    n, k, eta, sigma = 2000, 12, 0.05, 0.7
+    x0 = torch.randn(n, 2, generator=torch.Generator().manual_seed(4))
+    seed, step0 = 0x5EED1234, 77
+    a, sq, coef = em_coefficients(eta, sigma)
+    x = x0.to(cuda_device).clone()
+    spec = gpu.fused_spec()
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    _lib.call("ebm_langevin_chain_f32", spec.to_c(), x.data_ptr(), n, 2, k, a, sq, coef, None, 0, 0.0, 0.0, 1, None, None, None, seed, step0,
+              _lib.stream_handle(cuda_device))
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 1
+    noise = torch.empty(k, n, 2, device=cuda_device)
+    for i in range(k):
+        _lib.call("ebm_noise_fill_f32", noise[i].data_ptr(), n * 2, _lib.NOISE_NORMAL, seed, step0 + i, _lib.stream_handle(cuda_device))
+    noise = noise.cpu()
+    x32, x64 = x0.clone(), x0.double()
+    for i in range(k):  # the reference's update order (base_integrator.py:673-731) in fp32 and in fp64
+        x32 = (x32 - eta * cpu.gradient(x32)) + coef * (noise[i] * sq)
+        x64 = (x64 - eta * cpu64.gradient(x64)) + coef * (noise[i].double() * sq)
+    err_hip = (x.cpu().double() - x64).abs()
+    err_ref = (x32.double() - x64).abs()
+    assert err_hip.max().item() <= 4 * err_ref.max().item() + 1e-6, (err_hip.max().item(), err_ref.max().item())
+    assert err_hip.median().item() <= 4 * err_ref.median().item() + 1e-7
