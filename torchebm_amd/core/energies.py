@@ -618,9 +618,7 @@ class MLPEnergy(BaseModel):
             params = (n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
             if (self.fused_training and self.hidden in (64, 128) and self.in_dim <= 64 and self.hidden in self.FUSED_HIDDEN
                     and x.is_contiguous() and x.data_ptr() % 16 == 0 and _lib.is_built() and all(p.is_cuda for p in params)):
-                with torch.no_grad():
-                    packed = torch.cat([p.reshape(-1) for p in params])
-                return _FusedMLPTraining.apply(x, packed, int(self.hidden), *params)
+                return _FusedMLPTraining.apply(x, self._packed_parameters(), int(self.hidden), *params)
             return _ThinMLPEnergy.apply(x, *params)
         return self.net(x).squeeze(-1)
 
@@ -638,16 +636,31 @@ class MLPEnergy(BaseModel):
         return (type(n[0]) is nn.Linear and type(n[2]) is nn.Linear and type(n[4]) is nn.Linear and type(n[1]) is nn.SiLU
                 and type(n[3]) is nn.SiLU and n[4].out_features == 1 and all(l.bias is not None for l in (n[0], n[2], n[4])))
 
+    #: set by a caller that guarantees the parameters do not change while it is set (``ContrastiveDivergence.forward``: the sampler
+    #: call and the loss's model call of ONE step, nothing in between touches the weights): a dict in which the packed copy is kept
+    _pack_scope: Optional[dict] = None
+
+    def _packed_parameters(self) -> torch.Tensor:
+        """W1[H,in] b1[H] W2[H,H] b2[H] w3[H] b3[1] as one vector, the order include/ebm_hip.h documents -- packed on every call
+        (the weights train), or once per ``_pack_scope``."""
+        scope = self._pack_scope
+        if scope is not None and "packed" in scope:
+            return scope["packed"]
+        n = self.net
+        with torch.no_grad():
+            packed = torch.cat([p.detach().reshape(-1) for p in (n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)])
+        if scope is not None:
+            scope["packed"] = packed
+        return packed
+
     def fused_spec(self) -> Optional[FusedSpec]:
         if not self._is_exactly(MLPEnergy) or self.hidden not in self.FUSED_HIDDEN or self.in_dim > self.FUSED_MAX_DIM:
             return None
         w = self.net[0].weight
         if not w.is_cuda or w.dtype != torch.float32:
             return None
-        with torch.no_grad():  # W1[H,in] b1[H] W2[H,H] b2[H] w3[H] b3[1], the order include/ebm_hip.h documents
-            packed = torch.cat([p.detach().reshape(-1) for p in (
-                self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
-                self.net[4].weight, self.net[4].bias)])
+        with torch.no_grad():
+            packed = self._packed_parameters()
             # H = 128 beyond dim 64: the pre-split W1 image the chain kernel streams through LDS (include/ebm_hip.h,
             # ebm_mlp_w1_image_f32) -- rebuilt with the parameters, i.e. on every call, like `packed` itself
             image = None

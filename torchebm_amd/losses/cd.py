@@ -121,13 +121,29 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
                 "deprecated; set them on the constructor instead.",
             )
         starts = self.get_start_points(x, generator=generator)
-        negatives = self.sampler.sample(x=starts, n_steps=self.k_steps, model_kwargs=model_kwargs, generator=generator)
-        if self.persistent:
-            with torch.no_grad():
-                self.update_buffer(negatives)
-        for key in self._CD_OPTION_KEYS:
-            kwargs.setdefault(key, getattr(self, key))
-        loss = self.compute_loss(x, negatives, *args, model_kwargs=model_kwargs, generator=generator, **kwargs)
+        # Two things this method knows and its callees cannot: `starts` is a fresh tensor nobody else holds (the sampler may run its
+        # chains in it: no defensive copy of the state), and the weights do not change between the sampler call and the loss's model
+        # call (an energy that packs its parameters for the kernels packs them once).  Each is a 4 us launch of a 700 us step.
+        sampler, model = self.sampler, self.model
+        donate = getattr(sampler, "donate_input", None) is False and starts is not x
+        scoped = hasattr(model, "_pack_scope") and model._pack_scope is None
+        if donate:
+            sampler.donate_input = True
+        if scoped:
+            model._pack_scope = {}
+        try:
+            negatives = sampler.sample(x=starts, n_steps=self.k_steps, model_kwargs=model_kwargs, generator=generator)
+            if self.persistent:
+                with torch.no_grad():
+                    self.update_buffer(negatives)
+            for key in self._CD_OPTION_KEYS:
+                kwargs.setdefault(key, getattr(self, key))
+            loss = self.compute_loss(x, negatives, *args, model_kwargs=model_kwargs, generator=generator, **kwargs)
+        finally:
+            if donate:
+                sampler.donate_input = False
+            if scoped:
+                model._pack_scope = None
         return loss, negatives
 
     def _paired_loss_work(self, device: torch.device) -> torch.Tensor:

@@ -114,9 +114,16 @@ class GraphedTrainingStep:
     def _eager(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         loss, neg = self.loss_fn(x, generator=self.generator)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(self._unit(loss))
         self.optimizer.step()
         return loss.detach(), neg
+
+    def _unit(self, like: torch.Tensor) -> torch.Tensor:
+        """dL/dL = 1 as a tensor that already exists (``backward()`` without it fills a fresh one: a launch per step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != like.device or one.dtype != like.dtype:
+            one = self._one = torch.ones((), dtype=like.dtype, device=like.device)
+        return one
 
     def _side_stream(self, device: torch.device) -> torch.cuda.Stream:
         if self._stream is None or self._stream.device != device:
@@ -150,6 +157,7 @@ class GraphedTrainingStep:
         coords = _rng.DeviceCoords(dev)
         static_x = x.detach().clone()
         advance = torch.zeros(1, dtype=torch.int64, device=dev)  # steps the graph moves the coordinates by (filled below)
+        unit = self._unit(static_x.new_zeros(()))
         self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
         graph = torch.cuda.CUDAGraph()
         if self.generator is not None:
@@ -167,7 +175,7 @@ class GraphedTrainingStep:
                 gc.disable()
                 with torch.cuda.graph(graph, stream=self._side_stream(dev), capture_error_mode="thread_local"):
                     loss, neg = lf(static_x, generator=self.generator)
-                    loss.backward()
+                    loss.backward(unit)
                     self.optimizer.step()
                     coords.tensor[1:2].add_(advance)
             finally:
