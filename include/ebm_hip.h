@@ -357,42 +357,43 @@ EBM_API int ebm_energy_grad_f32(const ebm_energy_t* energy, const float* x, int6
                         int32_t dim, float* energy_out, float* grad_out, void* stream);
 
 /*
- * ABI 6 -- the BACKWARD pass of a training step through an EBM_ENERGY_MLP network, for the parameter gradients (what autograd does
- * for loss.backward() through the energies of torchebm/losses/contrastive_divergence.py:128-155; the network of
- * examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).  One launch evaluates the network on x[n, dim] and runs the
- * backward through it with the per-row seed dL/dE (seed[n]; NULL = 1) on the matrix cores, everything on-chip, and stores the
- * four activations the parameter gradients are made of, in TILES of 32 rows, hidden-major within a tile:
- *   acts = float[n_pad / 32][4][H][32],  n_pad = n rounded up to a multiple of 128 (tile t = rows 32 t .. 32 t + 31, one contiguous
- *   block of 16 H floats -- what one wavefront writes and what one step of ebm_mlp_param_grads_f32 reads; rows n .. n_pad - 1 are
- *   written too -- h1 of an all-zero row, the others 0: they contribute nothing to the products):
- *   [.][0] h1 = silu(W1 x + b1)   [.][1] seed h2 = seed silu(W2 h1 + b2)   [.][2] d2 = seed w3 silu'(a2)   [.][3] d1 = (W2^T d2) silu'(a1)
- * from which   dW2 = d2 h1^T,  db2 = d2 1,  dW1 = d1 x,  db1 = d1 1,  dw3 = (seed h2) 1 (a row sum),  db3 = sum seed   are small-output products over
- * K = n (ebm_mlp_param_grads_f32 below makes them in one pass).  energy_out (optional): E(x)[n];  grad_out (optional): seed dE/dx [n, dim].
- * The autograd graph of the same step materialises a1, h1, a2, h2 and their gradients -- some forty passes over [n, H] arrays;
- * this is one.  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  With seed = NULL and energy_out set it IS the training
- * forward (energies + unit-seed planes; the seed is then applied by ebm_mlp_param_grads_f32); without a gradient to prepare the
- * forward is ebm_energy_grad_f32 with grad_out = NULL, which runs the forward pass only.
+ * ABI 6 / 7 -- the forward + backward of a training step through an EBM_ENERGY_MLP network, for the parameter gradients (what autograd
+ * does for loss.backward() through the energies of torchebm/losses/contrastive_divergence.py:128-155; the network of
+ * examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31).  One launch evaluates the network on x[n, dim], runs the
+ * backward through it for a UNIT seed on the matrix cores, everything on-chip, and stores the three activation planes the parameter
+ * gradients are made of, in TILES of 32 rows, hidden-major within a tile:
+ *   acts = float[n_pad / 32][3][H][32],  n_pad = n rounded up to a multiple of 128 (tile t = rows 32 t .. 32 t + 31, one contiguous
+ *   block of 12 H floats -- what one wavefront writes and what one step of ebm_mlp_param_grads_f32 reads; rows n .. n_pad - 1 are
+ *   written too, with the values of an all-zero input row: the gradient pass gives them seed 0):
+ *   [.][0] h1 = silu(W1 x + b1)   [.][1] a2 = W2 h1 + b2   [.][2] d1 = (W2^T (w3 silu'(a2))) silu'(a1)
+ * (ABI 6 stored h1 | seed h2 | seed d2 | seed d1 as [4][H][n_pad]; h2 = silu(a2) and d2 = w3 silu'(a2) are functions of a2 and w3 that the
+ * gradient pass recomputes, a quarter of the bytes less).  From these   dW2 = d2 h1^T,  db2 = d2 1,  dW1 = d1 x,  db1 = d1 1,
+ * dw3 = h2 1,  db3 = 1   -- each summand weighted with its row's seed -- are small-output products over K = n
+ * (ebm_mlp_param_grads_f32 below makes them in one pass).  energy_out (optional): E(x)[n];  grad_out (optional): seed dE/dx [n, dim]
+ * (seed[n], NULL = 1, scales grad_out ONLY: the planes are seed-free).  The autograd graph of the same step materialises a1, h1, a2,
+ * h2 and their gradients -- some forty passes over [n, H] arrays; this is one.  Hidden width 64 or 128, dim <= 64 (EBM_EDIM
+ * otherwise).  With energy_out set it IS the training forward; without a gradient to prepare the forward is ebm_energy_grad_f32 with
+ * grad_out = NULL, which runs the forward pass only.
  */
 EBM_API int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x, int64_t n_chains, int32_t dim,
                                       const float* seed, float* energy_out, float* grad_out, float* acts, void* stream);
 
 /*
- * ABI 7 -- the parameter gradients themselves, from the planes ebm_mlp_backward_acts_f32 stored (acts = float[n_pad / 32][4][H][32], n_pad =
- * n_rows rounded up to a multiple of 128; ABI 6 had them as [4][H][n_pad]) and the rows x[n_rows, dim] they were made from, in ONE pass over the planes (the products above as six
- * library launches read them 2.2 times):
+ * ABI 7 -- the parameter gradients themselves, from the planes ebm_mlp_backward_acts_f32 stored (acts = float[n_pad / 32][3][H][32]:
+ * h1 | a2 | d1) and the rows x[n_rows, dim] they were made from, in ONE pass over the planes:
  *   grads_out = float[H dim + H + H H + H + H + 1], the packed parameter order of EBM_ENERGY_MLP:  dW1 | db1 | dW2 | db2 | dw3 | db3.
- * seed (optional, [n_rows]): the per-row dL/dE applied HERE, on load -- for planes stored with seed = NULL, so that one
- * ebm_mlp_backward_acts_f32 launch in the forward pass of a training step (energies + unit-seed planes) serves the backward pass too
- * (d2, d1 and the h2 row sum are linear in the seed); NULL = the planes are already scaled (db3 is then n_rows).
- * The products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation); every workgroup writes one partial record into
- * `work` and a second kernel adds the records in a fixed order: same inputs, same bits, whatever the scheduling.
- * work: device float[work_floats], work_floats >= ebm_mlp_param_grads_work_f32(hidden, dim, n_rows) (a per-device figure: one record per
- * CU; 0 for an unsupported shape).  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).  Reference: what autograd does for
- * loss.backward() through the nn.Linear weights (torchebm/losses/contrastive_divergence.py:128-155).
+ * seed (optional, [n_rows]; NULL = 1): the per-row dL/dE, applied HERE, on load (d1, d2 and h2 are linear in it), so that the ONE
+ * ebm_mlp_backward_acts_f32 launch of the forward pass serves the backward pass too.  w3: the last layer's weights [H] (d2 = w3
+ * silu'(a2); the packed parameter block + H dim + H + H H + H).  h2 and d2 are recomputed from a2 with the forward kernel's own
+ * arithmetic (hardware exp2 / rcp).  The products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation); every
+ * workgroup writes one partial record into `work` and a second kernel adds the records in a fixed order: same inputs, same bits,
+ * whatever the scheduling.  work: device float[work_floats], work_floats >= ebm_mlp_param_grads_work_f32(hidden, dim, n_rows) (a
+ * per-device figure: one record per CU; 0 for an unsupported shape).  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).
+ * Reference: what autograd does for loss.backward() through the nn.Linear weights (torchebm/losses/contrastive_divergence.py:128-155).
  */
 EBM_API int64_t ebm_mlp_param_grads_work_f32(int32_t hidden, int32_t dim, int64_t n_rows);
 EBM_API int ebm_mlp_param_grads_f32(const float* acts, int64_t n_rows, int32_t hidden, const float* x, int32_t dim, const float* seed,
-                                    float* work, int64_t work_floats, float* grads_out, void* stream);
+                                    const float* w3, float* work, int64_t work_floats, float* grads_out, void* stream);
 
 /* Column statistics for the sampler diagnostics (samplers/langevin_dynamics.py:173-185):
  * mean[dim], biased var[dim] clamped to [1e-10, 1e10].  `work` = device double[2*dim + 1], zeroed once by

@@ -139,7 +139,7 @@ _PROTOTYPES = {
     "ebm_energy_grad_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p]),
     "ebm_mlp_backward_acts_f32": (C.c_int, [_ENERGY_P, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "ebm_mlp_param_grads_work_f32": (C.c_int64, [_i32, _i32, _i64]),
-    "ebm_mlp_param_grads_f32": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i64, _p, _p]),
+    "ebm_mlp_param_grads_f32": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _p, _p]),
     "ebm_chain_stats_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "ebm_noise_fill_f32": (C.c_int, [_p, _i64, _i32, _u64, _u64, _p]),
     "ebm_noise_fill_dev_f32": (C.c_int, [_p, _i64, _i32, _p, _u64, _p]),

@@ -484,10 +484,10 @@ class _FusedMLPTraining(torch.autograd.Function):
     """The training forward / backward of ``MLPEnergy`` through the HIP library (round 5).
 
     Forward, when a parameter gradient will be asked for: ONE launch (``ebm_mlp_backward_acts_f32`` with a unit seed) evaluates the
-    network, writes the energies, runs the backward through the network on the matrix cores and stores the four activation planes the
-    parameter gradients are made of -- where autograd's graph of the same step writes and re-reads some forty ``[n, H]`` arrays.
+    network, writes the energies, runs the backward through the network on the matrix cores and stores the three activation planes the
+    parameter gradients are made of (h1, the pre-activation a2, d1) -- where autograd's graph of the same step writes and re-reads some forty ``[n, H]`` arrays.
     Backward: ONE pass over those planes (``ebm_mlp_param_grads_f32``: fp32 MFMA products over K = n, the per-row seed ``dL/dE``
-    applied on load -- the planes are linear in it --, partial records added in a fixed order) yields every parameter gradient.
+    applied on load, h2 and d2 recomputed from a2, partial records added in a fixed order) yields every parameter gradient.
     Without a gradient to prepare (``no_grad``, frozen parameters) the forward is the energy-only evaluation
     (``ebm_energy_grad_f32``).  Energies and gradients are those of the kernels: fp32-accurate (split-bf16 contractions with fp32
     accumulation in the network, exact fp32 products in the gradient pass), not bit-identical to ``self.net`` -- the tolerance tier
@@ -502,10 +502,10 @@ class _FusedMLPTraining(torch.autograd.Function):
         ctx.with_planes = bool(n) and any(ctx.needs_input_grad[3:])
         if ctx.with_planes:
             n_pad = (n + 127) // 128 * 128
-            acts = torch.empty(n_pad // 32, 4, hidden, 32, dtype=torch.float32, device=x.device)  # tiles of 32 rows: h1 | h2 | d2 | d1
+            acts = torch.empty(n_pad // 32, 3, hidden, 32, dtype=torch.float32, device=x.device)  # tiles of 32 rows: h1 | a2 | d1
             _lib.call("ebm_mlp_backward_acts_f32", spec.to_c(), x.data_ptr(), n, dim, None, energy.data_ptr(), None, acts.data_ptr(),
                       _lib.stream_handle(x.device))
-            ctx.save_for_backward(x, acts)
+            ctx.save_for_backward(x, acts, packed)
         else:
             if n:
                 _lib.call("ebm_energy_grad_f32", spec.to_c(), x.data_ptr(), n, dim, energy.data_ptr(), None, _lib.stream_handle(x.device))
@@ -522,12 +522,13 @@ class _FusedMLPTraining(torch.autograd.Function):
         if not ctx.with_planes:  # (an empty batch: every gradient is zero)
             flat = x.new_zeros(sum(sizes))
         else:
-            acts = ctx.saved_tensors[1]
+            acts, packed = ctx.saved_tensors[1], ctx.saved_tensors[2]
+            w3_ptr = packed.data_ptr() + 4 * (hidden * dim + hidden + hidden * hidden + hidden)  # W1 | b1 | W2 | b2 | w3 | b3
             work_floats = int(_lib.lib().ebm_mlp_param_grads_work_f32(hidden, dim, n))
             work = torch.empty(work_floats, dtype=torch.float32, device=x.device)
             flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
             seed = ge.contiguous()
-            _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), dim, seed.data_ptr(), work.data_ptr(), work_floats,
+            _lib.call("ebm_mlp_param_grads_f32", acts.data_ptr(), n, hidden, x.data_ptr(), dim, seed.data_ptr(), w3_ptr, work.data_ptr(), work_floats,
                       flat.data_ptr(), _lib.stream_handle(x.device))
         d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = flat.split(sizes)
         return None, None, None, d_w1.view(hidden, dim), d_b1, d_w2.view(hidden, hidden), d_b2, d_w3.view(1, hidden), d_b3

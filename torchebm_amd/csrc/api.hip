@@ -68,7 +68,7 @@ int launch_langevin_chain_mlp(const ebm_energy_t&, float*, int64_t, int32_t, int
 int launch_energy_grad_mlp(const ebm_energy_t&, const float*, int64_t, int32_t, float*, float*, hipStream_t);
 int launch_mlp_backward_acts(int32_t, const float*, const float*, int64_t, int32_t, const float*, float*, float*, float*, hipStream_t, const char*);
 int64_t mlp_param_grads_work_floats(int32_t hidden, int32_t dim, int64_t n);  // mlp_param_grads.hip
-int launch_mlp_param_grads(int32_t, const float*, const float*, int64_t, int32_t, const float*, float*, float*, hipStream_t, const char*);
+int launch_mlp_param_grads(int32_t, const float*, const float*, int64_t, int32_t, const float*, const float*, float*, float*, hipStream_t, const char*);
 int launch_probe_valu(float*, int32_t, int32_t, hipStream_t);
 int launch_probe_issue(float*, int32_t, int32_t, int32_t, hipStream_t);
 size_t mlp_w1_image_bytes(int32_t hidden, int32_t dim);  // mlp_wide_slab.hip
@@ -636,7 +636,7 @@ int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x, int64_
     return fail(EBM_EDIM, "%s: hidden width 64 or 128 and dim <= 64 (got %d, %d)", who, energy->n_comp, dim);
   if (n_chains == 0) return 0;
   if (!acts || !aligned16(acts) || (grad_out && !aligned16(grad_out))) return fail(EBM_EINVAL, "%s: acts / grad_out must be 16-byte aligned pointers", who);
-  if (((n_chains + 127) / 128 * 128) * 20 >= (1LL << 32)) return fail(EBM_EINVAL, "%s: too many rows for 32-bit lane offsets", who);
+  if (((n_chains + 127) / 128 * 128) * 20 >= (1LL << 32)) return fail(EBM_EINVAL, "%s: too many rows for 32-bit lane offsets", who);  // (a bound kept from the [4][H][n] layout)
   return launch_mlp_backward_acts(energy->n_comp, energy->dev0, x, n_chains, dim, seed, energy_out, grad_out, acts, (hipStream_t)stream, who);
 }
 
@@ -646,16 +646,16 @@ int64_t ebm_mlp_param_grads_work_f32(int32_t hidden, int32_t dim, int64_t n_rows
 }
 
 int ebm_mlp_param_grads_f32(const float* acts, int64_t n_rows, int32_t hidden, const float* x, int32_t dim, const float* seed,
-                            float* work, int64_t work_floats, float* grads_out, void* stream) {
+                            const float* w3, float* work, int64_t work_floats, float* grads_out, void* stream) {
   const char* who = "ebm_mlp_param_grads_f32";
   if ((hidden != 64 && hidden != 128) || dim < 1 || dim > 64)
     return fail(EBM_EDIM, "%s: hidden width 64 or 128 and dim <= 64 (got %d, %d)", who, hidden, dim);
   if (n_rows < 1) return fail(EBM_EINVAL, "%s: no rows", who);
-  if (!acts || !aligned16(acts) || !x || !grads_out || !work) return fail(EBM_EINVAL, "%s: NULL pointer, or acts not 16-byte aligned", who);
+  if (!acts || !aligned16(acts) || !x || !grads_out || !work || !w3) return fail(EBM_EINVAL, "%s: NULL pointer, or acts not 16-byte aligned", who);
   if (work_floats < mlp_param_grads_work_floats(hidden, dim, n_rows))
     return fail(EBM_EINVAL, "%s: workspace of %lld floats, need ebm_mlp_param_grads_work_f32() = %lld", who, (long long)work_floats,
                 (long long)mlp_param_grads_work_floats(hidden, dim, n_rows));
-  return launch_mlp_param_grads(hidden, acts, x, n_rows, dim, seed, work, grads_out, (hipStream_t)stream, who);
+  return launch_mlp_param_grads(hidden, acts, x, n_rows, dim, seed, w3, work, grads_out, (hipStream_t)stream, who);
 }
 
 int ebm_chain_stats_f32(const float* x, int64_t n_chains, int32_t dim, float* mean_out,

@@ -3,14 +3,14 @@
 // nn.Linear weights of examples/20-training/01-mcmc-losses/02-persistent-cd/main.py:21-31 (torchebm/losses/contrastive_divergence.py:128-155).
 //
 //   dW2 = sum_k s_k d2[:,k] h1[:,k]^T   db2 = sum_k s_k d2[:,k]   dW1 = sum_k s_k d1[:,k] x[k,:]   db1 = sum_k s_k d1[:,k]
-//   dw3 = sum_k s_k h2[:,k]             db3 = sum_k s_k
+//   dw3 = sum_k s_k h2[:,k]             db3 = sum_k s_k          with h2 = silu(a2), d2 = w3 silu'(a2) recomputed from the a2 plane
 //
-// are small-output products over K = n rows (131 072 for BASELINE config 5): 4 GFLOP next to 268 MB of planes -- an HBM-bound pass
+// are small-output products over K = n rows (131 072 for BASELINE config 5): 4 GFLOP next to 201 MB of planes -- an HBM-bound pass
 // if the planes are read ONCE.  The library route reads them 2.2 times in six launches (two row-block batched GEMMs at 2.5 TB/s,
 // four row reductions); this kernel reads every plane once:
-//   * one workgroup per CU walks chunks of KC = 32 rows -- one tile of the planes, a contiguous 16 H-float block: every load
-//     instruction of a wave is 1 KB of consecutive addresses --: global -> registers (seed scaling, the row sums) -> LDS, two
-//     stages, one barrier per chunk;
+//   * two workgroups per CU walk chunks of KC = 32 rows -- one tile of the planes, a contiguous 12 H-float block: every load
+//     instruction of a wave is 1 KB of consecutive addresses --: global -> registers (h2 / d2 from a2, seed scaling, the row sums)
+//     -> one LDS stage; while one workgroup multiplies the other loads and stages;
 //   * the products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): wave w owns a quadrant of dW2 and row
 //     tile w of dW1; both operands of a K-step come from the same [row][k] walk over an LDS tile (one ds_read_b128 = four K-steps);
 //     a K-step's two K indices are 8 t + e and 8 t + 4 + e -- any pairing works as long as both operands use it;
@@ -30,19 +30,20 @@ struct Shape {
   static constexpr int H = 32 * HT, DP = 32 * DT, XP = DP + 1;
   static constexpr int plane_floats = H * PITCH;
   static constexpr int stage_floats = 3 * plane_floats + KC * XP + 4;  // (+ 4: where the x staging slots a thread does not have land)
-  static constexpr size_t smem_bytes = (size_t)2 * stage_floats * sizeof(float);
+  static constexpr size_t smem_bytes = (size_t)stage_floats * sizeof(float);  // one stage: two workgroups share a CU
   // one partial record: W1 [H][DP] | b1 [H] | W2 [H][H] | b2 [H] | w3 [H] | b3
   static constexpr int off_w1 = 0, off_b1 = H * DP, off_w2 = off_b1 + H, off_b2 = off_w2 + H * H, off_w3 = off_b2 + H, off_b3 = off_w3 + H;
   static constexpr int record = off_b3 + 1;
 };
 
 struct Args {
-  const float* acts;   // [stride / 32][4][H][32]: h1 | h2 | d2 | d1 of 32 rows each, hidden-major (ebm_mlp_backward_acts_f32)
+  const float* acts;   // [stride / 32][3][H][32]: h1 | a2 | d1 of 32 rows each, hidden-major (ebm_mlp_backward_acts_f32)
+  const float* w3;     // [H]: the last layer's weights (d2 = w3 silu'(a2))
   int64_t stride;      // n rounded up to a multiple of 128
   const float* x;      // [n][dim]
   int64_t n;
   int32_t dim;
-  const float* seed;   // [n] or NULL (= 1: the planes are already scaled)
+  const float* seed;   // [n] or NULL (= 1)
   float* partials;     // [gridDim.x][record]
   int64_t chunks;      // stride / KC
 };
@@ -50,7 +51,7 @@ struct Args {
 extern __shared__ __attribute__((aligned(16))) float grads_smem[];
 
 template <int HT, int DT>
-__global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
+__global__ __launch_bounds__(kThreads, 2) void mlp_param_grads_kernel(Args a) {
   using S = Shape<HT, DT>;
   constexpr int H = S::H, DP = S::DP, XP = S::XP;
   constexpr int XI = (KC * DP + kThreads - 1) / kThreads;  // x elements a thread stages per chunk
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
   const int c4 = t & 7, r0 = t >> 3;
   const int dim = a.dim;
   const int64_t G = gridDim.x;
-  const auto stage = [](int i) { return grads_smem + i * S::stage_floats; };
+  float* const stage = grads_smem;
 
   // x staging: element idx = t + 256 i of the chunk's [KC][dim] block (fixed per thread)
   int xrow[XI], xcol[XI], xoff[XI];
@@ -70,34 +71,33 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
     xcol[i] = idx < KC * dim ? idx - (idx / dim) * dim : 0;
     xoff[i] = 3 * S::plane_floats + (xrow[i] >= 0 ? xrow[i] * XP + xcol[i] : KC * XP);  // (no slot: the spare word behind the block)
   }
-  for (int i = t; i < KC * XP; i += kThreads) {  // columns dim .. DP - 1 stay zero
-    stage(0)[3 * S::plane_floats + i] = 0.0f;
-    stage(1)[3 * S::plane_floats + i] = 0.0f;
-  }
+  for (int i = t; i < KC * XP; i += kThreads) stage[3 * S::plane_floats + i] = 0.0f;  // columns dim .. DP - 1 stay zero
 
   struct Regs {  // one chunk on its way from global memory to LDS
-    f32x4 h1[HT], h2[HT], d2[HT], d1[HT], s;
+    f32x4 h1[HT], a2[HT], d1[HT], s;
     float x[XI];
   };
-  Regs ra, rb;  // two chunks in flight: a chunk is requested two products ahead of the one that needs it (HBM latency under load
-                // is longer than one chunk's 5 k cycles of MFMAs)
-  float sum_d2[HT], sum_d1[HT], sum_h2[HT], sum_seed = 0.0f;
+  Regs rq;  // the chunk behind the one being multiplied
+  float sum_d2[HT], sum_d1[HT], sum_h2[HT], sum_seed = 0.0f, w3r[HT];
 #pragma unroll
-  for (int j = 0; j < HT; ++j) sum_d2[j] = sum_d1[j] = sum_h2[j] = 0.0f;
+  for (int j = 0; j < HT; ++j) {
+    sum_d2[j] = sum_d1[j] = sum_h2[j] = 0.0f;
+    w3r[j] = a.w3[r0 + 32 * j];  // this thread's rows of the planes
+  }
 
   const auto load_chunk = [&](Regs& q, int64_t c) __attribute__((always_inline)) {
     const int64_t col = c * KC + 4 * c4;
-    // chunk c = tile c of the planes: one contiguous [4][H][32] block; thread t reads floats 4 t .. 4 t + 3 of every 32-row slab
+    // chunk c = tile c of the planes: one contiguous [3][H][32] block; thread t reads floats 4 t .. 4 t + 3 of every 32-row slab
     // (nontemporal, like the stores that wrote them: read once)
-    const float* p = a.acts + c * (int64_t)(4 * H * KC) + 4 * t;
+    const float* p = a.acts + c * (int64_t)(3 * H * KC) + 4 * t;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
       q.h1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC));
-      q.h2[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + H * KC));
-      q.d2[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + 2 * H * KC));
-      q.d1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + 3 * H * KC));
+      q.a2[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + H * KC));
+      q.d1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32 * j * KC + 2 * H * KC));
     }
-    // (rows n .. stride - 1: the planes hold zeros there, and the seed is zero too -- db3 counts real rows only)
+    // (rows n .. stride - 1: the planes hold the values of an all-zero input row there; the seed is zero -- they contribute nothing)
+    // (guarded loads: a branch-free form with clamped indices was 20 % slower on the same box -- every lane then loads)
     q.s.x = col + 0 < a.n ? (a.seed ? a.seed[col + 0] : 1.0f) : 0.0f;
     q.s.y = col + 1 < a.n ? (a.seed ? a.seed[col + 1] : 1.0f) : 0.0f;
     q.s.z = col + 2 < a.n ? (a.seed ? a.seed[col + 2] : 1.0f) : 0.0f;
@@ -114,7 +114,15 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
     sum_seed += r0 == 0 ? add4(q.s) : 0.0f;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
-      const f32x4 d2 = q.d2[j] * q.s, d1 = q.d1[j] * q.s, h2 = q.h2[j] * q.s;
+      // layer 2's share from its pre-activation: sigma = 1 / (1 + exp(-a2)), h2 = a2 sigma, d2 = w3 (sigma + h2 (1 - sigma)) -- the
+      // arithmetic of the forward kernel's epilogue (hardware exp2 / rcp), two transcendentals per element in a memory-bound pass
+      const f32x4 ex = {__builtin_amdgcn_exp2f(q.a2[j].x * -1.44269504088896340736f), __builtin_amdgcn_exp2f(q.a2[j].y * -1.44269504088896340736f),
+                        __builtin_amdgcn_exp2f(q.a2[j].z * -1.44269504088896340736f), __builtin_amdgcn_exp2f(q.a2[j].w * -1.44269504088896340736f)};
+      const f32x4 sg = {__builtin_amdgcn_rcpf(ex.x + 1.0f), __builtin_amdgcn_rcpf(ex.y + 1.0f), __builtin_amdgcn_rcpf(ex.z + 1.0f),
+                        __builtin_amdgcn_rcpf(ex.w + 1.0f)};
+      const f32x4 hu = q.a2[j] * sg;
+      const f32x4 du = (sg + hu * (1.0f - sg)) * w3r[j];
+      const f32x4 d2 = du * q.s, d1 = q.d1[j] * q.s, h2 = hu * q.s;
       sum_d2[j] += add4(d2);
       sum_d1[j] += add4(d1);
       sum_h2[j] += add4(h2);
@@ -174,37 +182,25 @@ __global__ __launch_bounds__(kThreads) void mlp_param_grads_kernel(Args a) {
     }
   };
 
-  // chunk k of this workgroup = tile blockIdx.x + k G; it travels in ra (k even) / rb (k odd) and is multiplied out of stage k & 1
+  // A workgroup's chunk k = tile blockIdx.x + k G.  ONE LDS stage and one register set per workgroup, TWO workgroups per CU: while
+  // one multiplies a chunk (80 MFMAs of 64 cycles per wave) the other runs its register -> LDS pass or waits for its loads.  Measured
+  // (MI355X, n = 131 072) on the two-stage / one-workgroup form this replaces: 83 us = 27 (loads alone: the planes mostly hit the
+  // memory-side cache) + 15 (the pass) + 41 (the products) -- the three phases of a lone wave per SIMD add up whatever their order in
+  // the program (one or two chunks in flight, the pass behind or between the MFMAs: the same 83 - 87 us).
   const int64_t nk = (a.chunks - blockIdx.x + G - 1) / G;
   const auto chunk_of = [&](int64_t k) { return (int64_t)blockIdx.x + k * G; };
-  load_chunk(ra, chunk_of(0));
-  if (nk > 1) load_chunk(rb, chunk_of(1));
+  load_chunk(rq, chunk_of(0));
   __syncthreads();  // the zeroed x columns
-  store_chunk(ra, stage(0));
+  store_chunk(rq, stage);
   __syncthreads();
-  // (Measured, MI355X, n = 131 072: 83 - 87 us = 3.2 TB/s of plane reads, the same with one chunk in flight per thread or two, with
-  //  the register -> LDS pass behind the products or sliced between them: the pass is bound by memory, and the memory system is also
-  //  still writing back the 268 MB of planes the launch before this one produced.)
-  for (int64_t k = 0;; k += 2) {  // stage 0 holds chunk k; rb holds chunk k + 1, if there is one
-    if (k + 1 >= nk) {
-      compute(stage(0));
-      break;
-    }
-    if (k + 2 < nk) load_chunk(ra, chunk_of(k + 2));  // in flight behind the products of two chunks ...
+  for (int64_t k = 0; k < nk; ++k) {
+    if (k + 1 < nk) load_chunk(rq, chunk_of(k + 1));  // in flight behind the products
     __builtin_amdgcn_sched_barrier(0);
-    compute(stage(0));
-    __builtin_amdgcn_sched_barrier(0);  // ... and first touched after them
-    store_chunk(rb, stage(1));
-    __syncthreads();
-    if (k + 2 >= nk) {
-      compute(stage(1));
-      break;
-    }
-    if (k + 3 < nk) load_chunk(rb, chunk_of(k + 3));
+    compute(stage);
     __builtin_amdgcn_sched_barrier(0);
-    compute(stage(1));
-    __builtin_amdgcn_sched_barrier(0);
-    store_chunk(ra, stage(0));
+    if (k + 1 >= nk) break;
+    __syncthreads();  // every wave is done reading chunk k
+    store_chunk(rq, stage);
     __syncthreads();
   }
 
@@ -279,6 +275,7 @@ int grid_of(int64_t chunks) {
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  cus *= 2;  // two workgroups per CU (__launch_bounds__(256, 2), one 60 KB stage each)
   return (int)(chunks < cus ? chunks : cus);
 }
 
@@ -306,10 +303,10 @@ int64_t mlp_param_grads_work_floats(int32_t hidden, int32_t dim, int64_t n) {
   return record * mlpgrads::grid_of(chunks > 0 ? chunks : 1);
 }
 
-int launch_mlp_param_grads(int32_t hidden, const float* acts, const float* x, int64_t n, int32_t dim, const float* seed, float* work,
-                           float* out, hipStream_t st, const char* who) {
+int launch_mlp_param_grads(int32_t hidden, const float* acts, const float* x, int64_t n, int32_t dim, const float* seed, const float* w3,
+                           float* work, float* out, hipStream_t st, const char* who) {
   mlpgrads::Args a{};
-  a.acts = acts; a.stride = (n + 127) / 128 * 128; a.x = x; a.n = n; a.dim = dim; a.seed = seed; a.partials = work;
+  a.acts = acts; a.w3 = w3; a.stride = (n + 127) / 128 * 128; a.x = x; a.n = n; a.dim = dim; a.seed = seed; a.partials = work;
   a.chunks = a.stride / mlpgrads::KC;
   const int dt = (dim + 31) / 32;
   if (hidden == 64) return dt == 1 ? mlpgrads::launch<2, 1>(a, out, st, who) : mlpgrads::launch<2, 2>(a, out, st, who);

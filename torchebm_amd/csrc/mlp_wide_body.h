@@ -66,7 +66,7 @@ struct WideArgs {
   const char* w1_image;  // MODE 3: the pre-split W1 image (ebm_mlp_w1_image_f32), or null
   const uint64_t* rng_dev;  // ebm_langevin_chain_dev_f32: {seed, step} in device memory (step0 is then an offset from it), or null
   const float* seed;        // FAST = 3 (ebm_mlp_backward_acts_f32): dL/dE[n] of a training backward, or null (= 1)
-  float* acts;              // FAST = 3: the activation planes, tiled: [act_stride / 32][4][H][32] (h1 | h2 | d2 | d1 of 32 rows, hidden-major)
+  float* acts;              // FAST = 3: the activation planes, tiled: [act_stride / 32][3][H][32] (h1 | a2 | d1 of 32 rows, hidden-major)
   int64_t act_stride;       // ... the padded row count: n_chains rounded up to whole workgroups of 128 chains (no lane, no wave needs masking)
 };
 
@@ -262,11 +262,11 @@ tile_again:
     EBM_STAMP();
     constexpr bool eval_block_cuts = FAST != 0;
     constexpr bool eval_store_acts = FAST == 3;  // the backward pass of a training step: seed-scaled, activations stored (eval_b16.inc)
-    // the wave's tile of the activation planes: [n_pad / 32][4][H][32] floats -- one contiguous 16 H-float block per tile of 32 rows
-    [[maybe_unused]] float* act_base = FAST == 3 ? a.acts + (size_t)__builtin_amdgcn_readfirstlane((int)((sample - m) >> 5)) * (size_t)(4 * H * 32) : nullptr;
+    // the wave's tile of the activation planes: [n_pad / 32][3][H][32] floats -- one contiguous 12 H-float block per tile of 32 rows
+    [[maybe_unused]] float* act_base = FAST == 3 ? a.acts + (size_t)__builtin_amdgcn_readfirstlane((int)((sample - m) >> 5)) * (size_t)(3 * H * 32) : nullptr;
     if constexpr (FAST == 3) asm volatile("" : "+s"(act_base));  // (the store addresses are formed at their stores, not hoisted)
     [[maybe_unused]] const uint32_t act_lane = (uint32_t)((m + 128 * h) * sizeof(float));  // its column of the tile + its half's four rows
-    [[maybe_unused]] const float act_seed = (FAST == 3 && active && a.seed) ? a.seed[sample] : (FAST == 3 && !active ? 0.0f : 1.0f);
+    [[maybe_unused]] const float act_seed = (FAST == 3 && active && a.seed) ? a.seed[sample] : 1.0f;  // scales grad_out (the planes are seed-free)
     bool eval_energy_only = FAST != 1 && a.k_steps > 0 && step >= a.k_steps;  // the extra evaluation of a kept last step
     // (evaluation only, and nothing but the energy asked for: the forward pass alone -- the energies of a training forward)
     if (FAST == 0 && a.k_steps == 0 && !a.grad_out) eval_energy_only = true;
@@ -294,7 +294,7 @@ tile_again:
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int c = 32 * td + row_of(r, h);
-              if (c < dim) a.grad_out[sample * dim + c] = g[td][r];
+              if (c < dim) a.grad_out[sample * dim + c] = FAST == 3 ? g[td][r] * act_seed : g[td][r];
             }
         }
       }
