@@ -388,7 +388,7 @@ EBM_API int ebm_mlp_backward_acts_f32(const ebm_energy_t* energy, const float* x
  * arithmetic (hardware exp2 / rcp).  The products run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation); every
  * workgroup writes one partial record into `work` and a second kernel adds the records in a fixed order: same inputs, same bits,
  * whatever the scheduling.  work: device float[work_floats], work_floats >= ebm_mlp_param_grads_work_f32(hidden, dim, n_rows) (a
- * per-device figure: one record per CU; 0 for an unsupported shape).  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).
+ * per-device figure: two records per CU; 0 for an unsupported shape).  Hidden width 64 or 128, dim <= 64 (EBM_EDIM otherwise).
  * Reference: what autograd does for loss.backward() through the nn.Linear weights (torchebm/losses/contrastive_divergence.py:128-155).
  */
 EBM_API int64_t ebm_mlp_param_grads_work_f32(int32_t hidden, int32_t dim, int64_t n_rows);

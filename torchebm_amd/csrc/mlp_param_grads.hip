@@ -295,7 +295,7 @@ int launch(const Args& a0, float* out, hipStream_t st, const char* who) {
 
 }  // namespace mlpgrads
 
-// floats of workspace ebm_mlp_param_grads_f32 needs on the current device (one partial record per workgroup, one workgroup per CU)
+// floats of workspace ebm_mlp_param_grads_f32 needs on the current device (one partial record per workgroup, two workgroups per CU)
 int64_t mlp_param_grads_work_floats(int32_t hidden, int32_t dim, int64_t n) {
   const int64_t chunks = (n + 127) / 128 * 128 / mlpgrads::KC;
   const int64_t dp = 32 * ((dim + 31) / 32);
