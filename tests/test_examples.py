@@ -28,3 +28,13 @@ def test_example_runs_on_cpu(script):
 @pytest.mark.parametrize("script", SCRIPTS, ids=[os.path.basename(s) for s in SCRIPTS])
 def test_example_runs_on_gpu(script, cuda_device):
     assert "cuda" in _run(script, {})
+
+
+@pytest.mark.gpu
+def test_pcd_example_whole_step_graph_prints_the_eager_loop_losses(cuda_device):
+    """examples/pcd_two_moons.py with TORCHEBM_WHOLE_STEP_GRAPH=1 (utils.GraphedTrainingStep on a stream of changing batches) prints
+    the same loss lines as the plain loop."""
+    script = os.path.join(ROOT, "examples", "pcd_two_moons.py")
+    eager = [line for line in _run(script, {}).splitlines() if line.startswith("step")]
+    graphed = [line for line in _run(script, {"TORCHEBM_WHOLE_STEP_GRAPH": "1"}).splitlines() if line.startswith("step")]
+    assert eager and eager == graphed

@@ -31,6 +31,11 @@ captured one make the captured one drift from its eager loop -- plain PyTorch on
 (scripts/probes/torch_graph_adam_interference.py); a trainer that owns its GPU stream, as every training loop does, is
 bit-identical to its eager loop (tests/test_graphed_step_gpu.py).
 
+A second one, PyTorch's as well: an autograd graph through the model's parameters that was built on ANOTHER stream and is still alive
+when the step is captured (a loss tensor kept from an eager call on the default stream, say) leaves gradient-accumulation nodes pinned
+to that stream, and the captured backward then has to cross streams -- torch warns ("AccumulateGrad node's stream does not match") and
+the capture can abort.  Evaluate diagnostics under ``torch.no_grad()`` or drop their tensors before the third call.
+
 Refusals (``ValueError`` at construction or at the first call, each naming its reason): a sampler call that is not the
 plain fused call on an ``MLPEnergy`` (the only chain kernels that take device-resident coordinates), scheduled step
 sizes, conditioning kwargs, an optimiser that is not capturable, a model holding attributes a replay could not see
