@@ -226,3 +226,38 @@ def test_graphed_step_equals_the_eager_loop_across_shapes(cuda_device, in_dim, h
         assert not enabled or step.replays == steps - step.eager_steps
     assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+
+
+def test_graphed_step_refuses_capture_behind_a_stale_autograd_graph(cuda_device):
+    """An autograd graph through the parameters, built on the caller's stream and kept alive (a diagnostic tensor), makes torch's
+    engine cross streams in the captured backward -- which aborts the process.  The warm-up step sees torch's warning about it and the
+    capture is refused with a RuntimeError instead.  (Run in a child process: a missed detection would take the test run down.)"""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {root!r})
+        import torchebm_amd as ta
+        from torchebm_amd.utils import GraphedTrainingStep
+        dev = torch.device("cuda")
+        torch.manual_seed(0)
+        m = ta.MLPEnergy(2, device=dev)
+        s = ta.LangevinDynamics(m, step_size=0.1, device=dev)
+        cd = ta.ContrastiveDivergence(m, s, k_steps=5, persistent=True, buffer_size=1024, device=dev)
+        st = GraphedTrainingStep(cd, torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True))
+        x = torch.randn(512, 2, device=dev)
+        st(x)
+        keep = m(x).mean()  # gradients enabled, default stream, kept alive across the next calls
+        st(x)
+        try:
+            st(x)
+            print("CAPTURED")
+        except RuntimeError as exc:
+            print("REFUSED" if "another stream" in str(exc) else "OTHER: " + str(exc)[:200])
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert "REFUSED" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])

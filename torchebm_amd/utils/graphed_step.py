@@ -34,7 +34,8 @@ bit-identical to its eager loop (tests/test_graphed_step_gpu.py).
 A second one, PyTorch's as well: an autograd graph through the model's parameters that was built on ANOTHER stream and is still alive
 when the step is captured (a loss tensor kept from an eager call on the default stream, say) leaves gradient-accumulation nodes pinned
 to that stream, and the captured backward then has to cross streams -- torch warns ("AccumulateGrad node's stream does not match") and
-the capture can abort.  Evaluate diagnostics under ``torch.no_grad()`` or drop their tensors before the third call.
+the capture would abort the process.  The warm-up steps watch for that warning and the capture is then REFUSED (``RuntimeError``):
+evaluate diagnostics under ``torch.no_grad()`` or drop their tensors, and build a new ``GraphedTrainingStep``.
 
 Refusals (``ValueError`` at construction or at the first call, each naming its reason): a sampler call that is not the
 plain fused call on an ``MLPEnergy`` (the only chain kernels that take device-resident coordinates), scheduled step
@@ -144,8 +145,19 @@ class GraphedTrainingStep:
             return self._eager(x)
         cur, side = torch.cuda.current_stream(x.device), self._side_stream(x.device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            loss, neg = self._eager(x)
+        import warnings
+
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(side):
+                loss, neg = self._eager(x)
+        for w in seen:
+            if "AccumulateGrad node's stream does not match" in str(w.message):
+                # an autograd graph through the parameters, built on another stream, is still alive: capturing this backward would
+                # cross streams inside the capture and abort the process -- remember it and refuse to capture (see the module text)
+                self._stale_graph = True
+            else:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         cur.wait_stream(side)
         loss.record_stream(cur)
         neg.record_stream(cur)
@@ -214,6 +226,12 @@ class GraphedTrainingStep:
         key = self._key(x)
         g = self._g
         if g is None or g["key"] != key:
+            if getattr(self, "_stale_graph", False):
+                raise RuntimeError(
+                    "GraphedTrainingStep: an autograd graph through the model's parameters that was built on another stream is still alive "
+                    "(torch warned: \"AccumulateGrad node's stream does not match\") -- a tensor kept from an eager call of the model with "
+                    "gradients enabled, typically a diagnostic.  Capturing the step now would abort the process: evaluate diagnostics under "
+                    "torch.no_grad() (or drop their tensors), then build a new GraphedTrainingStep.")
             reason = self._static_refusal() or self._route_refusal(x)
             if reason:
                 raise ValueError(f"GraphedTrainingStep: {reason}")
