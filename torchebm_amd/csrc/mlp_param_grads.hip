@@ -5,9 +5,9 @@
 //   dW2 = sum_k s_k d2[:,k] h1[:,k]^T   db2 = sum_k s_k d2[:,k]   dW1 = sum_k s_k d1[:,k] x[k,:]   db1 = sum_k s_k d1[:,k]
 //   dw3 = sum_k s_k h2[:,k]             db3 = sum_k s_k          with h2 = silu(a2), d2 = w3 silu'(a2) recomputed from the a2 plane
 //
-// are small-output products over K = n rows (131 072 for BASELINE config 5): 4 GFLOP next to 201 MB of planes -- an HBM-bound pass
-// if the planes are read ONCE.  The library route reads them 2.2 times in six launches (two row-block batched GEMMs at 2.5 TB/s,
-// four row reductions); this kernel reads every plane once:
+// are small-output products over K = n rows (131 072 for BASELINE config 5): 4 GFLOP next to 201 MB of planes.  The library
+// route read (four) planes 2.2 times in six launches (two row-block batched GEMMs at 2.5 TB/s, four row reductions); this kernel reads
+// every plane once -- and is bound by neither the bytes nor the MFMAs but by the serial phases of a chunk (see the main loop):
 //   * two workgroups per CU walk chunks of KC = 32 rows -- one tile of the planes, a contiguous 12 H-float block: every load
 //     instruction of a wave is 1 KB of consecutive addresses --: global -> registers (h2 / d2 from a2, seed scaling, the row sums)
 //     -> one LDS stage; while one workgroup multiplies the other loads and stages;
