@@ -766,3 +766,37 @@ def test_paired_cd_loss_equals_the_op_by_op_form():
     assert out.item() == pytest.approx(0.1)
     (gb,) = torch.autograd.grad(out, bad)
     assert (gb[torch.arange(10) != 2] == 0).all()  # the constant sends no gradient (the NaN row's own entry is NaN * 0, as in autograd)
+
+
+def test_cd_forward_restores_the_sampler_and_model_switches_it_borrows():
+    """ContrastiveDivergence.forward lends the sampler its fresh start points (donate_input) and lets the energy pack its parameters once
+    (_pack_scope) for the duration of ONE step: both are back to their defaults afterwards, also when the sampler raises; a sampler the
+    user already configured with donate_input = True keeps it."""
+    torch.manual_seed(0)
+    model = ta.MLPEnergy(2, 64)
+    sampler = ta.LangevinDynamics(model, step_size=0.05)
+    cd = ta.ContrastiveDivergence(model, sampler, k_steps=2, persistent=True, buffer_size=64, init_steps=0)
+    x = torch.randn(16, 2)
+    seen = {}
+    plain_sample = sampler.sample
+
+    def spy(*a, **kw):
+        seen["donate"], seen["scope"] = sampler.donate_input, model._pack_scope
+        return plain_sample(*a, **kw)
+
+    sampler.sample = spy
+    loss, neg = cd(x)
+    assert seen["donate"] is True and isinstance(seen["scope"], dict)
+    assert sampler.donate_input is False and model._pack_scope is None and torch.isfinite(loss)
+
+    def boom(*a, **kw):
+        raise RuntimeError("sampler failed")
+
+    sampler.sample = boom
+    with pytest.raises(RuntimeError, match="sampler failed"):
+        cd(x)
+    assert sampler.donate_input is False and model._pack_scope is None
+    sampler.sample = plain_sample
+    sampler.donate_input = True  # the user's own choice survives
+    cd(x)
+    assert sampler.donate_input is True
