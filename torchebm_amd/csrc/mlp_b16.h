@@ -159,9 +159,17 @@ __device__ __forceinline__ void pair_split_b(Split8p& s, f32x2& r) {
   s.m[P] = pm;
   r = r - widen_pair(pm);
 }
+// (round 6) EBM_PIN: an epilogue is issued slot by slot behind MFMAs, and the slots of the tile that hides in a contraction's
+// tile-major tail sit in front of a branch (EBM_BLOCK_CUT / `eval_energy_only`) whose other successor does not use their results --
+// LLVM's code sinking then moved the whole epilogue (~300 instructions) out of the 36 - 48 MFMA gaps it was written into and
+// into the successor block, where it ran with the matrix pipe idle (scripts/isa_gaps.py: 96 empty gaps per evaluation).  A volatile
+// empty asm on the value a slot chain ends in keeps the chain where it is written.
+#define EBM_PIN(v) asm volatile("" : "+v"(v))
 template <int P>
 __device__ __forceinline__ void pair_split_c(Split8p& s, f32x2 r) {
-  s.l[P] = cvt_pair(r);
+  uint32_t lo = cvt_pair(r);
+  EBM_PIN(lo);
+  s.l[P] = lo;
 }
 template <int R0>
 __device__ __forceinline__ f32x2 pair_of(const f32x16& tile) {
