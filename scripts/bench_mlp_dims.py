@@ -16,7 +16,7 @@ from torchebm_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda")
 PEAK = 157.3
-n, k = 65536, 20
+n, k = 65536, int(os.environ.get("MLP_K", "20"))  # MLP_K=200: the per-step cost without the launch + staging share
 CASES = ((2, 128), (8, 128), (32, 128), (128, 128), (32, 64), (8, 256), (32, 256), (128, 256))
 if os.environ.get("MLP_CASES"):  # e.g. MLP_CASES=32x256,128x256
     CASES = tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["MLP_CASES"].split(","))

@@ -145,31 +145,67 @@ __device__ __forceinline__ f32x2 widen_pair(uint32_t packed) {
   w = (w << (u32x2){16u, 0u}) & (u32x2){0xffffffffu, 0xffff0000u};
   return __builtin_bit_cast(f32x2, w);
 }
-// stage A of a pair split: hi piece + residual; stage B: mid piece + residual; stage C: lo piece (the residual of B has at
-// most eight significant bits: the conversion is exact)
-template <int P>
-__device__ __forceinline__ void pair_split_a(Split8p& s, f32x2& r, f32x2 v) {
-  const uint32_t ph = cvt_pair(v);
-  s.h[P] = ph;
-  r = v - widen_pair(ph);
-}
-template <int P>
-__device__ __forceinline__ void pair_split_b(Split8p& s, f32x2& r) {
-  const uint32_t pm = cvt_pair(r);
-  s.m[P] = pm;
-  r = r - widen_pair(pm);
-}
 // (round 6) EBM_PIN: an epilogue is issued slot by slot behind MFMAs, and the slots of the tile that hides in a contraction's
 // tile-major tail sit in front of a branch (EBM_BLOCK_CUT / `eval_energy_only`) whose other successor does not use their results --
 // LLVM's code sinking then moved the whole epilogue (~300 instructions) out of the 36 - 48 MFMA gaps it was written into and
 // into the successor block, where it ran with the matrix pipe idle (scripts/isa_gaps.py: 96 empty gaps per evaluation).  A volatile
-// empty asm on the value a slot chain ends in keeps the chain where it is written.
+// empty asm on the values a slot chain ENDS in keeps the chain in the block it is written in (inside the block the MFMA / fill
+// fences keep the order).  One asm per tile epilogue, not per slot: the hazard recogniser puts an s_nop behind every asm.
 #define EBM_PIN(v) asm volatile("" : "+v"(v))
+// Pair arithmetic in two spellings (round 6; profiles/r06_mfma_valu_overlap.txt).  PK = true: <2 x float> operations, which select
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- half the issue slots of a lone wave, the form for MFMA-FREE stretches.  PK = false: the
+// same IEEE operations element by element (bit-identical results) -- the form for slots issued BEHIND an MFMA, where the first packed
+// instruction of a gap stalls the wave ~20 cycles (one v_pk_fma_f32 per gap: 54 cycles per MFMA; the two v_fma_f32 it replaces: 35).
+// The MLP units are compiled with -fno-slp-vectorize so that the element-wise spelling is not packed again (csrc/Makefile).
+template <bool PK> __device__ __forceinline__ f32x2 pmul(f32x2 a, f32x2 b) {
+  if constexpr (PK) return a * b; else return (f32x2){a.x * b.x, a.y * b.y};
+}
+template <bool PK> __device__ __forceinline__ f32x2 pmul(f32x2 a, float b) {
+  if constexpr (PK) return a * b; else return (f32x2){a.x * b, a.y * b};
+}
+template <bool PK> __device__ __forceinline__ f32x2 padd(f32x2 a, float b) {
+  if constexpr (PK) return a + b; else return (f32x2){a.x + b, a.y + b};
+}
+template <bool PK> __device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {
+  if constexpr (PK) return a - b; else return (f32x2){a.x - b.x, a.y - b.y};
+}
+template <bool PK> __device__ __forceinline__ f32x2 prsub(float a, f32x2 b) {  // a - b
+  if constexpr (PK) return a - b; else return (f32x2){a - b.x, a - b.y};
+}
+template <bool PK> __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) {
+  if constexpr (PK) return __builtin_elementwise_fma(a, b, c);
+  else return (f32x2){__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
+// stage A of a pair split: hi piece + residual; stage B: mid piece + residual; stage C: lo piece (the residual of B has at
+// most eight significant bits: the conversion is exact)
+template <int P, bool PK = true>
+__device__ __forceinline__ void pair_split_a(Split8p& s, f32x2& r, f32x2 v) {
+  const uint32_t ph = cvt_pair(v);
+  s.h[P] = ph;
+  r = psub<PK>(v, widen_pair(ph));
+}
+template <int P, bool PK = true>
+__device__ __forceinline__ void pair_split_b(Split8p& s, f32x2& r) {
+  const uint32_t pm = cvt_pair(r);
+  s.m[P] = pm;
+  r = psub<PK>(r, widen_pair(pm));
+}
+// The same split in micro-steps of two or three instructions (round 6: an epilogue is dealt out behind MFMAs ~5 instructions per
+// gap -- five hide, the sixth costs its issue time -- so its units must be finer than a stage): `piece`: the bf16 pair of v and its
+// widened copy; `resid`: what is left.
+template <int P, int STAGE>  // STAGE 0: hi, 1: mid
+__device__ __forceinline__ void pair_split_piece(Split8p& s, f32x2& wide, f32x2 v) {
+  const uint32_t pc = cvt_pair(v);
+  if constexpr (STAGE == 0) s.h[P] = pc; else s.m[P] = pc;
+  wide = widen_pair(pc);
+}
+template <bool PK>
+__device__ __forceinline__ void pair_split_resid(f32x2& r, f32x2 v, f32x2 wide) {
+  r = psub<PK>(v, wide);
+}
 template <int P>
 __device__ __forceinline__ void pair_split_c(Split8p& s, f32x2 r) {
-  uint32_t lo = cvt_pair(r);
-  EBM_PIN(lo);
-  s.l[P] = lo;
+  s.l[P] = cvt_pair(r);
 }
 template <int R0>
 __device__ __forceinline__ f32x2 pair_of(const f32x16& tile) {
@@ -336,6 +372,7 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs 
       const bf16x8 db = __builtin_bit_cast(bf16x8, (term == 0 || term == 2 || term == 5) ? b.h : ((term == 1 || term == 4) ? b.m : b.l));
       if constexpr (SETS == 2 && (term & 1)) extra = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[g & 1][it], db, extra, 0, 0, 0);
       else out[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[g & 1][it], db, out[it], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // (round 6: the MFMA FIRST -- left in one region with its fill, a group's first MFMA sank below it)
       fill(std::integral_constant<int, (kb * 6 + term) * NT + it>{});
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -354,6 +391,7 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs 
         const Split8p& b = bs(std::integral_constant<int, KBH + kbl>{});
         const bf16x8 db = __builtin_bit_cast(bf16x8, (term == 0 || term == 2 || term == 5) ? b.h : ((term == 1 || term == 4) ? b.m : b.l));
         out[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pt[it & 1][3 * kbl + grp], db, out[it], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         fill(std::integral_constant<int, KBH * 6 * NT + it * 12 + q>{});
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -363,10 +401,11 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs 
 }
 
 // Slots of a tile epilogue behind the MFMAs of one block (two K-blocks = NMB MFMAs): MFMA ob of the block runs slots
-// [48 ob / NMB, 48 (ob + 1) / NMB) of the 48 the epilogue of a 16-register tile is cut into.
-template <int NMB, int OB, class Slot>
+// [NS ob / NMB, NS (ob + 1) / NMB) of the NS the epilogue of a 16-register tile is cut into (round 6: micro-slots of 2 - 3
+// instructions -- 12 / 14 / 6 per pair for the three epilogues --, so that every gap gets its ~5).
+template <int NMB, int OB, int NS = 48, class Slot>
 __device__ __forceinline__ void run_slots(Slot slot) {
-  constexpr int s0 = 48 * OB / NMB, s1 = 48 * (OB + 1) / NMB;
+  constexpr int s0 = NS * OB / NMB, s1 = NS * (OB + 1) / NMB;
   static_for<s1 - s0>([&](auto k) __attribute__((always_inline)) { slot(std::integral_constant<int, s0 + decltype(k)::value>{}); });
 }
 

@@ -261,6 +261,8 @@ tile_again:
   for (int step = 0; step < n_evals; ++step) {
     EBM_STAMP();
     constexpr bool eval_block_cuts = FAST != 0;
+    constexpr bool eval_pin = true;
+    constexpr bool eval_need_energy = FAST != 1;  // (FAST = 1: no records, no evaluation-only launch -- nobody reads the energy)
     constexpr bool eval_store_acts = FAST == 3;  // the backward pass of a training step: seed-scaled, activations stored (eval_b16.inc)
     // the wave's tile of the activation planes: [n_pad / 32][3][H][32] floats -- one contiguous 12 H-float block per tile of 32 rows
     [[maybe_unused]] float* act_base = FAST == 3 ? a.acts + (size_t)__builtin_amdgcn_readfirstlane((int)((sample - m) >> 5)) * (size_t)(3 * H * 32) : nullptr;
@@ -278,6 +280,44 @@ tile_again:
       eval_energy_only = never != 0;
     }
     [[maybe_unused]] const bool slab_more = step + 1 < n_evals;
+    // (round 6) THIN + FAST (config 5's call): this step's noise does not depend on the evaluation, so it is drawn in 15 slots of <= 5
+    // instructions behind the MFMAs that have no epilogue to carry (eval_b16.inc `eval_aux`: tile 0's twelve of each tile-major tail) --
+    // Philox's ten rounds, the half of the counter this chain owns, one Box-Muller pair.  The same draws, bit for bit, as
+    // normal4_at() on (chain >> 1, step) followed by the odd / even select of the general path below.
+    constexpr bool aux_rng = MODE == 4 && (FAST == 1 || FAST == 2);
+    [[maybe_unused]] uint32_t ax0, ax1, ax2, ax3, axk0 = rkey.k0, axk1 = rkey.k1;
+    [[maybe_unused]] float axu = 0.0f, axrev = 0.0f, axr = 0.0f, eps_pre0 = 0.0f, eps_pre1 = 0.0f;
+    [[maybe_unused]] const auto eval_aux = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (aux_rng) {
+        if constexpr (k == 0) {
+          int64_t sm = sample;
+          asm volatile("" : "+v"(sm));  // (nothing derived from the chain index is hoisted out of the step loop)
+          const uint64_t group = (uint64_t)sm >> 1, stp = rstep0 + (uint64_t)step;
+          ax0 = (uint32_t)group; ax1 = (uint32_t)(group >> 32); ax2 = (uint32_t)stp; ax3 = (uint32_t)(stp >> 32);
+        } else if constexpr (k <= 10) {  // one Philox round (ebm_common.h philox4x32_10): two 32 x 32 -> 64 products, two 3-input xors
+          const uint64_t p0 = (uint64_t)0xD2511F53u * ax0, p1 = (uint64_t)0xCD9E8D57u * ax2;
+          const uint32_t n0 = xor3((uint32_t)(p1 >> 32), ax1, axk0), n2 = xor3((uint32_t)(p0 >> 32), ax3, axk1);
+          ax1 = (uint32_t)p1; ax3 = (uint32_t)p0; ax0 = n0; ax2 = n2;
+          axk0 += 0x9E3779B9u; axk1 += 0xBB67AE85u;
+        } else if constexpr (k == 11) {  // this chain's half of the counter: (x, y) for even chains, (z, w) for odd ones
+          const bool odd = (sample & 1) != 0;
+          const uint32_t ua = odd ? ax2 : ax0, ub = odd ? ax3 : ax1;  // (U4{c0, c1, c2, c3} = x, y, z, w)
+          axu = u01_open_low(ua);
+          axrev = (float)ub * 0x1p-32f;
+          asm volatile("" : "+v"(axu), "+v"(axrev));  // (slots 0 .. 11 sit in layer 2's tail, their users behind a block cut: mlp_b16.h EBM_PIN)
+        } else if constexpr (k == 12) {
+          axr = -1.38629436111989061883f * __builtin_amdgcn_logf(axu);
+        } else if constexpr (k == 13) {
+          axr = __builtin_amdgcn_sqrtf(axr);
+          eps_pre0 = __builtin_amdgcn_sinf(axrev);
+        } else if constexpr (k == 14) {
+          eps_pre1 = axr * __builtin_amdgcn_cosf(axrev);
+          eps_pre0 = axr * eps_pre0;
+          asm volatile("" : "+v"(eps_pre0), "+v"(eps_pre1));
+        }
+      }
+    };
 #include "mlp_wide_eval.inc"
     if (FAST != 1 && diag_pending >= 0) {
       wave_record_tail(a.diag_partials, a.diag_blocks, diag_pending, wave_id, dim, energy, active, false, lane);
@@ -338,6 +378,11 @@ tile_again:
             const F4 nrm = normal4_at(rkey, ((uint64_t)smp * (uint64_t)dim + (uint64_t)c0) >> 2, rstep0 + (uint64_t)step);
 #pragma unroll
             for (int i = 0; i < 4; ++i) eps[i] = nrm.v[i];
+          } else if constexpr (aux_rng) {  // dim == 2 on the THIN kernel: drawn behind the evaluation's MFMAs (eval_aux above)
+            if (td == 0 && q == 0) {
+              eps[0] = eps_pre0;
+              eps[1] = eps_pre1;
+            }
           } else if constexpr (FAST != 0) {  // dim == 2 (config 5's shape): a chain's two elements are half a Philox counter
             if (td == 0 && q == 0) {
               const F4 nrm = normal4_at(rkey, (uint64_t)smp >> 1, rstep0 + (uint64_t)step);

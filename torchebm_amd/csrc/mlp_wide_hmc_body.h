@@ -170,10 +170,11 @@ __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) 
             xr[td][r] = (32 * td + row_of(r, h) < dim) ? xn : 0.0f;
           }
       }
-      constexpr bool eval_energy_only = false, eval_block_cuts = false, eval_store_acts = false;
+      constexpr bool eval_energy_only = false, eval_block_cuts = false, eval_store_acts = false, eval_need_energy = true, eval_pin = false;
       [[maybe_unused]] float* const act_base = nullptr;
       [[maybe_unused]] constexpr uint32_t act_lane = 0;
       [[maybe_unused]] constexpr float act_seed = 1.0f;
+      [[maybe_unused]] const auto eval_aux = [](auto) __attribute__((always_inline)) {};  // (nothing to hide in the tails' empty gaps)
       [[maybe_unused]] constexpr bool slab_more = true;  // MODE 3: every evaluation asks for the next one's first slab (drained at the end)
 #include "mlp_wide_eval.inc"
       if (mode == 0) {  // H0 and the first (clamped) force

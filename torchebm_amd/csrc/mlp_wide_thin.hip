@@ -20,3 +20,10 @@ EBM_THIN(2) EBM_THIN(4)
 
 }  // namespace widemlp
 }  // namespace ebm
+
+#ifdef EBM_PHASE_TIMES
+// scripts/mlp_phase_times.py on a MODE 4 shape: build THIS file alone with -DEBM_PHASE_TIMES (the log is per translation unit)
+extern "C" __attribute__((visibility("default"))) int ebm_debug_phase_log(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ebm::widemlp::ebm_phase_log), (size_t)n * sizeof(unsigned long long));
+}
+#endif
