@@ -261,3 +261,30 @@ def test_graphed_step_refuses_capture_behind_a_stale_autograd_graph(cuda_device)
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert "REFUSED" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+
+
+def test_graphed_step_follows_a_changed_learning_rate(cuda_device):
+    """a float lr is a launch constant of the captured optimiser kernels -- the capture key holds every host-side scalar
+    (optimiser groups, the sampler's step size / noise scale / clamp, the loss's noise scale), so an LR-scheduler step or a manual
+    `param_groups[0]["lr"] = ...` re-captures instead of being silently ignored.  Same schedule on the eager loop: same weights."""
+    n, k, steps = 2048, 3, 24
+    data = two_moons(n, 0.05, seed=0, device=cuda_device)
+
+    def run(enabled):
+        model, cd, opt, gen, step = _setup(cuda_device, n, k, 4096, 0.05, enabled=enabled)
+        losses = []
+        for i in range(steps):
+            if i == 8:
+                opt.param_groups[0]["lr"] = 3e-3   # what torch.optim.lr_scheduler does to a float lr
+            if i == 16:
+                cd.sampler.schedulers["step_size"].start_value = cd.sampler.schedulers["step_size"].current_value = 0.05
+            losses.append(step(data)[0])
+        return model, torch.stack(losses), step
+
+    m_e, l_e, _ = run(False)
+    torch.cuda.synchronize()
+    m_g, l_g, step = run(True)
+    assert step.recaptures == 2
+    assert torch.equal(l_e, l_g)
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        assert torch.equal(pe, pg)

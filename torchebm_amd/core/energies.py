@@ -534,6 +534,14 @@ class _FusedMLPTraining(torch.autograd.Function):
         return None, None, None, d_w1.view(hidden, dim), d_b1, d_w2.view(hidden, hidden), d_b2, d_w3.view(1, hidden), d_b3
 
 
+def _functorch_active() -> bool:
+    """A ``torch.func`` transform (grad / vmap / jvp ...) is being traced: custom once-differentiable functions have no rules for it."""
+    try:
+        return torch._C._functorch.peek_interpreter_stack() is not None
+    except Exception:  # noqa: BLE001 -- an internal API: absent means no transform machinery either
+        return False
+
+
 class MLPEnergy(BaseModel):
     r"""Two-hidden-layer SiLU MLP energy ``E(x) = w_3^\top \mathrm{silu}(W_2\,\mathrm{silu}(W_1 x + b_1) + b_2) + b_3``
     -- the trainable energy of the reference's PCD example
@@ -600,6 +608,12 @@ class MLPEnergy(BaseModel):
     #: parameter gradients are then the KERNEL's (fp32-accurate, not bit-identical to ``self.net``).  False: torch ops forward
     #: (bit-identical to ``self.net``) with the hand-written torch backward (``_ThinMLPEnergy``).
     fused_training = True
+    #: True: ``forward`` always runs ``self.net`` under autograd -- for anything that differentiates the ENERGY TWICE through the
+    #: parameters (gradient penalties with ``create_graph=True``) or applies ``torch.func`` transforms: the hand-written training
+    #: paths above are once-differentiable custom functions (a second differentiation raises; it is never silently wrong) and
+    #: their energies under grad are the kernel's (fp32-accurate) while ``no_grad`` calls return ``self.net``'s bit for bit.
+    #: ``forward`` also switches itself to ``self.net`` while a ``torch.func`` transform is active.
+    higher_order = False
     #: a row's energy does not depend on the other rows of the batch (no batch statistics): a loss may evaluate data and negatives
     #: in one call (losses/cd.py)
     ROWS_INDEPENDENT = True
@@ -614,7 +628,8 @@ class MLPEnergy(BaseModel):
         # input needs no gradient (the sampler's step route, score-based losses and anything that differentiates twice keep
         # autograd's own graph through ``self.net``).
         if (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not x.requires_grad
-                and self.in_dim <= self.THIN_GRAD_MAX_IN and self._plain_net() and not torch.is_autocast_enabled()):
+                and not self.higher_order and self.in_dim <= self.THIN_GRAD_MAX_IN and self._plain_net()
+                and self._net_matches(x) and not torch.is_autocast_enabled() and not _functorch_active()):
             n = self.net
             params = (n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias)
             if (self.fused_training and self.hidden in (64, 128) and self.in_dim <= 64 and self.hidden in self.FUSED_HIDDEN
@@ -622,6 +637,14 @@ class MLPEnergy(BaseModel):
                 return _FusedMLPTraining.apply(x, self._packed_parameters(), int(self.hidden), *params)
             return _ThinMLPEnergy.apply(x, *params)
         return self.net(x).squeeze(-1)
+
+    def _net_matches(self, x: torch.Tensor) -> bool:
+        """The widths the kernels index the packed parameters by are the widths of ``self.net`` and of ``x`` (a wrong-width batch
+        must reach ``self.net`` and raise torch's shape error, not index ``packed`` as W1[H, x.shape[1]]; a ``net`` whose layers
+        were resized after construction is not the network ``hidden`` / ``in_dim`` describe)."""
+        n = self.net
+        return (x.shape[1] == self.in_dim == n[0].in_features and n[0].out_features == self.hidden == n[2].in_features
+                and n[2].out_features == self.hidden == n[4].in_features)
 
     def _plain_net(self) -> bool:
         """``self.net`` is the stack ``fused_spec`` packs, with nothing hooked into it (hooks see module calls; the

@@ -82,7 +82,10 @@ static bool hmc_geometry(const ebm_energy_t& e, int32_t dim, Geometry& geo) {
   if (!pick_geometry(dim, geo)) return false;
   // dim-32 full rows can be re-shaped to (G, NV) = (4,2) | (2,4) | (1,8); EBM_HMC_NV overrides
   static const int nv_env = ab_int("EBM_HMC_NV");
-  if (dim == 32 && (nv_env == 2 || nv_env == 4 || nv_env == 8)) geo = Geometry{8 / nv_env, nv_env, true};
+  // (not (1, 8) for a mixture of more than eight components: with identity mass that geometry exists only as hmc_ring.hip /
+  //  hmc_gmm32.hip, which stop at K = 8 -- launch_geo<GMM> would launch nothing and the call would return success: ADVICE r5)
+  if (dim == 32 && (nv_env == 2 || nv_env == 4 || nv_env == 8) && !(nv_env == 8 && e.kind == EBM_ENERGY_GMM && e.n_comp > 8))
+    geo = Geometry{8 / nv_env, nv_env, true};
   // measured on MI355X (profiles/r01_bench_kernels.jsonl): the small-mixture energy is fastest with
   // ONE lane per chain -- the means become wave-uniform scalar operands (no LDS traffic, no cross-lane
   // reduction): 1.22 ms per 10 transitions vs 1.76 for (2,4) and 2.3 for the generic (8,1)

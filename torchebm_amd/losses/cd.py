@@ -125,7 +125,9 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
         # chains in it: no defensive copy of the state), and the weights do not change between the sampler call and the loss's model
         # call (an energy that packs its parameters for the kernels packs them once).  Each is a 4 us launch of a 700 us step.
         sampler, model = self.sampler, self.model
-        donate = getattr(sampler, "donate_input", None) is False and starts is not x
+        # (storage, not identity: an overridden get_start_points may hand back a VIEW of the caller's batch)
+        fresh = starts is not x and starts._base is None and (x.numel() == 0 or starts.untyped_storage().data_ptr() != x.untyped_storage().data_ptr())
+        donate = getattr(sampler, "donate_input", None) is False and fresh
         scoped = hasattr(model, "_pack_scope") and model._pack_scope is None
         if donate:
             sampler.donate_input = True
@@ -145,6 +147,16 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
             if scoped:
                 model._pack_scope = None
         return loss, negatives
+
+    def _rows_independent(self) -> bool:
+        """The model declares a row's energy independent of the batch around it AND is verifiably the network that declaration was
+        made for: the class attribute is inherited by subclasses and survives a replaced ``net`` (train-mode BatchNorm, batch
+        statistics), and one call on [data | negatives] is one forward-hook event where the reference makes two."""
+        m = self.model
+        if not getattr(m, "ROWS_INDEPENDENT", False):
+            return False
+        plain = getattr(m, "_plain_net", None)
+        return bool(plain()) if callable(plain) else type(m).__dict__.get("ROWS_INDEPENDENT", False) is True
 
     def _paired_loss_work(self, device: torch.device) -> torch.Tensor:
         """The zeroed workspace of ``ebm_cd_loss_f32`` (every launch leaves it zeroed again); one per loss object and device."""
@@ -173,7 +185,7 @@ class ContrastiveDivergence(BaseContrastiveDivergence):
                 real = x + jitter
             else:
                 real = x
-            if (getattr(self.model, "ROWS_INDEPENDENT", False) and not cond and real.is_cuda and real.shape == pred_x.shape
+            if (self._rows_independent() and not cond and real.is_cuda and real.shape == pred_x.shape
                     and not real.requires_grad and not pred_x.requires_grad):
                 # one evaluation of both halves for an energy that declares every row's value independent of the batch around it
                 # (MLPEnergy): the same arithmetic per row in half the launches -- the loss's forward / backward is some sixty

@@ -69,6 +69,17 @@ class GraphedTrainingStep:
     kernels a config-5 step is ~0.65 ms of GPU work, and torch's default multi-tensor Adam adds 27 launches (~0.1 ms) to it;
     ``Adam(..., capturable=True, fused=True)`` is one launch (bench.py: ``with_torch_fused_adam``).
 
+    Host-side scalars are part of the capture: the optimiser's float hyper-parameters (``lr``, ``betas``, ``weight_decay`` ...), the
+    sampler's constant step size / noise scale / clamp bounds and the loss's ``noise_scale`` are launch constants of the captured
+    kernels.  Their VALUES are in the capture key, so changing one (an LR scheduler stepping a float ``lr``, a manual
+    ``param_groups[0]["lr"] = ...``) re-captures on the next call -- correct, but a capture costs tens of milliseconds: for a
+    per-step LR schedule give the optimiser a TENSOR lr (``Adam(lr=torch.tensor(1e-3, device=...), capturable=True)``), which the
+    captured kernels read at replay time.  ``recaptures`` counts the captures after the first.
+
+    Gradients: the captured backward allocates ``p.grad`` in the graph's memory pool and every replay rewrites those buffers.  Read
+    ``p.grad`` after a call if you need it, but do not call ``optimizer.zero_grad()`` yourself between calls -- it would detach
+    ``p.grad`` from the buffers the replays keep writing (the step zeroes its own gradients).
+
     ``enabled=False`` makes every call the eager step (same code path as the warm-up): the switch the tests use to
     compare the two.
     """
@@ -81,6 +92,7 @@ class GraphedTrainingStep:
         self.eager_steps, self.enabled, self.force = max(1, int(eager_steps)), enabled, force
         self.calls = 0
         self.replays = 0
+        self.recaptures = 0
         self._g = None
         self._stream = None
         reason = self._static_refusal()
@@ -163,11 +175,32 @@ class GraphedTrainingStep:
         neg.record_stream(cur)
         return loss, neg
 
+    @staticmethod
+    def _host_value(v):
+        """How a host-side hyper-parameter enters the capture key: a Python scalar is baked into the captured kernels' arguments (its
+        VALUE is the key: a change re-captures); a tensor is read by the kernels at replay time (its identity is the key)."""
+        if isinstance(v, torch.Tensor):
+            return ("tensor", v.data_ptr(), tuple(v.shape), v.dtype)
+        if isinstance(v, (list, tuple)):
+            return tuple(GraphedTrainingStep._host_value(e) for e in v)
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return v
+        return repr(v)
+
+    def _optimizer_key(self):
+        # every scalar of every parameter group (lr, betas, eps, weight_decay, momentum, ...): the captured optimiser kernels carry
+        # float hyper-parameters as launch constants, so an LR scheduler or a manual `param_groups[i]["lr"] = ...` between replays
+        # would otherwise be silently ignored.  A tensor lr (torch's capturable form) is live and keys by identity.
+        return tuple(tuple((k, self._host_value(g[k])) for k in sorted(g) if k != "params") for g in self.optimizer.param_groups)
+
     def _key(self, x: torch.Tensor):
-        lf = self.loss_fn
+        lf, s = self.loss_fn, self.loss_fn.sampler
+        sampler = (self._host_value(s.schedulers["step_size"].get_value()), self._host_value(s.schedulers["noise_scale"].get_value()),
+                   self._host_value(getattr(s, "clamp", None)), self._host_value(getattr(s, "fused_arithmetic", None)))
         return (tuple(x.shape), x.device, x.dtype, graph_state_key(lf.model), lf.training, lf.persistent, lf.buffer_size,
                 lf.k_steps, getattr(lf, "new_sample_ratio", None), getattr(lf, "energy_reg_weight", None),
-                getattr(lf, "add_noise_to_real", None))
+                getattr(lf, "add_noise_to_real", None), self._host_value(getattr(lf, "noise_scale", None)), sampler,
+                self._optimizer_key())
 
     def _capture(self, x: torch.Tensor, key) -> dict:
         lf, dev = self.loss_fn, x.device
@@ -235,6 +268,8 @@ class GraphedTrainingStep:
             reason = self._static_refusal() or self._route_refusal(x)
             if reason:
                 raise ValueError(f"GraphedTrainingStep: {reason}")
+            if g is not None:
+                self.recaptures += 1
             g = self._g = self._capture(x, key)
         if g["x"].data_ptr() != x.data_ptr():
             g["x"].copy_(x)
