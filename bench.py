@@ -742,6 +742,82 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                 # the same network at the reference's widest benchmark input (dim 128): W1's split image streamed through LDS (round 4)
                 "dim_128": wide(128, "langevin", dim=128)}
 
+    def c2_fused_arithmetic():
+        # the headline call with the opt-in contracted update (LangevinDynamics.fused_arithmetic = True, EBM_CHAIN_CONTRACTED, ABI 8):
+        # not the reference's rounding, hence an `extra` and never `value`; same workload, same timing protocol as the headline's kernel figure
+        n, dim, k = 1 << 20, 64, 200
+        gen = torch.Generator(device=device).manual_seed(1234)
+        x0 = torch.randn(n, dim, device=device, generator=gen)
+        res = {}
+        for name, flag in (("default", False), ("fused_arithmetic", True)):
+            s = ta.LangevinDynamics(ta.DoubleWellModel(device=device), step_size=ETA, noise_scale=SIGMA, device=device)
+            s.fused_arithmetic = flag
+            s.donate_input = True
+            x = x0.clone()
+            fn = lambda: s.sample(x=x, n_steps=k, generator=gen)  # noqa: E731
+            timed(fn, reps=4, warm=3, device=device)
+            kms = kernel_ms_of("ebm_langevin_chain_f32", fn, 10, device)
+            res[name] = {"kernel_ms_per_call": kms, "chain_steps_per_s": n * k / (kms * 1e-3)}
+        return {"name": "config2_fused_arithmetic", "workload": "BASELINE configs[1] (DoubleWell, n_chains=2^20, dim=64, k=200) through "
+                "LangevinDynamics.fused_arithmetic = True: x^2 - b^2 and x - eta g as FMAs, noise_scale * sqrt(step_size) folded into the "
+                "Box-Muller radius; opt-in, NOT the reference's rounding (the default is, bit for bit); kernel time by events, same run",
+                "metric": "chain-steps/s (kernel)", "value": res["fused_arithmetic"]["chain_steps_per_s"],
+                "default_same_protocol": res["default"], "fused": res["fused_arithmetic"],
+                "speedup": res["default"]["kernel_ms_per_call"] / res["fused_arithmetic"]["kernel_ms_per_call"]}
+
+    def reference_scales():
+        # The reference's OWN benchmark scales (benchmarks/conftest.py:35-39: small 64 x 8 x 50, medium 256 x 32 x 100, large
+        # 1024 x 128 x 200; registry.py:141-148, 368-370, 679-717: DoubleWellModel(barrier_height=2), step_size 1e-3,
+        # LangevinDynamics(noise_scale=1) and HamiltonianMonteCarlo(n_leapfrog_steps=10), timed through sampler.sample(x=x0, n_steps=...)).
+        # At these sizes the number is the HOST path: wall per call, the kernel's own time (events around the launch), and the
+        # Python time before / around the launch = wall - kernel; the oracle (CPU restatement of the same call) beside each.
+        import oracle
+        rows = []
+        for scale, (bs, dim, k) in (("small", (64, 8, 50)), ("medium", (256, 32, 100)), ("large", (1024, 128, 200))):
+            model = ta.DoubleWellModel(barrier_height=2.0, device=device)
+            x0 = torch.randn(bs, dim, device=device)
+            for sampler_name in ("LangevinDynamics", "HamiltonianMonteCarlo"):
+                if sampler_name == "LangevinDynamics":
+                    s = ta.LangevinDynamics(model, step_size=1e-3, noise_scale=1.0, device=device)
+                    entry = "ebm_langevin_chain_f32"
+                else:
+                    s = ta.HamiltonianMonteCarlo(model, step_size=1e-3, n_leapfrog_steps=10, device=device)
+                    entry = "ebm_hmc_chain_f32"
+                fn = lambda: s.sample(x=x0, n_steps=k, n_samples=bs, dim=dim)  # noqa: E731  (the reference's call, registry.py:716-717)
+                wall = timed(fn, reps=200, warm=30, device=device)
+                kms = kernel_ms_of(entry, fn, 50, device)
+                # the same call on the host cores: the oracle with pre-drawn noise (drawing it is part of the reference's call too,
+                # so it is inside the timed region), one thread count for all (these are 10 - 100 ms problems)
+                en = oracle.DoubleWell(2.0, 1.0)
+                xc = x0.cpu()
+                if sampler_name == "LangevinDynamics":
+                    def cpu_call():
+                        noise = torch.randn(k, bs, dim)
+                        return oracle.langevin_chain(en, xc, noise, [1e-3] * k, [1.0] * k)
+                else:
+                    def cpu_call():
+                        return oracle.hmc_chain(en, xc, torch.randn(k, bs, dim), torch.rand(k, bs), [1e-3] * k, 10)
+                cpu_call()
+                reps_cpu = 3 if scale == "large" else 5
+                t0 = time.perf_counter()
+                for _ in range(reps_cpu):
+                    cpu_call()
+                cpu_s = (time.perf_counter() - t0) / reps_cpu
+                rows.append({"scale": scale, "sampler": sampler_name, "batch_size": bs, "dim": dim, "n_steps": k,
+                             "wall_us_per_call": wall * 1e6, "kernel_us_per_call": None if kms is None else kms * 1e3,
+                             # (calls are queued back to back: where the kernel is longer than the Python around it the host share is hidden -- 0)
+                             "host_us_per_call": None if kms is None else max(0.0, wall * 1e6 - kms * 1e3),
+                             "chain_steps_per_s": bs * k / wall, "cpu_oracle_ms_per_call": cpu_s * 1e3,
+                             "cpu_oracle_chain_steps_per_s": bs * k / cpu_s, "cpu_threads": torch.get_num_threads()})
+        return {"name": "reference_benchmark_scales", "workload": "the reference's own benchmark scales (benchmarks/conftest.py:35-39, "
+                "registry.py:141-148,679-717): DoubleWellModel(barrier_height=2), step_size=1e-3, LangevinDynamics(noise_scale=1) and "
+                "HamiltonianMonteCarlo(n_leapfrog_steps=10) through sampler.sample(x=x0, n_steps=...); wall per call (median of 3 blocks of "
+                "100 calls), the kernel's time by events, host = wall - kernel (Python routing, RNG reservation, the output allocation, "
+                "the launch); cpu_oracle = the oracle's restatement of the same call on this box's host cores (noise drawn inside the call)",
+                "metric": "us per sample() call", "rows": rows}
+
+    guarded("config2_fused_arithmetic", c2_fused_arithmetic)
+    guarded("reference_benchmark_scales", reference_scales)
     guarded("config3_hmc_gmm8", c3)
     guarded("config4_shard", c4)
     guarded("config5_pcd_mlp", c5)

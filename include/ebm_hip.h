@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define EBM_ABI_VERSION 7
+#define EBM_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define EBM_API __attribute__((visibility("default")))
@@ -165,7 +165,16 @@ EBM_API int ebm_langevin_step_dev_f32(const float* x, const float* grad, float* 
  *                the launch.  EBM_EDIM / EBM_EKIND when this energy / dim has no in-kernel form (ask
  *                ebm_diag_layout first).
  *   noise        NULL (native RNG, steps offset .. offset+k-1), or [k_steps, n_chains, dim]
+ *   clamp_on     a flag word (ABI 8; 0 / 1 mean what they always did): EBM_CHAIN_CLAMP = 1 clamps to [cmin, cmax];
+ *                EBM_CHAIN_CONTRACTED = 2 PERMITS contracted arithmetic -- x^2 - b^2 and x - eta g as fused multiply-adds, the
+ *                coefficient noise_coef * sqrt_eta folded into the Box-Muller radius -- where a kernel has that form (element-wise
+ *                energies, the plain call: constant coefficients, no clamp, no trajectory, no records, the kernels' own draws:
+ *                8 of 76 vector instructions per float4 group-step fewer); every other call ignores the bit.  Not the
+ *                reference's rounding (core/base_integrator.py:711-731 rounds every multiply and add): same law, same Philox
+ *                field, last-bit differences per step.  Host side: `sampler.fused_arithmetic = True` on LangevinDynamics.
  */
+#define EBM_CHAIN_CLAMP      1
+#define EBM_CHAIN_CONTRACTED 2
 EBM_API int ebm_langevin_chain_f32(const ebm_energy_t* energy, float* x, int64_t n_chains, int32_t dim,
                            int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                            const float* coef_table, int32_t clamp_on, float cmin, float cmax,

@@ -144,3 +144,75 @@ def test_audit_kernel_cost_next_to_the_fast_body(cuda_device, capsys):
         print(f"\n[hmc audit] fast body {fast_ms:.3f} ms, literal body {audit_ms:.3f} ms ({audit_ms / fast_ms:.2f}x) per {T} transitions of "
               f"2^18 x 32, L = {L}; chains whose states differ by more than 5e-4: {(rel > 5e-4).float().mean().item():.2e}")
     assert audit_ms > fast_ms  # the literal sequence evaluates the gradient 2 L + 2 times per transition; the fast body L times
+
+
+def test_sampler_exact_option_runs_the_literal_kernel(cuda_device):
+    """`HamiltonianMonteCarlo(...).exact = True` -- the reference's operation sequence reachable from the API the
+    reference's users call.  Element-wise energies: the literal kernel (the same states as the ABI entry, seed for seed; diagnostics and
+    trajectories through the same launches); any other energy: the per-transition route on the reference's own torch operations."""
+    from torchebm_amd import _rng
+
+    n, dim, T, L, eps, seed = 1000, 32, 6, 9, 0.06, 99
+    model = ta.DoubleWellModel(device=cuda_device)
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(3)).to(cuda_device)
+    s = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, mass=1.3, device=cuda_device)
+    s.exact = True  # (an attribute: the constructor keeps the reference's signature -- its own tests pin `integrator` as the last parameter)
+    assert s._route(x0, {})[0] == "fused"
+    gen = torch.Generator(device=cuda_device).manual_seed(seed)
+    got = s.sample(x=x0, n_steps=T, generator=gen)
+    # the ABI entry on the same coordinates
+    x = x0.clone()
+    _lib.call("ebm_hmc_chain_audit_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, T, L, eps, None, _lib.MASS_SCALAR, 1.3, None, 1, None,
+              None, None, None, None, _rng.kernel_seed(seed), 0, _lib.stream_handle(cuda_device))
+    assert torch.equal(got, x)
+    # ... and it is not the fast body's state (same draws, other arithmetic), though close
+    fast = ta.HamiltonianMonteCarlo(model, step_size=eps, n_leapfrog_steps=L, mass=1.3, device=cuda_device).sample(
+        x=x0, n_steps=T, generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    assert not torch.equal(fast, got) and (fast - got).abs().median().item() < 1e-5
+    # diagnostics / trajectory with exact=True: same final state, acceptance in (0, 1]
+    traj, diag = s.sample(x=x0, n_steps=T, thin=2, return_trajectory=True, return_diagnostics=True,
+                          generator=torch.Generator(device=cuda_device).manual_seed(seed))
+    assert torch.equal(traj[:, -1], got) and diag["acceptance_rate"].shape == (T // 2,)
+    assert 0.0 < diag["acceptance_rate"].min().item() <= 1.0
+    # no literal kernel for a dense Gaussian: the reference's torch operations per transition (never the fast fused body)
+    g = ta.GaussianModel(torch.zeros(8), torch.eye(8), device=cuda_device)
+    sg = ta.HamiltonianMonteCarlo(g, step_size=0.1, n_leapfrog_steps=5, device=cuda_device)
+    sg.exact = True
+    assert sg._route(torch.zeros(64, 8, device=cuda_device), {})[0] == "step"
+    assert torch.isfinite(sg.sample(x=torch.zeros(64, 8, device=cuda_device), n_steps=3)).all()
+
+
+def test_exact_and_fast_bodies_full_size_differing_accept_decisions(cuda_device, capsys):
+    """The same call through both bodies at 2^18 x 32 (L = 20, 10 transitions, the kernels' own draws, one seed): REPORTED, not
+    bounded -- the fraction of accept decisions that differ, per transition and overall, and of chains whose final states differ.
+    (A decision differs where |u - a| is below what the two bodies' energies differ by; from the first differing decision on the
+    two chains are different chains.)  The line goes to the test log and to gpurun_out/ when that exists."""
+    import os
+
+    n, dim, T, L, eps, seed = 1 << 18, 32, 10, 20, 0.05, 7
+    desc = ta.DoubleWellModel(device=cuda_device).fused_spec().to_c()
+    x0 = torch.randn(n, dim, generator=torch.Generator(device=cuda_device).manual_seed(5), device=cuda_device).clamp_(-2.0, 2.0)
+    masks, states = {}, {}
+    for entry in ("ebm_hmc_chain_f32", "ebm_hmc_chain_audit_f32"):
+        extra = [None] if entry == "ebm_hmc_chain_f32" else []
+        x = x0.clone()
+        mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+        _lib.call(entry, desc, x.data_ptr(), n, dim, T, L, eps, None, 0, 0.0, None, 1, None, *extra, mask.data_ptr(), None, None, None,
+                  seed, 0, _lib.stream_handle(cuda_device))
+        masks[entry], states[entry] = mask.bool(), x
+    differ = masks["ebm_hmc_chain_f32"] != masks["ebm_hmc_chain_audit_f32"]
+    per_t = differ.float().mean(dim=1).tolist()
+    first = differ.float().cumsum(dim=0).clamp_(max=1.0)  # chains that have diverged by transition t
+    rel = ((states["ebm_hmc_chain_f32"] - states["ebm_hmc_chain_audit_f32"]).abs()
+           / states["ebm_hmc_chain_audit_f32"].abs().clamp(min=1.0)).amax(dim=1)
+    acc = masks["ebm_hmc_chain_audit_f32"].float().mean().item()
+    line = (f"[hmc exact vs fast] 2^18 x {dim}, L = {L}, {T} transitions, eps = {eps}: acceptance {acc:.4f}; accept decisions that differ: "
+            f"{differ.float().mean().item():.3e} overall, per transition {['%.1e' % v for v in per_t]}; chains with at least one differing "
+            f"decision {first[-1].mean().item():.3e}; chains whose final states differ by more than 5e-4: {(rel > 5e-4).float().mean().item():.3e}, "
+            f"by more than 1e-6: {(rel > 1e-6).float().mean().item():.3e}")
+    with capsys.disabled():
+        print("\n" + line)
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/hmc_exact_vs_fast.txt", "w") as f:
+            f.write(line + "\n")
+    assert differ.float().mean().item() < 0.05  # sanity only: the two bodies are the same sampler

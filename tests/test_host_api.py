@@ -58,10 +58,13 @@ def test_sample_signature(cls):
 
 
 def test_constructor_signatures_and_validation():
+    # the reference's parameters, in the reference's order, `integrator` last (the reference's own test_api_contract pins that); this
+    # package's switches (round 6: fused_arithmetic, exact; donate_input) are attributes, default off
     names = list(inspect.signature(ta.LangevinDynamics.__init__).parameters)[1:]
     assert names == ["model", "step_size", "noise_scale", "decay", "clamp", "dtype", "device", "integrator"]
     names = list(inspect.signature(ta.HamiltonianMonteCarlo.__init__).parameters)[1:]
     assert names == ["model", "step_size", "n_leapfrog_steps", "mass", "dtype", "device", "integrator"]
+    assert ta.LangevinDynamics.fused_arithmetic is False and ta.HamiltonianMonteCarlo.exact is False
     m = ta.DoubleWellModel()
     with pytest.raises(ValueError, match="step_size must be positive"):
         ta.LangevinDynamics(m, step_size=0.0)

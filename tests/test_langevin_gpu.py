@@ -307,3 +307,48 @@ def test_integrator_step_with_tensor_diffusion_runs_on_hip(cuda_device, shape):
     _lib.call("ebm_noise_fill_f32", field.data_ptr(), n * dim, _lib.NOISE_NORMAL, _rng.kernel_seed(9), 0, _lib.stream_handle(cuda_device))
     want2 = (xg + h * (1.0 * drift(xg, None))) + (2.0 * dg) ** 0.5 * (field * (h**0.5))
     assert torch.equal(got2, want2)
+
+
+def test_fused_arithmetic_opt_in_same_law_other_rounding(cuda_device):
+    """`LangevinDynamics(...).fused_arithmetic = True` (ABI 8, EBM_CHAIN_CONTRACTED) -- the element-wise energies'
+    plain k-step call with the update contracted (FMAs, the noise coefficient folded into the Box-Muller radius).  Same Philox
+    draws and the same law as the default: after one step the states agree to the last few ulps, after 200 the column moments
+    agree within their sampling error and a column's marginal passes a two-sample KS test against the default's; and the bit is a
+    PERMISSION -- a call the contracted kernel does not take (a clamp here) computes the default's states bit for bit.  The
+    default itself (reference rounding, bit-exact fixtures) is untouched: every other test of this file runs without the flag."""
+    from scipy import stats
+
+    n, dim = 1 << 16, 8
+    model = ta.DoubleWellModel(device=cuda_device)
+    x0 = torch.randn(n, dim, generator=torch.Generator().manual_seed(2)).to(cuda_device)
+    def mk(fused_arithmetic=False, **kw):
+        s = ta.LangevinDynamics(model, step_size=0.01, noise_scale=1.0, device=cuda_device, **kw)
+        s.fused_arithmetic = fused_arithmetic  # (an attribute: the constructor keeps the reference's signature)
+        return s
+
+    gen = lambda: torch.Generator(device=cuda_device).manual_seed(77)  # noqa: E731
+    c0 = hip_calls("ebm_langevin_chain_f32")
+    one_d, one_f = mk().sample(x=x0, n_steps=1, generator=gen()), mk(fused_arithmetic=True).sample(x=x0, n_steps=1, generator=gen())
+    assert hip_calls("ebm_langevin_chain_f32") == c0 + 2
+    assert not torch.equal(one_d, one_f)                      # another rounding ...
+    assert (one_d - one_f).abs().max().item() <= 2e-6          # ... of the same step (|x| ~ 1: a few ulps)
+    d, f = mk().sample(x=x0, n_steps=200, generator=gen()), mk(fused_arithmetic=True).sample(x=x0, n_steps=200, generator=gen())
+    assert torch.isfinite(f).all()
+    # the same draws drive both chains, so they stay close path-wise as well (the quartic well contracts differences)
+    assert (d - f).abs().median().item() < 1e-4
+    se = d.std(dim=0) / math.sqrt(n)
+    assert ((d.mean(dim=0) - f.mean(dim=0)).abs() <= 4 * math.sqrt(2) * se + 1e-4).all()
+    assert ((d.var(dim=0) - f.var(dim=0)).abs() <= 0.02 * d.var(dim=0)).all()
+    # against an INDEPENDENT default run (another seed): a two-sample KS test on |x_0| (the well is symmetric)
+    ind = mk().sample(x=x0, n_steps=200, generator=torch.Generator(device=cuda_device).manual_seed(78))
+    ks = stats.ks_2samp(f[:, 0].abs().cpu().numpy(), ind[:, 0].abs().cpu().numpy())
+    assert ks.pvalue > 1e-3, ks
+    # a permission, not an obligation: with a clamp there is no contracted kernel -- the default's states, bit for bit
+    cl_d = mk(clamp=(-1.5, 1.5)).sample(x=x0, n_steps=20, generator=gen())
+    cl_f = mk(clamp=(-1.5, 1.5), fused_arithmetic=True).sample(x=x0, n_steps=20, generator=gen())
+    assert torch.equal(cl_d, cl_f)
+    # ... and the flag word refuses bits it does not know
+    x = x0.clone()
+    with pytest.raises(ValueError, match="unknown bits"):
+        _lib.call("ebm_langevin_chain_f32", model.fused_spec().to_c(), x.data_ptr(), n, dim, 1, 0.01, 0.1, 1.4142135, None, 4, 0.0, 0.0,
+                  1, None, None, None, 1, 0, _lib.stream_handle(cuda_device))

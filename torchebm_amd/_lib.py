@@ -18,10 +18,11 @@ import torch  # imported first on purpose: it loads the HIP runtime (libamdhip64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # energy kinds / enums: keep in sync with include/ebm_hip.h
 ENERGY_DOUBLE_WELL, ENERGY_HARMONIC, ENERGY_GAUSSIAN, ENERGY_GMM, ENERGY_MLP = 0, 1, 2, 3, 4
+CHAIN_CLAMP, CHAIN_CONTRACTED = 1, 2  # the flag word `clamp_on` of the chain entries (ABI 8)
 NOISE_NORMAL, NOISE_UNIFORM, NOISE_RAW_U32 = 0, 1, 2
 MASS_NONE, MASS_SCALAR, MASS_DIAG = 0, 1, 2
 DIAG_LANGEVIN, DIAG_LANGEVIN_HEUN, DIAG_HMC = 0, 1, 2

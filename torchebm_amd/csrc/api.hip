@@ -17,7 +17,7 @@ int launch_langevin_step_diffusion(const float*, const float*, float*, const flo
                                    uint64_t, uint64_t, hipStream_t);
 int launch_langevin_chain_elem(int, float, float, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
-                               const float*, uint64_t, uint64_t, int heun, hipStream_t);
+                               const float*, uint64_t, uint64_t, int heun, int contracted, hipStream_t);
 int launch_langevin_chain_rows(const ebm_energy_t&, float*, int64_t, int32_t, int32_t, float, float,
                                float, const float*, int, float, float, int32_t, float*,
                                const float*, uint64_t, uint64_t, int heun, float* diag_partials, hipStream_t);
@@ -259,6 +259,10 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
     if (int r = reject_mlp(energy, who)) return r;
   }
   if (int r = check_state(x, n_chains, dim, who)) return r;
+  // ABI 8: `clamp_on` is a flag word -- bit 0 the clamp, bit 1 EBM_CHAIN_CONTRACTED (include/ebm_hip.h)
+  if (clamp_on & ~(EBM_CHAIN_CLAMP | EBM_CHAIN_CONTRACTED)) return fail(EBM_EINVAL, "%s: unknown bits in clamp_on (%d)", who, clamp_on);
+  const int contracted = (clamp_on & EBM_CHAIN_CONTRACTED) != 0;
+  clamp_on &= EBM_CHAIN_CLAMP;
   if (k_steps < 0 || thin < 1) return fail(EBM_EINVAL, "%s: k_steps=%d thin=%d", who, k_steps, thin);
   if (n_chains == 0 || k_steps == 0) return 0;
   if ((coef_table && !aligned16(coef_table)) || (traj && !aligned16(traj)) || (noise && !aligned16(noise)) ||
@@ -293,7 +297,7 @@ static int langevin_chain_impl(const char* who, int heun, const ebm_energy_t* en
   if (energy->kind == EBM_ENERGY_DOUBLE_WELL || energy->kind == EBM_ENERGY_HARMONIC)
     return launch_langevin_chain_elem(energy->kind, energy->s[0], energy->s[1], x, n_chains, dim,
                                       k_steps, eta, sqrt_eta, noise_coef, coef_table, clamp_on, cmin,
-                                      cmax, thin, traj, noise, seed, offset, heun, (hipStream_t)stream);
+                                      cmax, thin, traj, noise, seed, offset, heun, contracted, (hipStream_t)stream);
   if (!heun && energy->kind == EBM_ENERGY_GAUSSIAN && gauss_shift_supported(dim)) {
     // A/B switch: EBM_GAUSS_NOSHIFT=1 keeps the packed rows / the lane-group kernel for widths off multiples of 4
     static const bool no_shift = ab_switch("EBM_GAUSS_NOSHIFT");

@@ -131,6 +131,22 @@ __device__ __forceinline__ F4 normal4_at(RngKey key, uint64_t group, uint64_t st
   return n;
 }
 
+// The contracted form (ABI 8, EBM_CHAIN_CONTRACTED): the Box-Muller radius carries the update's whole noise coefficient
+// A = noise_coef * sqrt_eta, so the update adds the draw as it is -- one multiply per PAIR of normals where the reference order
+// (eps * sqrt_eta, then * noise_coef) spends two per normal.  Same Philox counters; rounding differs in the last bit.
+__device__ __forceinline__ F4 scaled_normal4_at(RngKey key, uint64_t group, uint64_t step, float A) {
+  const U4 o = philox_at(key, group, step);
+  F4 n;
+  const float r0 = A * __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u01_open_low(o.x)));
+  const float r1 = A * __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u01_open_low(o.z)));
+  const float v0 = (float)o.y * 0x1p-32f, v1 = (float)o.w * 0x1p-32f;
+  n.v[0] = r0 * __builtin_amdgcn_sinf(v0);
+  n.v[1] = r0 * __builtin_amdgcn_cosf(v0);
+  n.v[2] = r1 * __builtin_amdgcn_sinf(v1);
+  n.v[3] = r1 * __builtin_amdgcn_cosf(v1);
+  return n;
+}
+
 __device__ __forceinline__ uint32_t pick(U4 o, int r) {
   return r == 0 ? o.x : (r == 1 ? o.y : (r == 2 ? o.z : o.w));
 }

@@ -278,7 +278,7 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
                                int32_t k_steps, float eta, float sqrt_eta, float noise_coef,
                                const float* coef_table, int clamp_on, float cmin, float cmax,
                                int32_t thin, float* traj, const float* noise, uint64_t seed,
-                               uint64_t offset, int heun, hipStream_t st) {
+                               uint64_t offset, int heun, int contracted, hipStream_t st) {
   ChainArgs a{};
   a.x = x; a.n_elem = n_chains * (int64_t)dim; a.dim = dim; a.k_steps = k_steps;
   a.c = StepCoef{eta, sqrt_eta, noise_coef};
@@ -299,6 +299,13 @@ int launch_langevin_chain_elem(int kind, float s0, float s1, float* x, int64_t n
     else
       hipLaunchKernelGGL((langevin_chain_lean_kernel<EBM_ENERGY_HARMONIC, false, false, false, true>), grid, block, 0, st, a);
     return check_launch("ebm_langevin_heun_chain_f32");
+  }
+  // EBM_CHAIN_CONTRACTED: a permission, used where the contracted kernel exists -- the plain call (constant coefficients, no clamp,
+  // no trajectory, the kernels' own draws); every other call computes the reference's arithmetic as before
+  if (contracted && !noise && !heun && !traj && !coef_table && !clamp_on) {
+    if (kind == EBM_ENERGY_DOUBLE_WELL) hipLaunchKernelGGL((langevin_chain_lean_contracted_kernel<EBM_ENERGY_DOUBLE_WELL>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((langevin_chain_lean_contracted_kernel<EBM_ENERGY_HARMONIC>), grid, block, 0, st, a);
+    return check_launch("ebm_langevin_chain_f32");
   }
   if (!noise && !heun && (!traj || (dim & 3) == 0)) {
 #define EBM_LEAN_T(KIND, TB, CL)                                                                          \

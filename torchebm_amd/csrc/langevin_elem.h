@@ -98,7 +98,11 @@ extern __shared__ __attribute__((aligned(16))) float elem_smem[];
 // return_diagnostics=True without leaving the k-step launch.  Lanes past the end of the state stay in the
 // loop (they take part in the workgroup barriers) with nothing to load or store.  The k steps are then walked
 // as n_kept runs of `thin` steps (the hot inner loop is the plain one, unrolled by two).
-template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN, bool DIAG>
+// CONTRACT (ABI 8, EBM_CHAIN_CONTRACTED; the opt-in of `sampler.fused_arithmetic = True` on LangevinDynamics): the same step with the arithmetic
+// contracted -- the gradient's x^2 - b^2 and the drift x - eta g as fused multiply-adds, the noise coefficient folded into the
+// Box-Muller radius (ebm_common.h scaled_normal4_at): 8 of the loop's 76 vector instructions per float4 group fewer.  NOT the
+// reference's rounding (eager torch rounds every multiply and add); the same law, moments and Philox field.
+template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN, bool DIAG, bool CONTRACT = false>
 __device__ __forceinline__ void lean_body(const ChainArgs& a) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e0 = g * 4;
@@ -119,6 +123,21 @@ __device__ __forceinline__ void lean_body(const ChainArgs& a) {
     if constexpr (TABLE) {  // wave-uniform: scalar loads
       const float4 t = a.table[i];
       c.eta = t.x; c.sqrt_eta = t.y; c.noise_coef = t.z;
+    }
+    if constexpr (CONTRACT) {
+      static_assert(!TABLE && !CLAMP && !HEUN, "the contracted form exists for the plain call only");
+      const F4 e = scaled_normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i, c.noise_coef * c.sqrt_eta);  // (uniform product: scalar unit)
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        const v2f xv = {x.v[q], x.v[q + 1]}, ev = {e.v[q], e.v[q + 1]};
+        v2f gr;
+        if constexpr (KIND == EBM_ENERGY_DOUBLE_WELL) gr = ((4.0f * a.s0) * __builtin_elementwise_fma(xv, xv, v2f{-a.s1, -a.s1})) * xv;
+        else gr = (2.0f * a.s0) * xv;
+        const v2f nv2 = __builtin_elementwise_fma(v2f{-c.eta, -c.eta}, gr, xv) + ev;
+        x.v[q] = nv2.x;
+        x.v[q + 1] = nv2.y;
+      }
+      return;
     }
     const F4 eps = normal4_at(a.key, (uint64_t)g, a.step0 + (uint64_t)i);
     // gradient + update on explicit 2-vectors (packed-f32 instructions); written out this way because
@@ -197,6 +216,10 @@ __device__ __forceinline__ void lean_body(const ChainArgs& a) {
 template <int KIND, bool TABLE, bool CLAMP, bool TRAJ, bool HEUN = false>
 __global__ __launch_bounds__(kBlock) void langevin_chain_lean_kernel(ChainArgs a) {
   lean_body<KIND, TABLE, CLAMP, TRAJ, HEUN, false>(a);
+}
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void langevin_chain_lean_contracted_kernel(ChainArgs a) {
+  lean_body<KIND, false, false, false, false, false, true>(a);
 }
 
 // The DIAG form, held to 64 VGPRs (8 waves per SIMD like the plain kernel: the out-of-line generic emit() would

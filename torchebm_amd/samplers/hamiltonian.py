@@ -47,6 +47,28 @@ class HamiltonianMonteCarlo(BaseSampler):
             ``BaseSymplecticIntegrator`` instance matching the sampler's device/dtype.
     """
 
+    #: Opt-in, an ATTRIBUTE (``sampler.exact = True``; the constructor keeps the reference's signature, whose own tests pin
+    #: ``integrator`` as its last parameter).
+    #: ``False`` (default): the fused transition kernel's FAST leapfrog body -- merged half kicks, fused
+    #: multiply-adds, ``eps / m`` hoisted: not less accurate than the reference's own fp32 run against an fp64 referee
+    #: (medians 0.5 - 0.8x, tests/test_grid_gpu.py), identical accept decisions on every recorded fixture, but not the
+    #: reference's operation sequence: after 200 leapfrog steps a quarter of the chains differ from the reference's
+    #: states by more than 5e-4 (tests/test_hmc_audit_gpu.py reports the figure).  ``True``: the reference's safe-mode
+    #: sequence LITERALLY (torchebm/samplers/hmc.py:243-312, integrators/leapfrog.py:156-185: separate half kicks, every
+    #: multiply and add rounded on its own, the drift divided by ``max(m, 1e-10)`` per step, both scrubs, energy and
+    #: force re-evaluated at the top of every transition).  For the element-wise energies (``DoubleWellModel``,
+    #: ``HarmonicModel``; dim <= 256) that is one launch of the library's literal kernel -- given the same momenta and
+    #: uniforms the states are the reference's bit for bit -- at 1.9x the fast body's time (2 L + 2 evaluations per
+    #: transition instead of L; 1.18 against 0.61 ms at 2^18 x 32, L = 20, 10 transitions).  For every other energy
+    #: ``exact=True`` takes the per-transition route: the reference's own torch operations around the HIP momentum /
+    #: accept kernels.  (The in-kernel Philox field is the package's on every GPU route; ``exact`` is about the
+    #: arithmetic between the draws.)
+    exact: bool = False
+
+    #: energies the literal kernel (``ebm_hmc_chain_audit_f32``) takes, and its widest state
+    _EXACT_KINDS = (_lib.ENERGY_DOUBLE_WELL, _lib.ENERGY_HARMONIC)
+    _EXACT_MAX_DIM = 256
+
     def __init__(
         self,
         model: BaseModel,
@@ -130,6 +152,8 @@ class HamiltonianMonteCarlo(BaseSampler):
             spec = fused_spec_for(self.model, x, model_kwargs)
             if spec is not None and not spec.hmc:
                 spec = None  # (a wide MLP energy: fused for Langevin only)
+            if spec is not None and self.exact and not (spec.kind in self._EXACT_KINDS and x.shape[-1] <= self._EXACT_MAX_DIM):
+                spec = None  # exact=True without a literal kernel for this energy: the reference's torch operations, per transition
             if (spec is not None and spec.kind == _lib.ENERGY_GAUSSIAN and spec.dim is not None
                     and spec.dim > 160  # (up to 160: the split operands stay in LDS -- five tiles; widths off multiples of 4 on shifted rows)
                     and not (spec.dim <= 256 and spec.aux is not None)  # (161 .. 256: the slabs stream from the pre-split image -- one per alignment class off multiples of 4, up to 254)
@@ -397,6 +421,15 @@ class HamiltonianMonteCarlo(BaseSampler):
             eps = eps_vals[t0]
             table = self._eps_table(eps_vals, state.device)[t0 : t0 + n_mh]
         cptr = None if counts is None else counts.data_ptr() + 4 * t0
+        if self.exact:  # the literal body (no in-kernel records: `_sample_fused` asks for none)
+            assert records is None
+            _lib.call(
+                "ebm_hmc_chain_audit_f32",
+                spec_c, _lib.ptr(state), n, dim, n_mh, self.n_leapfrog_steps, eps, _lib.ptr(table),
+                kind, m_scalar, _lib.ptr(m_diag), thin, _lib.ptr(traj), None, cptr, None, None,
+                seed, step, stream,
+            )
+            return
         _lib.call(
             "ebm_hmc_chain_f32",
             spec_c, _lib.ptr(state), n, dim, n_mh, self.n_leapfrog_steps, eps, _lib.ptr(table),
@@ -422,7 +455,7 @@ class HamiltonianMonteCarlo(BaseSampler):
         spec_c = spec.to_c()
 
         if n_steps > 0 and n > 0:
-            layout = _lib.diag_layout(spec_c, _lib.DIAG_HMC, n, dim, False, want_traj) if (want_diag and n_kept > 0) else None
+            layout = _lib.diag_layout(spec_c, _lib.DIAG_HMC, n, dim, False, want_traj) if (want_diag and n_kept > 0 and not self.exact) else None
             if not want_diag or n_kept == 0:
                 self._launch_hmc(spec_c, state, n, dim, eps_vals, 0, n_steps, thin, traj, None, seed, step0, stream)
             elif layout is not None:

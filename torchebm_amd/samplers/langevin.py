@@ -467,11 +467,22 @@ class LangevinDynamics(BaseSampler):
             )
             return
         entry = "ebm_langevin_heun_chain_f32" if type(self.integrator) is HeunIntegrator else "ebm_langevin_chain_f32"
+        flags = clamp_on | (_lib.CHAIN_CONTRACTED if self.fused_arithmetic else 0)  # (ABI 8: a flag word; the bit is a permission)
         _lib.call(
             entry,
             spec_c, _lib.ptr(x), n, dim, k, a, sq, coef, _lib.ptr(tab),
-            clamp_on, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(records), None, seed, step, stream,
+            flags, cmin, cmax, thin, _lib.ptr(traj), _lib.ptr(records), None, seed, step, stream,
         )
+
+    #: Opt-in (an ATTRIBUTE, ``sampler.fused_arithmetic = True``: the constructor keeps the reference's signature, whose own tests pin
+    #: ``integrator`` as its last parameter).  ``False``: every kernel rounds each multiply and add of the update on its own, as the
+    #: reference's eager torch operations do (core/base_integrator.py:711-731) -- chains are the reference's bit for bit given the
+    #: same draws.  ``True`` PERMITS contracted arithmetic where a kernel has that form (the element-wise energies' plain k-step call:
+    #: ``x^2 - b^2`` and ``x - eta g`` as fused multiply-adds, ``noise_scale``'s coefficient times ``sqrt(step_size)`` folded into the
+    #: Box-Muller radius): the same Philox draws and the same law, states that differ from the default's in the last bits of every
+    #: step, 12 % more chain-steps per second on BASELINE config 2 (``EBM_CHAIN_CONTRACTED``, include/ebm_hip.h; bench.py
+    #: ``config2_fused_arithmetic``).  Calls without such a kernel run the default arithmetic.
+    fused_arithmetic: bool = False
 
     #: Opt-in: let the fused route update the caller's ``x`` in place and return it (no defensive copy of the
     #: state -- 256 MiB per call at BASELINE config 2).  Off by default: the reference never mutates its input.
