@@ -11,7 +11,7 @@ import sys
 src = open(sys.argv[1]).read().split("\n")
 key = sys.argv[2]
 start = next(i for i, l in enumerate(src) if l.startswith("_Z") and key in l and ":" in l.split(";")[0])
-end = next(i for i in range(start, len(src)) if "s_endpgm" in src[i])
+end = next(i for i in range(start, len(src)) if src[i].startswith(".Lfunc_end"))
 body = src[start:end]
 labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
 best = (0, 0, 0)

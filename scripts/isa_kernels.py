@@ -10,7 +10,7 @@ for i, nm in zip(starts, names):
     short = re.sub(r"^void ", "", re.sub(r"\(.*", "", nm.replace("(anonymous namespace)::", ""))).replace("ebm::", "")
     if flt not in short:
         continue
-    end = next((j for j in range(i, len(src)) if "s_endpgm" in src[j]), None)
+    end = next((j for j in range(i, len(src)) if src[j].startswith(".Lfunc_end")), None)
     if end is None:
         continue
     body = src[i:end]

@@ -23,7 +23,7 @@ for o in objs:
             m = re.search(r"\." + k + r":\s*(\S+)", blk)
             return m.group(1) if m else "?"
         name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
-        name = re.sub(r"^void ", "", re.sub(r"\(.*", "", name))
+        name = re.sub(r"^void ", "", re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")))
         if flt and not all(f in name for f in flt):
             continue
         print(f"{name[-78:]:78s} vgpr {g('vgpr_count'):>4} agpr {blk.split()[0]:>4} spill {g('vgpr_spill_count'):>4} "

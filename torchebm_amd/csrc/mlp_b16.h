@@ -227,7 +227,11 @@ struct NoFill {
     if (never_ != 0) __builtin_trap();          \
   } while (0)
 
+#ifdef EBM_ABL_NOWAIT  /* timing ablation only (scripts/ab_build.sh ... -DEBM_ABL_NOWAIT): wrong results */
+#define EBM_WAIT_LDS() do {} while (0)
+#else
 #define EBM_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f) /* lgkmcnt(0), vmcnt / expcnt untouched */
+#endif
 
 // The A operands of the two walks over an image of width C with R rows (split stride R 2 C).  Every address is ONE lane
 // register (per K-block of the forward walk; per (output tile, half) of the transposed walk) plus an immediate; the one
@@ -332,6 +336,9 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs 
   // operands of group (kb, grp) for every tile
   const auto load_group = [&](auto kbc, auto grpc, auto bufc) __attribute__((always_inline)) {
     constexpr int kb = decltype(kbc)::value, grp = decltype(grpc)::value, buf = decltype(bufc)::value;
+#ifdef EBM_ABL_NOLOAD  /* timing ablation only: the operands are whatever the registers hold */
+    if constexpr (kb > 0 || grp > 0) return;
+#endif
     if constexpr (!TR && grp == 0) fk = w.template fwd_kb<kb>();
     static_for<NT>([&](auto itc) __attribute__((always_inline)) {
       constexpr int it = decltype(itc)::value;
@@ -342,6 +349,9 @@ __device__ __forceinline__ void contract_pipe(f32x16 (&out)[NT], const W& w, Bs 
   Addr ft[2];  // TAIL, forward walk: the registers of the two K-blocks
   const auto load_tail = [&](auto itc) __attribute__((always_inline)) {
     constexpr int it = decltype(itc)::value;
+#ifdef EBM_ABL_NOLOAD
+    if constexpr (it > 0) return;
+#endif
     static_for<6>([&](auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;  // K-block q / 3 of the tail, group q % 3 (0: lo)
       if constexpr (TR) pt[it & 1][q] = W::template bwd_load<2 - q % 3, KBH + q / 3>(bt[it][0], bt[it][1]);

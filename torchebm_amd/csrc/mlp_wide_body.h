@@ -35,7 +35,7 @@ __host__ __device__ constexpr int wide_mode(int ht, int dt) {
 __host__ __device__ constexpr size_t wide_smem_bytes(int ht, int dt, int mode) {
   const int H = 32 * ht, DP = 32 * dt;
   return mode == 3 ? (size_t)3 * H * sizeof(float) + 2 * mlpb16::kSlabBytes + mlpb16::image_bytes(H, H)
-         : mode == 4 ? (size_t)5 * H * sizeof(float) + mlpb16::image_bytes(H, H)
+         : mode == 4 ? (size_t)7 * H * sizeof(float) + mlpb16::image_bytes(H, H)
          : mode == 1 ? (size_t)(16 * ht * kBlock + 3 * H) * sizeof(float)
          : mode == 2 ? (size_t)3 * H * sizeof(float) + mlpb16::image_bytes(H, H) + mlpb16::image_bytes(H, b16_cols(dt))
                      : (size_t)(H * (H + 1) + H * (DP + 1) + 3 * H) * sizeof(float);
@@ -212,6 +212,11 @@ __host__ __device__ constexpr int wide_min_blocks(int ht, int dt, int mode, int 
 }
 template <int HT, int DT, int MODE, int FAST = 0>
 __global__ __launch_bounds__(kBlock, wide_min_blocks(HT, DT, MODE, FAST)) void mlp_wide_chain_kernel(WideArgs a) {
+  // (round 6) THIN chain calls: the layers' pre-activations are held PRE-SCALED by -log2 e (b1, b2 and the forward copy of W1 are
+  // staged times -log2 e; layer 2 needs nothing -- its input silu(a1) comes out times -log2 e as well and W2 (L h1) + L b2 = L a2),
+  // so that sigmoid(a) = 1 / (1 + exp2(a')) costs no multiply per element: 128 vector instructions per evaluation fewer
+  // (mlp_wide_eval_b16.inc `EVAL_SCALED`).  The training forward (FAST = 3) stores activation planes and keeps the plain form.
+  constexpr bool EVAL_SCALED = MODE == 4 && (FAST == 1 || FAST == 2);
 #include "mlp_wide_setup.inc"
 
   // Evaluation-only launches (k_steps == 0: energies / gradients, the training backward) come back here for their next tile of

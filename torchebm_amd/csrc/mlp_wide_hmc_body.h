@@ -35,6 +35,7 @@ struct WideHmcArgs {
 // (mlp_wide_body.h); instantiated for the MODE 2 shapes without a diagonal mass in mlp_wide_hmc_fast.hip.
 template <int HT, int DT, int MODE, bool DIAGM, bool FAST = false>
 __global__ __launch_bounds__(kBlock, 1) void mlp_wide_hmc_kernel(WideHmcArgs a) {
+  constexpr bool EVAL_SCALED = false;  // (the chain kernel's THIN calls only: mlp_wide_body.h)
 #include "mlp_wide_setup.inc"
 
   // The accepted position stays in a.x (in/out): read at the top of a transition, written back by the chains that
