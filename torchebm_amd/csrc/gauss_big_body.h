@@ -518,41 +518,57 @@ struct ResCfg {
 template <int OT>
 constexpr size_t res_image_bytes() { return (size_t)OT * 3u * ResCfg<OT>::SLABU * 16u; }
 
-// FOLD (round 4, with IMG, plain call: no records, in-kernel draws): the step's normals are drawn BEHIND THE MFMAs as well, in
-// the slots the slab split left empty, and folded into the state in place -- x[t] += noise_coef (eps sqrt_eta) as soon as tile
-// t has served as a B operand for the last time (from the second half of stage t on) -- so the epilogue is x - eta g and no
-// register holds a normal.  One wave per SIMD issues ~one instruction per five cycles whatever runs beside it: the 32 Philox
-// calls of a 256-wide step in the epilogue cost more than the step's 768 MFMAs (scripts/ab_big.sh); behind them they cost
-// nothing while a slot holds <= 8 instructions.  The sum is associated (x + noise) - eta g instead of the reference's
-// (x - eta g) + noise (core/base_integrator.py:711-731): same three terms, each product rounded as there, one rounding in a
-// different place -- inside the tolerance these kernels are held to (bf16 x 3 contraction), not bit-identical to the
-// records / injected-noise instantiations, which keep the reference's order.
-// The plan: per quad 13 stages (counter | ten Philox rounds | two Box-Muller pairs with their fold), 52 per tile; stage k of the
-// step's 52 OT goes to the k-th take of the free slots in issue order, a slot taking ceil(left / free slots left) stages
-// (1, rarely 2) but never one of a tile that is still a B operand.
+// FOLD (round 4; re-done in round 6 -- with IMG, plain call: no records, in-kernel draws): the step's normals are drawn BEHIND THE
+// MFMAs, in the slots the slab split left empty, and folded into the state in place -- x[t] += noise_coef (eps sqrt_eta) as soon
+// as tile t has served as a B operand for the last time -- so the epilogue is x - eta g and no register holds a normal across the
+// contraction's end.  The sum is associated (x + noise) - eta g instead of the reference's (x - eta g) + noise
+// (core/base_integrator.py:711-731): the same three terms, each product rounded as there, one rounding in a different place --
+// inside the tolerance these kernels are held to (bf16 x 3 contraction); EVERY instantiation of this kernel (records, injected
+// noise, shifted rows) uses that association, so the native draws stay bit-identical to the materialised field and records do
+// not change the samples.
+// Round 4's version bought 1 - 5 % and was left off ("one wave per SIMD is bound by the instructions it issues, not by where they
+// stand").  What the pinned-stream measurements of round 6 say (profiles/r06_mfma_valu_overlap.txt): FIVE plain vector
+// instructions hide behind a 32-cycle MFMA and every further one costs its issue time -- and round 4's stages were 6 (a Philox
+// round with its key bump) to ~20 instructions (a Box-Muller pair with its fold), the folds piled up behind the last tiles (a tile's
+// draws waited for the tile to stop being an operand), and the MFMA shared a scheduling region with its slot.  Now: per quad one
+// FOLD stage + 21 DRAW stages of <= 5 instructions (counter | ten Philox rounds | two Box-Muller pairs in five stages each, the
+// scaled normals parked in four registers per quad); the draws run LAG = 4 quads (one tile) AHEAD of the folds, so only a fold waits
+// for its tile; a slot takes ceil(stages left / free slots left) stages; the MFMA is fenced from its slot.
 template <int OT>
 struct FoldPlan {
-  static constexpr int HALF = 6 * OT, SLOTS = 2 * HALF * OT, PER_TILE = 52, B_STEPS = 10;
+  static constexpr int HALF = 6 * OT, SLOTS = 2 * HALF * OT, B_STEPS = 10;
+  static constexpr int LAG = 4, NQ = 4 * OT, PER_QUAD = 22, NST = PER_QUAD * (NQ + LAG);
   int pos[SLOTS + 1];  // stages taken before slot i (slot = stage * 2 HALF + ordinal)
   static constexpr bool is_free(int s, int o) {
     if (o >= HALF) return true;
     if (o / 2 >= B_STEPS) return true;
     return (o % 2 == 1) && !(s + 1 < OT);
   }
+  // stage K: block b = K / 22; r == 0: the fold of quad b - LAG; r = 1 .. 21: draw stage r - 1 of quad b
+  static constexpr bool is_noop(int K) {
+    const int b = K / PER_QUAD, r = K % PER_QUAD;
+    return r == 0 ? b < LAG : b >= NQ;
+  }
+  static constexpr bool allowed(int K, int s, int o) {  // a fold waits until its tile is no longer a B operand
+    const int b = K / PER_QUAD, r = K % PER_QUAD;
+    if (r != 0 || b < LAG) return true;
+    return (b - LAG) / 4 < (o >= HALF ? s + 1 : s);
+  }
   constexpr FoldPlan() : pos{} {
-    int free_left = 0;
+    int free_left = 0, real_left = 0;
     for (int i = 0; i < SLOTS; ++i) free_left += is_free(i / (2 * HALF), i % (2 * HALF)) ? 1 : 0;
+    for (int K = 0; K < NST; ++K) real_left += is_noop(K) ? 0 : 1;
     int p = 0;
     for (int i = 0; i < SLOTS; ++i) {
       pos[i] = p;
       const int s = i / (2 * HALF), o = i % (2 * HALF);
       if (!is_free(s, o)) continue;
-      const int allowed = PER_TILE * (o >= HALF ? s + 1 : s);  // tiles that are no longer B operands
-      const int left = PER_TILE * OT - p;
-      int want = (left + free_left - 1) / free_left;
-      if (want > allowed - p) want = allowed - p;
-      if (want < 0) want = 0;
-      p += want;
+      int want = (real_left + free_left - 1) / free_left;
+      if (i + 1 == SLOTS) want = real_left;  // (the last slot takes whatever is left: the last tile's folds)
+      while (p < NST && (is_noop(p) || (want > 0 && allowed(p, s, o)))) {
+        if (!is_noop(p)) { --want; --real_left; }
+        ++p;
+      }
       --free_left;
     }
     pos[SLOTS] = p;
@@ -729,31 +745,67 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       static_for<8>([&](auto kc) { j0.step(kc); });
       b0 = j0.tri();
     }
-    // FOLD: the noise stages of this step (see FoldPlan)
+    // FOLD: the noise stages of this step (see FoldPlan): one quad's Philox state in flight, the scaled normals of LAG quads parked
     [[maybe_unused]] uint32_t nc0 = 0, nc1 = 0, nc2 = 0, nc3 = 0, nk0 = 0, nk1 = 0;
+    [[maybe_unused]] float nz[FoldPlan<OT>::LAG][4];
+    [[maybe_unused]] float bu = 0.0f, brev = 0.0f, br = 0.0f, bs = 0.0f;
     [[maybe_unused]] uint64_t n_row = (uint64_t)chain * (uint64_t)dim;
     if constexpr (FOLD) asm volatile("" : "+v"(n_row));
     [[maybe_unused]] auto noise_stage = [&](auto kc) {
-      constexpr int K = decltype(kc)::value, t = K / 52, q = (K % 52) / 13, sub = K % 13;
-      if constexpr (sub == 0) {
-        const uint64_t grp = (n_row + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2;
-        const uint64_t stp = a.step0 + (uint64_t)step;
-        nc0 = (uint32_t)grp; nc1 = (uint32_t)(grp >> 32); nc2 = (uint32_t)stp; nc3 = (uint32_t)(stp >> 32);
-        nk0 = a.key.k0; nk1 = a.key.k1;
-      } else if constexpr (sub <= 10) {  // one round of philox4x32_10 (ebm_common.h)
-        const uint64_t p0 = (uint64_t)0xD2511F53u * nc0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * nc2;
-        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), nc1, nk0);
-        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), nc3, nk1);
-        nc1 = (uint32_t)p1; nc3 = (uint32_t)p0; nc0 = n0; nc2 = n2;
-        nk0 += 0x9E3779B9u; nk1 += 0xBB67AE85u;
-      } else {
-        constexpr int e0 = 4 * q + 2 * (sub - 11);
-        float n0, n1;
-        if constexpr (sub == 11) box_muller(nc0, nc1, n0, n1);
-        else box_muller(nc2, nc3, n0, n1);
-        x[t][e0] = x[t][e0] + noise_coef * (n0 * sqrt_eta);
-        x[t][e0 + 1] = x[t][e0 + 1] + noise_coef * (n1 * sqrt_eta);
+      using P = FoldPlan<OT>;
+      constexpr int K = decltype(kc)::value, blk = K / P::PER_QUAD, r = K % P::PER_QUAD;
+      if constexpr (r == 0) {  // the fold of quad blk - LAG: its tile stopped being a B operand (FoldPlan::allowed)
+        if constexpr (blk >= P::LAG) {
+          constexpr int n = blk - P::LAG, t = n / 4, q = n % 4;
+          float f0 = x[t][4 * q] + nz[n % P::LAG][0], f1 = x[t][4 * q + 1] + nz[n % P::LAG][1];
+          float f2 = x[t][4 * q + 2] + nz[n % P::LAG][2], f3 = x[t][4 * q + 3] + nz[n % P::LAG][3];
+          // (every stage ends in a volatile asm on what it wrote: the stages are pure arithmetic whose results are wanted much later,
+          //  and without an ordering point the instruction selector's linearisation collects them at the end of the block -- round
+          //  4's fold sat in 8 clumps behind the stages' last MFMAs, scripts/isa_gapmap.py -- instead of behind the MFMAs they were
+          //  written behind)
+          asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));
+          x[t][4 * q] = f0; x[t][4 * q + 1] = f1; x[t][4 * q + 2] = f2; x[t][4 * q + 3] = f3;
+        }
+      } else if constexpr (blk < P::NQ) {
+        constexpr int t = blk / 4, q = blk % 4, sub = r - 1;  // draw stage sub = 0 .. 20 of quad (t, q)
+        if constexpr (sub == 0) {
+          const uint64_t grp = (n_row + (uint64_t)(32 * t + 8 * q + 4 * h)) >> 2;
+          const uint64_t stp = a.step0 + (uint64_t)step;
+          nc0 = (uint32_t)grp; nc1 = (uint32_t)(grp >> 32); nc2 = (uint32_t)stp; nc3 = (uint32_t)(stp >> 32);
+          nk0 = a.key.k0; nk1 = a.key.k1;
+          asm volatile("" : "+v"(nc0), "+v"(nc1));
+        } else if constexpr (sub <= 10) {  // one round of philox4x32_10 (ebm_common.h); the key schedule is uniform (scalar unit)
+          const uint64_t p0 = (uint64_t)0xD2511F53u * nc0;
+          const uint64_t p1 = (uint64_t)0xCD9E8D57u * nc2;
+          const uint32_t n0 = xor3((uint32_t)(p1 >> 32), nc1, nk0);
+          const uint32_t n2 = xor3((uint32_t)(p0 >> 32), nc3, nk1);
+          nc1 = (uint32_t)p1; nc3 = (uint32_t)p0; nc0 = n0; nc2 = n2;
+          nk0 += 0x9E3779B9u; nk1 += 0xBB67AE85u;
+          asm volatile("" : "+v"(nc0), "+v"(nc1), "+v"(nc2), "+v"(nc3));
+        } else {  // box_muller (ebm_common.h) on (nc0, nc1), then on (nc2, nc3), in five stages each; the same operations
+          constexpr int pr = (sub - 11) / 5, st = (sub - 11) % 5;
+          if constexpr (st == 0) {
+            bu = u01_open_low(pr == 0 ? nc0 : nc2);
+            brev = (float)(pr == 0 ? nc1 : nc3) * 0x1p-32f;
+            asm volatile("" : "+v"(bu), "+v"(brev));
+          } else if constexpr (st == 1) {
+            br = -1.38629436111989061883f * __builtin_amdgcn_logf(bu);
+            asm volatile("" : "+v"(br));
+          } else if constexpr (st == 2) {
+            br = __builtin_amdgcn_sqrtf(br);
+            bs = __builtin_amdgcn_sinf(brev);
+            asm volatile("" : "+v"(br), "+v"(bs));
+          } else if constexpr (st == 3) {
+            brev = br * __builtin_amdgcn_cosf(brev);  // n1
+            bs = br * bs;                              // n0
+            asm volatile("" : "+v"(brev), "+v"(bs));
+          } else {
+            float z0 = noise_coef * (bs * sqrt_eta), z1 = noise_coef * (brev * sqrt_eta);
+            asm volatile("" : "+v"(z0), "+v"(z1));
+            nz[blk % P::LAG][2 * pr] = z0;
+            nz[blk % P::LAG][2 * pr + 1] = z1;
+          }
+        }
       }
     };
     static_for<OT>([&](auto sc) {
@@ -839,10 +891,12 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
             const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
             if constexpr (!(EBM_BIG_EXP & 1)) g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
             else g0[term] += (float)acur[ai][0] * (float)bp[0];
+            __builtin_amdgcn_sched_barrier(0);  // (round 6: the MFMA first -- in one region with its slot it can sink below it)
             slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
             if constexpr (two) {
               if constexpr (!(EBM_BIG_EXP & 1)) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
               else g1[term] += (float)acur[3 + ai][0] * (float)bp[0];
+              __builtin_amdgcn_sched_barrier(0);
               slot(std::integral_constant<int, o0 + 2 * term + 1>{});
             }
           });
@@ -906,9 +960,20 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
-          float nv = x1;
-          if constexpr (!FOLD) {
+          // six tiles and more (dims 161 .. 256, where the plain call is the FOLD form): (x + noise) - eta g in EVERY instantiation
+          // (see FoldPlan; the FOLD form has the noise in x already).  Five tiles (dims 132 .. 160: this kernel only serves the calls
+          // with records there, the plain call is gauss_mfma.hip's LDS-resident kernel): the reference's (x - eta g) + noise, as there.
+          static_assert(!FOLD || OT >= 6, "the folded sum is the convention of the widths whose plain call folds");
+          float nv;
+          if constexpr (OT >= 6) {
+            float xn = x[t][4 * q + i];
+            if constexpr (!FOLD) {
+              const float dw = eps[i] * sqrt_eta;
+              xn = xn + noise_coef * dw;
+            }
+            nv = xn - eta * g[t][4 * q + i];
+          } else {
+            const float x1 = x[t][4 * q + i] - eta * g[t][4 * q + i];
             const float dw = eps[i] * sqrt_eta;
             nv = x1 + noise_coef * dw;
           }
@@ -995,14 +1060,11 @@ int launch_res_as(const BigArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, IMG>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
-// -DEBM_BIG_FOLD (scripts only): the plain call on the image draws its normals behind the MFMAs (FoldPlan).  Measured on the same
-// box, 2^17 chains x 20 steps, dims 192 / 224 / 256: 1.59 / 1.99 / 2.37 -> 1.51 / 1.93 / 2.34 ms -- one wave per SIMD is bound by
-// the instructions it issues, not by where they stand, and the matrix pipe's shadow was full already -- for which the native draws
-// stop being bit-identical to the materialised field (the fold re-associates the update).  Off.
-#ifdef EBM_BIG_FOLD
-constexpr bool kResFold = true;
-#else
+// The plain call on the image draws its normals behind the MFMAs (FoldPlan; round 6: on).  -DEBM_BIG_NOFOLD: the A/B build.
+#ifdef EBM_BIG_NOFOLD  // A/B builds: the plain call keeps its normals in the epilogue
 constexpr bool kResFold = false;
+#else
+constexpr bool kResFold = true;
 #endif
 template <int OT>
 int launch_res_plain_img(const BigArgs& a, hipStream_t st) {  // the plain call on the image (no records instantiation beside it)
@@ -1020,7 +1082,9 @@ int launch_res_plain_img(const BigArgs& a, hipStream_t st) {  // the plain call 
 template <int OT>
 int launch_res(const BigArgs& a, hipStream_t st) {
   if (a.prec_image && (reinterpret_cast<uintptr_t>(a.prec_image) & 15) == 0) {
-    if (kResFold && !a.diag.partials && !a.noise) return launch_res_plain_img<OT>(a, st);
+    if constexpr (OT >= 6) {
+      if (kResFold && !a.diag.partials && !a.noise) return launch_res_plain_img<OT>(a, st);
+    }
     return launch_res_as<OT, true>(a, st);
   }
   return launch_res_as<OT, false>(a, st);
