@@ -16,7 +16,7 @@ pids=""
 for u in $units; do
   b=$(basename "$u" .hip)
   extra=""
-  case "$b" in mlp*) extra="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form";; esac
+  case "$b" in mlp*) extra="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form";; gauss_res*) extra="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wno-unused-function \
     -Wno-pass-failed -Wno-array-bounds $extra "$@" -c "$u" -o "$root/build/ab_$name/$b.o" &
   pids="$pids $!"

@@ -480,17 +480,21 @@ __global__ __launch_bounds__((BigCfg<OT, NS>::THREADS), (BigCfg<OT, NS>::TWO_WG 
 // ---------------------------------------------------------------------------------
 // A three-way split of eight values in EIGHT steps of five / six instructions (mlp_b16.h: pair p = elements 2 p, 2 p + 1 = one
 // packed dword of each piece): step 2 p forms the hi piece of pair p and its residual, step 2 p + 1 the mid and lo pieces.
-struct SplitJob {
+template <bool PK>
+struct SplitJobT {
   f32x8 d;
   mlpb16::f32x2 r;
   mlpb16::Split8p t;
   template <class K>
   __device__ __forceinline__ void step(K) {
     constexpr int k = K::value, pr = k >> 1;
+    // (PK = false: element-wise arithmetic -- behind an MFMA a packed-f32 instruction stalls the wave ~20 cycles,
+    //  profiles/r06_mfma_valu_overlap.txt: the resident Langevin kernel, -1.3 % at dim 256; the HMC transition kernels of
+    //  gauss_stream_e.h keep the packed form -- they spill, and the longer element-wise stream cost them 3 - 12 %)
     if constexpr ((k & 1) == 0) {
-      mlpb16::pair_split_a<pr>(t, r, mlpb16::f32x2{d[2 * pr], d[2 * pr + 1]});
+      mlpb16::pair_split_a<pr, PK>(t, r, mlpb16::f32x2{d[2 * pr], d[2 * pr + 1]});
     } else {
-      mlpb16::pair_split_b<pr>(t, r);
+      mlpb16::pair_split_b<pr, PK>(t, r);
       mlpb16::pair_split_c<pr>(t, r);
     }
   }
@@ -500,6 +504,7 @@ struct SplitJob {
     return o;
   }
 };
+typedef SplitJobT<true> SplitJob;
 
 template <int OT>
 struct ResCfg {
@@ -732,14 +737,15 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
     // B operand of K-block (tile t, half kb2): d = x[t][8 kb2 ..] - mu, then its three-way split in five small steps -- the
     // steps are SLOTS behind the MFMAs (one wave per SIMD: work placed between two MFMAs issues while the first one runs;
     // placed before or after the MFMA block it adds its full issue time, ~40 % of the step as measured by scripts/ab_big.sh)
-    auto b_init = [&](SplitJob& jb, auto tc, auto kc, auto hc) {  // half hc of the eight differences
+    typedef SplitJobT<false> ResSplit;  // (element-wise: its steps sit behind MFMAs)
+    auto b_init = [&](ResSplit& jb, auto tc, auto kc, auto hc) {  // half hc of the eight differences
       constexpr int t = decltype(tc)::value, kb2 = decltype(kc)::value, hf = decltype(hc)::value;
       const f32x4 mm = *reinterpret_cast<const f32x4*>(mus + 32 * t + 16 * kb2 + 8 * hf + 4 * h);
 #pragma unroll
       for (int j = 0; j < 4; ++j) jb.d[4 * hf + j] = x[t][8 * kb2 + 4 * hf + j] - mm[j];
     };
     {  // K-block 0 of the step: its state registers were written by the previous update
-      SplitJob j0;
+      ResSplit j0;
       b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
       static_for<8>([&](auto kc) { j0.step(kc); });
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       if constexpr (IMG) dma_stage(buf ^ 1, sn);  // (the barrier that ended the stage before freed that buffer)
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
-      SplitJob jb1, jb0n;
+      ResSplit jb1, jb0n;
       // Slots: one behind every MFMA, each <= 6 .. 8 instructions (what fits a 32-cycle MFMA; more delays the next one).
       //   behind K-block 0 (HALF slots): the B operands of K-block 1 and of the next stage's K-block 0, alternating --
       //   2 init + 8 split steps each;   behind K-block 1: the next slab (its loads were issued at the top of the stage) --
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
       constexpr int A_STEPS = 5 * UPT, B_STEPS = 10;
       constexpr int A_PER = (A_STEPS + HALF - 1) / HALF;
       static_assert(2 * B_STEPS <= HALF && A_PER == 1, "the split work of a stage fits behind its MFMAs");
-      auto b_job = [&](SplitJob& jb, auto tc, auto kc, auto kk) {  // step kk of 10 of a B operand
+      auto b_job = [&](ResSplit& jb, auto tc, auto kc, auto kk) {  // step kk of 10 of a B operand
         constexpr int k = decltype(kk)::value;
         if constexpr (k < 2) b_init(jb, tc, kc, std::integral_constant<int, k>{});
         else jb.step(std::integral_constant<int, k - 2>{});
