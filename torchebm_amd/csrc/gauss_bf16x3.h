@@ -139,6 +139,7 @@ __device__ __forceinline__ void contract_general(const __bf16* __restrict__ aop,
         constexpr int set = (term & 1) ? S1 : 0;
         const bf16x8& db = (term == 0 || term == 2 || term == 5) ? dh : ((term == 1 || term == 4) ? dm : dl);
         acc[set][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[it], db, acc[set][it], 0, 0, 0);
+        if constexpr (!std::is_same<std::decay_t<Fill>, NoFill>::value) __builtin_amdgcn_sched_barrier(0);  // (round 6: the MFMA first, then its fill)
         fill(std::integral_constant<int, (kb * 6 + term) * NT + it>{});
       });
     });

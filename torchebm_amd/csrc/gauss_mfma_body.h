@@ -157,10 +157,15 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
       uint64_t e_row = (uint64_t)chain * (uint64_t)dim - (uint64_t)lo;
       asm volatile("" : "+v"(e_row));
       f32x16 eps[NT];
-      constexpr int QUADS = 4 * HIDE, PER_QUAD = 13, STAGES = QUADS * PER_QUAD;
+      // (round 6) 21 stages per quad of <= 5 instructions -- counter | ten Philox rounds | two Box-Muller pairs in five stages each --
+      // dealt EVENLY over the contraction's MFMAs (stages [S ord / N, S (ord + 1) / N) behind MFMA ord).  Before: 13 stages of 6 - 20
+      // instructions, two behind each of the first STAGES / 2 MFMAs and none behind the rest (dim 128: 104 gaps of 8 - 17
+      // instructions, 88 empty ones -- scripts/isa_gapmap.py); five plain instructions hide behind a 32-cycle MFMA, every further
+      // one costs its issue time, an empty gap wastes it (profiles/r06_mfma_valu_overlap.txt).
+      constexpr int QUADS = 4 * HIDE, PER_QUAD = 21, STAGES = QUADS * PER_QUAD;
       constexpr int N_MFMA = GKR > 0 ? Mix::kMfmas : 6 * NT * KBU;
-      constexpr int PER_MFMA = (STAGES + N_MFMA - 1) / N_MFMA;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, k0 = 0, k1 = 0;
+      float bu = 0.0f, brev = 0.0f, br = 0.0f, bs = 0.0f;
       auto stage = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
         if constexpr (S < STAGES) {
@@ -177,25 +182,33 @@ __device__ __forceinline__ void gauss_langevin_mfma_body(const GaussArgs& a) {
             const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
             c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
             k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-          } else if constexpr (sub == 11) {
-            float n0, n1;
-            box_muller(c0, c1, n0, n1);
-            eps[qd >> 2][4 * (qd & 3) + 0] = n0; eps[qd >> 2][4 * (qd & 3) + 1] = n1;
-          } else {
-            float n0, n1;
-            box_muller(c2, c3, n0, n1);
-            eps[qd >> 2][4 * (qd & 3) + 2] = n0; eps[qd >> 2][4 * (qd & 3) + 3] = n1;
+          } else {  // box_muller (ebm_common.h) on (c0, c1), then on (c2, c3): the same operations, five stages each
+            constexpr int pr = (sub - 11) / 5, st = (sub - 11) % 5;
+            if constexpr (st == 0) {
+              bu = u01_open_low(pr == 0 ? c0 : c2);
+              brev = (float)(pr == 0 ? c1 : c3) * 0x1p-32f;
+            } else if constexpr (st == 1) {
+              br = -1.38629436111989061883f * __builtin_amdgcn_logf(bu);
+            } else if constexpr (st == 2) {
+              br = __builtin_amdgcn_sqrtf(br);
+              bs = __builtin_amdgcn_sinf(brev);
+            } else if constexpr (st == 3) {
+              brev = __builtin_amdgcn_cosf(brev);
+            } else {
+              eps[qd >> 2][4 * (qd & 3) + 2 * pr] = br * bs;
+              eps[qd >> 2][4 * (qd & 3) + 2 * pr + 1] = br * brev;
+            }
           }
         }
       };
       auto behind_mfma = [&](auto ord) {
-        gauss3::static_for<PER_MFMA>([&](auto u) { stage(std::integral_constant<int, decltype(ord)::value * PER_MFMA + decltype(u)::value>{}); });
+        constexpr int o = decltype(ord)::value, s0 = (int)((long long)STAGES * o / N_MFMA), s1 = (int)((long long)STAGES * (o + 1) / N_MFMA);
+        gauss3::static_for<s1 - s0>([&](auto u) { stage(std::integral_constant<int, s0 + decltype(u)::value>{}); });
         __builtin_amdgcn_sched_barrier(0);
       };
       if constexpr (GKR > 0) Mix::grad(gm, gauss_smem, x, g, lane, behind_mfma);
       else gauss3::contract<NT, KBU>(aop, mus, x, g, lane, behind_mfma);
-      // (PER_MFMA * N_MFMA >= STAGES: nothing is left over)
-      static_assert(PER_MFMA * N_MFMA >= STAGES, "every stage has an MFMA to hide behind");
+      // (the last MFMA's share ends at STAGES: nothing is left over)
       if constexpr (HIDE < NT) {  // the remaining tiles: drawn now, one quad at a time
 #pragma unroll
         for (int t = HIDE; t < NT; ++t)
