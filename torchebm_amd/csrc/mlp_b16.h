@@ -122,14 +122,15 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ w, int row
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The pipelined contraction.  ONE wave per SIMD (the images leave room for one workgroup per CU, the live tiles for one wave
-// per SIMD) issues about one instruction per six cycles WHATEVER the instruction is (scripts/mlp_phase_times.py; the same
-// figure as the 39 % single-wave VALU rate of profiles/r02_valu_occupancy.txt and the "five fillers per MFMA gap" of the
-// programming guide): an evaluation is ~480 MFMAs of 32 cycles next to ~2500 other instructions, so what it costs is its
-// instruction COUNT, and the matrix time hides behind the issue time if -- and only if -- MFMAs and the rest alternate.
+// per SIMD) issues one vector instruction per 5.0 cycles (8.0 for a transcendental; profiles/r06_mfma_valu_overlap.txt, the pinned
+// stream), and FIVE of them hide behind a 32-cycle MFMA -- the sixth costs its issue time, a packed-f32 one 20 cycles more: per
+// gap max(32 + 0.5 n, 10 + 5 n).  An evaluation is ~400 - 500 MFMAs next to ~2 000 - 2 500 other instructions, 4 - 6 per MFMA, so what
+// it costs is its instruction COUNT -- provided MFMAs and the rest alternate, <= 5 per gap, nothing packed (round 6: see EBM_PIN and the
+// micro-slots below for what kept them from alternating).
 // Hence: the epilogue of the PREVIOUS contraction's tile j + 1 (which yields K-blocks 2 j + 2, 2 j + 3 of this one) is issued
 // in slices behind the MFMAs of this contraction's K-blocks 2 j, 2 j + 1 (`fill(ordinal)`, called once behind every MFMA
-// and fenced there); pairs stay <2 x float> from the accumulator to the packed conversion so that the arithmetic selects
-// v_pk_*; an operand address is one lane register + an immediate; a group's operands are awaited once.
+// and fenced there, the MFMA from its fill as well); pair arithmetic behind MFMAs is element-wise, in MFMA-free stretches packed
+// (pmul / pfma<PK>); an operand address is one lane register + an immediate; a group's operands are awaited once.
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

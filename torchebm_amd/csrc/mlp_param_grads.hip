@@ -188,7 +188,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_param_grads_kernel(Args a) {
   // memory-side cache) + 15 (the pass) + 41 (the products) -- the three phases of a lone wave per SIMD add up whatever their order in
   // the program (one or two chunks in flight, the pass behind or between the MFMAs: the same 83 - 87 us).  A split into ROLES -- 512
   // threads, on every SIMD one wave that only multiplies and one that only loads and stages, two LDS stages -- measured 82 us (+ 8 for 256
-  // records) against this form's 74 (+ 14) on the same box: a SIMD does not run one wave's vector work under another wave's MFMAs either.
+  // records) against this form's 74 (+ 14) on the same box.  (Round 5 read that as "a SIMD does not run one wave's vector work under another
+  // wave's MFMAs"; the pinned-stream measurement of round 6, profiles/r06_mfma_valu_overlap.txt, says it does -- at ~one vector instruction
+  // per 5 cycles in total beside a busy pipe -- and this launch is bound by its memory traffic, not by either.)
   const int64_t nk = (a.chunks - blockIdx.x + G - 1) / G;
   const auto chunk_of = [&](int64_t k) { return (int64_t)blockIdx.x + k * G; };
   load_chunk(rq, chunk_of(0));
