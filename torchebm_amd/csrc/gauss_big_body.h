@@ -585,7 +585,7 @@ struct FoldPlan {
 template <int OT, bool DIAG = false, bool IMG = false, bool FOLD = false, bool SH = false>
 __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   static_assert(!FOLD || (IMG && !DIAG), "FOLD is the plain call on the image");
-  static_assert(!SH || (IMG && !FOLD), "shifted rows: on the per-class images");
+  static_assert(!SH || IMG, "shifted rows: on the per-class images");  // (round 6: FOLD too -- a folded draw on a padding coordinate is zeroed by the update's select)
   using C = ResCfg<OT>;
   constexpr int UPT = C::UPT, SLABU = C::SLABU;
   extern __shared__ __align__(16) unsigned char big_smem[];
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
     [[maybe_unused]] uint32_t nc0 = 0, nc1 = 0, nc2 = 0, nc3 = 0, nk0 = 0, nk1 = 0;
     [[maybe_unused]] float nz[FoldPlan<OT>::LAG][4];
     [[maybe_unused]] float bu = 0.0f, brev = 0.0f, br = 0.0f, bs = 0.0f;
-    [[maybe_unused]] uint64_t n_row = (uint64_t)chain * (uint64_t)dim;
+    [[maybe_unused]] uint64_t n_row = (uint64_t)chain * (uint64_t)dim - (uint64_t)lo;  // (SH: tile coordinate 0 of the chain's shifted row)
     if constexpr (FOLD) asm volatile("" : "+v"(n_row));
     [[maybe_unused]] auto noise_stage = [&](auto kc) {
       using P = FoldPlan<OT>;
@@ -1032,6 +1032,12 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
   });
 }
 
+// The plain call on the image draws its normals behind the MFMAs (FoldPlan; round 6: on).  -DEBM_BIG_NOFOLD: the A/B build.
+#ifdef EBM_BIG_NOFOLD  // A/B builds: the plain call keeps its normals in the epilogue
+constexpr bool kResFold = false;
+#else
+constexpr bool kResFold = true;
+#endif
 // the SH instantiations' launcher (gauss_res_shift.hip)
 template <int OT>
 int launch_res_shift(const BigArgs& a, hipStream_t st) {
@@ -1046,7 +1052,13 @@ int launch_res_shift(const BigArgs& a, hipStream_t st) {
   const int64_t blocks = ceil_div64(ceil_div64(a.n_chains, a.sh_classes), 128) * a.sh_classes;  // class-major inside blockIdx: b % K
   if (blocks > 0x7fffffffLL) return fail(EBM_EINVAL, "ebm_langevin_chain_f32: too many chains for one launch");
   if (a.diag.partials) hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, true, true, false, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
-  else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, true, false, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  else if (kResFold && !a.noise) {  // the plain call: its normals drawn behind the MFMAs (FoldPlan), as on the aligned widths
+    static DeviceOnce fold_once;
+    if (fold_once.first())
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_res_langevin_kernel<OT, false, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+    hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, true, true, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
+  } else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, true, false, true>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
 
@@ -1066,12 +1078,6 @@ int launch_res_as(const BigArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((gauss_res_langevin_kernel<OT, false, IMG>), dim3((unsigned)blocks), dim3(256), C::SMEM, st, a);
   return check_launch("ebm_langevin_chain_f32");
 }
-// The plain call on the image draws its normals behind the MFMAs (FoldPlan; round 6: on).  -DEBM_BIG_NOFOLD: the A/B build.
-#ifdef EBM_BIG_NOFOLD  // A/B builds: the plain call keeps its normals in the epilogue
-constexpr bool kResFold = false;
-#else
-constexpr bool kResFold = true;
-#endif
 template <int OT>
 int launch_res_plain_img(const BigArgs& a, hipStream_t st) {  // the plain call on the image (no records instantiation beside it)
   using C = ResCfg<OT>;
