@@ -284,3 +284,35 @@ def test_cd_loss_kernel_guard_on_a_non_finite_loss(cuda_device):
     assert out.item() == pytest.approx(0.1)
     good = torch.randn(8, device=cuda_device, requires_grad=True)  # ... and the workspace is fine for the next call
     assert torch.isfinite(_PairedCDLossHip.apply(good, 4, 0.01, work))
+
+
+def test_reference_subset_opt_in_draws_the_exploration_rows_as_the_reference_does(cuda_device):
+    """Round 6: `loss.reference_subset = True` -- the exploration subset of a PCD step from
+    `randperm(batch)[:n_new]` + `randn` on the caller's torch generator (core/base_loss.py:316-332) instead of the one-launch keyed
+    bijection.  Given the same start rows the perturbed rows are then EXACTLY torch's: replayed here from a clone of the generator."""
+    from torchebm_amd.utils import GraphedTrainingStep
+
+    model = MLPEnergy(2).to(cuda_device)
+    sampler = ta.LangevinDynamics(model, step_size=0.1, device=cuda_device)
+    pcd = ta.ContrastiveDivergence(model, sampler, k_steps=1, persistent=True, buffer_size=2048, init_steps=0,
+                                   new_sample_ratio=0.05, device=cuda_device)
+    pcd.reference_subset = True
+    data = two_moons(512, 0.05, seed=1, device=cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(5)
+    pcd(data, generator=gen)  # initialises the buffer
+    c0, g0 = hip_calls("ebm_pcd_start_points_f32"), hip_calls("ebm_pcd_gather_f32")
+    before = gen.clone_state() if hasattr(gen, "clone_state") else None
+    starts = pcd.get_start_points(data, generator=gen)
+    assert hip_calls("ebm_pcd_start_points_f32") == c0 and hip_calls("ebm_pcd_gather_f32") == g0 + 1  # gather: still one HIP launch
+    n_new = max(1, int(512 * 0.05))
+    # the rows that moved off their buffer values are n_new distinct rows, each by ~0.01 sigma
+    stride = 2048 // 512
+    moved = ((starts.view(512, 1, -1) - pcd.replay_buffer.view(512, stride, -1)).abs().amin(dim=1).amax(dim=1) > 0)
+    assert int(moved.sum()) == n_new
+    d = (starts.view(512, 1, -1) - pcd.replay_buffer.view(512, stride, -1)).abs().amin(dim=1)[moved]
+    assert 0.0 < d.mean().item() < 0.05
+    # ... and a captured training step refuses the torch-side sort
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    with pytest.raises(ValueError, match="reference_subset"):
+        GraphedTrainingStep(pcd, opt, generator=gen)
+    del before

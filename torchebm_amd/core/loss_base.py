@@ -128,6 +128,14 @@ class BaseContrastiveDivergence(BaseLoss):
         self.buffer_initialized = True
         return self.replay_buffer
 
+    #: Opt-in (an attribute; round 6): draw the exploration subset of a persistent-CD step as the REFERENCE does
+    #: -- ``randperm(batch)[:n_new]`` and ``randn`` on the caller's torch generator (core/base_loss.py:316-332) -- instead of the one-launch
+    #: form (``ebm_pcd_start_points_f32``: exactly ``n_new`` rows through a keyed Feistel bijection, uniform over subsets to the tests'
+    #: resolution, normals from the kernels' Philox field).  The same marginal law either way; ``True`` costs a device sort and eight small
+    #: launches per step (0.13 ms of a 0.7 ms config-5 step) and cannot be part of a captured training step (``GraphedTrainingStep``
+    #: refuses it).  The stratified gather itself stays one HIP launch.
+    reference_subset: bool = False
+
     def get_start_points(self, x: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """Chain starts: a copy of the data (CD) or stratified reads of the buffer (PCD:
         one row per stride with a random in-stride offset, base_loss.py:266-337)."""
@@ -151,7 +159,7 @@ class BaseContrastiveDivergence(BaseLoss):
             stride = self.buffer_size // batch
             row_elems = self.replay_buffer[0].numel()
             starts = torch.empty((batch,) + tuple(self.replay_buffer.shape[1:]), dtype=self.dtype, device=self.device)
-            if self.new_sample_ratio > 0.0 and batch < 2**31:
+            if self.new_sample_ratio > 0.0 and batch < 2**31 and not self.reference_subset:
                 # ... and the exploration noise in the same launch (ebm_pcd_start_points_f32): the random subset of n_new rows comes
                 # from a keyed bijection instead of randperm's sort, the normals from the kernels' Philox field -- no torch-side draw,
                 # so a graph-captured step replays the eager loop's numbers (utils.graphed_step)

@@ -106,6 +106,8 @@ class GraphedTrainingStep:
         lf = self.loss_fn
         if torch.device(lf.device).type != "cuda" or lf.dtype != torch.float32:
             return "the loss must live on a CUDA device in float32"
+        if getattr(lf, "reference_subset", False) and getattr(lf, "new_sample_ratio", 0.0) > 0.0:
+            return "reference_subset=True draws the exploration subset with torch.randperm (a device sort on the caller's generator): not capturable"
         s = lf.sampler
         if type(s) is not LangevinDynamics:
             return "the sampler must be torchebm_amd.LangevinDynamics (its fused chain kernel is the one that takes device-resident RNG coordinates)"
