@@ -786,6 +786,16 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                 fn = lambda: s.sample(x=x0, n_steps=k, n_samples=bs, dim=dim)  # noqa: E731  (the reference's call, registry.py:716-717)
                 wall = timed(fn, reps=200, warm=30, device=device)
                 kms = kernel_ms_of(entry, fn, 50, device)
+                # the Python side alone: the time sample() takes to RETURN (routing, RNG reservation, allocation, the launch call) with
+                # the stream drained before every call, so that nothing of it hides behind a running kernel
+                host_only = []
+                for _ in range(60):
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    fn()
+                    host_only.append(time.perf_counter() - t0)
+                host_only.sort()
+                py_us = host_only[len(host_only) // 2] * 1e6
                 # the same call on the host cores: the oracle with pre-drawn noise (drawing it is part of the reference's call too,
                 # so it is inside the timed region), one thread count for all (these are 10 - 100 ms problems)
                 en = oracle.DoubleWell(2.0, 1.0)
@@ -807,13 +817,14 @@ def extra_measurements(device, valu_rate, loop_units=LEAN_LOOP_ISSUE_UNITS, cpu=
                              "wall_us_per_call": wall * 1e6, "kernel_us_per_call": None if kms is None else kms * 1e3,
                              # (calls are queued back to back: where the kernel is longer than the Python around it the host share is hidden -- 0)
                              "host_us_per_call": None if kms is None else max(0.0, wall * 1e6 - kms * 1e3),
+                             "python_us_until_sample_returns": py_us,
                              "chain_steps_per_s": bs * k / wall, "cpu_oracle_ms_per_call": cpu_s * 1e3,
                              "cpu_oracle_chain_steps_per_s": bs * k / cpu_s, "cpu_threads": torch.get_num_threads()})
         return {"name": "reference_benchmark_scales", "workload": "the reference's own benchmark scales (benchmarks/conftest.py:35-39, "
                 "registry.py:141-148,679-717): DoubleWellModel(barrier_height=2), step_size=1e-3, LangevinDynamics(noise_scale=1) and "
                 "HamiltonianMonteCarlo(n_leapfrog_steps=10) through sampler.sample(x=x0, n_steps=...); wall per call (median of 3 blocks of "
-                "100 calls), the kernel's time by events, host = wall - kernel (Python routing, RNG reservation, the output allocation, "
-                "the launch); cpu_oracle = the oracle's restatement of the same call on this box's host cores (noise drawn inside the call)",
+                "100 calls), the kernel's time by events, host = wall - kernel in a back-to-back loop, python_us_until_sample_returns = the call's own time on an idle stream (Python routing, RNG "
+                "reservation, the output allocation, the launch); cpu_oracle = the oracle's restatement of the same call on this box's host cores (noise drawn inside the call)",
                 "metric": "us per sample() call", "rows": rows}
 
     guarded("config2_fused_arithmetic", c2_fused_arithmetic)
