@@ -14,7 +14,7 @@ def timeit(fn, reps=3, warm=1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
 n = 1 << 17
-for dim in (164, 192, 224, 256):
+for dim in [int(d) for d in os.environ.get("HMC_DIMS", "164,192,224,256").split(",")]:
     g = torch.Generator().manual_seed(dim)
     a = torch.randn(dim, dim, generator=g)
     model = ta.GaussianModel(torch.zeros(dim), a @ a.t() / dim + 0.5 * torch.eye(dim), device=dev)

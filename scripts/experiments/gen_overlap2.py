@@ -7,6 +7,8 @@ filler instructions, each on its own register out of 16 independent chains (a ch
 filler ever waits for another).  Filler kinds: fma (v_fma_f32), pk (v_pk_fma_f32: R/2 of them = the same flops), mul
 (v_mul_f32), exp (v_exp_f32), mad64 (v_mad_u64_u32, Philox's multiply), cvt (v_cvt_pk_bf16_f32), bitop (v_bitop3_b32).
 In the D modes the filler waves run A/B times the trips (equal solo durations); D:mfma reads against A, D:valu against B.
+--agpr: the MFMA accumulators in the accumulation file (a[..], as in the kernels whose state fills the vector file), and three more
+filler kinds: accrd (v_accvgpr_read_b32), accwr (v_accvgpr_write_b32), ds128 (ds_read_b128, one s_waitcnt lgkmcnt(0) per trip).
 Modes:  A  MFMAs only      B  the fillers only (same stream with the MFMAs removed)      C  both, one wave per SIMD
         D  two waves per SIMD: waves 0-3 run A, waves 4-7 run B    D1  D with `s_setprio 1` on the filler waves
         D2  D with `s_setprio 1` on the MFMA waves
@@ -40,9 +42,16 @@ def filler(kind, j):
         return f"v_cvt_pk_bf16_f32 %{r}, %{r}, %[c]"
     if kind == "bitop":
         return f"v_bitop3_b32 %{r}, %{r}, %[ci], %[di] bitop3:0x96"
+    if kind == "accrd":
+        return f"v_accvgpr_read_b32 %{6 + j % 8}, %{14 + j % 8}"
+    if kind == "accwr":
+        return f"v_accvgpr_write_b32 %{14 + j % 8}, %{6 + j % 8}"
+    if kind == "ds128":
+        return f"ds_read_b128 %{6 + j % 8}, %[ci] offset:{(j % 8) * 4096}"
     raise ValueError(kind)
 
 
+ACC_C = "v"  # "a" with --agpr
 MFMA = "v_mfma_f32_32x32x16_bf16"  # or v_mfma_f32_16x16x32_bf16 (--m16: accumulators of 4 registers, same operands)
 
 
@@ -66,12 +75,14 @@ def trip(kind, R, mfma, valu, blocky=False):
             for _ in range(nf):
                 lines.append(filler(kind, j))
                 j += 1
+    if kind == "ds128" and valu:
+        lines.append("s_waitcnt lgkmcnt(0)")
     return lines
 
 
 def kernel(kind, R):
     pair = kind in ("pk", "mad64")
-    nch = 8 if pair else NCH
+    nch = 8 if pair or kind in ("accrd", "accwr", "ds128") else NCH
     chain_t = "v2" if kind == "pk" else ("unsigned long long" if kind == "mad64" else ("unsigned" if kind == "bitop" else "float"))
     name = f"k_{kind}_{R}"
     out = []
@@ -85,10 +96,18 @@ def kernel(kind, R):
         out.append(f"  unsigned long long ch[{nch}]; for (int i = 0; i < {nch}; ++i) ch[i] = threadIdx.x * 77ull + i;")
     elif kind == "bitop":
         out.append(f"  unsigned ch[{nch}]; for (int i = 0; i < {nch}; ++i) ch[i] = threadIdx.x * 77u + i;")
+    elif kind == "ds128":
+        out.append("  __shared__ float lds_[16384]; if (iters < 0) lds_[threadIdx.x] = 1.0f;")
+        out.append(f"  f32x4 ch[{nch}]; for (int i = 0; i < {nch}; ++i) ch[i] = (f32x4)(threadIdx.x * 1e-3f + i);")
     else:
         out.append(f"  float ch[{nch}]; for (int i = 0; i < {nch}; ++i) ch[i] = threadIdx.x * 1e-3f + i;")
     out.append("  const float c = 1.0001f, d = 1e-3f; const v2 c2 = {1.0001f, 1.0002f}, d2 = {1e-3f, 2e-3f};")
-    out.append("  const unsigned ci = 0xD2511F53u + threadIdx.x, di = 0x9E3779B9u;")
+    if kind == "ds128":
+        out.append("  const unsigned ci = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_ + (threadIdx.x & 63) * 16u, di = 0x9E3779B9u;")
+    else:
+        out.append("  const unsigned ci = 0xD2511F53u + threadIdx.x, di = 0x9E3779B9u;")
+    if kind in ("accrd", "accwr"):
+        out.append("  float ag[8]; for (int i = 0; i < 8; ++i) ag[i] = threadIdx.x * 1e-3f - i;")
     out.append("  const int wave = threadIdx.x >> 6;")
     out.append("  // role: 0 = both (C), 1 = MFMAs only (A), 2 = fillers only (B)")
     out.append("  // modes 6 (E: every wave runs C's stream) and 7 (F: every wave runs the blocky stream) at one or two waves per SIMD")
@@ -97,8 +116,10 @@ def kernel(kind, R):
     out.append("  if (mode == 5 && role == 1) __builtin_amdgcn_s_setprio(1);")
     out.append("  __syncthreads();")
     out.append("  const long long t0 = __builtin_readcyclecounter();")
-    ops = ", ".join([f'"+v"(acc{i})' for i in range(4)])
+    ops = ", ".join([f'"+{ACC_C}"(acc{i})' for i in range(4)])
     chain_ops = ", ".join([f'"+v"(ch[{i}])' for i in range(nch)])
+    if kind in ("accrd", "accwr"):
+        chain_ops += ", " + ", ".join([f'"+a"(ag[{i}])' for i in range(8)])
     ins = '[a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d), [c2] "v"(c2), [d2] "v"(d2), [ci] "v"(ci), [di] "v"(di)'
     # operand numbering: %0-3 acc, %4,%5 placeholders so that chains start at %6
     for role, (mf, vl) in ((0, (True, True)), (1, (True, False)), (2, (False, True)), (3, (True, True))):
@@ -116,8 +137,12 @@ def kernel(kind, R):
     out.append("  const long long t1 = __builtin_readcyclecounter();")
     out.append("  if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 8 + wave] = t1 - t0;")
     out.append("  float s = acc0[0] + acc1[1] + acc2[2] + acc3[3] + dummy0 + dummy1;")
+    if kind in ("accrd", "accwr"):
+        out.append("  for (int i = 0; i < 8; ++i) s += ag[i];")
     if kind == "pk":
         out.append(f"  for (int i = 0; i < {nch}; ++i) s += ch[i].x + ch[i].y;")
+    elif kind == "ds128":
+        out.append(f"  for (int i = 0; i < {nch}; ++i) s += ch[i].x + ch[i].w;")
     else:
         out.append(f"  for (int i = 0; i < {nch}; ++i) s += (float)ch[i];")
     out.append("  sink[blockIdx.x * blockDim.x + threadIdx.x] = s;")
@@ -191,7 +216,11 @@ int main() {
 
 
 def main():
-    global MFMA
+    global MFMA, ACC_C, KINDS
+    if "--agpr" in sys.argv:
+        sys.argv.remove("--agpr")
+        ACC_C = "a"
+        KINDS = ["fma", "accrd", "accwr", "ds128", "cvt"]
     m16 = "--m16" in sys.argv
     if m16:
         sys.argv.remove("--m16")
@@ -200,7 +229,7 @@ def main():
     rows = []
     for kind in KINDS:
         for R in R_LIST:
-            if kind != "fma" and R in (0, 1, 3, 5, 12):
+            if kind != "fma" and R in (0, 1, 3, 5, 12) and not (ACC_C == "a" and R in (1, 3)):
                 continue
             name, src = kernel(kind, R)
             out.append(src)

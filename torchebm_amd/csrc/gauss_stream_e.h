@@ -30,12 +30,19 @@ struct GaussStreamE {
 
   // request stage s of the image into buffer `buf`: 6 NT pieces of 1 KiB dealt round-robin to the four waves (assembly: see
   // gauss_big_body.h -- behind the builtin the compiler serialises every later LDS read)
+  // dma<T0, TN>: the part of the stage that output tiles T0 .. T0 + TN - 1 read -- per bf16 piece TN * 2 KiB in a row
+  template <int T0 = 0, int TN = NT>
   __device__ static __forceinline__ void dma(const GaussHmcArgs& a, const float* lds, int buf, int s) {
-    const char* src = a.prec_image + gbig::big_image_bytes<NT, 1>(32 * NT) + (size_t)s * STAGE_BYTES;
+    // (readfirstlane: out of line -- gauss_hmc_fallback -- the compiler no longer knows these are wave-uniform; free in a kernel)
+    const uint64_t src_v = (uint64_t)(uintptr_t)(a.prec_image + gbig::big_image_bytes<NT, 1>(32 * NT) + (size_t)s * STAGE_BYTES);
+    const char* src = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(src_v >> 32)) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)src_v));
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)lds + (uint32_t)buf * STAGE_BYTES;
-    for (int piece = wv; piece < (int)(STAGE_BYTES / 1024u); piece += kBlock / 64) {
-      const uint32_t voff = (uint32_t)(piece * 1024 + lane * 16), base = dst + (uint32_t)piece * 1024u;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)lds + (uint32_t)buf * STAGE_BYTES));
+    for (int c = wv; c < 6 * TN; c += kBlock / 64) {
+      const uint32_t at = (uint32_t)(c / (2 * TN)) * (uint32_t)(SLABU * 16) + (uint32_t)(T0 * 2048 + (c % (2 * TN)) * 1024);
+      const uint32_t voff = at + (uint32_t)(lane * 16), base = dst + at;
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
@@ -44,19 +51,33 @@ struct GaussStreamE {
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds, int lo) {  // shifted rows (a.prec_image: this class's)
     for (int i = threadIdx.x; i < 32 * NT; i += kBlock) lds[kSlabFloats + i] = (i >= lo && i - lo < a.dim) ? a.mean[i - lo] : 0.0f;
     dma(a, lds, 0, 0);
+    dma(a, lds, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds) {
     for (int i = threadIdx.x; i < 32 * NT; i += kBlock) lds[kSlabFloats + i] = i < a.dim ? a.mean[i] : 0.0f;
-    dma(a, lds, 0, 0);  // the first evaluation's first stage (the body's barrier follows)
+    dma(a, lds, 0, 0);  // the first evaluation's first two stages (the body's barrier follows)
+    dma(a, lds, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
 
   // g^T = Ps (x - mu)^T, E = 0.5 (x - mu) . g.  Stage s = the 32 columns 32 s .. of Ps = the two K-blocks whose B operands are
   // registers 0 .. 7 and 8 .. 15 of position tile s; six products per (out tile, K-block) as in gauss_bf16x3.h, smallest first.
+  // eval_tiles<T0, TN>: the OUTPUT tiles T0 .. T0 + TN - 1 only (a full pass over the stages; the B operands are split again) --
+  // gout[i] = g tile T0 + i, the return value that part of the energy.  (round 6) The transition body takes the force in PIECES
+  // (kPieces passes) and kicks the momentum piece by piece, so that position, momentum and a whole force array are never live together
+  // (mfma_hmc_body.h, PW).
+#ifndef EBM_PW_PIECES
+#define EBM_PW_PIECES 2
+#endif
+  static constexpr int kPieces = EBM_PW_PIECES;
+  static constexpr int kPieceTiles = (NT + kPieces - 1) / kPieces;
   __device__ __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
-    using gbig::SplitJob;
+    return eval_tiles<0, NT>(a, lds, x, g.t, m, h);
+  }
+  template <int T0, int TN>
+  __device__ __forceinline__ float eval_tiles(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h) {
     using gbig::Tri;
     using gauss3::bf16x8;
     using gauss3::static_for;
@@ -66,100 +87,174 @@ struct GaussStreamE {
     int hs = h, ms = m;
     asm volatile("" : "+v"(hs), "+v"(ms));  // (per call: nothing derived from the lane is hoisted out of the trajectory loop and spilled)
     const int rd_unit[2] = {hs * 32 + ((ms + 2 * hs) & 31), 64 + hs * 32 + ((ms + 2 * (2 + hs)) & 31)};  // this lane's operand slot per K-block
-    static_for<NT>([&](auto tc) {
+    static_for<TN>([&](auto tc) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g.t[decltype(tc)::value][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) gout[decltype(tc)::value][r] = 0.0f;
     });
-    auto b_init = [&](SplitJob& jb, auto tc, auto kc, auto hc) {  // half hc of the eight differences of K-block (t, kb2)
-      constexpr int t = decltype(tc)::value, kb2 = decltype(kc)::value, hf = decltype(hc)::value;
-      const f32x4 mm = *reinterpret_cast<const f32x4*>(mus + 32 * t + 16 * kb2 + 8 * hf + 4 * hs);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) jb.d[4 * hf + j] = x.t[t][8 * kb2 + 4 * hf + j] - mm[j];
+    // A B operand -- the eight differences x - mu of K-block (t, kb2), split three ways -- in MS = 20 micro-steps of two to four
+    // instructions (round 6: five plain vector instructions hide behind a 32-cycle MFMA, profiles/r06_mfma_valu_overlap.txt; the
+    // steps of gbig::SplitJob were five to eight, packed, all behind the first K-block's MFMAs): steps 0 .. 3 the differences of
+    // pair p (position registers come from the accumulation file: a read each), then per pair hi piece + its widened copy |
+    // residual | mid piece + copy | residual and lo piece.  Element-wise arithmetic (a packed-f32 instruction in a gap costs ~20 cycles).
+    struct MicroSplit {
+      f32x4 mm[2];  // the means of the eight elements (read at the start of the half the job runs in, ahead of the A operands)
+      gauss3::f32x8 d;
+      mlpb16::f32x2 r, wide;
+      mlpb16::Split8p t;
+      __device__ __forceinline__ Tri tri() const {
+        Tri o;
+        o.h = __builtin_bit_cast(bf16x8, t.h); o.m = __builtin_bit_cast(bf16x8, t.m); o.l = __builtin_bit_cast(bf16x8, t.l);
+        return o;
+      }
+    };
+    constexpr int MS = 20;
+    auto b_means = [&](MicroSplit& jb, auto tc, auto kc) {
+      constexpr int t = decltype(tc)::value, kb2 = decltype(kc)::value;
+      jb.mm[0] = *reinterpret_cast<const f32x4*>(mus + 32 * t + 16 * kb2 + 4 * hs);
+      jb.mm[1] = *reinterpret_cast<const f32x4*>(mus + 32 * t + 16 * kb2 + 8 + 4 * hs);
+    };
+    // (pin: a volatile empty asm on what the step ends in -- the operand of the NEXT stage is wanted only in the next stage, and
+    //  the instruction selector otherwise collects its whole split behind the stage's last MFMA: scripts/isa_gapmap.py)
+    auto b_micro = [&](MicroSplit& jb, auto tc, auto kc, auto kk, auto pinc) {
+      constexpr int t = decltype(tc)::value, kb2 = decltype(kc)::value, k = decltype(kk)::value;
+      constexpr bool pin = decltype(pinc)::value;
+      if constexpr (k < 4) {
+        jb.d[2 * k] = x.t[t][8 * kb2 + 2 * k] - jb.mm[k >> 1][2 * (k & 1)];
+        jb.d[2 * k + 1] = x.t[t][8 * kb2 + 2 * k + 1] - jb.mm[k >> 1][2 * (k & 1) + 1];
+        if constexpr (pin) asm volatile("" : "+v"(jb.d[2 * k]), "+v"(jb.d[2 * k + 1]));
+      } else {
+        constexpr int pr = (k - 4) >> 2, ph = (k - 4) & 3;
+        if constexpr (ph == 0) mlpb16::pair_split_piece<pr, 0>(jb.t, jb.wide, mlpb16::f32x2{jb.d[2 * pr], jb.d[2 * pr + 1]});
+        else if constexpr (ph == 1) mlpb16::pair_split_resid<false>(jb.r, mlpb16::f32x2{jb.d[2 * pr], jb.d[2 * pr + 1]}, jb.wide);
+        else if constexpr (ph == 2) mlpb16::pair_split_piece<pr, 1>(jb.t, jb.wide, jb.r);
+        else {
+          mlpb16::pair_split_resid<false>(jb.r, jb.r, jb.wide);
+          mlpb16::pair_split_c<pr>(jb.t, jb.r);
+        }
+        if constexpr (pin) {
+          if constexpr (ph == 0 || ph == 2) asm volatile("" : "+v"(jb.wide.x), "+v"(jb.wide.y));
+          else if constexpr (ph == 1) asm volatile("" : "+v"(jb.r.x), "+v"(jb.r.y));
+          else asm volatile("" : "+v"(jb.t.l[pr]));
+        }
+      }
+    };
+    constexpr int HALF = 6 * TN, PAIRS = (TN + 1) / 2, UNITS = 2 * PAIRS;  // a unit: (K-block, pair of output tiles) = 12 / 6 MFMAs
+    // the A operands of unit (kb2, pi) from the slab at sb: [piece][out tile][128 units]
+    auto read_a = [&](const bf16x8* sb, auto kc, auto pc, bf16x8 (&a6)[6]) {
+      constexpr int kb2 = decltype(kc)::value, pi = decltype(pc)::value, ot0 = T0 + 2 * pi, ot1 = 2 * pi + 1 < TN ? T0 + 2 * pi + 1 : T0 + 2 * pi;
+      const bf16x8* sr = sb + rd_unit[kb2];
+      a6[0] = sr[2 * SLABU + ot0 * 128]; a6[1] = sr[SLABU + ot0 * 128]; a6[2] = sr[ot0 * 128];
+      if constexpr (ot1 != ot0) {
+        a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
+      }
     };
     Tri b0;
+    bf16x8 acur[6];
     {
-      SplitJob j0;
-      b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      b_init(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-      static_for<8>([&](auto kc) { j0.step(kc); });
+      MicroSplit j0;
+      b_means(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      read_a(slab + (size_t)(gstage & 1) * 3 * SLABU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur);
+      static_for<MS>([&](auto kk) { b_micro(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kk, std::false_type{}); });
       b0 = j0.tri();
     }
+    // The stage loop, software-pipelined (round 6).  On entry to stage s: its slab has landed and is visible to the workgroup, the
+    // load of slab s + 1 is in flight, the A operands of the stage's first unit are in registers (requested behind the previous
+    // stage's last unit; for a call's first stage just above).  The stage's ONE synchronisation point stands in front of its LAST
+    // unit, whose operands were requested a unit earlier: wait for this wave's share of slab s + 1 and for its own LDS reads, barrier
+    // -- now slab s + 1 is visible and nobody reads slab s any more -- then request slab s + 2 into the buffer just freed and the
+    // next stage's first operands behind the last unit's MFMAs.  (Before: barrier at the stage's end, the first twelve operand reads
+    // of every stage and K-block issued in front of the MFMA that needs them -- the matrix pipe idle for an LDS round trip 2 NT
+    // times per pass.)  Slabs s + 1, s + 2 beyond this pass are the next piece's first two (T0N, TNN).
     static_for<NT>([&](auto sc) {
-      constexpr int s = decltype(sc)::value, sn = (s + 1) % NT;  // behind the last stage: stage 0 of the next evaluation
-      constexpr int HALF = 6 * NT, B_STEPS = 10;
-      static_assert(2 * B_STEPS <= HALF, "the split work of a stage fits behind its MFMAs");
+      constexpr int s = decltype(sc)::value;
+      constexpr int T0N = T0 + TN >= NT ? 0 : T0 + TN, TNN = TN == NT ? NT : (NT - T0N < kPieceTiles ? NT - T0N : kPieceTiles);
       const int buf = gstage & 1;
-      dma(a, lds, buf ^ 1, sn);  // (the barrier that ended the stage before freed that buffer)
-      __builtin_amdgcn_sched_barrier(0);
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
-      SplitJob jb1, jb0n;
-      auto b_job = [&](SplitJob& jb, auto tc, auto kc, auto kk) {  // step kk of 10 of a B operand
-        constexpr int k = decltype(kk)::value;
-        if constexpr (k < 2) b_init(jb, tc, kc, std::integral_constant<int, k>{});
-        else jb.step(std::integral_constant<int, k - 2>{});
-      };
-      auto slot = [&](auto oc) {  // behind MFMA o of the stage: the B operands of K-block 1 and of the next stage's K-block 0
-        constexpr int o = decltype(oc)::value;
-        if constexpr (o < HALF && o / 2 < B_STEPS) {
-          if constexpr (o % 2 == 0) b_job(jb1, sc, std::integral_constant<int, 1>{}, std::integral_constant<int, o / 2>{});
+      const bf16x8* sbn = slab + (size_t)(buf ^ 1) * 3 * SLABU;
+      MicroSplit jb1, jb0n;
+      // behind MFMA o of the stage: the first K-block's gaps hold the B operand of the second K-block, the second K-block's gaps the
+      // next stage's first -- dealt evenly over gaps 2 .. HALF - 2 of the half (the means are requested at the half's start; the last
+      // gap's results would be the next MFMA's operands)
+      auto slot = [&](auto oc) {
+        constexpr int o = decltype(oc)::value, ol = o % HALF, G0 = 2, NG = HALF - 1 - G0, ix = ol - G0;
+        constexpr int lo = (ix >= 0 && ix < NG) ? MS * ix / NG : 0, hi = (ix >= 0 && ix < NG) ? MS * (ix + 1) / NG : 0;
+#ifdef EBM_ABL_NOSPLIT
+        constexpr int hi2 = hi < 5 ? hi : (lo < 5 ? 5 : lo);
+#else
+        constexpr int hi2 = hi;
+#endif
+        static_for<(hi2 > lo ? hi2 - lo : 0)>([&](auto uc) {
+          constexpr int k = lo + decltype(uc)::value;
+          if constexpr (o < HALF) b_micro(jb1, sc, std::integral_constant<int, 1>{}, std::integral_constant<int, k>{}, std::false_type{});
           else if constexpr (s + 1 < NT)
-            b_job(jb0n, std::integral_constant<int, (s + 1 < NT ? s + 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, o / 2>{});
-        }
+            b_micro(jb0n, std::integral_constant<int, (s + 1 < NT ? s + 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, k>{}, std::true_type{});
+        });
         __builtin_amdgcn_sched_barrier(0);
       };
-      static_for<2>([&](auto kc) {
-        constexpr int kb2 = decltype(kc)::value;
-        constexpr int PAIRS = (NT + 1) / 2;
-        const Tri bb = kb2 == 0 ? b0 : jb1.tri();
-        auto read_a = [&](auto pc, bf16x8 (&a6)[6]) {
-          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < NT ? 2 * pi + 1 : 2 * pi;
-          const bf16x8* sr = sb + rd_unit[kb2];
-          a6[0] = sr[2 * SLABU + ot0 * 128]; a6[1] = sr[SLABU + ot0 * 128]; a6[2] = sr[ot0 * 128];
-          if constexpr (ot1 != ot0) {
-            a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
+      Tri bb = b0;
+      static_for<UNITS>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, kb2 = u / PAIRS, pi = u % PAIRS;
+        constexpr int l0 = 2 * pi, l1 = 2 * pi + 1 < TN ? 2 * pi + 1 : 2 * pi;  // local (piece) tile indices
+        constexpr bool two = l1 != l0;
+        constexpr int o0 = kb2 * HALF + 12 * pi;  // ordinal of this unit's first MFMA
+        if constexpr (pi == 0) {
+          if constexpr (kb2 == 0) b_means(jb1, sc, std::integral_constant<int, 1>{});
+          else {
+            if constexpr (s + 1 < NT) b_means(jb0n, std::integral_constant<int, (s + 1 < NT ? s + 1 : 0)>{}, std::integral_constant<int, 0>{});
+            bb = jb1.tri();
           }
-        };
-        bf16x8 acur[6];
-        read_a(std::integral_constant<int, 0>{}, acur);
-        static_for<PAIRS>([&](auto pc) {
-          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < NT ? 2 * pi + 1 : 2 * pi;
-          constexpr bool two = ot1 != ot0;
-          constexpr int o0 = kb2 * HALF + 12 * pi;  // ordinal of this pair's first MFMA
-          bf16x8 anext[6];
-          if constexpr (pi + 1 < PAIRS) read_a(std::integral_constant<int, pi + 1>{}, anext);
-          __builtin_amdgcn_sched_barrier(0);
-          f32x16 g0 = g.t[ot0], g1;
-          if constexpr (two) g1 = g.t[ot1];
-          static_for<6>([&](auto tc) {  // (term, operand) in issue order: Pl dh | Pm dm, Pm dh | Ph dl, Ph dm, Ph dh
-            constexpr int term = decltype(tc)::value;
-            constexpr int ai = term == 0 ? 0 : (term <= 2 ? 1 : 2);
-            const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
-            g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
-            slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
-            if constexpr (two) {
-              g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
-              slot(std::integral_constant<int, o0 + 2 * term + 1>{});
-            }
-          });
-          g.t[ot0] = g0;
-          if constexpr (two) g.t[ot1] = g1;
-          if constexpr (pi + 1 < PAIRS) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acur[i] = anext[i];
+        }
+        if constexpr (u + 1 == UNITS) {
+#ifndef EBM_ABL_NOSYNC
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __syncthreads();
+#endif
+#ifndef EBM_ABL_NODMA
+          if constexpr (s + 2 < NT) dma<T0, TN>(a, lds, buf, s + 2);
+          else dma<T0N, TNN>(a, lds, buf, s + 2 - NT);
+#endif
+        }
+        bf16x8 anext[6];
+        if constexpr (u + 1 < UNITS) read_a(sb, std::integral_constant<int, (u + 1) / PAIRS>{}, std::integral_constant<int, (u + 1) % PAIRS>{}, anext);
+        else if constexpr (s + 1 < NT) read_a(sbn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, anext);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 g0 = gout[l0], g1;
+        if constexpr (two) g1 = gout[l1];
+        static_for<6>([&](auto tc) {  // (term, operand) in issue order: Pl dh | Pm dm, Pm dh | Ph dl, Ph dm, Ph dh
+          constexpr int term = decltype(tc)::value;
+          constexpr int ai = term == 0 ? 0 : (term <= 2 ? 1 : 2);
+          const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
+#ifdef EBM_ABL_NOMFMA
+          asm volatile("" :: "v"(acur[ai]), "v"(bp));
+#else
+          g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
+#endif
+          slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
+          if constexpr (two) {
+#ifdef EBM_ABL_NOMFMA
+            asm volatile("" :: "v"(acur[3 + ai]), "v"(bp));
+#else
+            g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
+#endif
+            slot(std::integral_constant<int, o0 + 2 * term + 1>{});
           }
         });
+        gout[l0] = g0;
+        if constexpr (two) gout[l1] = g1;
+        if constexpr (u + 1 < UNITS || s + 1 < NT) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acur[i] = anext[i];
+        }
       });
       if constexpr (s + 1 < NT) b0 = jb0n.tri();
       ++gstage;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next slab have landed
-      __syncthreads();                                    // ... everybody's have, and this slab is read by everyone
     });
     float acc = 0.0f;
-    static_for<NT * 4>([&](auto ic) {
-      constexpr int t = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
+    static_for<TN * 4>([&](auto ic) {
+      constexpr int t = T0 + (decltype(ic)::value >> 2), tl = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
       const f32x4 mq = *reinterpret_cast<const f32x4*>(mus + 32 * t + 8 * q + 4 * hs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x.t[t][4 * q + i] - mq[i], g.t[t][4 * q + i], acc);
+      for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x.t[t][4 * q + i] - mq[i], gout[tl][4 * q + i], acc);
     });
     acc += __shfl_xor(acc, 32);
     return 0.5f * acc;

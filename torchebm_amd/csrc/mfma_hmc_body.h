@@ -54,6 +54,7 @@ struct GaussHmcArgs {
   int32_t sh_classes = 1;  // SHIFTED rows (SH kernels): 4 / gcd(dim, 4) alignment classes of chains, one per workgroup
   int32_t sh_lo = 0;       // ... and, set by the body in its own copy, this workgroup's row offset (what the energies see)
   int64_t sh_image_stride = 0;  // bytes between the classes' pre-split images (the streamed evaluation on shifted rows)
+  int32_t tr0 = 0;         // first transition to run (PW kernels hand a workgroup over to the literal body in mid-call: see gauss_hmc_fallback)
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -201,7 +202,23 @@ __device__ __forceinline__ bool vote_all(bool pred) {
 // SH: SHIFTED rows (widths off multiples of 4; gauss_mfma_body.h says how): a workgroup takes the chains of one alignment
 // class, tile coordinate j = coordinate j - lo of the chain; the tile coordinates outside [lo, lo + dim) are padding like
 // the ones beyond dim -- x = p = f = 0 throughout (loaded as 0, their momentum draw discarded, zero rows of the staged matrix).
-template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
+// (round 6) PW -- the force in PIECES (energies that offer eval_tiles<T0, TN> and kPieces / kPieceTiles: GaussStreamE).  At seven /
+// eight tiles position + momentum + force are 336 / 384 of a wave's 512 registers (of which only 256 can be operands of vector
+// instructions) and the allocator kept ~330 values per lane in scratch for the whole trajectory, moving them through every kick and
+// drift: 41 GB of traffic per launch at dim 256 (profiles/r05_pmc.json), 97 k cycles per evaluation against 24.6 k of MFMAs.  With PW a
+// leapfrog step evaluates the force one piece of output tiles at a time (a pass over the streamed matrix each) and kicks the momentum
+// of that piece at once -- p += eps f between interior steps, eps / 2 at the trajectory's ends: the two half kicks of the reference
+// merged, as in the element-wise fast body (hmc_kernel.h) -- so no force array outlives its piece.  Safe mode: the fast sequence is
+// what the literal one computes while every energy and momentum stays finite; a workgroup that sees anything else hands the REST of its
+// call (from the transition at hand, whose accepted state is in a.x) to the literal body, out of line (gauss_hmc_fallback).
+template <class E, class = void>
+struct piecewise_of { static constexpr bool value = false; };
+template <class E>
+struct piecewise_of<E, std::void_t<decltype(E::kPieces)>> { static constexpr bool value = true; };
+template <int NT, bool DIAGM, class E, bool DIAG, bool SH>
+__device__ __noinline__ void gauss_hmc_fallback(const GaussHmcArgs& a);
+
+template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false, bool PW = false>
 __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   constexpr bool CARRY = E::kCarry;
   const int sh_s = SH ? (int)(blockIdx.x % (unsigned)a_in.sh_classes) : 0;
@@ -319,8 +336,8 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   Tile<NT> x;
   load_rows(a.x, row, x);
   const int64_t traj_row = active ? chain * (int64_t)a.n_kept * dim - lo : 0;
-  int until_keep = a.thin;
-  int64_t keep_off = 0;
+  int until_keep = a.thin - a.tr0 % a.thin;  // (tr0 > 0: resumed in mid-call)
+  int64_t keep_off = (int64_t)(a.tr0 / a.thin) * dim;
   float eps = a.eps;
 
   // Energy and clamped force of the state the chain holds are CARRIED from transition to transition (as in
@@ -330,7 +347,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   // one slot per lane and register: [16 NT][kBlock].
   float* fpark_base = dsw_base + (kBlock / 64) * DIM;
   float* fpark = fpark_base + threadIdx.x;
-  int keep = 0;
+  int keep = a.tr0 / a.thin;
   Tile<NT> f;
   float e_cur = 0.0f;
   if constexpr (CARRY) {
@@ -342,7 +359,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       for (int r = 0; r < 16; ++r) fpark[(16 * t + r) * kBlock] = clamp_nanprop(-f.t[t][r], -1e6f, 1e6f);
   }
 
-  for (int tr = 0; tr < a.n_mh; ++tr) {
+  for (int tr = a.tr0; tr < a.n_mh; ++tr) {
     if (a.eps_table) eps = a.eps_table[tr];
     const float half_eps = 0.5f * eps;
     const float drift_scale = a.has_mass ? eps / a.mass_safe : eps;  // x += eps * p / max(m, 1e-10), one FMA per step
@@ -394,13 +411,79 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+    float e1 = 0.0f, h0 = 0.0f, k_end = 0.0f;
+    if constexpr (PW) {
+      static_assert(!CARRY && E::kEvalGivesEnergy, "PW: the energy comes with the force, nothing is carried");
+      constexpr int PT = E::kPieceTiles;
+      const float k_start = kinetic(p);  // K(p0): before the first half kick
+      bool bad = false;
+      // E(x), and p += kick * clamp(-dE/dx) piece by piece
+      auto eval_and_kick = [&](float kick) -> float {
+        float e = 0.0f;
+        gauss3::static_for<E::kPieces>([&](auto pc) {
+          constexpr int T0 = decltype(pc)::value * PT, TN = (NT - T0) < PT ? (NT - T0) : PT;
+          if constexpr (TN > 0) {
+            f32x16 gp[TN];
+            e += en.template eval_tiles<T0, TN>(a, elds, x, gp, m, h);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float fn = __builtin_amdgcn_fmed3f(-gp[t][r], -1e6f, 1e6f);
+                p.t[T0 + t][r] = __builtin_fmaf(kick, fn, p.t[T0 + t][r]);
+              }
+          }
+        });
+        if (!(__builtin_fabsf(e) < __builtin_inff())) bad = true;
+        return e;
+      };
+      e_cur = eval_and_kick(half_eps);
+      h0 = clamp_nanprop(e_cur, -1e10f, 1e10f) + k_start;
+      e1 = e_cur;
+      for (int l = 0; l < a.n_leapfrog; ++l) {
+        if constexpr (diag_mass) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const float4 ds4 = quad_of(dsw, t, qd);
+              const float ds[4] = {ds4.x, ds4.y, ds4.z, ds4.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) x.t[t][4 * qd + i] = __builtin_fmaf(ds[i], p.t[t][4 * qd + i], x.t[t][4 * qd + i]);
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x.t[t][r] = __builtin_fmaf(drift_scale, p.t[t][r], x.t[t][r]);
+        }
+        e1 = eval_and_kick(l + 1 < a.n_leapfrog ? eps : half_eps);
+      }
+      // (a momentum that left the finite range stays outside it -- every kick is finite -- and shows in K(p) at the end; a non-finite
+      //  force shows in the energy that came with it: E = (x - mu) . g / 2)
+      k_end = kinetic(p);
+      if (!(k_end < __builtin_inff())) bad = true;
+#ifdef EBM_ABL_NOBAD
+      bad = false;
+#endif
+      if (!vote_all<E>(!bad)) {
+        // something left the fast path's domain: this workgroup finishes its call -- from this transition on, whose accepted state is
+        // in a.x -- in the literal body (every wave of the workgroup: the evaluation has barriers inside)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the slab requested for "the next evaluation" has landed)
+        __syncthreads();
+        GaussHmcArgs rest = a_in;
+        rest.tr0 = tr;
+        gauss_hmc_fallback<NT, DIAGM, E, DIAG, SH>(rest);
+        return;
+      }
+    } else {
     // ---- H0 and the first (clamped) force: the carried pair
     if constexpr (!CARRY) {
       e_cur = en.eval(a, elds, x, f, m, h);
       if constexpr (!E::kEvalGivesEnergy) e_cur = E::energy(a, elds, x, m, h);
     }
     const float e0 = e_cur;
-    const float h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
+    h0 = clamp_nanprop(e0, -1e10f, 1e10f) + kinetic(p);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -410,7 +493,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       }
 
     // ---- L leapfrog steps in safe mode (see hmc_kernel.h: leapfrog_steps for the fast / literal split)
-    float e1 = e0;
+    e1 = e0;
     for (int l = 0; l < a.n_leapfrog; ++l) {
       if constexpr (diag_mass) {
 #pragma unroll
@@ -485,8 +568,10 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
         scrubbed = true;
       }
     }
+    }
     if constexpr (!E::kEvalGivesEnergy) e1 = E::energy(a, elds, x, m, h);
-    const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + kinetic(p);
+    if constexpr (!PW) k_end = kinetic(p);
+    const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + k_end;
 
     // ---- Metropolis accept (samplers/hmc.py:277-292)
     const float dlt = clamp_nanprop(h0 - h1, -50.0f, 50.0f);
@@ -534,20 +619,25 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   }
 }
 
+template <int NT, bool DIAGM, class E, bool DIAG, bool SH>
+__device__ __noinline__ void gauss_hmc_fallback(const GaussHmcArgs& a) {
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH, false>(a);
+}
+
 // dims 32 / 64 run best held to 256 VGPRs (two waves per SIMD: 0.62 vs 0.80 ms at dim 64), dims 96 / 128
 // need more than that for the state alone.  (Two entry points because hipcc 7.2 silently ignores a
 // template-dependent __launch_bounds__ argument.)
 template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock, 2) void gauss_hmc_mfma_kernel_w2(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH, piecewise_of<E>::value>(a);
 }
 template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock) void gauss_hmc_mfma_kernel(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH, piecewise_of<E>::value>(a);
 }
 template <int NT, bool DIAGM, class E, bool DIAG = false, bool SH = false>
 __global__ __launch_bounds__(kBlock, 3) void gauss_hmc_mfma_kernel_w3(GaussHmcArgs a) {
-  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH>(a);
+  gauss_hmc_mfma_body<NT, DIAGM, E, DIAG, SH, piecewise_of<E>::value>(a);
 }
 
 // WAVES: hold the kernel to 2 or 3 waves per SIMD (256 / 168 VGPRs); 0: unconstrained
