@@ -143,3 +143,39 @@ def test_safe_mode_literal_path_is_taken_by_the_whole_workgroup(cuda_device):
     fin = torch.isfinite(want["x"][wild])
     assert torch.equal(torch.isfinite(x[wild]), fin)
     assert ((x[wild][fin] - want["x"][wild][fin]).abs() / want["x"][wild][fin].abs().clamp(min=1.0)).max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("dim,thin", [(192, 1), (224, 2), (256, 2)])
+def test_mid_call_hand_over_to_the_literal_body(cuda_device, dim, thin):
+    """(round 6) The one-launch kernel evaluates the force in pieces with merged kicks -- the fast sequence -- and a WORKGROUP that
+    meets a non-finite energy or momentum hands the rest of its call, from the transition at hand, to the literal body (out of line,
+    gauss_hmc_fallback).  Here one chain of the first workgroup draws an absurd momentum in transition 2 and one of the third in
+    transition 4: accept decisions, final states and the kept trajectory rows of ALL chains -- before and after the hand-over, with
+    the thinning counter resumed in mid-call -- are the oracle's (integrators/leapfrog.py:165-185, samplers/hmc.py:243-312)."""
+    n, T, L, eps = 300, 6, 4, 0.05
+    model, en, g = _gauss(dim, cuda_device, seed=5)
+    x0 = torch.randn(n, dim, generator=g)
+    p, u = torch.randn(T, n, dim, generator=g), torch.rand(T, n, generator=g)
+    p[2, 5] *= 1e37      # x overflows in the first drift: E = inf (a later transition than the first: tr0 > 0)
+    p[4, 290] *= 1e25    # the third workgroup, and at a kept / not kept boundary of thin = 2
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, thin=thin, want_traj=True, want_margins=True)
+    spec = model.fused_spec()
+    x = x0.to(cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    cnt = torch.zeros(T, dtype=torch.int32, device=cuda_device)
+    traj = torch.full((n, T // thin, dim), float("nan"), device=cuda_device)
+    pd, ud = p.to(cuda_device), u.to(cuda_device)
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, dim, T, L, eps, None, 0, 0.0, None, thin, traj.data_ptr(), None,
+              mask.data_ptr(), cnt.data_ptr(), pd.data_ptr(), ud.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    torch.cuda.synchronize()
+    x, mask, traj = x.cpu(), mask.cpu().bool(), traj.cpu()
+    clear = want["margins"] > 2e-4
+    assert torch.equal(mask[clear], want["accepted"][clear])
+    assert not mask[2, 5] and not mask[4, 290]          # the absurd proposals are rejected, as in the reference
+    assert torch.equal(cnt.cpu(), mask.sum(dim=1).to(torch.int32))
+    ok = clear.all(dim=0)
+    assert ok.float().mean().item() > 0.9
+    assert torch.isfinite(x).all() and torch.isfinite(traj).all()
+    assert ((x[ok] - want["x"][ok]).abs() / want["x"][ok].abs().clamp(min=1.0)).max().item() <= 5e-4
+    wt = want["trajectory"]
+    assert ((traj[ok] - wt[ok]).abs() / wt[ok].abs().clamp(min=1.0)).max().item() <= 5e-4
