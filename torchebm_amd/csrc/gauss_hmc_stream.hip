@@ -29,3 +29,9 @@ int launch_hmc_chain_gauss_stream(const ebm_energy_t& e, float* x, int64_t n_cha
 }
 
 }  // namespace ebm
+
+#ifdef EBM_PHASE_TIMES
+extern "C" __attribute__((visibility("default"))) int ebm_debug_hmc_phase_log(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ebm::ebm_hmc_phase_log), (size_t)n * sizeof(unsigned long long));
+}
+#endif

@@ -16,6 +16,24 @@
 namespace ebm {
 namespace {
 
+// -DEBM_PHASE_TIMES (scripts/hmc_stream_phase_times.py only; build gauss_hmc_stream.hip alone with it): wave 0 of workgroup 0 logs
+// the shader clock at the boundaries of every pass of the evaluation -- entry | per stage: start, in front of the sync, behind it |
+// stages done | energy done -- relative times; a stamp drains nothing but fences the scheduler.
+#ifdef EBM_PHASE_TIMES
+__device__ unsigned long long ebm_hmc_phase_log[16];
+// class c: 0 entry (first operand) | 1 units in front of the sync | 2 sync | 3 last unit | 4 energy part | 5 between passes
+#define EBM_HSTAMP(c)                                                                \
+  do {                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+    if (ph_last_) ph_acc_[c] += now_ - ph_last_;                                     \
+    ph_last_ = now_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+  } while (0)
+#else
+#define EBM_HSTAMP(c) do {} while (0)
+#endif
+
 template <int NT>
 struct GaussStreamE {
   using C = gbig::ResCfg<NT>;
@@ -26,6 +44,9 @@ struct GaussStreamE {
   static constexpr bool kEvalGivesEnergy = true;
   static constexpr bool kCarry = false;      // (no LDS left for a parked force: L + 1 evaluations per transition, as the reference)
   static constexpr bool kBlockVote = true;   // barriers inside eval()
+#ifdef EBM_PHASE_TIMES
+  unsigned long long ph_last_ = 0, ph_acc_[6] = {0, 0, 0, 0, 0, 0};
+#endif
   int gstage = 0;  // stages done so far: its parity is the buffer the next stage reads (NT may be odd; the pipeline runs across calls)
 
   // request stage s of the image into buffer `buf`: 6 NT pieces of 1 KiB dealt round-robin to the four waves (assembly: see
@@ -48,6 +69,30 @@ struct GaussStreamE {
                    : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
     }
   }
+  // ... the same request, this wave's chunks I0 .. I0 + NI - 1 only (its i-th chunk: c = wave + 4 i): inside eval_tiles the requests
+  // go out one or two behind an MFMA -- the CU's one texture-address unit takes a 1 KiB request every ~16 cycles, and a wave that
+  // issues its six in a row stands in that queue with the matrix pipe idle (scripts/hmc_stream_phase_times.py: the unit that
+  // carried the requests took 1 130 cycles for 384 of MFMAs)
+  template <int T0, int TN, int I0, int NI>
+  __device__ static __forceinline__ void dma_chunks(const GaussHmcArgs& a, const float* lds, int buf, int s) {
+    const uint64_t src_v = (uint64_t)(uintptr_t)(a.prec_image + gbig::big_image_bytes<NT, 1>(32 * NT) + (size_t)s * STAGE_BYTES);
+    const char* src = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(src_v >> 32)) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)src_v));
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)lds + (uint32_t)buf * STAGE_BYTES));
+#pragma unroll
+    for (int i = I0; i < I0 + NI; ++i) {
+      const int c = wv + (kBlock / 64) * i;
+      if ((kBlock / 64) * (i + 1) <= 6 * TN || c < 6 * TN) {  // (the first: known when compiled -- no branch)
+        const uint32_t at = (uint32_t)(c / (2 * TN)) * (uint32_t)(SLABU * 16) + (uint32_t)(T0 * 2048 + (c % (2 * TN)) * 1024);
+        const uint32_t voff = at + (uint32_t)(lane * 16), base = dst + at;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
+      }
+    }
+  }
   __device__ static __forceinline__ void stage(const GaussHmcArgs& a, float* lds, int lo) {  // shifted rows (a.prec_image: this class's)
     for (int i = threadIdx.x; i < 32 * NT; i += kBlock) lds[kSlabFloats + i] = (i >= lo && i - lo < a.dim) ? a.mean[i - lo] : 0.0f;
     dma(a, lds, 0, 0);
@@ -65,19 +110,20 @@ struct GaussStreamE {
   // g^T = Ps (x - mu)^T, E = 0.5 (x - mu) . g.  Stage s = the 32 columns 32 s .. of Ps = the two K-blocks whose B operands are
   // registers 0 .. 7 and 8 .. 15 of position tile s; six products per (out tile, K-block) as in gauss_bf16x3.h, smallest first.
   // eval_tiles<T0, TN>: the OUTPUT tiles T0 .. T0 + TN - 1 only (a full pass over the stages; the B operands are split again) --
-  // gout[i] = g tile T0 + i, the return value that part of the energy.  (round 6) The transition body takes the force in PIECES
+  // gout[i] = g tile T0 + i, the return value that part of the energy (want_e = false: 0 -- the force only).  (round 6) The transition body takes the force in PIECES
   // (kPieces passes) and kicks the momentum piece by piece, so that position, momentum and a whole force array are never live together
   // (mfma_hmc_body.h, PW).
-#ifndef EBM_PW_PIECES
-#define EBM_PW_PIECES 2
+#ifndef EBM_PW_PIECES8
+#define EBM_PW_PIECES8 3
 #endif
-  static constexpr int kPieces = EBM_PW_PIECES;
+  static constexpr int kPieces = NT == 8 ? EBM_PW_PIECES8 : 2;
   static constexpr int kPieceTiles = (NT + kPieces - 1) / kPieces;
   __device__ __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
     return eval_tiles<0, NT>(a, lds, x, g.t, m, h);
   }
   template <int T0, int TN>
-  __device__ __forceinline__ float eval_tiles(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h) {
+  __device__ __forceinline__ float eval_tiles(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h,
+                                              bool want_e = true) {
     using gbig::Tri;
     using gauss3::bf16x8;
     using gauss3::static_for;
@@ -148,6 +194,16 @@ struct GaussStreamE {
         a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
       }
     };
+    // ... and TWO of them at a time (part i of three): an LDS read holds the wave's issue for 16 cycles -- two behind an MFMA cost
+    // 8, six in a row 96 with the matrix pipe idle for most of it (profiles/r06_mfma_valu_overlap.txt, ds128)
+    auto read_a_part = [&](const bf16x8* sb, auto kc, auto pc, auto ic, bf16x8 (&a6)[6]) {
+      constexpr int kb2 = decltype(kc)::value, pi = decltype(pc)::value, ot0 = T0 + 2 * pi, ot1 = 2 * pi + 1 < TN ? T0 + 2 * pi + 1 : T0 + 2 * pi;
+      constexpr int i = decltype(ic)::value;  // piece 2 - i (low first, as the MFMAs use them) of both tiles
+      const bf16x8* sr = sb + rd_unit[kb2];
+      a6[i] = sr[(2 - i) * SLABU + ot0 * 128];
+      if constexpr (ot1 != ot0) a6[3 + i] = sr[(2 - i) * SLABU + ot1 * 128];
+    };
+    EBM_HSTAMP(5);
     Tri b0;
     bf16x8 acur[6];
     {
@@ -171,6 +227,7 @@ struct GaussStreamE {
       const int buf = gstage & 1;
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
       const bf16x8* sbn = slab + (size_t)(buf ^ 1) * 3 * SLABU;
+      EBM_HSTAMP((s == 0 ? 0 : 3));
       MicroSplit jb1, jb0n;
       // behind MFMA o of the stage: the first K-block's gaps hold the B operand of the second K-block, the second K-block's gaps the
       // next stage's first -- dealt evenly over gaps 2 .. HALF - 2 of the half (the means are requested at the half's start; the last
@@ -205,18 +262,32 @@ struct GaussStreamE {
           }
         }
         if constexpr (u + 1 == UNITS) {
+          EBM_HSTAMP(1);
 #ifndef EBM_ABL_NOSYNC
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __syncthreads();
 #endif
-#ifndef EBM_ABL_NODMA
-          if constexpr (s + 2 < NT) dma<T0, TN>(a, lds, buf, s + 2);
-          else dma<T0N, TNN>(a, lds, buf, s + 2 - NT);
-#endif
+          EBM_HSTAMP(2);
         }
+        // the request for slab s + 2 (into the buffer the barrier just freed): this wave's chunks, dealt over the last unit's gaps
+        auto request = [&](auto jc) {
+#ifndef EBM_ABL_NODMA
+          if constexpr (u + 1 == UNITS) {
+            constexpr int j = decltype(jc)::value, NMF = two ? 12 : 6;
+            constexpr int TNR = s + 2 < NT ? TN : TNN, NCH = (6 * TNR + kBlock / 64 - 1) / (kBlock / 64), PER = (NCH + NMF - 1) / NMF;
+            if constexpr (j * PER < NCH) {
+              constexpr int n = (j + 1) * PER <= NCH ? PER : NCH - j * PER;
+              if constexpr (s + 2 < NT) dma_chunks<T0, TN, j * PER, n>(a, lds, buf, s + 2);
+              else dma_chunks<T0N, TNN, j * PER, n>(a, lds, buf, s + 2 - NT);
+            }
+          }
+#endif
+        };
         bf16x8 anext[6];
-        if constexpr (u + 1 < UNITS) read_a(sb, std::integral_constant<int, (u + 1) / PAIRS>{}, std::integral_constant<int, (u + 1) % PAIRS>{}, anext);
-        else if constexpr (s + 1 < NT) read_a(sbn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, anext);
+        auto prefetch = [&](auto ic) {  // part i of the next unit's operands
+          if constexpr (u + 1 < UNITS) read_a_part(sb, std::integral_constant<int, (u + 1) / PAIRS>{}, std::integral_constant<int, (u + 1) % PAIRS>{}, ic, anext);
+          else if constexpr (s + 1 < NT) read_a_part(sbn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ic, anext);
+        };
         __builtin_amdgcn_sched_barrier(0);
         f32x16 g0 = gout[l0], g1;
         if constexpr (two) g1 = gout[l1];
@@ -229,6 +300,8 @@ struct GaussStreamE {
 #else
           g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
 #endif
+          if constexpr (term < 3) prefetch(tc);
+          request(std::integral_constant<int, (two ? 2 : 1) * term>{});
           slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
           if constexpr (two) {
 #ifdef EBM_ABL_NOMFMA
@@ -236,6 +309,7 @@ struct GaussStreamE {
 #else
             g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
 #endif
+            request(std::integral_constant<int, 2 * term + 1>{});
             slot(std::integral_constant<int, o0 + 2 * term + 1>{});
           }
         });
@@ -249,6 +323,8 @@ struct GaussStreamE {
       if constexpr (s + 1 < NT) b0 = jb0n.tri();
       ++gstage;
     });
+    EBM_HSTAMP(3);
+    if (!want_e) return 0.0f;  // (wave-uniform: one copy of the code serves the trajectory's interior and its last step)
     float acc = 0.0f;
     static_for<TN * 4>([&](auto ic) {
       constexpr int t = T0 + (decltype(ic)::value >> 2), tl = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
@@ -257,6 +333,14 @@ struct GaussStreamE {
       for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x.t[t][4 * q + i] - mq[i], gout[tl][4 * q + i], acc);
     });
     acc += __shfl_xor(acc, 32);
+    asm volatile("" : "+v"(acc));
+    EBM_HSTAMP(4);
+#ifdef EBM_PHASE_TIMES
+    if (gstage == NT * 20 && blockIdx.x == 0 && threadIdx.x == 0) {  // (ten evaluations in: the first pass's "between" is the prologue)
+      for (int i = 0; i < 6; ++i) ebm_hmc_phase_log[i] = ph_acc_[i];
+      ebm_hmc_phase_log[6] = (unsigned long long)(gstage / NT);
+    }
+#endif
     return 0.5f * acc;
   }
 };

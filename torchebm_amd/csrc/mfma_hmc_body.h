@@ -418,13 +418,16 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       const float k_start = kinetic(p);  // K(p0): before the first half kick
       bool bad = false;
       // E(x), and p += kick * clamp(-dE/dx) piece by piece
-      auto eval_and_kick = [&](float kick) -> float {
+      // (want_e: the energy is wanted at the trajectory's two ends only -- H0, H1.  Nothing is lost for the safe mode: a position
+      //  that leaves the finite range inside the trajectory never comes back -- the kicks are clamped -- and shows in the last energy,
+      //  a non-finite force in the momentum and in K(p) at the end)
+      auto eval_and_kick = [&](float kick, bool want_e) __attribute__((always_inline)) -> float {  // (beyond the inliner's budget at eight tiles)
         float e = 0.0f;
         gauss3::static_for<E::kPieces>([&](auto pc) {
           constexpr int T0 = decltype(pc)::value * PT, TN = (NT - T0) < PT ? (NT - T0) : PT;
           if constexpr (TN > 0) {
             f32x16 gp[TN];
-            e += en.template eval_tiles<T0, TN>(a, elds, x, gp, m, h);
+            e += en.template eval_tiles<T0, TN>(a, elds, x, gp, m, h, want_e);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
@@ -437,7 +440,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
         if (!(__builtin_fabsf(e) < __builtin_inff())) bad = true;
         return e;
       };
-      e_cur = eval_and_kick(half_eps);
+      e_cur = eval_and_kick(half_eps, true);
       h0 = clamp_nanprop(e_cur, -1e10f, 1e10f) + k_start;
       e1 = e_cur;
       for (int l = 0; l < a.n_leapfrog; ++l) {
@@ -457,7 +460,8 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) x.t[t][r] = __builtin_fmaf(drift_scale, p.t[t][r], x.t[t][r]);
         }
-        e1 = eval_and_kick(l + 1 < a.n_leapfrog ? eps : half_eps);
+        const bool last = l + 1 == a.n_leapfrog;
+        e1 = eval_and_kick(last ? half_eps : eps, last);
       }
       // (a momentum that left the finite range stays outside it -- every kick is finite -- and shows in K(p) at the end; a non-finite
       //  force shows in the energy that came with it: E = (x - mu) . g / 2)
