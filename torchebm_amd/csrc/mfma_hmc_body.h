@@ -55,6 +55,7 @@ struct GaussHmcArgs {
   int32_t sh_lo = 0;       // ... and, set by the body in its own copy, this workgroup's row offset (what the energies see)
   int64_t sh_image_stride = 0;  // bytes between the classes' pre-split images (the streamed evaluation on shifted rows)
   int32_t tr0 = 0;         // first transition to run (PW kernels hand a workgroup over to the literal body in mid-call: see gauss_hmc_fallback)
+  int32_t resumed = 0;     // ... a single WAVE does (energies without barriers inside): LDS is staged, no workgroup barrier may be met
 };
 
 extern __shared__ __attribute__((aligned(16))) float gauss_hmc_smem[];
@@ -152,6 +153,32 @@ struct GaussE {
     return gauss_eval<NT, B3, KT>(lds, lds + kMatFloats, x, g, m, h);
   }
   __device__ static __forceinline__ float energy(const GaussHmcArgs&, const float*, const Tile<NT>&, int, int) { return 0.0f; }
+  // (round 6) the force in PIECES for the transition body's PW path (four / five tiles on the split contraction: position,
+  // momentum and force are 192 / 240 registers beside ~150 of operands): eval() already forms the output two tiles at a time
+  // (contract_pieces) -- here a piece is handed out as soon as it is done, and the body kicks its momentum tiles at once.
+  static constexpr bool kPiecewise = B3 && NT >= 4;
+  static constexpr int kPieceTiles = 2, kPieces = (NT + 1) / 2;
+  template <int T0, int TN>
+  __device__ __forceinline__ float eval_tiles(const GaussHmcArgs&, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h,
+                                              bool want_e = true) const {
+    const float* mus = lds + kMatFloats;
+    f32x16 xb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      xb[t] = x.t[t];
+      if constexpr (T0 > 0) asm volatile("" : "+v"(xb[t]));  // (an opaque copy: gauss_bf16x3.h, contract_pieces)
+    }
+    gauss3::contract_general<TN, 2 * NT, true, gauss3::NoFill, NT, T0, 2 * NT - KT>(reinterpret_cast<const __bf16*>(lds), mus, xb, gout, m + 32 * h);
+    if (!want_e) return 0.0f;
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 16 * T0; s < 16 * (T0 + TN); ++s) {
+      const int k = 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
+      acc = __builtin_fmaf(x.t[s >> 4][s & 15] - mus[k], gout[(s >> 4) - T0][s & 15], acc);
+    }
+    acc += __shfl_xor(acc, 32);
+    return 0.5f * acc;
+  }
 };
 
 // Isotropic Gaussian mixture, up to 32 components: gmm_bf16x3.h (both K x dim passes of the gradient on the bf16 matrix
@@ -215,6 +242,8 @@ template <class E, class = void>
 struct piecewise_of { static constexpr bool value = false; };
 template <class E>
 struct piecewise_of<E, std::void_t<decltype(E::kPieces)>> { static constexpr bool value = true; };
+template <int NT, bool B3, int KT>
+struct piecewise_of<GaussE<NT, B3, KT>, void> { static constexpr bool value = GaussE<NT, B3, KT>::kPiecewise; };
 template <int NT, bool DIAGM, class E, bool DIAG, bool SH>
 __device__ __noinline__ void gauss_hmc_fallback(const GaussHmcArgs& a);
 
@@ -234,8 +263,13 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   // rows / columns of the parameters are zero, their momentum draw is discarded) and are never loaded or stored
   const int dim = a.dim;
   const int hi = lo + dim;
-  if constexpr (SH) E::stage(a, elds, lo);
-  else E::stage(a, elds);
+  // (a single wave that resumes its call in the literal body -- gauss_hmc_fallback, energies without barriers inside -- finds LDS
+  //  staged and must not meet a workgroup barrier)
+  const bool staged = !BlockVote<E>::value && a.resumed != 0;
+  if (!staged) {
+    if constexpr (SH) E::stage(a, elds, lo);
+    else E::stage(a, elds);
+  }
   // Diagonal mass (samplers/hmc.py:136-159, integrators/leapfrog.py:116-149): the raw masses sit in LDS (padded
   // with 1), every lane reads the four of a quad with one broadcast float4; the drift factors eps / max(m, 1e-10)
   // of a transition go through a row of this wave's own (lanes of one K-half hold the same coordinates).
@@ -243,9 +277,11 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
   float* dsw_base = mraw + DIM;
   float* dsw = dsw_base + (threadIdx.x >> 6) * DIM;          // [DIM], this wave's
   constexpr bool diag_mass = DIAGM;
-  if constexpr (diag_mass)
-    for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = (i >= lo && i < hi) ? a.mass_diag[i - lo] : 1.0f;
-  __syncthreads();
+  if (!staged) {
+    if constexpr (diag_mass)
+      for (int i = threadIdx.x; i < DIM; i += kBlock) mraw[i] = (i >= lo && i < hi) ? a.mass_diag[i - lo] : 1.0f;
+    __syncthreads();
+  }
 
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
@@ -471,12 +507,15 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       bad = false;
 #endif
       if (!vote_all<E>(!bad)) {
-        // something left the fast path's domain: this workgroup finishes its call -- from this transition on, whose accepted state is
-        // in a.x -- in the literal body (every wave of the workgroup: the evaluation has barriers inside)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the slab requested for "the next evaluation" has landed)
-        __syncthreads();
+        // something left the fast path's domain: this workgroup (the evaluation has barriers inside: every wave of it) or this wave
+        // finishes its call -- from this transition on, whose accepted state is in a.x -- in the literal body
+        if constexpr (BlockVote<E>::value) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the slabs requested ahead have landed)
+          __syncthreads();
+        }
         GaussHmcArgs rest = a_in;
         rest.tr0 = tr;
+        rest.resumed = 1;
         gauss_hmc_fallback<NT, DIAGM, E, DIAG, SH>(rest);
         return;
       }
