@@ -145,11 +145,11 @@ def test_safe_mode_literal_path_is_taken_by_the_whole_workgroup(cuda_device):
     assert ((x[wild][fin] - want["x"][wild][fin]).abs() / want["x"][wild][fin].abs().clamp(min=1.0)).max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("dim,thin", [(192, 1), (224, 2), (256, 2)])
+@pytest.mark.parametrize("dim,thin", [(192, 1), (224, 2), (256, 2), (128, 1), (160, 2)])
 def test_mid_call_hand_over_to_the_literal_body(cuda_device, dim, thin):
     """(round 6) The one-launch kernel evaluates the force in pieces with merged kicks -- the fast sequence -- and a WORKGROUP that
     meets a non-finite energy or momentum hands the rest of its call, from the transition at hand, to the literal body (out of line,
-    gauss_hmc_fallback).  Here one chain of the first workgroup draws an absurd momentum in transition 2 and one of the third in
+    gauss_hmc_fallback; at dims 100 ... 160 -- the LDS-resident contraction, no barriers inside -- a single WAVE does).  Here one chain of the first workgroup draws an absurd momentum in transition 2 and one of the third in
     transition 4: accept decisions, final states and the kept trajectory rows of ALL chains -- before and after the hand-over, with
     the thinning counter resumed in mid-call -- are the oracle's (integrators/leapfrog.py:165-185, samplers/hmc.py:243-312)."""
     n, T, L, eps = 300, 6, 4, 0.05

@@ -39,15 +39,26 @@ struct GaussStreamE {
   using C = gbig::ResCfg<NT>;
   static constexpr int SLABU = C::SLABU;
   static constexpr uint32_t STAGE_BYTES = 3u * SLABU * 16u;
-  static constexpr int kSlabFloats = (int)(2u * STAGE_BYTES / 4u);
-  static constexpr int kLdsFloats = kSlabFloats + 32 * NT;  // [2 buffers][3 pieces][SLABU units] | mu
+#ifndef EBM_STREAM_BUFS
+#define EBM_STREAM_BUFS 2
+#endif
+  // Two slab buffers.  -DEBM_STREAM_BUFS=3 (round 6, measured, off): slab s + 2 requested while stage s runs, into the buffer stage
+  // s - 1 read (free since that stage's barrier; 3 x 48 KB at eight tiles -- with the means and the masses 154 of the CU's 160 KB),
+  // its requests dealt over a whole stage's gaps instead of standing in the last unit behind the barrier that freed their target,
+  // the sync waiting by count (vmcnt(n): vector memory operations complete in order).  Same times within the run-to-run spread
+  // (3.05 / 3.33 / 4.24 / 5.41 against 3.04 / 3.35 / 4.00 / 5.56 ms at dims 164 / 192 / 224 / 256): the requests are not what the last
+  // unit waits for.
+  static constexpr int kBufs = EBM_STREAM_BUFS;
+  static constexpr int kSlabFloats = (int)((uint32_t)kBufs * STAGE_BYTES / 4u);
+  static constexpr int kLdsFloats = kSlabFloats + 32 * NT;  // [kBufs buffers][3 pieces][SLABU units] | mu
   static constexpr bool kEvalGivesEnergy = true;
   static constexpr bool kCarry = false;      // (no LDS left for a parked force: L + 1 evaluations per transition, as the reference)
   static constexpr bool kBlockVote = true;   // barriers inside eval()
 #ifdef EBM_PHASE_TIMES
   unsigned long long ph_last_ = 0, ph_acc_[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  int gstage = 0;  // stages done so far: its parity is the buffer the next stage reads (NT may be odd; the pipeline runs across calls)
+  int gstage = 0;  // stages done so far
+  int gbuf = 0;    // the buffer the next stage reads (the pipeline runs across calls)
 
   // request stage s of the image into buffer `buf`: 6 NT pieces of 1 KiB dealt round-robin to the four waves (assembly: see
   // gauss_big_body.h -- behind the builtin the compiler serialises every later LDS read)
@@ -209,7 +220,7 @@ struct GaussStreamE {
     {
       MicroSplit j0;
       b_means(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      read_a(slab + (size_t)(gstage & 1) * 3 * SLABU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur);
+      read_a(slab + (size_t)gbuf * 3 * SLABU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur);
       static_for<MS>([&](auto kk) { b_micro(j0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kk, std::false_type{}); });
       b0 = j0.tri();
     }
@@ -224,9 +235,14 @@ struct GaussStreamE {
     static_for<NT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       constexpr int T0N = T0 + TN >= NT ? 0 : T0 + TN, TNN = TN == NT ? NT : (NT - T0N < kPieceTiles ? NT - T0N : kPieceTiles);
-      const int buf = gstage & 1;
+      const int buf = gbuf, bufn = buf + 1 == kBufs ? 0 : buf + 1;
+      const int buf2 = kBufs == 3 ? (bufn + 1 == kBufs ? 0 : bufn + 1) : buf;  // where slab s + 2 goes
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
-      const bf16x8* sbn = slab + (size_t)(buf ^ 1) * 3 * SLABU;
+      const bf16x8* sbn = slab + (size_t)bufn * 3 * SLABU;
+      constexpr int TNR = s + 2 < NT ? TN : TNN;                                // slab s + 2: its tiles,
+      constexpr int NCH = (6 * TNR + kBlock / 64 - 1) / (kBlock / 64);         // ... the requests of a wave (the last one not every wave's)
+      constexpr int NCH_ALL = 6 * TNR / (kBlock / 64);                          // ... those every wave makes
+      constexpr int O_LAST = HALF + 12 * (PAIRS - 1);                           // ordinal of the last unit's first MFMA
       EBM_HSTAMP((s == 0 ? 0 : 3));
       MicroSplit jb1, jb0n;
       // behind MFMA o of the stage: the first K-block's gaps hold the B operand of the second K-block, the second K-block's gaps the
@@ -264,17 +280,30 @@ struct GaussStreamE {
         if constexpr (u + 1 == UNITS) {
           EBM_HSTAMP(1);
 #ifndef EBM_ABL_NOSYNC
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          // three buffers: this stage's requests (slab s + 2) are in flight behind slab s + 1's -- vector memory operations complete
+          // in order, so "at most as many outstanding as every wave has requested since" says slab s + 1 has landed
+          if constexpr (kBufs == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NCH_ALL) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __syncthreads();
 #endif
           EBM_HSTAMP(2);
         }
-        // the request for slab s + 2 (into the buffer the barrier just freed): this wave's chunks, dealt over the last unit's gaps
+        // the request for slab s + 2, this wave's chunks.  Three buffers: dealt over the gaps in FRONT of the sync (all of them
+        // issued before it: the count it waits for); two: into the buffer the barrier just freed, over the last unit's gaps
         auto request = [&](auto jc) {
 #ifndef EBM_ABL_NODMA
-          if constexpr (u + 1 == UNITS) {
-            constexpr int j = decltype(jc)::value, NMF = two ? 12 : 6;
-            constexpr int TNR = s + 2 < NT ? TN : TNN, NCH = (6 * TNR + kBlock / 64 - 1) / (kBlock / 64), PER = (NCH + NMF - 1) / NMF;
+          constexpr int j = decltype(jc)::value;  // ordinal within the unit
+          if constexpr (kBufs == 3) {
+            constexpr int o = o0 + j;
+            if constexpr (u + 1 < UNITS) {
+              constexpr int i0 = (o * NCH + O_LAST - 1) / O_LAST, i1 = ((o + 1) * NCH + O_LAST - 1) / O_LAST;  // chunks i with i O_LAST / NCH in [o, o + 1)
+              if constexpr (i1 > i0) {
+                if constexpr (s + 2 < NT) dma_chunks<T0, TN, i0, i1 - i0>(a, lds, buf2, s + 2);
+                else dma_chunks<T0N, TNN, i0, i1 - i0>(a, lds, buf2, s + 2 - NT);
+              }
+            }
+          } else if constexpr (u + 1 == UNITS) {
+            constexpr int NMF = two ? 12 : 6, PER = (NCH + NMF - 1) / NMF;
             if constexpr (j * PER < NCH) {
               constexpr int n = (j + 1) * PER <= NCH ? PER : NCH - j * PER;
               if constexpr (s + 2 < NT) dma_chunks<T0, TN, j * PER, n>(a, lds, buf, s + 2);
@@ -322,17 +351,19 @@ struct GaussStreamE {
       });
       if constexpr (s + 1 < NT) b0 = jb0n.tri();
       ++gstage;
+      gbuf = bufn;
     });
     EBM_HSTAMP(3);
-    if (!want_e) return 0.0f;  // (wave-uniform: one copy of the code serves the trajectory's interior and its last step)
     float acc = 0.0f;
-    static_for<TN * 4>([&](auto ic) {
-      constexpr int t = T0 + (decltype(ic)::value >> 2), tl = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
-      const f32x4 mq = *reinterpret_cast<const f32x4*>(mus + 32 * t + 8 * q + 4 * hs);
+    if (want_e) {  // (wave-uniform: one copy of the code serves the trajectory's interior and its last step)
+      static_for<TN * 4>([&](auto ic) {
+        constexpr int t = T0 + (decltype(ic)::value >> 2), tl = decltype(ic)::value >> 2, q = decltype(ic)::value & 3;
+        const f32x4 mq = *reinterpret_cast<const f32x4*>(mus + 32 * t + 8 * q + 4 * hs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x.t[t][4 * q + i] - mq[i], gout[tl][4 * q + i], acc);
-    });
-    acc += __shfl_xor(acc, 32);
+        for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(x.t[t][4 * q + i] - mq[i], gout[tl][4 * q + i], acc);
+      });
+      acc += __shfl_xor(acc, 32);
+    }
     asm volatile("" : "+v"(acc));
     EBM_HSTAMP(4);
 #ifdef EBM_PHASE_TIMES
