@@ -2,8 +2,8 @@
 """Shader-clock phases of the dense-Gaussian one-launch HMC kernel (dims 164 .. 256), debug build only:
     scripts/ab_build.sh PH gauss_hmc_stream.hip -DEBM_PHASE_TIMES && cp ab/PH.so torchebm_amd/libebm_hip.so   (then, on the GPU box)
     python scripts/hmc_stream_phase_times.py [dim]
-Wave 0 of workgroup 0 adds up s_memtime differences per phase class over the first 20 passes (= 10 evaluations; a pass = one piece
-of the force) in registers and writes the sums once -- no memory traffic in the loop; a stamp still drains the wave's LDS queue."""
+Wave 0 of workgroup 0 adds up s_memtime differences per phase class over the first 20 passes (a pass = one piece of the force: two per
+evaluation, three at eight tiles) in registers and writes the sums once -- no memory traffic in the loop; a stamp still drains the wave's LDS queue."""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -27,9 +27,9 @@ t = np.array(list(buf), dtype=np.int64)
 passes = int(t[6])
 names = ["entry: first operand (means, split, A reads)", "units in front of the sync", "sync (waitcnt + barrier)", "last unit of a stage (+ DMA requests, next operands)",
          "energy part", "between passes (kicks, drift, loop; the first: the prologue)"]
-tp = (nt + 1) // 2
-mf = 6 * 2 * (tp + (nt - tp)) * nt * 32 / 2   # MFMA cycles per pass on average (pieces of tp and nt - tp tiles)
-print(f"dim {dim}: ticks per PASS (average of {passes}; two passes = one evaluation); MFMA floor per pass {mf:.0f}")
+pieces = 3 if nt == 8 else 2
+mf = 6 * 2 * nt * nt * 32 / pieces   # MFMA cycles per pass on average (an evaluation = 12 nt^2 MFMAs of 32 cycles, in `pieces` passes)
+print(f"dim {dim}: ticks per PASS (average of {passes}; {pieces} passes = one evaluation); MFMA floor per pass {mf:.0f}")
 tot = 0
 for i, nm in enumerate(names):
     print(f"  {nm:62s} {t[i] / passes:9.0f}")
