@@ -698,6 +698,21 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
                    : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
     }
   };
+  // ... one request of it (this wave's i-th: piece wave + 4 i), for the slots: the CU's texture-address unit takes a 1 KiB request
+  // every ~16 cycles and a wave that issues its 9 .. 12 in a row stands in that queue with the matrix pipe idle (round 6,
+  // scripts/hmc_stream_phase_times.py on the HMC kernels that share this stage loop) -- one behind every fourth MFMA of K-block 0
+  [[maybe_unused]] auto dma_piece = [&](int buf, int s, auto ic) {
+    constexpr uint32_t STAGE_BYTES = 3u * SLABU * 16u;
+    constexpr int i = decltype(ic)::value;
+    const char* src = image + big_image_bytes<OT, 1>(32 * OT) + (size_t)s * STAGE_BYTES;
+    const int piece = __builtin_amdgcn_readfirstlane(wave) + 4 * i;
+    if (4 * (i + 1) <= (int)(STAGE_BYTES / 1024u) || piece < (int)(STAGE_BYTES / 1024u)) {
+      const uint32_t voff = (uint32_t)(piece * 1024 + lane * 16), base = slab_lds + (uint32_t)buf * STAGE_BYTES + (uint32_t)piece * 1024u;
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(src), "s"(base) : "memory");
+    }
+  };
   // the first slab
   [[maybe_unused]] f32x4 ra[IMG ? 1 : UPT];
   if constexpr (IMG) {
@@ -814,12 +829,33 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         }
       }
     };
+    // the A operands of unit (kb2, pi) from the slab at `base`: [piece][out tile][128 units]; read_a_part: piece 2 - i (low first, as
+    // the MFMAs use them) of both tiles
+    auto read_a = [&](const bf16x8* base, auto kc, auto pc, bf16x8 (&a6)[6]) {
+      constexpr int kb2 = decltype(kc)::value, pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
+      const bf16x8* sr = base + rd_unit[kb2];
+      a6[0] = sr[2 * SLABU + ot0 * 128]; a6[1] = sr[SLABU + ot0 * 128]; a6[2] = sr[ot0 * 128];
+      if constexpr (ot1 != ot0) {
+        a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
+      }
+    };
+    auto read_a_part = [&](const bf16x8* base, auto kc, auto pc, auto ic, bf16x8 (&a6)[6]) {
+      constexpr int kb2 = decltype(kc)::value, pi = decltype(pc)::value, i = decltype(ic)::value;
+      constexpr int ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
+      const bf16x8* sr = base + rd_unit[kb2];
+      a6[i] = sr[(2 - i) * SLABU + ot0 * 128];
+      if constexpr (ot1 != ot0) a6[3 + i] = sr[(2 - i) * SLABU + ot1 * 128];
+    };
+    bf16x8 acur[6];
+    if constexpr (IMG) read_a(slab + (size_t)(gstage & 1) * 3 * SLABU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur);
     static_for<OT>([&](auto sc) {
       constexpr int s = decltype(sc)::value, sn = (s + 1) % OT;  // the stage after the last one is stage 0 of the next step
       constexpr int HALF = 6 * OT;                                // MFMAs per K-block
       const int buf = gstage & 1;
       constexpr int sn2 = (s + 2) % OT;  // the slab requested during this stage
+#ifdef EBM_RES_DMA_BLOCK
       if constexpr (IMG) dma_stage(buf ^ 1, sn);  // (the barrier that ended the stage before freed that buffer)
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;
       ResSplit jb1, jb0n;
@@ -852,6 +888,10 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
           constexpr int i = s * 2 * HALF + o, k0 = plan.pos[i], k1 = plan.pos[i + 1];
           static_for<k1 - k0>([&](auto kk) { noise_stage(std::integral_constant<int, k0 + decltype(kk)::value>{}); });
         }
+#ifndef EBM_RES_DMA_BLOCK
+        // the next slab's requests (the barrier that ended the stage before freed its buffer): 1.5 OT per wave, HALF / 4 gaps
+        if constexpr (IMG && o < HALF && o % 4 == 1) dma_piece(buf ^ 1, sn, std::integral_constant<int, o / 4>{});
+#endif
         if constexpr (o < HALF) {
           if constexpr (EBM_BIG_EXP & 32) {
           } else if constexpr (o % 2 == 0 && o / 2 < B_STEPS) {
@@ -867,57 +907,63 @@ __global__ __launch_bounds__(256) void gauss_res_langevin_kernel(BigArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      static_for<2>([&](auto kc) {
-        constexpr int kb2 = decltype(kc)::value;
-        constexpr int PAIRS = (OT + 1) / 2;
-        const Tri bb = kb2 == 0 ? b0 : jb1.tri();
-        auto read_a = [&](auto pc, bf16x8 (&a6)[6]) {
-          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
-          const bf16x8* sr = sb + rd_unit[kb2];
-          a6[0] = sr[2 * SLABU + ot0 * 128]; a6[1] = sr[SLABU + ot0 * 128]; a6[2] = sr[ot0 * 128];
-          if constexpr (ot1 != ot0) {
-            a6[3] = sr[2 * SLABU + ot1 * 128]; a6[4] = sr[SLABU + ot1 * 128]; a6[5] = sr[ot1 * 128];
-          }
-        };
-        bf16x8 acur[6];
-        read_a(std::integral_constant<int, 0>{}, acur);
-        static_for<PAIRS>([&](auto pc) {
-          constexpr int pi = decltype(pc)::value, ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
-          constexpr bool two = ot1 != ot0;
-          constexpr int o0 = kb2 * HALF + 12 * pi;  // ordinal of this pair's first MFMA
-          bf16x8 anext[6];
-          if constexpr (pi + 1 < PAIRS) read_a(std::integral_constant<int, pi + 1>{}, anext);
-          __builtin_amdgcn_sched_barrier(0);
-          f32x16 g0 = g[ot0], g1;
-          if constexpr (two) g1 = g[ot1];
-          // (term, operand) in issue order: smallest products first
-          static_for<6>([&](auto tc) {
-            constexpr int term = decltype(tc)::value;
-            constexpr int ai = term == 0 ? 0 : (term <= 2 ? 1 : 2);                    // Pl | Pm Pm | Ph Ph Ph
-            const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
-            if constexpr (!(EBM_BIG_EXP & 1)) g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
-            else g0[term] += (float)acur[ai][0] * (float)bp[0];
-            __builtin_amdgcn_sched_barrier(0);  // (round 6: the MFMA first -- in one region with its slot it can sink below it)
-            slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
-            if constexpr (two) {
-              if constexpr (!(EBM_BIG_EXP & 1)) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
-              else g1[term] += (float)acur[3 + ai][0] * (float)bp[0];
-              __builtin_amdgcn_sched_barrier(0);
-              slot(std::integral_constant<int, o0 + 2 * term + 1>{});
-            }
-          });
-          g[ot0] = g0;
-          if constexpr (two) g[ot1] = g1;
-          if constexpr (pi + 1 < PAIRS) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acur[i] = anext[i];
+      // A unit = (K-block, pair of output tiles) = 12 / 6 MFMAs.  (round 6) The operands of unit u + 1 are requested behind the first
+      // three MFMAs of unit u, TWO reads at a time -- an LDS read holds the wave's issue for 16 cycles: two behind an MFMA cost 8,
+      // six in a row 96 with the matrix pipe idle (profiles/r06_mfma_valu_overlap.txt, ds128) -- and across the K-block boundary
+      // too; only the stage's first unit reads in front of its MFMAs (its slab became visible at the barrier just passed).
+      constexpr int PAIRS = (OT + 1) / 2, UNITS2 = 2 * PAIRS;
+      // IMG (the slabs arrive by LDS-direct loads): the stage's ONE synchronisation point stands in front of its LAST unit, whose
+      // operands are in registers by then -- wait for this wave's share of the next slab and for its own LDS reads, barrier: the
+      // next slab is visible and nobody reads this one any more -- and the next stage's first operands are requested behind the
+      // last unit's MFMAs (was: barrier at the stage's end, then six reads in front of the next stage's first MFMA).  A step's
+      // first stage reads its first operands in front of its MFMAs (above the stage loop).
+      const bf16x8* sbn = slab + (size_t)(buf ^ 1) * 3 * SLABU;
+      if constexpr (!IMG) read_a(sb, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur);
+      Tri bb = b0;
+      static_for<UNITS2>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, kb2 = u / PAIRS, pi = u % PAIRS;
+        constexpr int ot0 = 2 * pi, ot1 = 2 * pi + 1 < OT ? 2 * pi + 1 : 2 * pi;
+        constexpr bool two = ot1 != ot0;
+        constexpr int o0 = kb2 * HALF + 12 * pi;  // ordinal of this unit's first MFMA
+        if constexpr (kb2 == 1 && pi == 0) bb = jb1.tri();
+        if constexpr (IMG && u + 1 == UNITS2) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          if constexpr (!(EBM_BIG_EXP & 16)) __syncthreads();
+        }
+        bf16x8 anext[6];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 g0 = g[ot0], g1;
+        if constexpr (two) g1 = g[ot1];
+        // (term, operand) in issue order: smallest products first
+        static_for<6>([&](auto tc) {
+          constexpr int term = decltype(tc)::value;
+          constexpr int ai = term == 0 ? 0 : (term <= 2 ? 1 : 2);                    // Pl | Pm Pm | Ph Ph Ph
+          const bf16x8& bp = (term == 0 || term == 2 || term == 5) ? bb.h : ((term == 1 || term == 4) ? bb.m : bb.l);
+          if constexpr (!(EBM_BIG_EXP & 1)) g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ai], bp, g0, 0, 0, 0);
+          else g0[term] += (float)acur[ai][0] * (float)bp[0];
+          __builtin_amdgcn_sched_barrier(0);  // (round 6: the MFMA first -- in one region with its slot it can sink below it)
+          if constexpr (term < 3 && u + 1 < UNITS2)
+            read_a_part(sb, std::integral_constant<int, (u + 1) / PAIRS>{}, std::integral_constant<int, (u + 1) % PAIRS>{}, tc, anext);
+          else if constexpr (term < 3 && IMG && s + 1 < OT)
+            read_a_part(sbn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, tc, anext);
+          slot(std::integral_constant<int, o0 + (two ? 2 : 1) * term>{});
+          if constexpr (two) {
+            if constexpr (!(EBM_BIG_EXP & 1)) g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[3 + ai], bp, g1, 0, 0, 0);
+            else g1[term] += (float)acur[3 + ai][0] * (float)bp[0];
+            __builtin_amdgcn_sched_barrier(0);
+            slot(std::integral_constant<int, o0 + 2 * term + 1>{});
           }
         });
+        g[ot0] = g0;
+        if constexpr (two) g[ot1] = g1;
+        if constexpr (u + 1 < UNITS2 || (IMG && s + 1 < OT)) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acur[i] = anext[i];
+        }
       });
       if constexpr (s + 1 < OT) b0 = jb0n.tri();
       ++gstage;
-      if constexpr (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next slab have landed
-      if constexpr (!(EBM_BIG_EXP & 16)) __syncthreads();  // the next slab is written, this one is read by everyone
+      if constexpr (!IMG && !(EBM_BIG_EXP & 16)) __syncthreads();  // the next slab is written, this one is read by everyone
       // (a block cut here -- the OT unrolled stages are ONE basic block -- was tried: more spills in the plain kernels, dim 224 2.31 -> 2.84 ms)
     });
 
