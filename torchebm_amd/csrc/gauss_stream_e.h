@@ -5,7 +5,11 @@
 // arrive ready-made from the pre-split copy of Ps (ebm_gauss_prec_image_f32: the resident Langevin kernel's layout,
 // gauss_big_body.h) by LDS-direct loads, double-buffered, one stage ahead of the MFMAs that read them; the B operands are split
 // from the position registers in slots behind the MFMAs.  Up to 160 dims the images stay resident in LDS (gauss_hmc_mfma.hip);
-// beyond 256 the position, momentum and force of 32 chains no longer fit a wave's registers (the sampler's GEMM route).
+// beyond 256 the position and momentum of 32 chains no longer fit a wave's registers (the sampler's GEMM route).
+// Round 6: the force comes in PIECES of output tiles (eval_tiles<T0, TN>: a pass over the stages each, requesting only the slab
+// part the piece reads) which the body kicks into the momentum at once -- position, momentum and a whole force array are never
+// live together (round 5: 1 045 spilled values per lane at eight tiles, 41 GB of scratch traffic per launch) -- and the stage loop is
+// software-pipelined (one sync per stage in front of its last unit, operands a unit ahead): docs/design/gaussian_big.md "Round 6".
 // Before round 4 these widths ran per transition as library GEMMs + element-wise kernels: dim 256, 2^17 chains, 5 transitions
 // of 10 leapfrog steps 18.6 ms.
 // Reference: samplers/hmc.py:201-315 (transition), integrators/leapfrog.py:116-187, core/base_model.py:181-210 (energy).
@@ -16,9 +20,11 @@
 namespace ebm {
 namespace {
 
-// -DEBM_PHASE_TIMES (scripts/hmc_stream_phase_times.py only; build gauss_hmc_stream.hip alone with it): wave 0 of workgroup 0 logs
-// the shader clock at the boundaries of every pass of the evaluation -- entry | per stage: start, in front of the sync, behind it |
-// stages done | energy done -- relative times; a stamp drains nothing but fences the scheduler.
+// -DEBM_PHASE_TIMES (scripts/hmc_stream_phase_times.py only; build gauss_hmc_stream.hip alone with it): wave 0 of workgroup 0 adds
+// up shader-clock differences per phase class in registers (no memory traffic in the loop; a stamp waits for the wave's LDS / scalar
+// queue and fences the scheduler) and writes the sums once, after its 20th pass.
+// -DEBM_ABL_NODMA / NOSYNC / NOSPLIT / NOMFMA / NOBAD: timing ablations (wrong results): no slab requests / no waits and barriers /
+// a quarter of the operand split / no MFMAs / never hand over to the literal body.
 #ifdef EBM_PHASE_TIMES
 __device__ unsigned long long ebm_hmc_phase_log[16];
 // class c: 0 entry (first operand) | 1 units in front of the sync | 2 sync | 3 last unit | 4 energy part | 5 between passes
