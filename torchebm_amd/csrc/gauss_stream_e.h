@@ -133,8 +133,18 @@ struct GaussStreamE {
 #ifndef EBM_PW_PIECES8
 #define EBM_PW_PIECES8 3
 #endif
-  static constexpr int kPieces = NT == 8 ? EBM_PW_PIECES8 : 2;
-  static constexpr int kPieceTiles = (NT + kPieces - 1) / kPieces;
+#ifndef EBM_PW_PIECES7
+#define EBM_PW_PIECES7 2
+#endif
+  static constexpr int kPieces = NT == 8 ? EBM_PW_PIECES8 : (NT == 7 ? EBM_PW_PIECES7 : 2);
+  // piece pi = tiles piece_t0(pi) .. + piece_tn(pi) - 1: NT / kPieces tiles each, the first NT % kPieces pieces one more
+  static constexpr int piece_tn(int pi) { return NT / kPieces + (pi < NT % kPieces ? 1 : 0); }
+  static constexpr int piece_t0(int pi) { return pi * (NT / kPieces) + (pi < NT % kPieces ? pi : NT % kPieces); }
+  static constexpr int piece_of(int t0) {  // the piece that starts at tile t0
+    for (int pi = 0; pi < kPieces; ++pi)
+      if (piece_t0(pi) == t0) return pi;
+    return 0;
+  }
   __device__ __forceinline__ float eval(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, Tile<NT>& g, int m, int h) {
     return eval_tiles<0, NT>(a, lds, x, g.t, m, h);
   }
@@ -240,7 +250,8 @@ struct GaussStreamE {
     // times per pass.)  Slabs s + 1, s + 2 beyond this pass are the next piece's first two (T0N, TNN).
     static_for<NT>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      constexpr int T0N = T0 + TN >= NT ? 0 : T0 + TN, TNN = TN == NT ? NT : (NT - T0N < kPieceTiles ? NT - T0N : kPieceTiles);
+      constexpr int PIN = (piece_of(T0) + 1) % kPieces;  // the next piece (the literal body's one piece -- TN = NT -- follows itself)
+      constexpr int T0N = TN == NT ? 0 : piece_t0(PIN), TNN = TN == NT ? NT : piece_tn(PIN);
       const int buf = gbuf, bufn = buf + 1 == kBufs ? 0 : buf + 1;
       const int buf2 = kBufs == 3 ? (bufn + 1 == kBufs ? 0 : bufn + 1) : buf;  // where slab s + 2 goes
       const bf16x8* sb = slab + (size_t)buf * 3 * SLABU;

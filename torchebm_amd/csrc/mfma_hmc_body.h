@@ -157,7 +157,9 @@ struct GaussE {
   // momentum and force are 192 / 240 registers beside ~150 of operands): eval() already forms the output two tiles at a time
   // (contract_pieces) -- here a piece is handed out as soon as it is done, and the body kicks its momentum tiles at once.
   static constexpr bool kPiecewise = B3 && NT >= 4;
-  static constexpr int kPieceTiles = 2, kPieces = (NT + 1) / 2;
+  static constexpr int kPieces = (NT + 1) / 2;
+  static constexpr int piece_t0(int pi) { return 2 * pi; }
+  static constexpr int piece_tn(int pi) { return NT - 2 * pi < 2 ? NT - 2 * pi : 2; }
   template <int T0, int TN>
   __device__ __forceinline__ float eval_tiles(const GaussHmcArgs&, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h,
                                               bool want_e = true) const {
@@ -229,7 +231,7 @@ __device__ __forceinline__ bool vote_all(bool pred) {
 // SH: SHIFTED rows (widths off multiples of 4; gauss_mfma_body.h says how): a workgroup takes the chains of one alignment
 // class, tile coordinate j = coordinate j - lo of the chain; the tile coordinates outside [lo, lo + dim) are padding like
 // the ones beyond dim -- x = p = f = 0 throughout (loaded as 0, their momentum draw discarded, zero rows of the staged matrix).
-// (round 6) PW -- the force in PIECES (energies that offer eval_tiles<T0, TN> and kPieces / kPieceTiles: GaussStreamE).  At seven /
+// (round 6) PW -- the force in PIECES (energies that offer eval_tiles<T0, TN>, kPieces and piece_t0 / piece_tn: GaussStreamE, GaussE from four tiles).  At seven /
 // eight tiles position + momentum + force are 336 / 384 of a wave's 512 registers (of which only 256 can be operands of vector
 // instructions) and the allocator kept ~330 values per lane in scratch for the whole trajectory, moving them through every kick and
 // drift: 41 GB of traffic per launch at dim 256 (profiles/r05_pmc.json), 97 k cycles per evaluation against 24.6 k of MFMAs.  With PW a
@@ -450,7 +452,6 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
     float e1 = 0.0f, h0 = 0.0f, k_end = 0.0f;
     if constexpr (PW) {
       static_assert(!CARRY && E::kEvalGivesEnergy, "PW: the energy comes with the force, nothing is carried");
-      constexpr int PT = E::kPieceTiles;
       const float k_start = kinetic(p);  // K(p0): before the first half kick
       bool bad = false;
       // E(x), and p += kick * clamp(-dE/dx) piece by piece
@@ -460,7 +461,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       auto eval_and_kick = [&](float kick, bool want_e) __attribute__((always_inline)) -> float {  // (beyond the inliner's budget at eight tiles)
         float e = 0.0f;
         gauss3::static_for<E::kPieces>([&](auto pc) {
-          constexpr int T0 = decltype(pc)::value * PT, TN = (NT - T0) < PT ? (NT - T0) : PT;
+          constexpr int T0 = E::piece_t0(decltype(pc)::value), TN = E::piece_tn(decltype(pc)::value);
           if constexpr (TN > 0) {
             f32x16 gp[TN];
             e += en.template eval_tiles<T0, TN>(a, elds, x, gp, m, h, want_e);
