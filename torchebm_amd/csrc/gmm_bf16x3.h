@@ -101,6 +101,49 @@ struct Mixture {
       for (int r = 0; r < 16; ++r) g[t][r] = a.invs2 * (x[t][r] - g[t][r] * inv);
     return sum;
   }
+  // The same gradient in two calls, for bodies that take the force in PIECES of output tiles (mfma_hmc_body.h PW): weights() -- the
+  // logits' contraction and the softmax, once per evaluation: w (one tile) and its sum -- and grad_tiles<T0, TN>() -- the weighted
+  // mean of tiles T0 .. T0 + TN - 1 and the gradient of those tiles.  Same arithmetic as grad().
+  __device__ static __forceinline__ float weights(const Params& a, const float* lds, const f32x16 (&x)[NT], f32x16 (&w)[1], int lane) {
+    const int h = lane >> 5;
+    f32x16 dot[1];
+    gauss3::contract_general<1, 2 * NT, false>(reinterpret_cast<const __bf16*>(lds), nullptr, x, dot, lane);
+    const float* cvec = lds + kA1Floats + kA2Floats;
+    float top = -__builtin_inff();
+#pragma unroll
+    for (int q = 0; q < KR / 4; ++q) {
+      const float4 c4 = *reinterpret_cast<const float4*>(cvec + 8 * q + 4 * h);
+      const float cq[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[0][4 * q + i] = __builtin_fmaf(dot[0][4 * q + i], a.invs2, cq[i]);
+        top = __builtin_fmaxf(top, w[0][4 * q + i]);
+      }
+    }
+    top = __builtin_fmaxf(top, __shfl_xor(top, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < KR) {
+        w[0][r] = __expf(w[0][r] - top);
+        sum += w[0][r];
+      } else {
+        w[0][r] = 0.0f;
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    return sum;
+  }
+  template <int T0, int TN>
+  __device__ static __forceinline__ void grad_tiles(const Params& a, const float* lds, const f32x16 (&x)[NT], const f32x16 (&w)[1], float sum,
+                                                    f32x16 (&g)[TN], int lane) {
+    gauss3::contract_general<TN, KBC, false, gauss3::NoFill, NT, T0>(reinterpret_cast<const __bf16*>(lds + kA1Floats), nullptr, w, g, lane);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = a.invs2 * (x[T0 + t][r] - g[t][r] * inv);
+  }
   // the exact energy, difference form, online logsumexp over the components
   __device__ static __forceinline__ float energy(const Params& a, const float* lds, const f32x16 (&x)[NT], int lane) {
     const int h = lane >> 5;

@@ -207,6 +207,22 @@ struct GmmE {
   __device__ static __forceinline__ float energy(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, int m, int h) {
     return M::energy(params(a), lds, x.t, m + 32 * h);
   }
+  // (round 6) the force in PIECES of two output tiles for the transition body's PW path (five tiles and more: nothing is carried):
+  // the softmax weights once per evaluation (kept here between the pieces), the weighted mean and the gradient piece by piece
+  static constexpr bool kPiecewise = !kCarry;
+  static constexpr int kPieces = (NT + 1) / 2;
+  static constexpr int piece_t0(int pi) { return 2 * pi; }
+  static constexpr int piece_tn(int pi) { return NT - 2 * pi < 2 ? NT - 2 * pi : 2; }
+  f32x16 w_[1];
+  float sum_ = 0.0f;
+  template <int T0, int TN>
+  __device__ __forceinline__ float eval_tiles(const GaussHmcArgs& a, const float* lds, const Tile<NT>& x, f32x16 (&gout)[TN], int m, int h,
+                                              bool want_e = true) {
+    if constexpr (T0 == 0) sum_ = M::weights(params(a), lds, x.t, w_, m + 32 * h);
+    M::template grad_tiles<T0, TN>(params(a), lds, x.t, w_, sum_, gout, m + 32 * h);
+    if constexpr (T0 == 0) return want_e ? M::energy(params(a), lds, x.t, m + 32 * h) : 0.0f;  // (the exact energy, once per evaluation that wants it)
+    else return 0.0f;
+  }
 };
 
 // DIAGM: diagonal mass (its own instantiation: as a run-time switch it cost the plain kernels their register allocation)
@@ -246,6 +262,8 @@ template <class E>
 struct piecewise_of<E, std::void_t<decltype(E::kPieces)>> { static constexpr bool value = true; };
 template <int NT, bool B3, int KT>
 struct piecewise_of<GaussE<NT, B3, KT>, void> { static constexpr bool value = GaussE<NT, B3, KT>::kPiecewise; };
+template <int NT, int KR>
+struct piecewise_of<GmmE<NT, KR>, void> { static constexpr bool value = GmmE<NT, KR>::kPiecewise; };
 template <int NT, bool DIAGM, class E, bool DIAG, bool SH>
 __device__ __noinline__ void gauss_hmc_fallback(const GaussHmcArgs& a);
 
@@ -451,7 +469,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
 
     float e1 = 0.0f, h0 = 0.0f, k_end = 0.0f;
     if constexpr (PW) {
-      static_assert(!CARRY && E::kEvalGivesEnergy, "PW: the energy comes with the force, nothing is carried");
+      static_assert(!CARRY, "PW: nothing is carried");  // (the energy: with the force, or -- mixtures -- from E's own exact form, at the ends)
       const float k_start = kinetic(p);  // K(p0): before the first half kick
       bool bad = false;
       // E(x), and p += kick * clamp(-dE/dx) piece by piece
@@ -613,7 +631,7 @@ __device__ __forceinline__ void gauss_hmc_mfma_body(const GaussHmcArgs& a_in) {
       }
     }
     }
-    if constexpr (!E::kEvalGivesEnergy) e1 = E::energy(a, elds, x, m, h);
+    if constexpr (!E::kEvalGivesEnergy && !PW) e1 = E::energy(a, elds, x, m, h);
     if constexpr (!PW) k_end = kinetic(p);
     const float h1 = clamp_nanprop(e1, -1e10f, 1e10f) + k_end;
 
