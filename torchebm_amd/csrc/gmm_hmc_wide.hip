@@ -11,6 +11,11 @@
 //   six tiles  (161 .. 192)   K = 8: 2.2 -> 1.9-2.1 K = 16: 4.4 -> 1.9-2.3 K = 32: 4.0-5.0
 //   seven      (193 .. 224)   K = 8: 2.3 -> 2.7 (stays on the lane-group kernel)   K = 16: 4.4 -> 2.7-2.9   K = 32: 4.4-5.0
 //   eight      (225 .. 256)   K = 8: 2.5 -> 4.7, K = 16: 4.6 -> 5.9 (dim 256 itself: 1.6 / 2.2 -> 4.5 / 6.2): not instantiated.
+// Round 6: with up to 16 components the force comes in PIECES of two tiles that are kicked into the momentum at once (GmmE::eval_tiles:
+// the softmax weights once per evaluation, the weighted mean piece by piece; mfma_hmc_body.h PW) -- 639 -> 291 spilled values at
+// seven tiles -- and seven tiles pay for every component count:
+//   K = 8:  129 .. 192: 0.70-0.93 -> 0.63-0.90   200 / 224: 2.29 / 2.34 (lane-group) -> 1.23 / 1.21
+//   K = 16: 129 .. 192: 0.84-1.16 -> 0.75-1.09   200 / 224: 1.78 / 1.80 -> 1.42 / 1.45        (K = 32: one piece, as before)
 // Reference: torchebm/samplers/hmc.py:243-312 over the mixture energy.
 #include "mfma_hmc_body.h"
 
@@ -23,8 +28,8 @@ constexpr bool kSh = false;
 #endif
 // tile coordinates a row can reach: the width itself, or (shifted rows) plus the largest class offset
 inline int32_t extent(int32_t dim) { return kSh ? dim + ((dim & 1) ? 3 : 2) : dim; }
-// five and six tiles for every component count, seven from nine components (measured: the table above)
-inline bool tiles_pay(int32_t ext, int32_t n_comp) { return ext <= 192 || (ext <= 224 && n_comp > 8); }
+// five to seven tiles for every component count (measured: the tables above)
+inline bool tiles_pay(int32_t ext, int32_t) { return ext <= 224; }  // (round 5: seven tiles from nine components only)
 
 template <int NT>
 int launch_nt(const GaussHmcArgs& a, hipStream_t st) {

@@ -209,7 +209,9 @@ struct GmmE {
   }
   // (round 6) the force in PIECES of two output tiles for the transition body's PW path (five tiles and more: nothing is carried):
   // the softmax weights once per evaluation (kept here between the pieces), the weighted mean and the gradient piece by piece
-  static constexpr bool kPiecewise = !kCarry;
+  // (up to 16 components: measured -3 ... -20 % at dims 129 ... 224, 2^16 chains x 4 transitions x L = 10; with 17 ... 32 -- two
+  //  K-blocks of weights -- the pieces cost +9 ... +42 % and the one-piece form stays)
+  static constexpr bool kPiecewise = !kCarry && KR <= 8;
   static constexpr int kPieces = (NT + 1) / 2;
   static constexpr int piece_t0(int pi) { return 2 * pi; }
   static constexpr int piece_tn(int pi) { return NT - 2 * pi < 2 ? NT - 2 * pi : 2; }
