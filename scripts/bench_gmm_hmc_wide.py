@@ -13,7 +13,7 @@ def timeit(fn, reps=5, warm=2):
     return sorted(ts)[len(ts) // 2]
 n = 1 << 16
 for K in (8, 16, 32):
-    for dim in (128, 129, 132, 160, 190, 192, 200, 224, 254, 256):
+    for dim in [int(d) for d in os.environ.get("GMM_DIMS", "128,129,132,160,190,192,200,224,254,256").split(",")]:
         g = torch.Generator().manual_seed(dim)
         m = ta.GaussianMixtureModel(torch.randn(K, dim, generator=g) * 2.0, sigma=1.0, device=dev)
         x = torch.randn(n, dim, device=dev)
