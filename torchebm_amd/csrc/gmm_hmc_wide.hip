@@ -16,9 +16,10 @@
 // seven tiles -- and seven tiles pay for every component count:
 //   K = 8:  129 .. 192: 0.70-0.93 -> 0.63-0.90   200 / 224: 2.29 / 2.34 (lane-group) -> 1.23 / 1.21
 //   K = 16: 129 .. 192: 0.84-1.16 -> 0.75-1.09   200 / 224: 1.78 / 1.80 -> 1.42 / 1.45        (K = 32: one piece, as before)
-// and EIGHT tiles (225 .. 255; 451 spilled values) with up to 16 components:
+// and EIGHT tiles (225 .. 255; 451 - 485 spilled values):
 //   K = 8:  228 .. 254: 2.37-2.49 (lane-group) -> 1.73-1.79      K = 16: 4.48-4.55 -> 2.02-2.10
-//   (dim 256 itself stays on the lane-group kernels, at their best there: K = 8 1.61 against 1.74, K = 16 2.12 against 2.04)
+//   K = 32 (in pieces at eight tiles only): 228 .. 254: 8.49-8.57 -> 3.69-3.78
+//   (dim 256 itself stays on the lane-group kernels, at their best there: K = 8 1.61 against 1.74, K = 16 2.12 against 2.04, K = 32 3.84 / 3.84)
 // Reference: torchebm/samplers/hmc.py:243-312 over the mixture energy.
 #include "mfma_hmc_body.h"
 
@@ -39,7 +40,10 @@ inline int32_t extent(int32_t dim) { return kSh ? dim + ((dim & 1) ? 3 : 2) : di
 #endif
 inline bool tiles_pay(int32_t ext, int32_t n_comp, int32_t dim) {
   if (ext <= 224) return true;
-  if (EBM_GMM_WIDE_8 == 0 || ext > 256 || n_comp > 16) return false;
+#ifndef EBM_GMM_WIDE_8_K32
+#define EBM_GMM_WIDE_8_K32 1
+#endif
+  if (EBM_GMM_WIDE_8 == 0 || ext > 256 || (n_comp > 16 && !EBM_GMM_WIDE_8_K32)) return false;
   return EBM_GMM_WIDE_8 == 1 || dim != 256;
 }
 
@@ -75,9 +79,10 @@ int launch_hmc_chain_gmm_wide(
     case 5: return launch_nt<5>(a, st);
     case 6: return launch_nt<6>(a, st);
     case 7: return launch_nt<7>(a, st);
-    default:  // eight tiles: up to 16 components (tiles_pay)
+    default:  // eight tiles (tiles_pay)
       if (a.n_comp <= 8) return launch_policy<8, false, GmmE<8, 4>, 0, false, kSh>(a, st);
-      return launch_policy<8, false, GmmE<8, 8>, 0, false, kSh>(a, st);
+      if (a.n_comp <= 16) return launch_policy<8, false, GmmE<8, 8>, 0, false, kSh>(a, st);
+      return launch_policy<8, false, GmmE<8, 16>, 0, false, kSh>(a, st);
   }
 }
 

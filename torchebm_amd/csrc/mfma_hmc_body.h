@@ -211,7 +211,7 @@ struct GmmE {
   // the softmax weights once per evaluation (kept here between the pieces), the weighted mean and the gradient piece by piece
   // (up to 16 components: measured -3 ... -20 % at dims 129 ... 224, 2^16 chains x 4 transitions x L = 10; with 17 ... 32 -- two
   //  K-blocks of weights -- the pieces cost +9 ... +42 % and the one-piece form stays)
-  static constexpr bool kPiecewise = !kCarry && KR <= 8;
+  static constexpr bool kPiecewise = !kCarry && (KR <= 8 || NT == 8);  // (eight tiles: in pieces or not at all)
   static constexpr int kPieces = (NT + 1) / 2;
   static constexpr int piece_t0(int pi) { return 2 * pi; }
   static constexpr int piece_tn(int pi) { return NT - 2 * pi < 2 ? NT - 2 * pi : 2; }
