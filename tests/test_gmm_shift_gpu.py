@@ -149,3 +149,44 @@ def test_wide_hmc_injected_draws_give_the_oracles_accept_mask(cuda_device, dim):
     keep = torch.ones(n, dtype=torch.bool); keep[7] = False
     err = ((got[keep] - ref["x"][keep]).abs() / ref["x"][keep].abs().clamp(min=1.0)).amax(dim=1)
     assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()
+
+
+@pytest.mark.parametrize("K,dim,thin", [(8, 160, 1), (16, 224, 2), (8, 240, 2), (32, 252, 1), (16, 254, 2)])
+def test_wide_hmc_mid_call_hand_over_to_the_literal_body(cuda_device, K, dim, thin):
+    """(round 6) The wide mixture kernels take the force in pieces with merged kicks (mfma_hmc_body.h PW; GmmE::eval_tiles) and a
+    WAVE that meets a non-finite energy or momentum finishes its call -- from the transition at hand, the thinning counter resumed --
+    in the literal body (gauss_hmc_fallback).  Absurd momentum draws in transitions 2 and 4: decisions, final states and kept rows of
+    all chains are the oracle's (samplers/hmc.py:243-312, integrators/leapfrog.py:165-185)."""
+    n, T, L, eps = 200, 6, 4, 0.08
+    model, en, g = _mixture(K, dim, cuda_device, seed=4)
+    x0 = torch.randn(n, dim, generator=g).clamp_(-2.0, 2.0)
+    p, u = torch.randn(T, n, dim, generator=g), torch.rand(T, n, generator=g)
+    p[2, 5] *= 1e37
+    p[4, 190] *= 1e25
+    want = oracle.hmc_chain(en, x0, p, u, [eps] * T, L, thin=thin, want_traj=True, want_margins=True)
+    x = x0.to(cuda_device)
+    mask = torch.empty(T, n, dtype=torch.uint8, device=cuda_device)
+    cnt = torch.zeros(T, dtype=torch.int32, device=cuda_device)
+    traj = torch.full((n, T // thin, dim), float("nan"), device=cuda_device)
+    pd, ud = p.to(cuda_device), u.to(cuda_device)
+    spec = model.fused_spec()
+    _lib.call("ebm_hmc_chain_f32", spec.to_c(), x.data_ptr(), n, dim, T, L, eps, None, 0, 0.0, None, thin, traj.data_ptr(), None,
+              mask.data_ptr(), cnt.data_ptr(), pd.data_ptr(), ud.data_ptr(), 0, 0, _lib.stream_handle(cuda_device))
+    torch.cuda.synchronize()
+    x, mask, traj = x.cpu(), mask.cpu().bool(), traj.cpu()
+    # The two absurd chains themselves are outside what is compared: at |x| ~ 1e36 every logit of the reference's logsumexp is -inf,
+    # its autograd force NaN (scrubbed: p = 0, H1 = 1e10, accepted against H0 = inf), where the kernel's analytic force -- the |x|^2
+    # term cancelled -- is finite and its H0 - H1 = inf - inf is rejected.  What the test is about is everybody ELSE in their waves.
+    absurd = torch.zeros(n, dtype=torch.bool)
+    absurd[[5, 190]] = True
+    clear = (want["margins"] > 2e-4) & ~absurd
+    assert torch.equal(mask[clear], want["accepted"][clear])
+    assert torch.equal(cnt.cpu(), mask.sum(dim=1).to(torch.int32))
+    ok = (want["margins"] > 2e-4).all(dim=0) & ~absurd
+    assert ok.float().mean().item() > 0.9
+    assert torch.isfinite(x[~absurd]).all() and torch.isfinite(traj[~absurd]).all()
+    err = ((x[ok] - want["x"][ok]).abs() / want["x"][ok].abs().clamp(min=1.0)).amax(dim=1)
+    assert (err <= 5e-4).float().mean().item() >= 0.97 and (err <= 5e-3).all(), err.max().item()
+    wt = want["trajectory"]
+    errt = ((traj[ok] - wt[ok]).abs() / wt[ok].abs().clamp(min=1.0)).reshape(int(ok.sum()), -1).amax(dim=1)
+    assert (errt <= 5e-4).float().mean().item() >= 0.97 and (errt <= 5e-3).all(), errt.max().item()
